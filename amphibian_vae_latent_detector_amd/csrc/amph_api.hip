@@ -1,0 +1,913 @@
+// libamph: C-ABI entry points (include/amph.h), context and host-side preparation.
+//
+// Host preparation restates, in double precision then float32 exactly as librosa
+// 0.9.2 does, the tables the reference gets from librosa at
+// latent_space_exploration/map_detector_core.py:219-228 (periodic Hann window,
+// Slaney mel filterbank) plus FFT twiddles, and re-lays the encoder weights out
+// for the NHWC implicit-GEMM kernels.
+#include "../../include/amph.h"
+#include "amph_internal.h"
+
+#include <atomic>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+using namespace amph;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct Stage {
+    std::string name;
+    double flops_per_chunk = 0, bytes_per_chunk = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    long long launches = 0;
+    double total_ms = 0;
+};
+
+struct GemmLayer {
+    ConvGemmParams prm{};   // x / y / M / splits filled per call
+    int bm = 128;
+    float* d_w = nullptr;
+    float* d_scale = nullptr;
+    float* d_shift = nullptr;
+    int n_pad = 0;
+};
+
+}  // namespace
+
+struct amph_ctx {
+    int device = 0;
+    int max_batch = 0;
+    amph_frontend_config cfg{};
+    amph_encoder_spec spec{};
+    bool has_encoder = false;
+    std::string err;
+
+    // front-end tables
+    int n_frames = 0, frames_per_block = 8;
+    float* d_window = nullptr;
+    float2* d_tw_a = nullptr;
+    float2* d_tw_b = nullptr;
+    float2* d_tw_post = nullptr;
+    int32_t *d_mel_start = nullptr, *d_mel_len = nullptr, *d_mel_wofs = nullptr;
+    float* d_mel_w = nullptr;
+    std::vector<float> mel_basis;          // dense [n_mels][F] for amph_get_mel_basis
+
+    // encoder
+    ConvFirstParams first{};
+    float *d_first_w = nullptr, *d_first_scale = nullptr, *d_first_shift = nullptr;
+    std::vector<GemmLayer> gemm;           // conv layers 2.. then the head GEMM last
+    float* d_head_bias = nullptr;
+    int head_splits = 1;
+    int flat = 0, latent = 0;
+
+    // workspace (sized for max_batch)
+    float* ws_scale = nullptr;
+    int32_t* ws_ok = nullptr;
+    float* ws_melpow = nullptr;
+    float* ws_image = nullptr;
+    std::vector<float*> ws_act;            // one per conv layer
+    float* ws_partial = nullptr;
+    // radial scratch
+    float* d_centroids = nullptr;
+    double* d_thr = nullptr;
+    int32_t* d_rank = nullptr;
+
+    // host staging for the *_host entry point
+    hipStream_t copy_stream = nullptr, compute_stream = nullptr;
+    int16_t* pin_in[2] = {nullptr, nullptr};
+    int16_t* dev_in[2] = {nullptr, nullptr};
+    int32_t* dev_len[2] = {nullptr, nullptr};
+    hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
+    size_t stage_samples = 0;
+
+    bool profiling = false;
+    std::vector<Stage> stages;
+    hipStream_t last_stream = nullptr;
+};
+
+namespace {
+
+int fail(amph_ctx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(c, expr)                                                                          \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) return fail((c), AMPH_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+template <typename T>
+hipError_t upload(T** dptr, const std::vector<T>& h) {
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(dptr), std::max<size_t>(h.size(), 1) * sizeof(T));
+    if (e != hipSuccess) return e;
+    if (!h.empty()) e = hipMemcpy(*dptr, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+    return e;
+}
+
+// ---- Slaney mel scale (librosa.hz_to_mel / mel_to_hz, htk=False) -------------
+constexpr double kFsp = 200.0 / 3.0;
+constexpr double kMinLogHz = 1000.0;
+const double kMinLogMel = kMinLogHz / kFsp;
+const double kLogStep = std::log(6.4) / 27.0;
+double hz_to_mel(double f) { return f >= kMinLogHz ? kMinLogMel + std::log(f / kMinLogHz) / kLogStep : f / kFsp; }
+double mel_to_hz(double m) { return m >= kMinLogMel ? kMinLogHz * std::exp(kLogStep * (m - kMinLogMel)) : kFsp * m; }
+// numpy.linspace(start, stop, num, endpoint=True)
+std::vector<double> linspace(double start, double stop, int num) {
+    std::vector<double> v(num);
+    if (num == 1) { v[0] = start; return v; }
+    const double step = (stop - start) / (double)(num - 1);
+    for (int i = 0; i < num; ++i) v[i] = (double)i * step + start;
+    v[num - 1] = stop;
+    return v;
+}
+
+// librosa.filters.mel(sr, n_fft, n_mels, fmin, fmax, htk=False, norm="slaney", dtype=float32)
+std::vector<float> mel_filterbank(int sr, int n_fft, int n_mels, double fmin, double fmax) {
+    const int F = 1 + n_fft / 2;
+    std::vector<float> w((size_t)n_mels * F, 0.0f);
+    const std::vector<double> fftfreqs = linspace(0.0, (double)sr / 2.0, F);
+    std::vector<double> mel_f = linspace(hz_to_mel(fmin), hz_to_mel(fmax), n_mels + 2);
+    for (auto& m : mel_f) m = mel_to_hz(m);
+    for (int i = 0; i < n_mels; ++i) {
+        const double fd0 = mel_f[i + 1] - mel_f[i], fd1 = mel_f[i + 2] - mel_f[i + 1];
+        const double enorm = 2.0 / (mel_f[i + 2] - mel_f[i]);
+        for (int k = 0; k < F; ++k) {
+            const double lower = -(mel_f[i] - fftfreqs[k]) / fd0;
+            const double upper = (mel_f[i + 2] - fftfreqs[k]) / fd1;
+            const float tri = (float)std::max(0.0, std::min(lower, upper));     // float32 store
+            w[(size_t)i * F + k] = (float)((double)tri * enorm);               // weights *= enorm
+        }
+    }
+    return w;
+}
+
+int pick_head_splits(int n_slices) {
+    int best = 1;
+    for (int s = 1; s <= 16; ++s)
+        if (n_slices % s == 0) best = s;
+    return best;
+}
+
+void record_begin(amph_ctx* c, int stage, hipStream_t s, hipEvent_t* a, hipEvent_t* b) {
+    (void)stage;
+    hipEventCreate(a);
+    hipEventCreate(b);
+    hipEventRecord(*a, s);
+    c->last_stream = s;
+}
+
+struct StageTimer {
+    amph_ctx* c;
+    int stage;
+    hipStream_t s;
+    hipEvent_t a = nullptr, b = nullptr;
+    StageTimer(amph_ctx* c_, int stage_, hipStream_t s_) : c(c_), stage(stage_), s(s_) {
+        if (c->profiling) record_begin(c, stage, s, &a, &b);
+    }
+    ~StageTimer() {
+        if (c->profiling) {
+            hipEventRecord(b, s);
+            c->stages[stage].pending.emplace_back(a, b);
+        }
+    }
+};
+
+enum { ST_RMS = 0, ST_STFT = 1, ST_DBNORM = 2, ST_CONV0 = 3 };
+
+int stage_head_gemm(const amph_ctx* c) { return ST_CONV0 + c->spec.n_conv; }
+int stage_head_reduce(const amph_ctx* c) { return ST_CONV0 + c->spec.n_conv + 1; }
+
+int build_frontend(amph_ctx* c) {
+    const amph_frontend_config& f = c->cfg;
+    if (f.n_fft != 2048) return fail(c, AMPH_ERR_UNSUPPORTED, "n_fft=%d: this build implements n_fft=2048 only", f.n_fft);
+    if (f.hop_length <= 0 || (f.hop_length & 1)) return fail(c, AMPH_ERR_UNSUPPORTED, "hop_length must be positive and even");
+    if (f.n_samples <= 0 || f.n_mels <= 0 || f.target_frames <= 0 || f.sr <= 0)
+        return fail(c, AMPH_ERR_INVALID_ARG, "non-positive front-end parameter");
+    if (f.pad_mode == 0 && f.n_samples <= f.n_fft / 2)
+        return fail(c, AMPH_ERR_UNSUPPORTED, "reflect padding needs n_samples > n_fft/2");
+    if (f.pad_mode != 0 && f.pad_mode != 1) return fail(c, AMPH_ERR_INVALID_ARG, "pad_mode must be 0 or 1");
+    c->n_frames = 1 + f.n_samples / f.hop_length;
+    c->frames_per_block = 8;
+
+    const int n_fft = f.n_fft, Nc = n_fft / 2, L = 64, TLO = 4;
+    const double PI = 3.14159265358979323846;
+    std::vector<float> win(n_fft);
+    for (int n = 0; n < n_fft; ++n) win[n] = (float)(0.5 - 0.5 * std::cos(2.0 * PI * (double)n / (double)n_fft));
+    std::vector<float2> twa(16 * L), twb(16 * TLO), twp(Nc / 2 + 1);
+    for (int k1 = 0; k1 < 16; ++k1)
+        for (int t = 0; t < L; ++t) {
+            const double a = -2.0 * PI * (double)((t * k1) % Nc) / (double)Nc;
+            twa[k1 * L + t] = make_float2((float)std::cos(a), (float)std::sin(a));
+        }
+    for (int k2a = 0; k2a < 16; ++k2a)
+        for (int t = 0; t < TLO; ++t) {
+            const double a = -2.0 * PI * (double)((t * k2a) % L) / (double)L;
+            twb[k2a * TLO + t] = make_float2((float)std::cos(a), (float)std::sin(a));
+        }
+    for (int k = 0; k <= Nc / 2; ++k) {
+        const double a = -2.0 * PI * (double)k / (double)n_fft;
+        twp[k] = make_float2((float)std::cos(a), (float)std::sin(a));
+    }
+    HIP_TRY(c, upload(&c->d_window, win));
+    HIP_TRY(c, upload(&c->d_tw_a, twa));
+    HIP_TRY(c, upload(&c->d_tw_b, twb));
+    HIP_TRY(c, upload(&c->d_tw_post, twp));
+
+    const int F = 1 + n_fft / 2;
+    c->mel_basis = mel_filterbank(f.sr, n_fft, f.n_mels, f.fmin, f.fmax);
+    std::vector<int32_t> st(f.n_mels), ln(f.n_mels), wo(f.n_mels);
+    std::vector<float> wv;
+    for (int m = 0; m < f.n_mels; ++m) {
+        int first = -1, last = -1;
+        for (int k = 0; k < F; ++k)
+            if (c->mel_basis[(size_t)m * F + k] != 0.0f) { if (first < 0) first = k; last = k; }
+        st[m] = first < 0 ? 0 : first;
+        ln[m] = first < 0 ? 0 : last - first + 1;
+        wo[m] = (int32_t)wv.size();
+        for (int k = 0; k < ln[m]; ++k) wv.push_back(c->mel_basis[(size_t)m * F + st[m] + k]);
+    }
+    HIP_TRY(c, upload(&c->d_mel_start, st));
+    HIP_TRY(c, upload(&c->d_mel_len, ln));
+    HIP_TRY(c, upload(&c->d_mel_wofs, wo));
+    HIP_TRY(c, upload(&c->d_mel_w, wv));
+    return AMPH_OK;
+}
+
+int build_encoder(amph_ctx* c, const float* hw, size_t n_floats) {
+    const amph_encoder_spec& sp = c->spec;
+    if (sp.n_conv < 1 || sp.n_conv > AMPH_MAX_CONV_LAYERS) return fail(c, AMPH_ERR_INVALID_ARG, "n_conv out of range");
+    if (sp.in_frames != c->cfg.target_frames || sp.in_mels != c->cfg.n_mels)
+        return fail(c, AMPH_ERR_INVALID_ARG, "encoder input %dx%d != front end %dx%d", sp.in_frames, sp.in_mels,
+                    c->cfg.target_frames, c->cfg.n_mels);
+    if (sp.conv[0].c_in != 1) return fail(c, AMPH_ERR_UNSUPPORTED, "first conv layer must have c_in == 1");
+    // expected blob size
+    size_t need = 0;
+    int H = sp.in_frames, W = sp.in_mels;
+    std::vector<int> hs, wsz;
+    for (int i = 0; i < sp.n_conv; ++i) {
+        const amph_conv_layer& l = sp.conv[i];
+        if (l.kernel < 1 || l.stride < 1 || l.pad < 0 || l.c_out < 1) return fail(c, AMPH_ERR_INVALID_ARG, "bad conv layer %d", i);
+        if (i > 0 && l.c_in != sp.conv[i - 1].c_out) return fail(c, AMPH_ERR_INVALID_ARG, "conv %d c_in mismatch", i);
+        if (l.c_out % 4) return fail(c, AMPH_ERR_UNSUPPORTED, "c_out must be a multiple of 4 (layer %d)", i);
+        need += (size_t)l.c_out * l.c_in * l.kernel * l.kernel + 5 * (size_t)l.c_out;
+        H = (H + 2 * l.pad - l.kernel) / l.stride + 1;
+        W = (W + 2 * l.pad - l.kernel) / l.stride + 1;
+        if (H < 1 || W < 1) return fail(c, AMPH_ERR_INVALID_ARG, "conv %d output is empty", i);
+        hs.push_back(H);
+        wsz.push_back(W);
+    }
+    const int D = sp.latent_dim;
+    if (D < 1) return fail(c, AMPH_ERR_INVALID_ARG, "latent_dim < 1");
+    const int C_last = sp.conv[sp.n_conv - 1].c_out;
+    const int flat = C_last * H * W;
+    need += 2 * ((size_t)D * flat + D);
+    if (n_floats != need)
+        return fail(c, AMPH_ERR_INVALID_ARG, "weight blob has %zu floats, spec needs %zu", n_floats, need);
+    c->flat = flat;
+    c->latent = D;
+
+    const float* pw = hw;
+    int Hin = sp.in_frames, Win = sp.in_mels;
+    for (int i = 0; i < sp.n_conv; ++i) {
+        const amph_conv_layer& l = sp.conv[i];
+        const int kk = l.kernel * l.kernel;
+        const float* w = pw;                       pw += (size_t)l.c_out * l.c_in * kk;
+        const float* bias = pw;                    pw += l.c_out;
+        const float* g = pw;                       pw += l.c_out;
+        const float* beta = pw;                    pw += l.c_out;
+        const float* mean = pw;                    pw += l.c_out;
+        const float* var = pw;                     pw += l.c_out;
+        // BatchNorm eval as torch's CPU kernel folds it: alpha = weight / sqrt(var + eps),
+        // y = x * alpha + (bias_bn - mean * alpha); the conv bias is folded into the shift.
+        const int n_pad = (l.c_out + 63) / 64 * 64;
+        std::vector<float> alpha(n_pad, 0.0f), shift(n_pad, 0.0f);
+        for (int o = 0; o < l.c_out; ++o) {
+            const float invstd = 1.0f / std::sqrt(var[o] + sp.bn_eps);
+            alpha[o] = invstd * g[o];
+            shift[o] = (beta[o] - mean[o] * alpha[o]) + bias[o] * alpha[o];
+        }
+        if (i == 0) {
+            std::vector<float> wf((size_t)kk * l.c_out);
+            for (int o = 0; o < l.c_out; ++o)
+                for (int t = 0; t < kk; ++t) wf[(size_t)t * l.c_out + o] = w[(size_t)o * kk + t];
+            HIP_TRY(c, upload(&c->d_first_w, wf));
+            HIP_TRY(c, upload(&c->d_first_scale, alpha));
+            HIP_TRY(c, upload(&c->d_first_shift, shift));
+            ConvFirstParams& p = c->first;
+            p.w = c->d_first_w; p.scale = c->d_first_scale; p.shift = c->d_first_shift;
+            p.H = Hin; p.W = Win; p.OH = hs[i]; p.OW = wsz[i]; p.C_out = l.c_out;
+            p.k = l.kernel; p.stride = l.stride; p.pad = l.pad;
+        } else {
+            if (l.c_in % 4) return fail(c, AMPH_ERR_UNSUPPORTED, "c_in must be a multiple of 4 (layer %d)", i);
+            GemmLayer gl;
+            const int K = kk * l.c_in, K_pad = (K + 31) / 32 * 32;
+            std::vector<float> wg((size_t)n_pad * K_pad, 0.0f);
+            for (int o = 0; o < l.c_out; ++o)
+                for (int ci = 0; ci < l.c_in; ++ci)
+                    for (int t = 0; t < kk; ++t)
+                        wg[(size_t)o * K_pad + (size_t)t * l.c_in + ci] = w[((size_t)o * l.c_in + ci) * kk + t];
+            HIP_TRY(c, upload(&gl.d_w, wg));
+            HIP_TRY(c, upload(&gl.d_scale, alpha));
+            HIP_TRY(c, upload(&gl.d_shift, shift));
+            gl.n_pad = n_pad;
+            ConvGemmParams& p = gl.prm;
+            p.w = gl.d_w; p.scale = gl.d_scale; p.shift = gl.d_shift;
+            p.H = Hin; p.W = Win; p.C_in = l.c_in; p.OH = hs[i]; p.OW = wsz[i]; p.N = l.c_out;
+            p.k = l.kernel; p.stride = l.stride; p.pad = l.pad; p.K = K; p.K_pad = K_pad;
+            p.epilogue = 0; p.splits = 1;
+            c->gemm.push_back(gl);
+        }
+        Hin = hs[i];
+        Win = wsz[i];
+    }
+    // head: [fc_mu; fc_logvar] as one [2D][flat] matrix, columns permuted from the NCHW
+    // flatten index c*H*W + h*W + w to the NHWC one (h*W + w)*C + c.
+    {
+        const float* wmu = pw;  pw += (size_t)D * flat;
+        const float* bmu = pw;  pw += D;
+        const float* wlv = pw;  pw += (size_t)D * flat;
+        const float* blv = pw;  pw += D;
+        if (flat % 4) return fail(c, AMPH_ERR_UNSUPPORTED, "flatten size must be a multiple of 4");
+        const int N = 2 * D, n_pad = (N + 63) / 64 * 64, K_pad = (flat + 31) / 32 * 32;
+        std::vector<float> wg((size_t)n_pad * K_pad, 0.0f), bias(N);
+        const int HW = H * W;
+        for (int n = 0; n < N; ++n) {
+            const float* src = n < D ? wmu + (size_t)n * flat : wlv + (size_t)(n - D) * flat;
+            for (int ch = 0; ch < C_last; ++ch)
+                for (int px = 0; px < HW; ++px) wg[(size_t)n * K_pad + (size_t)px * C_last + ch] = src[(size_t)ch * HW + px];
+            bias[n] = n < D ? bmu[n] : blv[n - D];
+        }
+        GemmLayer gl;
+        HIP_TRY(c, upload(&gl.d_w, wg));
+        HIP_TRY(c, upload(&c->d_head_bias, bias));
+        gl.n_pad = n_pad;
+        ConvGemmParams& p = gl.prm;
+        p.w = gl.d_w; p.scale = nullptr; p.shift = nullptr;
+        p.H = 1; p.W = 1; p.C_in = flat; p.OH = 1; p.OW = 1; p.N = N; p.k = 1; p.stride = 1; p.pad = 0;
+        p.K = flat; p.K_pad = K_pad; p.epilogue = 1;
+        c->head_splits = pick_head_splits(K_pad / 32);
+        p.splits = c->head_splits;
+        gl.bm = 64;
+        c->gemm.push_back(gl);
+    }
+    return AMPH_OK;
+}
+
+int alloc_workspace(amph_ctx* c) {
+    const int MB = c->max_batch;
+    const amph_frontend_config& f = c->cfg;
+    HIP_TRY(c, hipMalloc((void**)&c->ws_scale, (size_t)MB * sizeof(float)));
+    HIP_TRY(c, hipMalloc((void**)&c->ws_ok, (size_t)MB * sizeof(int32_t)));
+    HIP_TRY(c, hipMalloc((void**)&c->ws_melpow, (size_t)MB * c->n_frames * f.n_mels * sizeof(float)));
+    HIP_TRY(c, hipMalloc((void**)&c->ws_image, (size_t)MB * f.target_frames * f.n_mels * sizeof(float)));
+    if (c->has_encoder) {
+        int H = c->spec.in_frames, W = c->spec.in_mels;
+        for (int i = 0; i < c->spec.n_conv; ++i) {
+            const amph_conv_layer& l = c->spec.conv[i];
+            H = (H + 2 * l.pad - l.kernel) / l.stride + 1;
+            W = (W + 2 * l.pad - l.kernel) / l.stride + 1;
+            float* p = nullptr;
+            HIP_TRY(c, hipMalloc((void**)&p, (size_t)MB * H * W * l.c_out * sizeof(float)));
+            c->ws_act.push_back(p);
+        }
+        HIP_TRY(c, hipMalloc((void**)&c->ws_partial, (size_t)c->head_splits * MB * 2 * c->latent * sizeof(float)));
+    }
+    return AMPH_OK;
+}
+
+void build_stages(amph_ctx* c) {
+    const amph_frontend_config& f = c->cfg;
+    const double N = f.n_samples, T = c->n_frames, Fb = 1 + f.n_fft / 2, M = f.n_mels;
+    auto add = [&](const char* name, double flops, double bytes) {
+        Stage s;
+        s.name = name;
+        s.flops_per_chunk = flops;
+        s.bytes_per_chunk = bytes;
+        c->stages.push_back(s);
+    };
+    add("rms_scale", 2.0 * N, 2.0 * N);
+    add("stft_mel", T * (f.n_fft + 2.5 * f.n_fft * std::log2((double)f.n_fft)) + 3.0 * Fb * T + 4.0 * Fb * T,
+        2.0 * N + 4.0 * T * M);
+    add("dbnorm", 12.0 * M * T, 4.0 * T * M + 4.0 * f.target_frames * M);
+    if (c->has_encoder) {
+        int H = c->spec.in_frames, W = c->spec.in_mels;
+        for (int i = 0; i < c->spec.n_conv; ++i) {
+            const amph_conv_layer& l = c->spec.conv[i];
+            const double in_b = 4.0 * H * W * l.c_in;
+            H = (H + 2 * l.pad - l.kernel) / l.stride + 1;
+            W = (W + 2 * l.pad - l.kernel) / l.stride + 1;
+            char nm[32];
+            snprintf(nm, sizeof nm, "conv%d", i + 1);
+            add(nm, 2.0 * l.kernel * l.kernel * l.c_in * l.c_out * H * W, in_b + 4.0 * H * W * l.c_out);
+        }
+        add("head_gemm", 2.0 * c->flat * 2.0 * c->latent, 4.0 * c->flat + 8.0 * c->latent * c->head_splits);
+        add("head_reduce", 2.0 * c->latent * c->head_splits, 8.0 * c->latent * (c->head_splits + 1));
+    }
+}
+
+// encoder on ws_image-like input; x is [nb][T][M]
+int run_encoder(amph_ctx* c, const float* d_x, int nb, float* d_mu, float* d_logvar, hipStream_t s) {
+    {
+        StageTimer t(c, ST_CONV0, s);
+        ConvFirstParams p = c->first;
+        p.x = d_x;
+        p.y = c->ws_act[0];
+        launch_conv_first(p, nb, s);
+    }
+    const int n_gemm = (int)c->gemm.size();
+    for (int gi = 0; gi < n_gemm; ++gi) {
+        const bool head = gi == n_gemm - 1;
+        GemmLayer& gl = c->gemm[gi];
+        ConvGemmParams p = gl.prm;
+        p.x = c->ws_act[gi];
+        p.M = nb * p.OH * p.OW;
+        int bm = 128;
+        if (head) {
+            p.y = c->ws_partial;
+            bm = 64;
+        } else {
+            p.y = c->ws_act[gi + 1];
+            // keep >= ~2 workgroups per CU when the layer is small
+            const long long wg128 = (long long)((p.M + 127) / 128) * ((p.N + 63) / 64);
+            if (wg128 < 512) bm = 64;
+        }
+        StageTimer t(c, head ? stage_head_gemm(c) : ST_CONV0 + 1 + gi, s);
+        launch_conv_gemm(p, bm, s);
+    }
+    {
+        StageTimer t(c, stage_head_reduce(c), s);
+        HeadReduceParams p;
+        p.partial = c->ws_partial; p.bias = c->d_head_bias; p.splits = c->head_splits; p.D = c->latent;
+        p.mu = d_mu; p.logvar = d_logvar;
+        launch_head_reduce(p, nb, s);
+    }
+    return AMPH_OK;
+}
+
+StftParams make_stft(amph_ctx* c, const WaveSrc& src, float* melpow) {
+    StftParams p{};
+    p.src = src;
+    p.n_samples = c->cfg.n_samples; p.n_fft = c->cfg.n_fft; p.hop = c->cfg.hop_length; p.n_frames = c->n_frames;
+    p.pad_mode = c->cfg.pad_mode; p.frames_per_block = c->frames_per_block;
+    p.tiles_per_row = (c->n_frames + c->frames_per_block - 1) / c->frames_per_block;
+    p.window = c->d_window; p.tw_a = c->d_tw_a; p.tw_b = c->d_tw_b; p.tw_post = c->d_tw_post;
+    p.n_mels = c->cfg.n_mels; p.mel_start = c->d_mel_start; p.mel_len = c->d_mel_len; p.mel_wofs = c->d_mel_wofs;
+    p.mel_w = c->d_mel_w; p.melpow = melpow;
+    return p;
+}
+
+// front end for one batch: wave rows -> melpow (-> image)
+int run_frontend(amph_ctx* c, const void* d_wave, bool pcm16, int nb, int n_in, const int32_t* d_len, int apply_rms,
+                 int32_t* d_rms_ok, float* melpow, hipStream_t s) {
+    WaveSrc src{};
+    src.wave = d_wave; src.row_stride = n_in; src.lengths = d_len; src.n_in = n_in;
+    src.scale = nullptr; src.requant = 0;
+    if (apply_rms) {
+        StageTimer t(c, ST_RMS, s);
+        int32_t* okp = d_rms_ok ? d_rms_ok : c->ws_ok;
+        if (pcm16) launch_rms_scale_pcm16((const int16_t*)d_wave, n_in, d_len, n_in, nb, c->ws_scale, okp, s);
+        else launch_rms_scale_f32((const float*)d_wave, n_in, d_len, n_in, nb, c->ws_scale, okp, s);
+        src.scale = c->ws_scale;
+        src.requant = 1;
+    } else if (d_rms_ok) {
+        hipMemsetAsync(d_rms_ok, 0, (size_t)nb * sizeof(int32_t), s);
+    }
+    {
+        StageTimer t(c, ST_STFT, s);
+        launch_stft_mel(make_stft(c, src, melpow), nb, pcm16 ? 1 : 0, s);
+    }
+    return AMPH_OK;
+}
+
+int run_dbnorm(amph_ctx* c, const float* melpow, int nb, int layout, float* out, hipStream_t s) {
+    StageTimer t(c, ST_DBNORM, s);
+    DbNormParams p;
+    p.melpow = melpow; p.n_frames = c->n_frames; p.n_mels = c->cfg.n_mels; p.target_frames = c->cfg.target_frames;
+    p.layout = layout; p.out = out;
+    launch_dbnorm(p, nb, s);
+    return AMPH_OK;
+}
+
+int check_launch(amph_ctx* c, const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(c, AMPH_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+    return AMPH_OK;
+}
+
+int encode_common(amph_ctx* c, const void* d_wave, bool pcm16, int64_t n_rows, int n_in, const int32_t* d_len,
+                  int apply_rms, float* d_mu, float* d_logvar, int32_t* d_rms_ok, hipStream_t s) {
+    if (!c) return AMPH_ERR_INVALID_ARG;
+    if (!c->has_encoder) return fail(c, AMPH_ERR_INVALID_ARG, "context was created without encoder weights");
+    if (n_rows < 0 || n_in <= 0 || (n_rows > 0 && (!d_wave || !d_mu))) return fail(c, AMPH_ERR_INVALID_ARG, "bad encode arguments");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t esz = pcm16 ? 2 : 4;
+    const int D = c->latent;
+    for (int64_t off = 0; off < n_rows; off += c->max_batch) {
+        const int nb = (int)std::min<int64_t>(c->max_batch, n_rows - off);
+        const char* w = (const char*)d_wave + (size_t)off * n_in * esz;
+        run_frontend(c, w, pcm16, nb, n_in, d_len ? d_len + off : nullptr, apply_rms, d_rms_ok ? d_rms_ok + off : nullptr,
+                     c->ws_melpow, s);
+        run_dbnorm(c, c->ws_melpow, nb, 1, c->ws_image, s);
+        run_encoder(c, c->ws_image, nb, d_mu + off * D, d_logvar ? d_logvar + off * D : nullptr, s);
+    }
+    return check_launch(c, "encode");
+}
+
+}  // namespace
+
+// ============================================================================
+// C-ABI
+// ============================================================================
+extern "C" {
+
+int amph_abi_version(void) { return AMPH_ABI_VERSION; }
+
+const char* amph_last_error(const amph_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int amph_create(const amph_frontend_config* cfg, const amph_encoder_spec* spec, const float* h_weights,
+                size_t n_weight_floats, int device, int max_batch, amph_ctx** out_ctx) {
+    if (!cfg || !out_ctx || max_batch < 1) return fail(nullptr, AMPH_ERR_INVALID_ARG, "amph_create: null config/out or max_batch < 1");
+    *out_ctx = nullptr;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0) return fail(nullptr, AMPH_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= n_dev) return fail(nullptr, AMPH_ERR_NO_DEVICE, "device %d out of range (%d visible)", device, n_dev);
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, AMPH_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return fail(nullptr, AMPH_ERR_NO_DEVICE, "hipGetDeviceProperties failed");
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, AMPH_ERR_NO_DEVICE, "device %d is %s; libamph is built for gfx950 only", device, prop.gcnArchName);
+
+    amph_ctx* c = new amph_ctx();
+    c->device = device;
+    c->max_batch = max_batch;
+    c->cfg = *cfg;
+    int rc = build_frontend(c);
+    if (rc == AMPH_OK && h_weights) {
+        if (!spec) rc = fail(c, AMPH_ERR_INVALID_ARG, "weights given without an encoder spec");
+        else {
+            c->spec = *spec;
+            c->has_encoder = true;
+            rc = build_encoder(c, h_weights, n_weight_floats);
+        }
+    }
+    if (rc == AMPH_OK) rc = alloc_workspace(c);
+    if (rc == AMPH_OK) {
+        build_stages(c);
+        const int lds = (int)stft_mel_lds_bytes(c->cfg.n_fft, c->cfg.hop_length, c->frames_per_block);
+        if (lds > 160 * 1024) rc = fail(c, AMPH_ERR_UNSUPPORTED, "frame tile needs %d bytes of LDS", lds);
+        else rc = amph::stft_mel_configure(lds) == hipSuccess ? AMPH_OK : fail(c, AMPH_ERR_HIP, "hipFuncSetAttribute failed");
+    }
+    if (rc != AMPH_OK) {
+        g_create_error = c->err;
+        amph_destroy(c);
+        return rc;
+    }
+    *out_ctx = c;
+    return AMPH_OK;
+}
+
+void amph_destroy(amph_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipDeviceSynchronize();
+    auto fr = [](void* p) { if (p) hipFree(p); };
+    fr(c->d_window); fr(c->d_tw_a); fr(c->d_tw_b); fr(c->d_tw_post);
+    fr(c->d_mel_start); fr(c->d_mel_len); fr(c->d_mel_wofs); fr(c->d_mel_w);
+    fr(c->d_first_w); fr(c->d_first_scale); fr(c->d_first_shift);
+    for (auto& g : c->gemm) { fr(g.d_w); fr(g.d_scale); fr(g.d_shift); }
+    fr(c->d_head_bias);
+    fr(c->ws_scale); fr(c->ws_ok); fr(c->ws_melpow); fr(c->ws_image);
+    for (auto p : c->ws_act) fr(p);
+    fr(c->ws_partial); fr(c->d_centroids); fr(c->d_thr); fr(c->d_rank);
+    for (int i = 0; i < 2; ++i) {
+        if (c->pin_in[i]) hipHostFree(c->pin_in[i]);
+        fr(c->dev_in[i]); fr(c->dev_len[i]);
+        if (c->ev_copied[i]) hipEventDestroy(c->ev_copied[i]);
+        if (c->ev_done[i]) hipEventDestroy(c->ev_done[i]);
+    }
+    if (c->copy_stream) hipStreamDestroy(c->copy_stream);
+    if (c->compute_stream) hipStreamDestroy(c->compute_stream);
+    for (auto& st : c->stages)
+        for (auto& pr : st.pending) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+    delete c;
+}
+
+int amph_raw_frames(const amph_ctx* c) { return c ? c->n_frames : -1; }
+int amph_latent_dim(const amph_ctx* c) { return c ? c->latent : -1; }
+int amph_max_batch(const amph_ctx* c) { return c ? c->max_batch : -1; }
+
+int amph_get_mel_basis(const amph_ctx* c, float* h_out, size_t n_floats) {
+    if (!c || !h_out || n_floats != c->mel_basis.size()) return AMPH_ERR_INVALID_ARG;
+    std::memcpy(h_out, c->mel_basis.data(), n_floats * sizeof(float));
+    return AMPH_OK;
+}
+
+int amph_rms_normalize_f32(amph_ctx* c, const float* d_in, int n_rows, int n, float* d_out, int32_t* d_ok, void* stream) {
+    if (!c) return AMPH_ERR_INVALID_ARG;
+    if (n_rows < 0 || n <= 0 || (n_rows > 0 && (!d_in || !d_out))) return fail(c, AMPH_ERR_INVALID_ARG, "bad rms arguments");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    for (int off = 0; off < n_rows; off += c->max_batch) {
+        const int nb = std::min(c->max_batch, n_rows - off);
+        int32_t* okp = d_ok ? d_ok + off : c->ws_ok;
+        launch_rms_scale_f32(d_in + (size_t)off * n, n, nullptr, n, nb, c->ws_scale, okp, s);
+        launch_rms_apply_f32(d_in + (size_t)off * n, nb, n, c->ws_scale, okp, d_out + (size_t)off * n, s);
+    }
+    return check_launch(c, "rms_normalize_f32");
+}
+
+int amph_rms_normalize_pcm16(amph_ctx* c, const int16_t* d_in, int n_rows, int n, int16_t* d_out, int32_t* d_ok, void* stream) {
+    if (!c) return AMPH_ERR_INVALID_ARG;
+    if (n_rows < 0 || n <= 0 || (n_rows > 0 && (!d_in || !d_out))) return fail(c, AMPH_ERR_INVALID_ARG, "bad rms arguments");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    for (int off = 0; off < n_rows; off += c->max_batch) {
+        const int nb = std::min(c->max_batch, n_rows - off);
+        int32_t* okp = d_ok ? d_ok + off : c->ws_ok;
+        launch_rms_scale_pcm16(d_in + (size_t)off * n, n, nullptr, n, nb, c->ws_scale, okp, s);
+        launch_rms_apply_pcm16(d_in + (size_t)off * n, nb, n, c->ws_scale, okp, d_out + (size_t)off * n, s);
+    }
+    return check_launch(c, "rms_normalize_pcm16");
+}
+
+int amph_mel_power_f32(amph_ctx* c, const float* d_wave, int n_rows, int n_in, const int32_t* d_lengths,
+                       float* d_melpow_out, void* stream) {
+    if (!c) return AMPH_ERR_INVALID_ARG;
+    if (n_rows < 0 || n_in <= 0 || (n_rows > 0 && (!d_wave || !d_melpow_out))) return fail(c, AMPH_ERR_INVALID_ARG, "bad mel arguments");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    const size_t per = (size_t)c->n_frames * c->cfg.n_mels;
+    for (int off = 0; off < n_rows; off += c->max_batch) {
+        const int nb = std::min(c->max_batch, n_rows - off);
+        run_frontend(c, d_wave + (size_t)off * n_in, false, nb, n_in, d_lengths ? d_lengths + off : nullptr, 0, nullptr,
+                     d_melpow_out + (size_t)off * per, s);
+    }
+    return check_launch(c, "mel_power_f32");
+}
+
+int amph_mel_f32(amph_ctx* c, const float* d_wave, int n_rows, int n_in, const int32_t* d_lengths, int layout,
+                 float* d_mel_out, void* stream) {
+    if (!c) return AMPH_ERR_INVALID_ARG;
+    if (n_rows < 0 || n_in <= 0 || (layout != 0 && layout != 1) || (n_rows > 0 && (!d_wave || !d_mel_out)))
+        return fail(c, AMPH_ERR_INVALID_ARG, "bad mel arguments");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    const size_t per = (size_t)c->cfg.target_frames * c->cfg.n_mels;
+    for (int off = 0; off < n_rows; off += c->max_batch) {
+        const int nb = std::min(c->max_batch, n_rows - off);
+        run_frontend(c, d_wave + (size_t)off * n_in, false, nb, n_in, d_lengths ? d_lengths + off : nullptr, 0, nullptr,
+                     c->ws_melpow, s);
+        run_dbnorm(c, c->ws_melpow, nb, layout, d_mel_out + (size_t)off * per, s);
+    }
+    return check_launch(c, "mel_f32");
+}
+
+int amph_encoder_forward(amph_ctx* c, const float* d_x, int n_rows, float* d_mu, float* d_logvar, void* stream) {
+    if (!c) return AMPH_ERR_INVALID_ARG;
+    if (!c->has_encoder) return fail(c, AMPH_ERR_INVALID_ARG, "context was created without encoder weights");
+    if (n_rows < 0 || (n_rows > 0 && (!d_x || !d_mu))) return fail(c, AMPH_ERR_INVALID_ARG, "bad encoder arguments");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    const size_t per = (size_t)c->cfg.target_frames * c->cfg.n_mels;
+    const int D = c->latent;
+    for (int off = 0; off < n_rows; off += c->max_batch) {
+        const int nb = std::min(c->max_batch, n_rows - off);
+        run_encoder(c, d_x + (size_t)off * per, nb, d_mu + (size_t)off * D, d_logvar ? d_logvar + (size_t)off * D : nullptr, s);
+    }
+    return check_launch(c, "encoder_forward");
+}
+
+int amph_encode_pcm16(amph_ctx* c, const int16_t* d_pcm, int64_t n_rows, int n_in, const int32_t* d_lengths, int apply_rms,
+                      float* d_mu, float* d_logvar, int32_t* d_rms_ok, void* stream) {
+    return encode_common(c, d_pcm, true, n_rows, n_in, d_lengths, apply_rms, d_mu, d_logvar, d_rms_ok, (hipStream_t)stream);
+}
+
+int amph_encode_f32(amph_ctx* c, const float* d_wave, int64_t n_rows, int n_in, const int32_t* d_lengths, int apply_rms,
+                    float* d_mu, float* d_logvar, int32_t* d_rms_ok, void* stream) {
+    return encode_common(c, d_wave, false, n_rows, n_in, d_lengths, apply_rms, d_mu, d_logvar, d_rms_ok, (hipStream_t)stream);
+}
+
+int amph_encode_pcm16_host(amph_ctx* c, const int16_t* h_pcm, int64_t n_rows, int n_in, const int32_t* h_lengths,
+                           int apply_rms, float* h_mu, float* h_logvar, int32_t* h_rms_ok) {
+    if (!c) return AMPH_ERR_INVALID_ARG;
+    if (!c->has_encoder) return fail(c, AMPH_ERR_INVALID_ARG, "context was created without encoder weights");
+    if (n_rows < 0 || n_in <= 0 || (n_rows > 0 && (!h_pcm || !h_mu))) return fail(c, AMPH_ERR_INVALID_ARG, "bad encode arguments");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int MB = c->max_batch, D = c->latent;
+    const size_t need = (size_t)MB * n_in;
+    if (!c->copy_stream) {
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->compute_stream, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) {
+            HIP_TRY(c, hipEventCreateWithFlags(&c->ev_copied[i], hipEventDisableTiming));
+            HIP_TRY(c, hipEventCreateWithFlags(&c->ev_done[i], hipEventDisableTiming));
+            HIP_TRY(c, hipMalloc((void**)&c->dev_len[i], (size_t)MB * sizeof(int32_t)));
+        }
+    }
+    if (c->stage_samples < need) {
+        for (int i = 0; i < 2; ++i) {
+            if (c->pin_in[i]) hipHostFree(c->pin_in[i]);
+            if (c->dev_in[i]) hipFree(c->dev_in[i]);
+            HIP_TRY(c, hipHostMalloc((void**)&c->pin_in[i], need * sizeof(int16_t), hipHostMallocDefault));
+            HIP_TRY(c, hipMalloc((void**)&c->dev_in[i], need * sizeof(int16_t)));
+        }
+        c->stage_samples = need;
+    }
+    float *d_mu = nullptr, *d_lv = nullptr;
+    int32_t* d_ok = nullptr;
+    HIP_TRY(c, hipMalloc((void**)&d_mu, std::max<size_t>(1, (size_t)n_rows * D) * sizeof(float)));
+    if (h_logvar) HIP_TRY(c, hipMalloc((void**)&d_lv, std::max<size_t>(1, (size_t)n_rows * D) * sizeof(float)));
+    if (h_rms_ok) HIP_TRY(c, hipMalloc((void**)&d_ok, std::max<size_t>(1, (size_t)n_rows) * sizeof(int32_t)));
+    int rc = AMPH_OK;
+    int slot = 0;
+    bool used[2] = {false, false};
+    for (int64_t off = 0; off < n_rows && rc == AMPH_OK; off += MB, slot ^= 1) {
+        const int nb = (int)std::min<int64_t>(MB, n_rows - off);
+        if (used[slot]) hipEventSynchronize(c->ev_done[slot]);          // staging slot free again
+        std::memcpy(c->pin_in[slot], h_pcm + (size_t)off * n_in, (size_t)nb * n_in * sizeof(int16_t));
+        hipMemcpyAsync(c->dev_in[slot], c->pin_in[slot], (size_t)nb * n_in * sizeof(int16_t), hipMemcpyHostToDevice, c->copy_stream);
+        if (h_lengths)
+            hipMemcpyAsync(c->dev_len[slot], h_lengths + off, (size_t)nb * sizeof(int32_t), hipMemcpyHostToDevice, c->copy_stream);
+        hipEventRecord(c->ev_copied[slot], c->copy_stream);
+        hipStreamWaitEvent(c->compute_stream, c->ev_copied[slot], 0);
+        rc = encode_common(c, c->dev_in[slot], true, nb, n_in, h_lengths ? c->dev_len[slot] : nullptr, apply_rms,
+                           d_mu + (size_t)off * D, d_lv ? d_lv + (size_t)off * D : nullptr, d_ok ? d_ok + off : nullptr,
+                           c->compute_stream);
+        hipEventRecord(c->ev_done[slot], c->compute_stream);
+        used[slot] = true;
+    }
+    if (rc == AMPH_OK) {
+        hipError_t e = hipStreamSynchronize(c->compute_stream);
+        if (e == hipSuccess && n_rows > 0) e = hipMemcpy(h_mu, d_mu, (size_t)n_rows * D * sizeof(float), hipMemcpyDeviceToHost);
+        if (e == hipSuccess && h_logvar && n_rows > 0) e = hipMemcpy(h_logvar, d_lv, (size_t)n_rows * D * sizeof(float), hipMemcpyDeviceToHost);
+        if (e == hipSuccess && h_rms_ok && n_rows > 0) e = hipMemcpy(h_rms_ok, d_ok, (size_t)n_rows * sizeof(int32_t), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(c, AMPH_ERR_HIP, "encode_pcm16_host: %s", hipGetErrorString(e));
+    } else {
+        hipStreamSynchronize(c->compute_stream);
+    }
+    hipFree(d_mu);
+    if (d_lv) hipFree(d_lv);
+    if (d_ok) hipFree(d_ok);
+    return rc;
+}
+
+int amph_decide_radial(amph_ctx* c, const float* d_z, int64_t n_rows, int dim, const float* h_centroids,
+                       const double* h_thresholds, const int32_t* h_rank, int n_species, int32_t* d_pred, float* d_best_d,
+                       void* stream) {
+    if (!c) return AMPH_ERR_INVALID_ARG;
+    if (n_rows < 0 || dim < 1 || dim > kMaxRadialDim || n_species < 0 || n_species > kMaxSpecies ||
+        (n_species > 0 && (!h_centroids || !h_thresholds || !h_rank)) || (n_rows > 0 && (!d_z || !d_pred || !d_best_d)))
+        return fail(c, AMPH_ERR_INVALID_ARG, "bad radial arguments (dim <= %d, species <= %d)", kMaxRadialDim, kMaxSpecies);
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    if (!c->d_centroids) {
+        HIP_TRY(c, hipMalloc((void**)&c->d_centroids, (size_t)kMaxSpecies * kMaxRadialDim * sizeof(float)));
+        HIP_TRY(c, hipMalloc((void**)&c->d_thr, kMaxSpecies * sizeof(double)));
+        HIP_TRY(c, hipMalloc((void**)&c->d_rank, kMaxSpecies * sizeof(int32_t)));
+    }
+    if (n_species > 0) {
+        // small synchronous copies of pageable host memory: complete before returning to the caller
+        HIP_TRY(c, hipMemcpyAsync(c->d_centroids, h_centroids, (size_t)n_species * dim * sizeof(float), hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(c->d_thr, h_thresholds, (size_t)n_species * sizeof(double), hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(c->d_rank, h_rank, (size_t)n_species * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    }
+    RadialParams p;
+    p.z = d_z; p.centroids = c->d_centroids; p.thresholds = c->d_thr; p.rank = c->d_rank; p.K = n_species; p.D = dim;
+    p.pred = d_pred; p.best_d = d_best_d;
+    if (n_rows > 0) launch_decide_radial(p, n_rows, s);
+    return check_launch(c, "decide_radial");
+}
+
+// ---------------------------------------------------------------------------- WAV ingest
+static int read_wav_file(const char* path, int expect_sr, int16_t* out, int max_samples, int32_t* out_len) {
+    if (out_len) *out_len = 0;
+    if (!path || !out || max_samples < 0) return AMPH_ERR_INVALID_ARG;
+    std::memset(out, 0, (size_t)max_samples * sizeof(int16_t));
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return AMPH_ERR_IO;
+    unsigned char hdr[12];
+    int rc = AMPH_ERR_IO;
+    bool have_fmt = false;
+    if (std::fread(hdr, 1, 12, f) == 12 && !std::memcmp(hdr, "RIFF", 4) && !std::memcmp(hdr + 8, "WAVE", 4)) {
+        for (;;) {
+            unsigned char ch[8];
+            if (std::fread(ch, 1, 8, f) != 8) break;
+            const uint32_t sz = ch[4] | (ch[5] << 8) | (ch[6] << 16) | ((uint32_t)ch[7] << 24);
+            if (!std::memcmp(ch, "fmt ", 4)) {
+                unsigned char fm[40] = {0};
+                const size_t rd = std::min<size_t>(sz, sizeof fm);
+                if (std::fread(fm, 1, rd, f) != rd || rd < 16) break;
+                if (sz > rd) std::fseek(f, (long)(sz - rd), SEEK_CUR);
+                if (sz & 1) std::fseek(f, 1, SEEK_CUR);
+                int fmt = fm[0] | (fm[1] << 8);
+                const int channels = fm[2] | (fm[3] << 8);
+                const uint32_t sr = fm[4] | (fm[5] << 8) | (fm[6] << 16) | ((uint32_t)fm[7] << 24);
+                const int bits = fm[14] | (fm[15] << 8);
+                if (fmt == 0xFFFE && rd >= 26) fmt = fm[24] | (fm[25] << 8);      // WAVE_FORMAT_EXTENSIBLE sub-format
+                if (fmt != 1 || bits != 16 || channels != 1 || (expect_sr > 0 && (int)sr != expect_sr)) { rc = AMPH_ERR_UNSUPPORTED; break; }
+                have_fmt = true;
+            } else if (!std::memcmp(ch, "data", 4)) {
+                if (!have_fmt) break;
+                const size_t avail = sz / 2;
+                const size_t want = std::min<size_t>(avail, (size_t)max_samples);
+                const size_t got = std::fread(out, 2, want, f);
+                if (out_len) *out_len = (int32_t)got;
+                rc = (got == want || sz == 0xFFFFFFFFu) ? AMPH_OK : AMPH_ERR_IO;
+                if (rc != AMPH_OK && got > 0 && got < want) rc = AMPH_OK;           // truncated file: keep what is there (libsndfile does)
+                break;
+            } else {
+                if (std::fseek(f, (long)(sz + (sz & 1)), SEEK_CUR) != 0) break;
+            }
+        }
+    }
+    std::fclose(f);
+    return rc;
+}
+
+int amph_wav_read_pcm16(const char* path, int expect_sr, int16_t* h_out, int max_samples, int32_t* out_len) {
+    return read_wav_file(path, expect_sr, h_out, max_samples, out_len);
+}
+
+int amph_wav_read_many(const char* const* paths, int n_files, int expect_sr, int16_t* h_out, int max_samples,
+                       int32_t* h_lengths, int32_t* h_status, int n_threads) {
+    if (n_files < 0 || (n_files > 0 && (!paths || !h_out || !h_lengths || !h_status))) return AMPH_ERR_INVALID_ARG;
+    n_threads = std::max(1, std::min(n_threads, std::max(1, n_files)));
+    std::atomic<int> next{0};
+    auto work = [&]() {
+        for (;;) {
+            const int i = next.fetch_add(1);
+            if (i >= n_files) break;
+            h_status[i] = read_wav_file(paths[i], expect_sr, h_out + (size_t)i * max_samples, max_samples, &h_lengths[i]);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < n_threads; ++t) pool.emplace_back(work);
+    work();
+    for (auto& t : pool) t.join();
+    return AMPH_OK;
+}
+
+void* amph_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+void amph_host_free(void* p) { if (p) hipHostFree(p); }
+
+// ---------------------------------------------------------------------------- profiling
+int amph_profile_enable(amph_ctx* c, int on) {
+    if (!c) return AMPH_ERR_INVALID_ARG;
+    c->profiling = on != 0;
+    return AMPH_OK;
+}
+int amph_profile_stage_count(const amph_ctx* c) { return c ? (int)c->stages.size() : 0; }
+const char* amph_profile_stage_name(const amph_ctx* c, int stage) {
+    if (!c || stage < 0 || stage >= (int)c->stages.size()) return "";
+    return c->stages[stage].name.c_str();
+}
+int amph_profile_read(amph_ctx* c, int stage, int64_t* out_launches, double* out_total_ms, double* out_flops_per_chunk,
+                      double* out_bytes_per_chunk) {
+    if (!c || stage < 0 || stage >= (int)c->stages.size()) return AMPH_ERR_INVALID_ARG;
+    Stage& st = c->stages[stage];
+    for (auto& pr : st.pending) {
+        hipEventSynchronize(pr.second);
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) { st.total_ms += ms; st.launches += 1; }
+        hipEventDestroy(pr.first);
+        hipEventDestroy(pr.second);
+    }
+    st.pending.clear();
+    if (out_launches) *out_launches = st.launches;
+    if (out_total_ms) *out_total_ms = st.total_ms;
+    if (out_flops_per_chunk) *out_flops_per_chunk = st.flops_per_chunk;
+    if (out_bytes_per_chunk) *out_bytes_per_chunk = st.bytes_per_chunk;
+    return AMPH_OK;
+}
+int amph_profile_reset(amph_ctx* c) {
+    if (!c) return AMPH_ERR_INVALID_ARG;
+    for (auto& st : c->stages) {
+        for (auto& pr : st.pending) { hipEventSynchronize(pr.second); hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+        st.pending.clear();
+        st.launches = 0;
+        st.total_ms = 0;
+    }
+    return AMPH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,118 @@
+// Internal declarations shared by the HIP translation units of libamph.
+// Kernel parameter blocks are plain structs passed by value.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace amph {
+
+// ----------------------------------------------------------------------------
+// Front end
+// ----------------------------------------------------------------------------
+constexpr int kFrontThreads = 256;      // 4 waves per workgroup
+constexpr int kExStride = 68;           // exchange row stride in float2 (64 + 4 pad)
+constexpr int kZPad = 4;                // float2 of padding per 256-point block of Z
+
+struct WaveSrc {
+    const void* wave;        // int16_t or float rows
+    long long row_stride;    // in samples
+    const int32_t* lengths;  // nullable: valid samples per row
+    int n_in;                // valid samples per row when lengths == nullptr
+    const float* scale;      // nullable: per-row RMS scale (1.0 when gated)
+    int requant;             // emulate the PCM16 write/read of 00_normalize (x*32767, rint, /32768)
+};
+
+struct StftParams {
+    WaveSrc src;
+    int n_samples;           // N after fix_length
+    int n_fft, hop, n_frames;
+    int pad_mode;            // 0 reflect, 1 constant
+    int frames_per_block;    // FT
+    int tiles_per_row;       // ceil(n_frames / FT)
+    const float* window;     // [n_fft] periodic Hann
+    const float2* tw_a;      // [16][L]  W_Nc^(t*k1)
+    const float2* tw_b;      // [16][T_LO] W_L^(t_lo*k2a)
+    const float2* tw_post;   // [Nc/2 + 1] W_{2Nc}^k
+    int n_mels;
+    const int32_t* mel_start;  // [n_mels] first FFT bin of the filter
+    const int32_t* mel_len;    // [n_mels] number of non-zero bins
+    const int32_t* mel_wofs;   // [n_mels] offset into mel_w
+    const float* mel_w;
+    float* melpow;           // [B][n_frames][n_mels]
+};
+
+struct DbNormParams {
+    const float* melpow;     // [B][n_frames][n_mels]
+    int n_frames, n_mels, target_frames;
+    int layout;              // 0: out [B][n_mels][target]; 1: out [B][target][n_mels]
+    float* out;
+};
+
+void launch_rms_scale_pcm16(const int16_t* in, long long row_stride, const int32_t* lengths, int n_in,
+                            int n_rows, float* scale, int32_t* ok, hipStream_t s);
+void launch_rms_scale_f32(const float* in, long long row_stride, const int32_t* lengths, int n_in,
+                          int n_rows, float* scale, int32_t* ok, hipStream_t s);
+void launch_rms_apply_f32(const float* in, int n_rows, int n, const float* scale, const int32_t* ok, float* out,
+                          hipStream_t s);
+void launch_rms_apply_pcm16(const int16_t* in, int n_rows, int n, const float* scale, const int32_t* ok, int16_t* out,
+                            hipStream_t s);
+// sample_is_pcm16: 1 -> src.wave is int16_t, 0 -> float
+void launch_stft_mel(const StftParams& p, int n_rows, int sample_is_pcm16, hipStream_t s);
+size_t stft_mel_lds_bytes(int n_fft, int hop, int frames_per_block);
+hipError_t stft_mel_configure(int lds_bytes);   // raises the dynamic-LDS limit of the STFT kernels
+void launch_dbnorm(const DbNormParams& p, int n_rows, hipStream_t s);
+
+// ----------------------------------------------------------------------------
+// Encoder
+// ----------------------------------------------------------------------------
+struct ConvFirstParams {     // C_in == 1 direct convolution, NHWC output
+    const float* x;          // [B][H][W]
+    const float* w;          // [k*k][C_out]  (tap-major, channel fastest)
+    const float* scale;      // [C_out] BN alpha = gamma / sqrt(var + eps)
+    const float* shift;      // [C_out] BN beta' = (bias - mean) * alpha + beta
+    float* y;                // [B][OH][OW][C_out]
+    int H, W, OH, OW, C_out, k, stride, pad;
+};
+
+struct ConvGemmParams {      // implicit GEMM: M = B*OH*OW, N = C_out, K = k*k*C_in (kh, kw, ci)
+    const float* x;          // NHWC [B][H][W][C_in]
+    const float* w;          // [N_pad][K_pad], k contiguous, zero padded
+    const float* scale;      // [N_pad] (epilogue 0) or nullptr
+    const float* shift;      // [N_pad]
+    float* y;                // epilogue 0: NHWC [M][N]; epilogue 1: partials [splits][M][N]
+    int H, W, C_in, OH, OW, N, k, stride, pad;
+    int K, K_pad;            // true and padded (multiple of 32) reduction length
+    int M;                   // B*OH*OW
+    int epilogue;            // 0: y = relu(acc*scale + shift); 1: raw partial sums (split-K)
+    int splits;              // gridDim.z; each split reduces K_pad/32/splits slices
+};
+
+struct HeadReduceParams {    // mu/logvar = sum_s partial[s] + bias
+    const float* partial;    // [splits][B][2D]
+    const float* bias;       // [2D]
+    int splits, D;
+    float* mu;               // [B][D]
+    float* logvar;           // nullable [B][D]
+};
+
+void launch_conv_first(const ConvFirstParams& p, int n_rows, hipStream_t s);
+void launch_conv_gemm(const ConvGemmParams& p, int bm, hipStream_t s);
+void launch_head_reduce(const HeadReduceParams& p, int n_rows, hipStream_t s);
+
+// ----------------------------------------------------------------------------
+// Radial decision
+// ----------------------------------------------------------------------------
+constexpr int kMaxSpecies = 64;
+constexpr int kMaxRadialDim = 128;
+struct RadialParams {
+    const float* z;          // [B][D]
+    const float* centroids;  // device [K][D]
+    const double* thresholds;// device [K]
+    const int32_t* rank;     // device [K]
+    int K, D;
+    int32_t* pred;
+    float* best_d;
+};
+void launch_decide_radial(const RadialParams& p, long long n_rows, hipStream_t s);
+
+}  // namespace amph

@@ -1,0 +1,245 @@
+"""Drop-in mirror of the reference's importable hot-path surface,
+`latent_space_exploration/map_detector_core.py`, on MI355X HIP kernels.
+
+Same names, keyword sets, return types and error behaviour:
+
+  load_encoder(encoder_pt, encoder_yaml, project_root, device)      ref :150-179
+  wav_to_mel(wav_path, *, sr, duration, n_mels, fmin, fmax,
+             hop_length, n_fft, target_frames) -> torch f32 [M, T]   ref :198-237
+  encode_wav_to_latent(encoder, wav_path, device, *, ...) -> np f32 [D]   ref :240-300
+  crop_or_pad_time(mel, target_frames)                               ref :185-195
+  find_project_root / resolve_default_* / load_json / save_json / summarize_1d   ref :48-101
+
+plus the batched form the reference lacks (it loops batch-1,
+08_fit_radial_detector.py:488-503): `encode_chunks`.
+
+Per-file failures raise ordinary Python exceptions (callers catch `Exception`
+per file and continue: 08_fit_radial_detector.py:504-506); nothing aborts the
+process.  There is no CPU path: `device` must be a `cuda` device.
+"""
+from __future__ import annotations
+
+import json
+from pathlib import Path
+from typing import Any, Dict, Optional
+
+import numpy as np
+import torch
+
+from . import wavio
+from .config import PAD_REFLECT, EncoderSpec, FrontendConfig
+from .encoder import TARGET, AmphSession, HipEncoder
+
+
+# ---------------------------------------------------------------------------
+# Paths / IO (host-side helpers the reference's callers import alongside)
+# ---------------------------------------------------------------------------
+def find_project_root(start: Path) -> Path:
+    here = Path(start).resolve()
+    probe = here
+    for _ in range(15):
+        if (probe / "downloaded_models").exists() and (probe / "latent_space_exploration").exists():
+            return probe
+        probe = probe.parent
+    return here
+
+
+def _must_exist(p: Path, what: str) -> Path:
+    if not p.exists():
+        raise FileNotFoundError(f"No encontré {what} en: {p}")
+    return p
+
+
+def resolve_default_config(project_root: Path) -> Path:
+    return _must_exist(Path(project_root) / "config.json", "config.json")
+
+
+_MODEL_DIR = "bird_net_vae_audio_splitted_encoder_v0"
+
+
+def resolve_default_encoder_pt(project_root: Path) -> Path:
+    return _must_exist(Path(project_root) / "models" / _MODEL_DIR / "model.pt", "encoder .pt")
+
+
+def resolve_default_encoder_yaml(project_root: Path) -> Path:
+    return _must_exist(Path(project_root) / "models" / _MODEL_DIR / "bird_net_vae_audio_splitted.yaml", "encoder YAML")
+
+
+def load_json(path: Path) -> Dict[str, Any]:
+    with open(path, "r", encoding="utf-8") as fh:
+        data = json.load(fh)
+    if not isinstance(data, dict):
+        raise ValueError("JSON no es un objeto dict.")
+    return data
+
+
+def save_json(path: Path, obj: Dict[str, Any]) -> None:
+    with open(path, "w", encoding="utf-8") as fh:
+        json.dump(obj, fh, indent=2, ensure_ascii=False)
+
+
+def summarize_1d(x: np.ndarray) -> Dict[str, float]:
+    keys = (("min", None), ("p05", 0.05), ("p50", 0.50), ("p95", 0.95), ("max", None))
+    if x.size == 0:
+        return {k: float("nan") for k, _ in keys}
+    out = {}
+    for k, q in keys:
+        out[k] = float(np.min(x) if k == "min" else np.max(x) if k == "max" else np.quantile(x, q))
+    return out
+
+
+# ---------------------------------------------------------------------------
+# Encoder loading
+# ---------------------------------------------------------------------------
+def _load_spec_yaml(encoder_yaml: Path) -> EncoderSpec:
+    import yaml
+    with open(encoder_yaml, "r", encoding="utf-8") as fh:
+        cfg = yaml.safe_load(fh)
+    enc = cfg.get("encoder") if isinstance(cfg, dict) else None
+    if not (isinstance(enc, dict) and "_target_" in enc):
+        raise RuntimeError("El YAML no contiene un bloque 'encoder:' con _target_.")
+    if enc["_target_"] != TARGET:
+        raise RuntimeError(f"encoder._target_ = {enc['_target_']!r}: this build only instantiates {TARGET!r} "
+                           "(the reference's soundscape_vae factory is not available)")
+    return EncoderSpec.from_dict(enc)
+
+
+def load_encoder(encoder_pt: Path, encoder_yaml: Path, project_root: Path, device: torch.device,
+                 max_batch: int = 256) -> HipEncoder:
+    """Checkpoint -> encoder on `device`, eval semantics.  Accepts the reference's
+    `{"state_dict": ...}` and flat-tensor-dict checkpoint forms; a pickled
+    nn.Module cannot be loaded safely (weights_only) and is rejected."""
+    del project_root  # the reference only uses it to extend sys.path for Hydra
+    try:
+        ckpt = torch.load(str(encoder_pt), map_location="cpu", weights_only=True)
+    except FileNotFoundError:
+        raise
+    except Exception as e:  # noqa: BLE001
+        raise RuntimeError(f"No pude leer el checkpoint de forma segura (weights_only): {e}") from e
+    state = None
+    if isinstance(ckpt, dict):
+        if isinstance(ckpt.get("state_dict"), dict):
+            state = ckpt["state_dict"]
+        elif ckpt and all(torch.is_tensor(v) for v in ckpt.values()):
+            state = ckpt
+    if state is None:
+        raise RuntimeError("No encontré state_dict en el checkpoint.")
+    spec = _load_spec_yaml(Path(encoder_yaml))
+    return HipEncoder(spec, state, device, max_batch=max_batch).eval()
+
+
+# ---------------------------------------------------------------------------
+# Audio -> mel -> latent
+# ---------------------------------------------------------------------------
+def crop_or_pad_time(mel: np.ndarray, target_frames: int) -> np.ndarray:
+    frames = mel.shape[1]
+    extra = frames - target_frames
+    if extra == 0:
+        return mel
+    if extra > 0:
+        lo = extra // 2
+        return mel[:, lo:lo + target_frames]
+    left = (-extra) // 2
+    return np.pad(mel, ((0, 0), (left, -extra - left)), mode="constant")
+
+
+def _config(sr, duration, n_mels, fmin, fmax, hop_length, n_fft, target_frames, pad_mode=PAD_REFLECT) -> FrontendConfig:
+    if not duration > 0:
+        raise RuntimeError("duration must be > 0 on the HIP path (fixed-length chunks)")
+    return FrontendConfig(sr=int(sr), duration=float(duration), n_fft=int(n_fft), hop_length=int(hop_length),
+                          n_mels=int(n_mels), fmin=float(fmin), fmax=float(fmax), target_frames=int(target_frames),
+                          pad_mode=pad_mode)
+
+
+_frontend_sessions: Dict[tuple, AmphSession] = {}
+
+
+def _frontend_session(cfg: FrontendConfig, device) -> AmphSession:
+    dev = torch.device(device if device is not None else "cuda")
+    key = (cfg, dev.index if dev.index is not None else torch.cuda.current_device())
+    s = _frontend_sessions.get(key)
+    if s is None:
+        s = AmphSession(cfg, None, None, dev, max_batch=64)
+        _frontend_sessions[key] = s
+    return s
+
+
+def _load_wave(wav_path: Path, cfg: FrontendConfig):
+    """-> (array [n], n_valid): int16 through the native reader for mono PCM16,
+    float32 otherwise.  Only the first n_samples are needed (fix_length truncates)."""
+    wav_path = Path(wav_path)
+    if not wav_path.exists():
+        raise FileNotFoundError(f"No existe WAV: {wav_path}")
+    try:
+        return wavio.read_pcm16_mono(wav_path, cfg.sr, cfg.n_samples)
+    except NotImplementedError:
+        y = wavio.load_float_mono(wav_path, cfg.sr)[:cfg.n_samples]
+        return y, y.shape[0]
+
+
+def wav_to_mel(wav_path: Path, *, sr: int, duration: float, n_mels: int, fmin: float, fmax: float, hop_length: int,
+               n_fft: int, target_frames: int, device: Optional[torch.device] = None) -> torch.Tensor:
+    """float32 [n_mels, target_frames] on the host, computed by the HIP front end."""
+    cfg = _config(sr, duration, n_mels, fmin, fmax, hop_length, n_fft, target_frames)
+    sess = _frontend_session(cfg, device)
+    y, n_valid = _load_wave(Path(wav_path), cfg)
+    if y.dtype == np.int16:
+        y = y.astype(np.float32) / np.float32(32768.0)
+    mel = sess.mel(y[None], lengths=np.array([n_valid], dtype=np.int32), layout=0)
+    return mel[0].cpu()
+
+
+def _adapt_output(out) -> np.ndarray:
+    """The reference's output adapter (ref :272-300), same rules and messages."""
+    if isinstance(out, torch.Tensor):
+        t = out
+    elif isinstance(out, (list, tuple)):
+        t = next((o for o in out if isinstance(o, torch.Tensor)), None)
+        if t is None:
+            raise RuntimeError("Salida del encoder es tuple/list sin tensor.")
+    elif isinstance(out, dict):
+        t = next((out[k] for k in ("z", "latent", "mu", "mean", "embedding")
+                  if isinstance(out.get(k), torch.Tensor)), None)
+        if t is None:
+            t = next((v for v in out.values() if isinstance(v, torch.Tensor)), None)
+        if t is None:
+            raise RuntimeError("Salida del encoder es dict sin tensor.")
+    else:
+        raise RuntimeError(f"No sé interpretar salida del encoder: {type(out)}")
+    if t.ndim == 3:
+        t = t.mean(dim=1)
+    if t.ndim > 2:
+        t = t.reshape(t.shape[0], -1)
+    z = t.detach().cpu().numpy()
+    if z.shape[0] != 1:
+        raise RuntimeError(f"Esperaba batch=1, obtuve: {z.shape}")
+    return z[0].astype(np.float32)
+
+
+@torch.no_grad()
+def encode_wav_to_latent(encoder, wav_path: Path, device: torch.device, *, sr: int, duration: float, n_mels: int,
+                         fmin: float, fmax: float, hop_length: int, n_fft: int, target_frames: int) -> np.ndarray:
+    cfg = _config(sr, duration, n_mels, fmin, fmax, hop_length, n_fft, target_frames)
+    y, n_valid = _load_wave(Path(wav_path), cfg)
+    if isinstance(encoder, HipEncoder):
+        sess = encoder.session(cfg)
+        mu, _, _ = sess.encode(y[None], lengths=np.array([n_valid], dtype=np.int32), apply_rms=False)
+        return _adapt_output((mu,))
+    # a caller-supplied module (any callable on x = [1,1,T,M]): HIP front end + the reference adapter
+    sess = _frontend_session(cfg, device)
+    if y.dtype == np.int16:
+        y = y.astype(np.float32) / np.float32(32768.0)
+    x = sess.mel(y[None], lengths=np.array([n_valid], dtype=np.int32), layout=1).unsqueeze(1)
+    return _adapt_output(encoder(x.to(device)))
+
+
+@torch.no_grad()
+def encode_chunks(encoder: HipEncoder, chunks, device: Optional[torch.device] = None, *, sr: int, duration: float,
+                  n_mels: int, fmin: float, fmax: float, hop_length: int, n_fft: int, target_frames: int,
+                  lengths=None, apply_rms: bool = False, return_tensor: bool = False):
+    """Batched encode: chunks [B, n] int16 (raw PCM16) or float32, host or device -> latents [B, D].
+    apply_rms=True fuses 00_normalize_dataset_rms.py (incl. its PCM16 write/read) in front."""
+    del device
+    cfg = _config(sr, duration, n_mels, fmin, fmax, hop_length, n_fft, target_frames)
+    mu, _, _ = encoder.session(cfg).encode(chunks, lengths=lengths, apply_rms=apply_rms)
+    return mu if return_tensor else mu.cpu().numpy()

@@ -1,0 +1,202 @@
+/*
+ * amph.h — C-ABI of the MI355X (gfx950) chunk -> latent encoder.
+ *
+ * The reference (vpobleteacustica/amphibian-vae-latent-detector) has no FFI,
+ * plugin or operator layer: its seam for this path is the Python function
+ * surface of latent_space_exploration/map_detector_core.py.  Each entry point
+ * below names the reference interface it replaces (file:line, relative to the
+ * reference repository).  INTEGRATION.md shows the ctypes binding a reference
+ * maintainer would add.
+ *
+ * Conventions
+ *   - plain C types only; all `d_*` pointers are DEVICE (HBM) pointers, `h_*`
+ *     pointers are host pointers; buffers are caller-owned.
+ *   - every call returns an amph_status; amph_last_error(ctx) gives the text.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream);
+ *     device entry points are stream-ordered and return without synchronising.
+ *   - one context per device and per host thread (thread-compatible).
+ */
+#ifndef AMPH_H_
+#define AMPH_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AMPH_ABI_VERSION 1
+#define AMPH_MAX_CONV_LAYERS 8
+
+typedef enum amph_status {
+    AMPH_OK = 0,
+    AMPH_ERR_INVALID_ARG = 1,   /* bad pointer / size / unsupported configuration */
+    AMPH_ERR_NO_DEVICE = 2,     /* no gfx950 device, or HIP runtime failure at create */
+    AMPH_ERR_HIP = 3,           /* a HIP call failed; see amph_last_error */
+    AMPH_ERR_IO = 4,            /* WAV file unreadable / not PCM16 / wrong sample rate */
+    AMPH_ERR_UNSUPPORTED = 5    /* valid request outside what the kernels implement */
+} amph_status;
+
+/* Mel front-end parameters: the keyword set of wav_to_mel / encode_wav_to_latent
+ * (map_detector_core.py:198-209, 241-254). */
+typedef struct amph_frontend_config {
+    int32_t sr;
+    int32_t n_samples;      /* int(sr * duration), map_detector_core.py:213 */
+    int32_t n_fft;
+    int32_t hop_length;
+    int32_t n_mels;
+    float fmin;
+    float fmax;
+    int32_t target_frames;
+    int32_t pad_mode;       /* 0 = reflect (librosa 0.9.2 stft default), 1 = constant */
+} amph_frontend_config;
+
+typedef struct amph_conv_layer {
+    int32_t c_in, c_out, kernel, stride, pad;
+} amph_conv_layer;
+
+/* Encoder = n_conv x [conv2d + BatchNorm2d(eval) + ReLU] on [B,1,T,M], flatten in
+ * NCHW order, two linear heads (mu, logvar).  Stands in for the module the
+ * reference instantiates at map_detector_core.py:175-179 (not in its repo). */
+typedef struct amph_encoder_spec {
+    int32_t in_frames;      /* H = target_frames */
+    int32_t in_mels;        /* W = n_mels        */
+    int32_t n_conv;
+    amph_conv_layer conv[AMPH_MAX_CONV_LAYERS];
+    float bn_eps;
+    int32_t latent_dim;
+} amph_encoder_spec;
+
+typedef struct amph_ctx amph_ctx;
+
+/* -------------------------------------------------------------------------
+ * Lifetime.  Replaces load_encoder (map_detector_core.py:150-179): weights are
+ * handed over as one flat fp32 blob in this order, PyTorch layouts:
+ *   per conv layer i: weight[c_out][c_in][k][k], bias[c_out],
+ *                     bn_weight[c_out], bn_bias[c_out], bn_running_mean[c_out],
+ *                     bn_running_var[c_out]
+ *   fc_mu.weight[D][flat], fc_mu.bias[D], fc_logvar.weight[D][flat], fc_logvar.bias[D]
+ * `h_weights` may be NULL to build a front-end-only context (spec may be NULL too).
+ * `max_batch` sizes the per-batch workspace (chunks processed per kernel launch).
+ * ------------------------------------------------------------------------- */
+int amph_abi_version(void);
+int amph_create(const amph_frontend_config* cfg, const amph_encoder_spec* spec,
+                const float* h_weights, size_t n_weight_floats,
+                int device, int max_batch, amph_ctx** out_ctx);
+void amph_destroy(amph_ctx* ctx);
+const char* amph_last_error(const amph_ctx* ctx);   /* ctx may be NULL: create-time error */
+
+/* Geometry derived from the configuration. */
+int amph_raw_frames(const amph_ctx* ctx);     /* T_raw = 1 + n_samples / hop_length */
+int amph_latent_dim(const amph_ctx* ctx);
+int amph_max_batch(const amph_ctx* ctx);
+/* Dense Slaney mel filterbank the context uses, float32 [n_mels][1 + n_fft/2]
+ * (what librosa.filters.mel returns inside melspectrogram, map_detector_core.py:219). */
+int amph_get_mel_basis(const amph_ctx* ctx, float* h_out, size_t n_floats);
+
+/* -------------------------------------------------------------------------
+ * rms_normalize — 00_normalize_dataset_rms.py:29-38 (target 0.05, gate 1e-4,
+ * eps 1e-8, clip [-1,1]).  d_ok[b] = 1 if scaled, 0 if the silence gate left the
+ * row unchanged.  Rows are `n` samples long with a row stride of `n`.
+ * The _pcm16 form is what 00's process_folder writes to disk
+ * (00_normalize_dataset_rms.py:51-57): decode q/32768, normalise, quantise
+ * rint(x*32767).
+ * ------------------------------------------------------------------------- */
+int amph_rms_normalize_f32(amph_ctx* ctx, const float* d_in, int n_rows, int n,
+                           float* d_out, int32_t* d_ok, void* stream);
+int amph_rms_normalize_pcm16(amph_ctx* ctx, const int16_t* d_in, int n_rows, int n,
+                             int16_t* d_out, int32_t* d_ok, void* stream);
+
+/* -------------------------------------------------------------------------
+ * wav_to_mel — map_detector_core.py:198-237, starting from the decoded signal.
+ * Rows of `n_in` float32 samples (row stride n_in); d_lengths (nullable) gives
+ * the valid sample count per row; each row is zero-padded / truncated to
+ * n_samples (:212-217).  layout 0: d_mel_out is [B][n_mels][target_frames] (the
+ * tensor wav_to_mel returns); layout 1: [B][target_frames][n_mels] (= the
+ * [B,1,T,M] encoder input of map_detector_core.py:268).
+ * ------------------------------------------------------------------------- */
+int amph_mel_f32(amph_ctx* ctx, const float* d_wave, int n_rows, int n_in,
+                 const int32_t* d_lengths, int layout, float* d_mel_out, void* stream);
+/* Raw mel power spectrogram before dB (librosa.feature.melspectrogram output,
+ * map_detector_core.py:219-228), [B][T_raw][n_mels]; for kernel-level parity tests. */
+int amph_mel_power_f32(amph_ctx* ctx, const float* d_wave, int n_rows, int n_in,
+                       const int32_t* d_lengths, float* d_melpow_out, void* stream);
+
+/* -------------------------------------------------------------------------
+ * encoder(x) — map_detector_core.py:270 with x = [B,1,T,M] float32 (:268).
+ * Writes mu[B][D] and (nullable) logvar[B][D].
+ * ------------------------------------------------------------------------- */
+int amph_encoder_forward(amph_ctx* ctx, const float* d_x, int n_rows,
+                         float* d_mu, float* d_logvar, void* stream);
+
+/* -------------------------------------------------------------------------
+ * encode — the fused chunk -> latent path: [rms_normalize + PCM16 write/read
+ * (00_normalize_dataset_rms.py:51-57)] -> wav_to_mel -> encoder -> mu
+ * (encode_wav_to_latent, map_detector_core.py:240-300, for n_rows chunks at once;
+ * the reference is batch-1 and loops, 08_fit_radial_detector.py:488-503).
+ * Any n_rows >= 0; processed internally in batches of max_batch.
+ * d_rms_ok (nullable): 1 if the row was RMS-scaled, 0 if gated / apply_rms == 0.
+ * ------------------------------------------------------------------------- */
+int amph_encode_pcm16(amph_ctx* ctx, const int16_t* d_pcm, int64_t n_rows, int n_in,
+                      const int32_t* d_lengths, int apply_rms,
+                      float* d_mu, float* d_logvar, int32_t* d_rms_ok, void* stream);
+int amph_encode_f32(amph_ctx* ctx, const float* d_wave, int64_t n_rows, int n_in,
+                    const int32_t* d_lengths, int apply_rms,
+                    float* d_mu, float* d_logvar, int32_t* d_rms_ok, void* stream);
+/* Host-buffer convenience: stages through pinned memory, copies H2D on a side
+ * stream overlapped with compute, copies mu back; synchronises before returning. */
+int amph_encode_pcm16_host(amph_ctx* ctx, const int16_t* h_pcm, int64_t n_rows, int n_in,
+                           const int32_t* h_lengths, int apply_rms,
+                           float* h_mu, float* h_logvar, int32_t* h_rms_ok);
+
+/* -------------------------------------------------------------------------
+ * Radial decision — 10_benchmark_folder_detection.py:175-199 with l2 from
+ * 09_evaluate_wav_detection.py:354-355.  K species in config order; accept k if
+ * (double)||z - mu_k||_2 <= thr[k]; among accepted choose the smallest
+ * h_rank[k] (rank = index in PRIORITY_ORDER, then sorted-name order for the
+ * rest; computed by the host binding).  d_pred[b] = species index or -1
+ * (NO_DETECT); d_best_d[b] = min_k distance.  Norms use numpy's float32
+ * pairwise summation order so equal z gives an equal decision.
+ * ------------------------------------------------------------------------- */
+int amph_decide_radial(amph_ctx* ctx, const float* d_z, int64_t n_rows, int dim,
+                       const float* h_centroids, const double* h_thresholds,
+                       const int32_t* h_rank, int n_species,
+                       int32_t* d_pred, float* d_best_d, void* stream);
+
+/* -------------------------------------------------------------------------
+ * WAV ingest — the libsndfile decode inside librosa.load
+ * (map_detector_core.py:210) for mono PCM16 RIFF files already at `sr`.
+ * Reads up to max_samples int16 samples into h_out (zero-filled beyond the
+ * file's length); *out_len = samples in the file (clamped to max_samples).
+ * amph_wav_read_many fills rows of a [n_files][max_samples] (pinned or
+ * pageable) buffer with a pool of `n_threads` host threads; h_status[i] is an
+ * amph_status per file (bad files are flagged, the batch continues:
+ * 08_fit_radial_detector.py:504-506).
+ * ------------------------------------------------------------------------- */
+int amph_wav_read_pcm16(const char* path, int expect_sr, int16_t* h_out, int max_samples,
+                        int32_t* out_len);
+int amph_wav_read_many(const char* const* paths, int n_files, int expect_sr,
+                       int16_t* h_out, int max_samples, int32_t* h_lengths,
+                       int32_t* h_status, int n_threads);
+/* Pinned host allocation for the ingest buffers (hipHostMalloc / hipHostFree). */
+void* amph_host_alloc(size_t bytes);
+void amph_host_free(void* p);
+
+/* -------------------------------------------------------------------------
+ * Per-kernel timing with HIP events on the launch stream (bench.py's roofline
+ * leg).  While enabled every kernel launch of the encode path is bracketed by
+ * an event pair; amph_profile_read synchronises, then reports for stage i its
+ * name, launch count and total milliseconds since the last reset.
+ * ------------------------------------------------------------------------- */
+int amph_profile_enable(amph_ctx* ctx, int on);
+int amph_profile_stage_count(const amph_ctx* ctx);
+const char* amph_profile_stage_name(const amph_ctx* ctx, int stage);
+int amph_profile_read(amph_ctx* ctx, int stage, int64_t* out_launches, double* out_total_ms,
+                      double* out_flops_per_chunk, double* out_bytes_per_chunk);
+int amph_profile_reset(amph_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AMPH_H_ */
