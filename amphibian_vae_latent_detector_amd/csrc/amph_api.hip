@@ -89,6 +89,8 @@ struct amph_ctx {
     size_t stage_samples = 0;
 
     bool profiling = false;
+    int profile_only = -1;                 // -1: every stage; >= 0: only that stage
+    std::vector<hipEvent_t> event_pool;    // recycled timing events
     std::vector<Stage> stages;
     hipStream_t last_stream = nullptr;
 };
@@ -164,12 +166,11 @@ int pick_head_splits(int n_slices) {
     return best;
 }
 
-void record_begin(amph_ctx* c, int stage, hipStream_t s, hipEvent_t* a, hipEvent_t* b) {
-    (void)stage;
-    hipEventCreate(a);
-    hipEventCreate(b);
-    hipEventRecord(*a, s);
-    c->last_stream = s;
+hipEvent_t take_event(amph_ctx* c) {
+    hipEvent_t e = nullptr;
+    if (!c->event_pool.empty()) { e = c->event_pool.back(); c->event_pool.pop_back(); }
+    else (void)hipEventCreate(&e);
+    return e;
 }
 
 struct StageTimer {
@@ -177,12 +178,19 @@ struct StageTimer {
     int stage;
     hipStream_t s;
     hipEvent_t a = nullptr, b = nullptr;
+    bool on;
     StageTimer(amph_ctx* c_, int stage_, hipStream_t s_) : c(c_), stage(stage_), s(s_) {
-        if (c->profiling) record_begin(c, stage, s, &a, &b);
+        on = c->profiling && (c->profile_only < 0 || c->profile_only == stage);
+        if (on) {
+            a = take_event(c);
+            b = take_event(c);
+            (void)hipEventRecord(a, s);
+            c->last_stream = s;
+        }
     }
     ~StageTimer() {
-        if (c->profiling) {
-            hipEventRecord(b, s);
+        if (on) {
+            (void)hipEventRecord(b, s);
             c->stages[stage].pending.emplace_back(a, b);
         }
     }
@@ -486,7 +494,7 @@ int run_frontend(amph_ctx* c, const void* d_wave, bool pcm16, int nb, int n_in, 
         src.scale = c->ws_scale;
         src.requant = 1;
     } else if (d_rms_ok) {
-        hipMemsetAsync(d_rms_ok, 0, (size_t)nb * sizeof(int32_t), s);
+        (void)hipMemsetAsync(d_rms_ok, 0, (size_t)nb * sizeof(int32_t), s);
     }
     {
         StageTimer t(c, ST_STFT, s);
@@ -584,9 +592,9 @@ int amph_create(const amph_frontend_config* cfg, const amph_encoder_spec* spec, 
 
 void amph_destroy(amph_ctx* c) {
     if (!c) return;
-    hipSetDevice(c->device);
-    hipDeviceSynchronize();
-    auto fr = [](void* p) { if (p) hipFree(p); };
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    auto fr = [](void* p) { if (p) (void)hipFree(p); };
     fr(c->d_window); fr(c->d_tw_a); fr(c->d_tw_b); fr(c->d_tw_post);
     fr(c->d_mel_start); fr(c->d_mel_len); fr(c->d_mel_wofs); fr(c->d_mel_w);
     fr(c->d_first_w); fr(c->d_first_scale); fr(c->d_first_shift);
@@ -596,15 +604,16 @@ void amph_destroy(amph_ctx* c) {
     for (auto p : c->ws_act) fr(p);
     fr(c->ws_partial); fr(c->d_centroids); fr(c->d_thr); fr(c->d_rank);
     for (int i = 0; i < 2; ++i) {
-        if (c->pin_in[i]) hipHostFree(c->pin_in[i]);
+        if (c->pin_in[i]) (void)hipHostFree(c->pin_in[i]);
         fr(c->dev_in[i]); fr(c->dev_len[i]);
-        if (c->ev_copied[i]) hipEventDestroy(c->ev_copied[i]);
-        if (c->ev_done[i]) hipEventDestroy(c->ev_done[i]);
+        if (c->ev_copied[i]) (void)hipEventDestroy(c->ev_copied[i]);
+        if (c->ev_done[i]) (void)hipEventDestroy(c->ev_done[i]);
     }
-    if (c->copy_stream) hipStreamDestroy(c->copy_stream);
-    if (c->compute_stream) hipStreamDestroy(c->compute_stream);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->compute_stream) (void)hipStreamDestroy(c->compute_stream);
     for (auto& st : c->stages)
-        for (auto& pr : st.pending) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+        for (auto& pr : st.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (auto e : c->event_pool) (void)hipEventDestroy(e);
     delete c;
 }
 
@@ -722,8 +731,8 @@ int amph_encode_pcm16_host(amph_ctx* c, const int16_t* h_pcm, int64_t n_rows, in
     }
     if (c->stage_samples < need) {
         for (int i = 0; i < 2; ++i) {
-            if (c->pin_in[i]) hipHostFree(c->pin_in[i]);
-            if (c->dev_in[i]) hipFree(c->dev_in[i]);
+            if (c->pin_in[i]) (void)hipHostFree(c->pin_in[i]);
+            if (c->dev_in[i]) (void)hipFree(c->dev_in[i]);
             HIP_TRY(c, hipHostMalloc((void**)&c->pin_in[i], need * sizeof(int16_t), hipHostMallocDefault));
             HIP_TRY(c, hipMalloc((void**)&c->dev_in[i], need * sizeof(int16_t)));
         }
@@ -739,17 +748,17 @@ int amph_encode_pcm16_host(amph_ctx* c, const int16_t* h_pcm, int64_t n_rows, in
     bool used[2] = {false, false};
     for (int64_t off = 0; off < n_rows && rc == AMPH_OK; off += MB, slot ^= 1) {
         const int nb = (int)std::min<int64_t>(MB, n_rows - off);
-        if (used[slot]) hipEventSynchronize(c->ev_done[slot]);          // staging slot free again
+        if (used[slot]) (void)hipEventSynchronize(c->ev_done[slot]);          // staging slot free again
         std::memcpy(c->pin_in[slot], h_pcm + (size_t)off * n_in, (size_t)nb * n_in * sizeof(int16_t));
-        hipMemcpyAsync(c->dev_in[slot], c->pin_in[slot], (size_t)nb * n_in * sizeof(int16_t), hipMemcpyHostToDevice, c->copy_stream);
+        (void)hipMemcpyAsync(c->dev_in[slot], c->pin_in[slot], (size_t)nb * n_in * sizeof(int16_t), hipMemcpyHostToDevice, c->copy_stream);
         if (h_lengths)
-            hipMemcpyAsync(c->dev_len[slot], h_lengths + off, (size_t)nb * sizeof(int32_t), hipMemcpyHostToDevice, c->copy_stream);
-        hipEventRecord(c->ev_copied[slot], c->copy_stream);
-        hipStreamWaitEvent(c->compute_stream, c->ev_copied[slot], 0);
+            (void)hipMemcpyAsync(c->dev_len[slot], h_lengths + off, (size_t)nb * sizeof(int32_t), hipMemcpyHostToDevice, c->copy_stream);
+        (void)hipEventRecord(c->ev_copied[slot], c->copy_stream);
+        (void)hipStreamWaitEvent(c->compute_stream, c->ev_copied[slot], 0);
         rc = encode_common(c, c->dev_in[slot], true, nb, n_in, h_lengths ? c->dev_len[slot] : nullptr, apply_rms,
                            d_mu + (size_t)off * D, d_lv ? d_lv + (size_t)off * D : nullptr, d_ok ? d_ok + off : nullptr,
                            c->compute_stream);
-        hipEventRecord(c->ev_done[slot], c->compute_stream);
+        (void)hipEventRecord(c->ev_done[slot], c->compute_stream);
         used[slot] = true;
     }
     if (rc == AMPH_OK) {
@@ -759,11 +768,11 @@ int amph_encode_pcm16_host(amph_ctx* c, const int16_t* h_pcm, int64_t n_rows, in
         if (e == hipSuccess && h_rms_ok && n_rows > 0) e = hipMemcpy(h_rms_ok, d_ok, (size_t)n_rows * sizeof(int32_t), hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = fail(c, AMPH_ERR_HIP, "encode_pcm16_host: %s", hipGetErrorString(e));
     } else {
-        hipStreamSynchronize(c->compute_stream);
+        (void)hipStreamSynchronize(c->compute_stream);
     }
-    hipFree(d_mu);
-    if (d_lv) hipFree(d_lv);
-    if (d_ok) hipFree(d_ok);
+    (void)hipFree(d_mu);
+    if (d_lv) (void)hipFree(d_lv);
+    if (d_ok) (void)hipFree(d_ok);
     return rc;
 }
 
@@ -868,12 +877,14 @@ void* amph_host_alloc(size_t bytes) {
     if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
     return p;
 }
-void amph_host_free(void* p) { if (p) hipHostFree(p); }
+void amph_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
 // ---------------------------------------------------------------------------- profiling
 int amph_profile_enable(amph_ctx* c, int on) {
     if (!c) return AMPH_ERR_INVALID_ARG;
     c->profiling = on != 0;
+    c->profile_only = on >= 2 ? on - 2 : -1;
+    if (c->profile_only >= (int)c->stages.size()) { c->profiling = false; return fail(c, AMPH_ERR_INVALID_ARG, "no such stage"); }
     return AMPH_OK;
 }
 int amph_profile_stage_count(const amph_ctx* c) { return c ? (int)c->stages.size() : 0; }
@@ -886,11 +897,11 @@ int amph_profile_read(amph_ctx* c, int stage, int64_t* out_launches, double* out
     if (!c || stage < 0 || stage >= (int)c->stages.size()) return AMPH_ERR_INVALID_ARG;
     Stage& st = c->stages[stage];
     for (auto& pr : st.pending) {
-        hipEventSynchronize(pr.second);
+        (void)hipEventSynchronize(pr.second);
         float ms = 0.0f;
         if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) { st.total_ms += ms; st.launches += 1; }
-        hipEventDestroy(pr.first);
-        hipEventDestroy(pr.second);
+        c->event_pool.push_back(pr.first);
+        c->event_pool.push_back(pr.second);
     }
     st.pending.clear();
     if (out_launches) *out_launches = st.launches;
@@ -902,7 +913,11 @@ int amph_profile_read(amph_ctx* c, int stage, int64_t* out_launches, double* out
 int amph_profile_reset(amph_ctx* c) {
     if (!c) return AMPH_ERR_INVALID_ARG;
     for (auto& st : c->stages) {
-        for (auto& pr : st.pending) { hipEventSynchronize(pr.second); hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+        for (auto& pr : st.pending) {
+            (void)hipEventSynchronize(pr.second);
+            c->event_pool.push_back(pr.first);
+            c->event_pool.push_back(pr.second);
+        }
         st.pending.clear();
         st.launches = 0;
         st.total_ms = 0;

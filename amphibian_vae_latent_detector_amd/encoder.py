@@ -263,8 +263,10 @@ class AmphSession:
         return pred, best
 
     # -- profiling
-    def profile_enable(self, on: bool):
-        self._chk(N.lib.amph_profile_enable(self._ctx, 1 if on else 0))
+    def profile_enable(self, on, only_stage: Optional[int] = None):
+        """on=False: off; on=True: every stage; only_stage=i: bracket stage i alone."""
+        mode = 0 if not on else (1 if only_stage is None else 2 + int(only_stage))
+        self._chk(N.lib.amph_profile_enable(self._ctx, mode))
 
     def profile_reset(self):
         self._chk(N.lib.amph_profile_reset(self._ctx))

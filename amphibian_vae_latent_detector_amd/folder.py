@@ -1,0 +1,177 @@
+"""Folder-level batch encode, sharded across the GPUs of one node.
+
+Replaces the encode loop of latent_space_exploration/08_fit_radial_detector.py:461-520
+(species in config order, name-sorted WAVs, optional seeded `random.sample`,
+per-file failures counted not fatal, `cache_npz/Z_<root>_<species>.npz` cache).
+The reference is a batch-1 single-process loop; here the ordered chunk list is cut
+into contiguous per-rank slices (one process per GPU), each rank decodes its WAVs
+with libamph's host thread pool, encodes them with the HIP kernels, and ONE
+all-gather (RCCL over xGMI when the process group's backend is nccl) concatenates
+the latent matrix.  Every chunk is encoded independently of its batch, so the
+sharded result is bit-identical to the single-GPU one.
+"""
+from __future__ import annotations
+
+import math
+import random
+from pathlib import Path
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import wavio
+from .config import FrontendConfig
+
+
+def list_species_wavs(chunks_dir: Path, species_list: Sequence[str], max_per_class: int = 0,
+                      skip: Sequence[str] = ()) -> Dict[str, List[Path]]:
+    """08_fit_radial_detector.py:461-484.  The caller seeds `random` once
+    (`random.seed(seed)`, :374); species in `skip` (served from cache) draw nothing
+    from the RNG, exactly as in the reference."""
+    out: Dict[str, List[Path]] = {}
+    for sp in species_list:
+        sp_dir = (Path(chunks_dir) / sp).resolve()
+        if sp in skip or not sp_dir.exists():
+            continue
+        wavs = sorted(sp_dir.glob("*.wav"))
+        if not wavs:
+            continue
+        if max_per_class and len(wavs) > max_per_class:
+            wavs = random.sample(wavs, max_per_class)
+        out[sp] = wavs
+    return out
+
+
+def plan_shards(n_items: int, world_size: int) -> Tuple[List[Tuple[int, int]], int]:
+    """Contiguous slices [r*per, (r+1)*per) with per = ceil(n/world); the tail ranks
+    may be short or empty (they pad with dummy rows for the all-gather)."""
+    per = max(1, math.ceil(n_items / max(1, world_size)))
+    return [(min(n_items, r * per), min(n_items, (r + 1) * per)) for r in range(world_size)], per
+
+
+def _dist_info(group=None) -> Tuple[int, int]:
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def encode_paths(encoder, paths: Sequence[Path], cfg: FrontendConfig, *, apply_rms: bool = False,
+                 loader_threads: int = 8, file_batch: int = 4096) -> Tuple[torch.Tensor, np.ndarray]:
+    """Decode + encode a list of WAVs on this rank's GPU.
+    Returns (Z [n, D] float32 device tensor, status [n] int32; 0 = ok)."""
+    sess = encoder.session(cfg)
+    n = len(paths)
+    Z = torch.zeros((n, sess.latent_dim), dtype=torch.float32, device=sess.device)
+    status = np.zeros(n, dtype=np.int32)
+    # with RMS normalisation the whole file contributes to the RMS (00 normalises the file,
+    # 07 truncates afterwards): read up to 4x the chunk length, enough for any chunked dataset
+    max_samples = cfg.n_samples * (4 if apply_rms else 1)
+    for off in range(0, n, file_batch):
+        part = paths[off:off + file_batch]
+        pcm, lengths, st, pin = wavio.read_many_pcm16(part, cfg.sr, max_samples, n_threads=loader_threads, pinned=True)
+        try:
+            status[off:off + len(part)] = st
+            dev_pcm = torch.from_numpy(pcm).to(sess.device, non_blocking=True)
+            sess.encode(dev_pcm, lengths=lengths, apply_rms=apply_rms, out_mu=Z[off:off + len(part)])
+            torch.cuda.current_stream(sess.device).synchronize()
+        finally:
+            del pcm
+            wavio.free_pinned(pin)
+    return Z, status
+
+
+def gather_rows(local: torch.Tensor, per: int, n_total: int, group=None) -> torch.Tensor:
+    """All-gather equal-size row blocks (padded to `per` rows) and drop the padding."""
+    rank, world = _dist_info(group)
+    if world == 1:
+        return local[:n_total]
+    pad = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[:local.shape[0]] = local
+    full = torch.empty((world * per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(full, pad, group=group)
+    return full[:n_total]
+
+
+def encode_file_list(encoder, paths: Sequence[Path], cfg: FrontendConfig, *, apply_rms: bool = False, group=None,
+                     loader_threads: int = 8,
+                     encode_fn: Optional[Callable[[Sequence[Path]], Tuple[torch.Tensor, np.ndarray]]] = None
+                     ) -> Tuple[np.ndarray, np.ndarray]:
+    """Sharded encode of an ordered path list -> (Z [n, D] float32, status [n] int32) on every rank.
+    `encode_fn(paths) -> (Z tensor, status)` replaces the HIP encode in host-logic tests
+    (gloo on CPU); it has no default other than the HIP path."""
+    rank, world = _dist_info(group)
+    n = len(paths)
+    shards, per = plan_shards(n, world)
+    lo, hi = shards[rank]
+    mine = list(paths[lo:hi])
+    if encode_fn is None:
+        Zl, st = encode_paths(encoder, mine, cfg, apply_rms=apply_rms, loader_threads=loader_threads)
+    else:
+        Zl, st = encode_fn(mine)
+    stl = torch.from_numpy(np.ascontiguousarray(st, dtype=np.int32)).to(Zl.device)
+    Z = gather_rows(Zl, per, n, group)
+    S = gather_rows(stl, per, n, group)
+    return Z.cpu().numpy().astype(np.float32, copy=False), S.cpu().numpy()
+
+
+def encode_folder(encoder, chunks_dir: Path, species_list: Sequence[str], cfg: FrontendConfig, *,
+                  max_per_class: int = 0, seed: int = 123, cache_dir: Optional[Path] = None, apply_rms: bool = False,
+                  group=None, loader_threads: int = 8, encode_fn=None, verbose: bool = True
+                  ) -> Tuple[Dict[str, np.ndarray], Dict[str, int]]:
+    """08_fit_radial_detector.py:374,461-520 -> ({species: Z [N_sp, D]}, {species: n_failed}).
+    With cache_dir, per-species `Z_<chunks_dir.name>_<sp>.npz` files (keys Z, failed, root)
+    are read when present and written (by rank 0) otherwise: the reference's cache format."""
+    rank, _ = _dist_info(group)
+    chunks_dir = Path(chunks_dir).resolve()
+    random.seed(seed)
+    np.random.seed(seed)
+    say = print if (verbose and rank == 0) else (lambda *a, **k: None)
+
+    Z_by: Dict[str, np.ndarray] = {}
+    failed_by: Dict[str, int] = {}
+    cached = []
+    if cache_dir is not None:
+        cache_dir = Path(cache_dir)
+        for sp in species_list:
+            cp = cache_dir / f"Z_{chunks_dir.name}_{sp}.npz"
+            if cp.exists() and (chunks_dir / sp).exists():
+                data = np.load(cp)
+                Z_by[sp] = data["Z"].astype(np.float32)
+                failed_by[sp] = int(data["failed"]) if "failed" in data else 0
+                cached.append(sp)
+                say(f"🧊 {sp}: cargado cache {cp.name} -> N={Z_by[sp].shape[0]}")
+    wavs_by = list_species_wavs(chunks_dir, species_list, max_per_class, skip=cached)
+    for sp in species_list:
+        if sp not in cached and sp not in wavs_by:
+            say(f"⚠️ {sp}: carpeta no existe o sin wavs en {chunks_dir / sp} (se omite).")
+
+    order = [sp for sp in species_list if sp in wavs_by]
+    flat: List[Path] = [p for sp in order for p in wavs_by[sp]]
+    if flat:
+        Z, status = encode_file_list(encoder, flat, cfg, apply_rms=apply_rms, group=group,
+                                     loader_threads=loader_threads, encode_fn=encode_fn)
+        pos = 0
+        for sp in order:
+            k = len(wavs_by[sp])
+            zs, ss = Z[pos:pos + k], status[pos:pos + k]
+            for p, s in zip(wavs_by[sp], ss):
+                if s != 0:
+                    say(f"⚠️ {sp}: fallo {p.name}: status {int(s)}")
+            pos += k
+            good = ss == 0
+            if not good.any():
+                say(f"❌ {sp}: no se pudo codificar nada (se omite).")
+                continue
+            Zm = np.ascontiguousarray(zs[good], dtype=np.float32)
+            Z_by[sp] = Zm
+            failed_by[sp] = int((~good).sum())
+            say(f"🧪 {sp}: encoded N={Zm.shape[0]} (failed={failed_by[sp]})")
+            if cache_dir is not None and rank == 0:
+                cache_dir.mkdir(parents=True, exist_ok=True)
+                np.savez_compressed(cache_dir / f"Z_{chunks_dir.name}_{sp}.npz", Z=Zm, failed=failed_by[sp],
+                                    root=str(chunks_dir))
+    # keep config order
+    Z_by = {sp: Z_by[sp] for sp in species_list if sp in Z_by}
+    return Z_by, failed_by

@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 1 s / 22.05 kHz audio chunks encoded to latents per second.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path (RMS normalise + PCM16 hand-off -> STFT/mel ->
+dB/standardise -> thesis-shape VAE encoder -> mu) over the BASELINE.json configs[1]
+workload: 10 000 synthetic chunks resident in HBM, processed in batches of 256, fp32.
+With N > 1 every rank holds its own 10 000-chunk shard (weak scaling, one process per
+GPU) and the step ends with the single RCCL all-gather that concatenates the latent
+matrix.  Rank 0 prints ONE JSON line.
+
+Extra objects on that line:
+  roofline      the dominant kernel (largest share of GPU time, found in a fully
+                instrumented warm-up pass): algorithmic FLOPs (or bytes) per launch /
+                its mean launch duration from HIP events recorded on the launch
+                stream INSIDE the timed region, against the gfx950 peak.
+  hbm_roofline  the whole path's algorithmic bytes/s (2N + 4D per chunk, PCM16 in)
+                against 8 TB/s - the figure BASELINE.json's metric asks for.
+  cpu_baseline  the CPU oracle driven like the reference's batch-1 loop
+                (08_fit_radial_detector.py:488-503) on a bounded sample, rank 0, N = 1.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: f32-input MFMA = fp32 vector peak
+PEAK_HBM_GBS = 8000.0             # HBM3E spec peak
+
+
+def cpu_baseline(cfg, spec, state, pcm, budget_s):
+    """Reference-shaped loop on the host cores: per chunk, batch 1, in order."""
+    from oracle import encoder as oenc
+    from oracle import frontend as ofe
+    tenc = oenc.build_torch_encoder(spec.to_dict(), state)
+    kw = cfg.mel_kwargs()
+
+    def run(max_s):
+        t0 = time.perf_counter()
+        n = 0
+        for q in pcm:
+            y, _ = ofe.normalize_pcm16_chunk(q, True)
+            oenc.encode_mel_to_latent(tenc, ofe.wave_to_mel(y, **kw))
+            n += 1
+            if time.perf_counter() - t0 > max_s:
+                break
+        return n / (time.perf_counter() - t0), n
+
+    default_threads = torch.get_num_threads()
+    run(1.0)                                         # warm caches / thread pools
+    v_def, n_def = run(budget_s * 0.6)
+    torch.set_num_threads(1)
+    v_one, n_one = run(budget_s * 0.4)
+    torch.set_num_threads(default_threads)
+    return {"value": round(v_def, 2), "unit": "chunks/s", "cores": default_threads, "kind": "port",
+            "sample": f"first {n_def} chunks of the config-2 set, batch-1 loop, numpy/scipy front end + torch-CPU "
+                      f"encoder at library-default threading ({default_threads} torch threads, os.cpu_count()={os.cpu_count()})",
+            "value_1thread": round(v_one, 2), "sample_1thread": f"{n_one} chunks, torch.set_num_threads(1)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--chunks", type=int, default=10000, help="chunks per GPU per step (config 2: 10k)")
+    ap.add_argument("--batch", type=int, default=256, help="chunks per kernel launch (config 2: 256)")
+    ap.add_argument("--preset", default="bench-1s")
+    ap.add_argument("--spec", default="thesis-shape")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="0 disables the CPU baseline leg")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit(f"--gpus {args.gpus} needs one process per GPU: launch with "
+                     f"python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...")
+        sys.exit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X; there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
+
+    from amphibian_vae_latent_detector_amd import PRESETS, SPECS
+    from amphibian_vae_latent_detector_amd.encoder import HipEncoder, random_init_state
+    from amphibian_vae_latent_detector_amd.synth import synth_batch_pcm16
+
+    cfg = PRESETS[args.preset]
+    spec = SPECS[args.spec](cfg.target_frames, cfg.n_mels)
+    state = random_init_state(spec, seed=0)
+    enc = HipEncoder(spec, state, dev, max_batch=args.batch)
+    sess = enc.session(cfg)
+    D = spec.latent_dim
+
+    # synthetic chunks of this rank's shard (distinct per rank), resident in HBM before timing
+    idx = np.arange(rank * args.chunks, (rank + 1) * args.chunks)
+    pcm_host = synth_batch_pcm16(idx, cfg.n_samples, cfg.sr)
+    pcm = torch.from_numpy(pcm_host).to(dev)
+    mu = torch.empty((args.chunks, D), dtype=torch.float32, device=dev)
+    gathered = torch.empty((world * args.chunks, D), dtype=torch.float32, device=dev) if world > 1 else None
+
+    def step():
+        sess.encode(pcm, apply_rms=True, out_mu=mu)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, mu)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    # warm-up; the first warm-up step is fully instrumented to find the dominant kernel
+    sess.profile_enable(True)
+    step()
+    torch.cuda.synchronize(dev)
+    stages = sess.profile_read()
+    sess.profile_enable(False)
+    sess.profile_reset()
+    dom = max(range(len(stages)), key=lambda i: stages[i]["total_ms"])
+    for _ in range(max(0, args.warmup - 1)):
+        step()
+    sess.profile_enable(True, only_stage=dom)          # two event records per batch inside the timed region
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    prof = sess.profile_read()[dom]
+    sess.profile_enable(False)
+
+    if rank == 0:
+        total_chunks = world * args.chunks * args.steps
+        value = total_chunks / elapsed
+        launches = max(1, prof["launches"])
+        ms = prof["total_ms"] / launches
+        chunks_per_launch = args.chunks * args.steps / launches
+        is_mfma = prof["stage"].startswith("conv") and prof["stage"] != "conv1" or prof["stage"] == "head_gemm"
+        if is_mfma:
+            ach = prof["flops_per_chunk"] * chunks_per_launch / (ms * 1e-3) / 1e12
+            roof = {"kernel": prof["stage"], "bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None}
+        else:
+            ach = prof["bytes_per_chunk"] * chunks_per_launch / (ms * 1e-3) / 1e9
+            roof = {"kernel": prof["stage"], "bound": "hbm", "achieved": round(ach, 2), "peak": PEAK_HBM_GBS,
+                    "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 5), "traffic": None,
+                    "valu_tflops": round(prof["flops_per_chunk"] * chunks_per_launch / (ms * 1e-3) / 1e12, 3)}
+        roof.update({"avg_launch_ms": round(ms, 5), "launches": int(prof["launches"]),
+                     "chunks_per_launch": round(chunks_per_launch, 1),
+                     "share_of_gpu_time": round(stages[dom]["total_ms"] / max(1e-9, sum(s["total_ms"] for s in stages)), 3)})
+        alg_bytes = 2 * cfg.n_samples + 4 * D
+        per_gpu = value / world
+        line = {
+            "metric": "1 s audio chunks encoded to latent/sec", "value": round(value, 1), "unit": "chunks/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE.json configs[1]: {args.chunks} synthetic 1 s / {cfg.sr} Hz PCM16 chunks per GPU "
+                                   f"resident in HBM, preset {args.preset}, {args.spec} VAE encoder (latent_dim {D}), "
+                                   f"batch {args.batch}, RMS normalise + mel + encoder, fp32",
+                       "chunks_per_gpu": args.chunks, "batch": args.batch, "parallelism": f"dp{world} (chunk shards, 1 all-gather)"},
+            "roofline": roof,
+            "hbm_roofline": {"algorithmic_bytes_per_chunk": alg_bytes, "achieved_GBps_per_gpu": round(per_gpu * alg_bytes / 1e9, 2),
+                             "peak_GBps": PEAK_HBM_GBS, "frac": round(per_gpu * alg_bytes / 1e9 / PEAK_HBM_GBS, 6)},
+            "stage_ms_per_batch": {s["stage"]: round(s["total_ms"] / max(1, s["launches"]), 5) for s in stages if s["launches"]},
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            line["cpu_baseline"] = cpu_baseline(cfg, spec, state, pcm_host[:4000], args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

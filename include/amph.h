@@ -185,9 +185,12 @@ void amph_host_free(void* p);
 
 /* -------------------------------------------------------------------------
  * Per-kernel timing with HIP events on the launch stream (bench.py's roofline
- * leg).  While enabled every kernel launch of the encode path is bracketed by
- * an event pair; amph_profile_read synchronises, then reports for stage i its
- * name, launch count and total milliseconds since the last reset.
+ * leg).  amph_profile_enable(ctx, 0) = off, 1 = bracket every kernel launch of
+ * the encode path with an event pair, 2 + i = bracket only stage i (two event
+ * records per batch: cheap enough to leave on inside a timed region).
+ * amph_profile_read synchronises, then reports for stage i its launch count and
+ * total milliseconds since the last reset, with the stage's algorithmic FLOPs
+ * and bytes per chunk.
  * ------------------------------------------------------------------------- */
 int amph_profile_enable(amph_ctx* ctx, int on);
 int amph_profile_stage_count(const amph_ctx* ctx);

@@ -1,0 +1,87 @@
+"""N>1 path on CPU: world_size-2 gloo process group, folder sharding + all-gather.
+The HIP encode is replaced by an injected encode_fn (the CPU oracle on real WAV files),
+which is the only place the product accepts one; the sharded result must equal the
+single-process result bit-for-bit."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parents[1]
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+from amphibian_vae_latent_detector_amd import PRESETS, SPECS  # noqa: E402
+from amphibian_vae_latent_detector_amd import folder as pfolder  # noqa: E402
+from amphibian_vae_latent_detector_amd import synth  # noqa: E402
+from amphibian_vae_latent_detector_amd.encoder import random_init_state  # noqa: E402
+
+CFG = PRESETS["bench-1s"]
+SPECIES = list(synth.SPECIES)
+
+
+def _oracle_encode_fn():
+    from oracle import encoder as oenc
+    from oracle import frontend as ofe
+    spec = SPECS["tiny"](CFG.target_frames, CFG.n_mels)
+    tenc = oenc.build_torch_encoder(spec.to_dict(), random_init_state(spec, seed=0))
+    torch.set_num_threads(1)
+
+    def fn(paths):
+        Z = np.zeros((len(paths), spec.latent_dim), np.float32)
+        st = np.zeros(len(paths), np.int32)
+        for i, p in enumerate(paths):
+            try:
+                Z[i] = oenc.encode_mel_to_latent(tenc, ofe.wav_to_mel(p, **CFG.mel_kwargs()))
+            except Exception:  # noqa: BLE001   (per-file failure -> flagged row, batch continues)
+                st[i] = 4
+        return torch.from_numpy(Z), st
+    return fn
+
+
+def _worker(rank, world, port, root, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        Z, failed = pfolder.encode_folder(None, Path(root), SPECIES, CFG, max_per_class=3, seed=123,
+                                          cache_dir=Path(out_dir) / "cache", encode_fn=_oracle_encode_fn(), verbose=False)
+        np.savez(Path(out_dir) / f"rank{rank}.npz", failed=np.array([failed[s] for s in Z]), **Z)
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_sharded_folder_encode_equals_single_process(tmp_path):
+    root = tmp_path / "train_chunks_norm"
+    synth.write_synth_folder(root, 19, CFG.n_samples, CFG.sr)        # 5,5,5,4 files; sampling keeps 3 each
+    (root / SPECIES[1] / "chunk_000001.wav").write_bytes(b"broken")   # one unreadable file in the sample pool
+    single, failed1 = pfolder.encode_folder(None, root, SPECIES, CFG, max_per_class=3, seed=123,
+                                            encode_fn=_oracle_encode_fn(), verbose=False)
+    assert list(single) == SPECIES and sum(z.shape[0] for z in single.values()) + sum(failed1.values()) == 12
+    out = tmp_path / "out"
+    out.mkdir()
+    mp.spawn(_worker, args=(2, _free_port(), str(root), str(out)), nprocs=2, join=True)
+    r0, r1 = np.load(out / "rank0.npz"), np.load(out / "rank1.npz")
+    for sp in SPECIES:
+        assert np.array_equal(r0[sp], single[sp]) and np.array_equal(r1[sp], single[sp]), sp
+    assert r0["failed"].tolist() == [failed1[s] for s in SPECIES] == r1["failed"].tolist()
+    # rank 0 wrote the reference-format cache
+    d = np.load(out / "cache" / f"Z_train_chunks_norm_{SPECIES[0]}.npz")
+    assert np.array_equal(d["Z"], single[SPECIES[0]])
+
+
+def test_gather_rows_pads_and_trims_single_process():
+    x = torch.arange(12, dtype=torch.float32).reshape(4, 3)
+    assert torch.equal(pfolder.gather_rows(x, 4, 3), x[:3])

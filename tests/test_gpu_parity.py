@@ -1,0 +1,424 @@
+"""GPU parity tests: the HIP path, called through the C-ABI (ctypes), against the CPU
+oracle on the same seeded inputs, against the golden vectors captured from the
+reference's own functions, and - at BASELINE.json's full config-2 size - through
+size-independent properties.
+
+Tolerances (fp32 path; BASELINE.json north_star: latents within 1e-4 relative):
+  integer / index results (PCM16 output, decisions, rms_ok flags)   bit-exact
+  rms_normalize float32                                             4e-7 relative
+  mel power per chunk                                               1e-5 relative L2
+  standardised mel image                                            1e-4 absolute
+  latents: per-vector ||dz||2/||z||2 <= 1e-4 and |dz| <= 1e-4*max(1,|z|)   
+"""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+TOL = 1e-4
+
+
+# ----------------------------------------------------------------------------- fixtures
+@pytest.fixture(scope="module")
+def env():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need an MI355X; there is no CPU fallback to test instead")
+    from amphibian_vae_latent_detector_amd import PRESETS, SPECS
+    from amphibian_vae_latent_detector_amd import _native as N
+    from amphibian_vae_latent_detector_amd.encoder import AmphSession, HipEncoder, random_init_state
+    from amphibian_vae_latent_detector_amd.synth import synth_batch_pcm16
+    from oracle import encoder as oenc
+    from oracle import frontend as ofe
+    from oracle import radial as orad
+
+    class E:
+        pass
+    e = E()
+    e.PRESETS, e.SPECS, e.N = PRESETS, SPECS, N
+    e.AmphSession, e.HipEncoder, e.random_init_state, e.synth = AmphSession, HipEncoder, random_init_state, synth_batch_pcm16
+    e.oenc, e.ofe, e.orad = oenc, ofe, orad
+    e.cfg = PRESETS["bench-1s"]
+    return e
+
+
+@pytest.fixture(scope="module")
+def fe(env):
+    return env.AmphSession(env.cfg, None, None, DEV, max_batch=8)
+
+
+def _encoders(env, name, cfg=None, max_batch=8):
+    cfg = cfg or env.cfg
+    spec = env.SPECS[name](cfg.target_frames, cfg.n_mels)
+    state = env.random_init_state(spec, seed=0)
+    return env.HipEncoder(spec, state, DEV, max_batch=max_batch), env.oenc.build_torch_encoder(spec.to_dict(), state), spec
+
+
+def _oracle_latents(env, tenc, pcm, cfg, apply_rms=True):
+    out = []
+    for q in pcm:
+        y, _ = env.ofe.normalize_pcm16_chunk(q, apply_rms)
+        out.append(env.oenc.encode_mel_to_latent(tenc, env.ofe.wave_to_mel(y, **cfg.mel_kwargs())))
+    return np.stack(out)
+
+
+def _assert_latents(z_gpu, z_cpu, tol=TOL):
+    for r in range(z_cpu.shape[0]):
+        assert rel_l2(z_gpu[r], z_cpu[r]) <= tol, (r, rel_l2(z_gpu[r], z_cpu[r]))
+    assert np.all(np.abs(z_gpu - z_cpu) <= tol * np.maximum(1.0, np.abs(z_cpu)))
+
+
+# ----------------------------------------------------------------------------- the library that runs is the HIP one
+def test_native_library_is_loaded_and_device_is_gfx950(env, fe):
+    maps = Path("/proc/self/maps").read_text()
+    assert "libamph.so" in maps
+    assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
+    assert fe.raw_frames == 58
+
+
+def test_mel_basis_equals_librosa_restatement(env, fe):
+    want = env.ofe.mel_filterbank(env.cfg.sr, env.cfg.n_fft, env.cfg.n_mels, env.cfg.fmin, env.cfg.fmax)
+    got = fe.mel_basis()
+    assert np.array_equal(got != 0, want != 0)
+    np.testing.assert_allclose(got, want, rtol=2e-7, atol=0)
+
+
+# ----------------------------------------------------------------------------- K0: rms_normalize
+@pytest.mark.parametrize("case", ["noise_quiet", "noise_loud", "tone", "silent", "below_gate", "clipping", "short"])
+def test_rms_normalize_f32_against_reference_vectors(env, fe, golden, case):
+    g = golden("rms_normalize.npz")
+    out, ok = fe.rms_normalize(g[f"in_{case}"])
+    assert bool(ok.cpu().numpy()[0]) == bool(g[f"ok_{case}"])
+    want = g[f"out_{case}"]
+    if not bool(g[f"ok_{case}"]):
+        assert np.array_equal(out.cpu().numpy()[0], want)            # gated rows are returned untouched
+    else:
+        np.testing.assert_allclose(out.cpu().numpy()[0], want, rtol=4e-7, atol=0)
+        assert np.abs(out.cpu().numpy()).max() <= 1.0
+
+
+def test_rms_normalize_pcm16_bit_exact(env, fe):
+    pcm = env.synth(list(range(20)) + [49], env.cfg.n_samples, env.cfg.sr)
+    out, ok = fe.rms_normalize(pcm)
+    out, ok = out.cpu().numpy(), ok.cpu().numpy()
+    for r in range(pcm.shape[0]):
+        y, good = env.ofe.rms_normalize(env.ofe.pcm16_to_float(pcm[r]))
+        assert bool(ok[r]) == bool(good)
+        assert np.array_equal(out[r], env.ofe.float_to_pcm16(y))
+    assert ok[-1] == 0 and not out[-1].any()
+
+
+# ----------------------------------------------------------------------------- K1/K2: STFT + mel power
+def test_mel_power_against_oracle(env, fe):
+    cfg = env.cfg
+    pcm = env.synth([0, 1, 2, 3, 4, 5, 6, 7, 8, 49], cfg.n_samples, cfg.sr)
+    y = env.ofe.pcm16_to_float(pcm)
+    got = fe.mel_power(y).cpu().numpy()
+    assert got.shape == (10, 58, 64)
+    for r in range(10):
+        want = env.ofe.melspectrogram(y[r], cfg.sr, cfg.n_fft, cfg.hop_length, cfg.n_mels, cfg.fmin, cfg.fmax).T
+        assert rel_l2(got[r], want) <= 1e-5
+        assert np.abs(got[r] - want).max() <= 2e-6 * max(want.max(), 1e-30)
+    assert not got[9].any()
+
+
+def test_mel_power_pure_tone_and_impulse(env, fe):
+    """Known spectra: a bin-centred tone and a unit impulse (flat spectrum)."""
+    cfg = env.cfg
+    n = np.arange(cfg.n_samples)
+    k0 = 200
+    tone = np.cos(2 * np.pi * k0 * n / cfg.n_fft).astype(np.float32)
+    imp = np.zeros(cfg.n_samples, np.float32)
+    imp[5000] = 1.0
+    got = fe.mel_power(np.stack([tone, imp])).cpu().numpy()
+    for r, y in enumerate((tone, imp)):
+        want = env.ofe.melspectrogram(y, cfg.sr, cfg.n_fft, cfg.hop_length, cfg.n_mels, cfg.fmin, cfg.fmax).T
+        assert np.abs(got[r] - want).max() <= 3e-6 * want.max()
+    basis = fe.mel_basis()
+    m_peak = int(np.argmax(basis[:, k0]))
+    assert int(np.argmax(got[0, 20])) == m_peak                       # energy lands in the filter that owns bin k0
+
+
+@pytest.mark.parametrize("pad_mode", [0, 1])
+def test_mel_image_against_oracle_both_pad_modes(env, pad_mode):
+    from dataclasses import replace
+    cfg = replace(env.cfg, pad_mode=pad_mode)
+    sess = env.AmphSession(cfg, None, None, DEV, max_batch=4)
+    pcm = env.synth(list(range(9)), cfg.n_samples, cfg.sr)
+    y = env.ofe.pcm16_to_float(pcm)
+    got = sess.mel(y, layout=0).cpu().numpy()
+    got_t = sess.mel(y, layout=1).cpu().numpy()
+    want = np.stack([env.ofe.wave_to_mel(v, pad_mode="reflect" if pad_mode == 0 else "constant", **cfg.mel_kwargs()) for v in y])
+    assert np.abs(got - want).max() <= 1e-4
+    assert np.array_equal(got_t, got.transpose(0, 2, 1))
+    assert not got[:, :, :3].any() and not got[:, :, 61:].any()         # zero pad 3 left / 3 right (58 -> 64)
+    sess.close()
+
+
+def test_fix_length_padding_truncation_and_ragged_lengths(env, fe):
+    cfg = env.cfg
+    N = cfg.n_samples
+    pcm = env.synth([3, 4, 5, 6], N + 4000, cfg.sr)
+    y = env.ofe.pcm16_to_float(pcm)
+    lengths = np.array([N + 4000, N, 9000, 0], dtype=np.int32)          # longer, exact, shorter, empty
+    got = fe.mel(y, lengths=lengths, layout=0).cpu().numpy()
+    for r in range(4):
+        want = env.ofe.wave_to_mel(y[r, :lengths[r]], **cfg.mel_kwargs())
+        assert np.abs(got[r] - want).max() <= 1e-4, r
+    assert not got[3].any()
+    short = fe.mel(y[:, :9000], layout=0).cpu().numpy()                 # n_in < n_samples without lengths
+    assert np.abs(short[0] - env.ofe.wave_to_mel(y[0, :9000], **cfg.mel_kwargs())).max() <= 1e-4
+
+
+# ----------------------------------------------------------------------------- K4/K5: encoder
+@pytest.mark.parametrize("name", ["tiny", "thesis-shape"])
+def test_encoder_forward_against_torch_cpu(env, name):
+    enc, tenc, spec = _encoders(env, name)
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((11, 1, 64, 64)).astype(np.float32)        # 11 rows over max_batch 8: two launches
+    mu, lv = enc(torch.from_numpy(x))
+    with torch.no_grad():
+        mu_o, lv_o = tenc(torch.from_numpy(x))
+    _assert_latents(mu.cpu().numpy(), mu_o.numpy(), 1e-5)
+    _assert_latents(lv.cpu().numpy(), lv_o.numpy(), 1e-5)
+    z = np.zeros((1, 1, 64, 64), np.float32)                           # all-zero image (silent chunk)
+    mu0, _ = enc(torch.from_numpy(z))
+    with torch.no_grad():
+        _assert_latents(mu0.cpu().numpy(), tenc(torch.from_numpy(z))[0].numpy(), 1e-5)
+    with pytest.raises(RuntimeError, match="expects"):
+        enc(torch.zeros(1, 1, 32, 64))
+
+
+def test_encoder_odd_shapes_generic_path(env):
+    """Non power-of-two geometry: 5x5 stride-1 first layer, C_out not a multiple of 64, K padded to 32."""
+    from amphibian_vae_latent_detector_amd import EncoderSpec
+    from dataclasses import replace
+    cfg = replace(env.cfg, n_mels=40, target_frames=60)
+    spec = EncoderSpec(in_frames=60, in_mels=40, conv=((1, 12, 5, 1, 2), (12, 20, 3, 2, 1), (20, 36, 3, 3, 0)), latent_dim=5)
+    state = env.random_init_state(spec, seed=4)
+    enc = env.HipEncoder(spec, state, DEV, max_batch=4)
+    sess = enc.session(cfg)
+    tenc = env.oenc.build_torch_encoder(spec.to_dict(), state)
+    x = np.random.default_rng(2).standard_normal((6, 1, 60, 40)).astype(np.float32)
+    mu, lv = sess.encoder_forward(torch.from_numpy(x))
+    with torch.no_grad():
+        mu_o, lv_o = tenc(torch.from_numpy(x))
+    _assert_latents(mu.cpu().numpy(), mu_o.numpy(), 1e-5)
+    _assert_latents(lv.cpu().numpy(), lv_o.numpy(), 1e-5)
+
+
+# ----------------------------------------------------------------------------- fused path, BASELINE configs
+def test_config1_100_chunks_tiny_vae_end_to_end(env):
+    """BASELINE.json configs[0]: 100 synthetic 1 s / 22.05 kHz chunks, tiny VAE (latent_dim 8)."""
+    enc, tenc, spec = _encoders(env, "tiny", max_batch=32)
+    pcm = env.synth(list(range(100)), env.cfg.n_samples, env.cfg.sr)
+    mu, lv, ok = enc.session(env.cfg).encode(pcm, apply_rms=True, want_logvar=True)
+    z = mu.cpu().numpy()
+    assert z.shape == (100, 8) and np.isfinite(z).all()
+    _assert_latents(z, _oracle_latents(env, tenc, pcm, env.cfg))
+    ok = ok.cpu().numpy()
+    assert ok[49] == 0 and ok[99] == 0 and ok.sum() == 98               # the two silent chunks fail the RMS gate
+    assert np.array_equal(z[49], z[99])                                  # silence -> identical latents
+
+
+def test_config2_thesis_shape_subset_and_full_size_properties(env):
+    """BASELINE.json configs[1]: 10k chunks, thesis-shape encoder (latent_dim 32), batch 256, fp32.
+    Oracle diff on a 320-chunk subset; on all 10 000: determinism, batch-composition
+    invariance, permutation equivariance, finiteness."""
+    cfg = env.cfg
+    enc, tenc, spec = _encoders(env, "thesis-shape", max_batch=256)
+    sess = enc.session(cfg)
+    n = 10000
+    pcm = env.synth(list(range(n)), cfg.n_samples, cfg.sr)
+    dev_pcm = torch.from_numpy(pcm).to(DEV)
+    mu, _, ok = sess.encode(dev_pcm, apply_rms=True)
+    z = mu.cpu().numpy()
+    assert z.shape == (n, 32) and np.isfinite(z).all() and int(ok.sum()) == n - n // 50
+    sub = np.r_[0:256, 4990:5022, 9968:10000]
+    _assert_latents(z[sub], _oracle_latents(env, tenc, pcm[sub], cfg))
+    mu2, _, _ = sess.encode(dev_pcm, apply_rms=True)
+    assert torch.equal(mu, mu2)                                          # deterministic
+    perm = torch.from_numpy(np.random.default_rng(0).permutation(n)).to(DEV)
+    mu3, _, _ = sess.encode(dev_pcm[perm].contiguous(), apply_rms=True)
+    assert torch.equal(mu3, mu[perm])                                    # rows independent of batch position
+    enc_small, _, _ = _encoders(env, "thesis-shape", max_batch=37)       # other batch size, same bits
+    mu4, _, _ = enc_small.session(cfg).encode(dev_pcm[:1000], apply_rms=True)
+    assert torch.equal(mu4, mu[:1000])
+    mu_h, ok_h = sess.encode_host(pcm[:700], apply_rms=True)             # pinned host path
+    assert np.array_equal(mu_h, z[:700]) and np.array_equal(ok_h, ok.cpu().numpy()[:700])
+
+
+def test_encode_edge_cases(env):
+    cfg = env.cfg
+    enc, tenc, spec = _encoders(env, "tiny", max_batch=8)
+    sess = enc.session(cfg)
+    mu, _, ok = sess.encode(np.zeros((0, cfg.n_samples), np.int16), apply_rms=True)      # empty batch
+    assert tuple(mu.shape) == (0, 8)
+    pcm = env.synth([10, 11, 12, 13, 14], cfg.n_samples + 3000, cfg.sr)
+    lengths = np.array([cfg.n_samples + 3000, cfg.n_samples, 5000, 1, 0], dtype=np.int32)
+    for apply_rms in (False, True):
+        mu, _, ok = sess.encode(pcm, lengths=lengths, apply_rms=apply_rms)
+        want = []
+        for r in range(5):
+            q = pcm[r, :lengths[r]]
+            y, good = env.ofe.normalize_pcm16_chunk(q, apply_rms) if q.size else (np.zeros(0, np.float32), False)
+            want.append(env.oenc.encode_mel_to_latent(tenc, env.ofe.wave_to_mel(y, **cfg.mel_kwargs())))
+            if apply_rms:
+                assert bool(ok[r]) == bool(good), r                     # RMS is over the whole file, before truncation
+        _assert_latents(mu.cpu().numpy(), np.stack(want))
+    # float32 input carrying the same samples gives the same bits as PCM16 input
+    y = env.ofe.pcm16_to_float(pcm)
+    a, _, _ = sess.encode(pcm, apply_rms=True)
+    b, _, _ = sess.encode(y, apply_rms=True)
+    assert torch.equal(a, b)
+    # full-scale square wave: clipping + quantisation extremes
+    sq = np.where(np.arange(cfg.n_samples) % 100 < 50, 32767, -32768).astype(np.int16)[None]
+    mu, _, _ = sess.encode(sq, apply_rms=True)
+    _assert_latents(mu.cpu().numpy(), _oracle_latents(env, tenc, sq, cfg))
+
+
+def test_reference_default_preset_crop_path(env):
+    """The reference's own defaults: 48 kHz, 5 s, 626 STFT frames centre-cropped to 192."""
+    cfg = env.PRESETS["ref-default"]
+    enc, tenc, spec = _encoders(env, "tiny", cfg=cfg, max_batch=2)
+    pcm = env.synth([0, 1, 2], cfg.n_samples, cfg.sr)
+    sess = enc.session(cfg)
+    assert sess.raw_frames == 626
+    y = env.ofe.pcm16_to_float(pcm)
+    mel = sess.mel(y, layout=0).cpu().numpy()
+    want = np.stack([env.ofe.wave_to_mel(v, **cfg.mel_kwargs()) for v in y])
+    assert mel.shape == (3, 64, 192) and np.abs(mel - want).max() <= 1e-4
+    mu, _, _ = sess.encode(pcm, apply_rms=True)
+    _assert_latents(mu.cpu().numpy(), _oracle_latents(env, tenc, pcm, cfg))
+
+
+def test_unsupported_and_invalid_configurations_raise(env):
+    from dataclasses import replace
+    with pytest.raises(env.N.AmphError, match="AMPH_ERR_UNSUPPORTED"):
+        env.AmphSession(replace(env.cfg, n_fft=1024), None, None, DEV)
+    with pytest.raises(env.N.AmphError, match="AMPH_ERR_UNSUPPORTED"):
+        env.AmphSession(replace(env.cfg, duration=0.02), None, None, DEV)        # reflect pad longer than the chunk
+    spec = env.SPECS["tiny"](64, 64)
+    blob = np.zeros(10, np.float32)
+    with pytest.raises(env.N.AmphError, match="weight blob"):
+        env.AmphSession(env.cfg, spec, blob, DEV)
+    enc, _, _ = _encoders(env, "tiny")
+    with pytest.raises(RuntimeError, match="front end produces"):
+        enc.session(replace(env.cfg, target_frames=96))
+
+
+# ----------------------------------------------------------------------------- K6: radial decision
+def test_radial_decisions_bit_identical_to_reference(env, fe, golden):
+    from amphibian_vae_latent_detector_amd.radial import RadialDetector
+    g = golden("radial_decide.npz")
+    cfg = json.loads(str(g["cfg_json"]))
+    det = RadialDetector.from_config(cfg, latent_dim=8)
+    pred, best = det.decide(fe, g["Z"])
+    got = [det.names[i] if i >= 0 else "" for i in pred.tolist()]
+    assert got == [str(s) for s in g["pred"]]
+    assert np.array_equal(pred >= 0, g["detected"])
+    assert np.array_equal(best.astype(np.float64), g["best_d"])          # float32 distances, exactly numpy's
+    rng = np.random.default_rng(5)                                       # D = 32 (8 <= n <= 128 pairwise branch) and D = 5 (< 8)
+    for D in (32, 5, 100):
+        Z = rng.standard_normal((257, D)).astype(np.float32)
+        cents = {f"s{k}": rng.standard_normal(D).astype(np.float32) for k in range(4)}
+        thr = {f"s{k}": float(np.sqrt(D) * 1.35) for k in range(4)}
+        det = RadialDetector(cents, thr, D, priority=["s2", "s0"])
+        pred, best = det.decide(fe, Z)
+        for r in range(257):
+            d, sp, bd = env.orad.decide(Z[r], cents, thr, ["s2", "s0"])
+            assert (det.names[pred[r]] if pred[r] >= 0 else None) == sp and float(best[r]) == bd
+
+
+# ----------------------------------------------------------------------------- the drop-in Python surface
+def test_map_detector_core_surface(env, tmp_path):
+    from amphibian_vae_latent_detector_amd import map_detector_core as core
+    from amphibian_vae_latent_detector_amd import synth
+    from amphibian_vae_latent_detector_amd.encoder import save_checkpoint
+    cfg = env.cfg
+    spec = env.SPECS["tiny"](cfg.target_frames, cfg.n_mels)
+    state = env.random_init_state(spec, seed=0)
+    pt, ym = tmp_path / "model.pt", tmp_path / "enc.yaml"
+    save_checkpoint(pt, ym, spec, state)
+    encoder = core.load_encoder(pt, ym, tmp_path, torch.device("cuda"))
+    tenc = env.oenc.build_torch_encoder(spec.to_dict(), state)
+    q = synth.synth_chunk_pcm16(0, cfg.n_samples + 500, cfg.sr)
+    wav = tmp_path / "chunk_000000.wav"
+    synth.write_wav_pcm16(wav, q, cfg.sr)
+    kw = cfg.mel_kwargs()
+    mel = core.wav_to_mel(wav, **kw)
+    want_mel = env.ofe.wav_to_mel(wav, **kw)
+    assert isinstance(mel, torch.Tensor) and mel.dtype == torch.float32 and tuple(mel.shape) == (64, 64) and mel.device.type == "cpu"
+    assert np.abs(mel.numpy() - want_mel).max() <= 1e-4
+    z = core.encode_wav_to_latent(encoder, wav, torch.device("cuda"), **kw)
+    assert isinstance(z, np.ndarray) and z.dtype == np.float32 and z.shape == (8,)
+    _assert_latents(z[None], env.oenc.encode_mel_to_latent(tenc, want_mel)[None])
+    # a caller-supplied torch module goes through the HIP front end + the reference adapter
+    z2 = core.encode_wav_to_latent(tenc.to("cuda"), wav, torch.device("cuda"), **kw)
+    _assert_latents(z2[None], env.oenc.encode_mel_to_latent(tenc.cpu(), want_mel)[None])
+    # stereo file: channel mean on the float path
+    st = np.stack([q, q], axis=1)
+    synth.write_wav_pcm16(tmp_path / "st.wav", st, cfg.sr)
+    z3 = core.encode_wav_to_latent(encoder, tmp_path / "st.wav", torch.device("cuda"), **kw)
+    _assert_latents(z3[None], z[None], 1e-6)
+    # batched form
+    pcm = env.synth(list(range(5)), cfg.n_samples, cfg.sr)
+    zb = core.encode_chunks(encoder, pcm, **kw)
+    _assert_latents(zb, _oracle_latents(env, tenc, pcm, cfg, apply_rms=False))
+    # error behaviour: ordinary per-file exceptions
+    with pytest.raises(FileNotFoundError):
+        core.encode_wav_to_latent(encoder, tmp_path / "nope.wav", torch.device("cuda"), **kw)
+    synth.write_wav_pcm16(tmp_path / "sr.wav", q, 48000)
+    with pytest.raises(RuntimeError, match="sample rate"):
+        core.encode_wav_to_latent(encoder, tmp_path / "sr.wav", torch.device("cuda"), **kw)
+    (tmp_path / "junk.wav").write_bytes(b"junk")
+    with pytest.raises(Exception):
+        core.wav_to_mel(tmp_path / "junk.wav", **kw)
+
+
+def test_folder_encode_fit_and_decisions_match_cpu(env, tmp_path):
+    """Integration: 100-chunk folder -> latents -> radial fit -> decisions, CPU vs GPU."""
+    from amphibian_vae_latent_detector_amd import folder as pfolder
+    from amphibian_vae_latent_detector_amd import radial as prad
+    from amphibian_vae_latent_detector_amd import synth
+    cfg = env.cfg
+    enc, tenc, spec = _encoders(env, "tiny", max_batch=16)
+    root = tmp_path / "train_chunks_norm"
+    made = synth.write_synth_folder(root, 100, cfg.n_samples, cfg.sr)
+    (root / synth.SPECIES[2] / "chunk_000002.wav").write_bytes(b"RIFFbroken")
+    Zg, failed = pfolder.encode_folder(enc, root, list(synth.SPECIES), cfg, cache_dir=tmp_path / "cache_npz", verbose=False)
+    assert failed[synth.SPECIES[2]] == 1 and sum(z.shape[0] for z in Zg.values()) == 99
+    Zc = {}
+    for sp in synth.SPECIES:
+        paths = [p for p in sorted((root / sp).glob("*.wav")) if p.stat().st_size > 100]
+        Zc[sp] = np.stack([env.oenc.encode_mel_to_latent(tenc, env.ofe.wav_to_mel(p, **cfg.mel_kwargs())) for p in paths])
+        _assert_latents(Zg[sp], Zc[sp])
+    for q_out in (0.10, 0.25):
+        rg = prad.fit_radial_detector(Zg, 0.95, q_out, verbose=False)
+        rc = prad.fit_radial_detector(Zc, 0.95, q_out, verbose=False)
+        for sp in synth.SPECIES:
+            assert abs(rg["thresholds"][sp] - rc["thresholds"][sp]) <= 1e-4 * rc["thresholds"][sp]
+        det = prad.RadialDetector({k: np.array(v, np.float32) for k, v in rc["centroids"].items()}, rc["thresholds"], 8)
+        allg, allc = np.concatenate(list(Zg.values())), np.concatenate(list(Zc.values()))
+        pred, best = det.decide(enc.session(cfg), allg)
+        margins = []
+        for r in range(allc.shape[0]):
+            d, sp, bd = env.orad.decide(allc[r], {k: np.array(v, np.float32) for k, v in rc["centroids"].items()}, rc["thresholds"])
+            dists = [env.orad.l2(allc[r] - np.array(rc["centroids"][s], np.float32)) for s in det.names]
+            margins.append(min(abs(x - rc["thresholds"][s]) / rc["thresholds"][s] for x, s in zip(dists, det.names)))
+            if margins[-1] > 1e-4:                                     # decisions identical away from the threshold
+                assert (det.names[pred[r]] if pred[r] >= 0 else None) == sp, (r, margins[-1])
+        assert len(margins) == 99
+    d = np.load(tmp_path / "cache_npz" / f"Z_train_chunks_norm_{synth.SPECIES[0]}.npz")
+    assert np.array_equal(d["Z"], Zg[synth.SPECIES[0]]) and int(d["failed"]) == 0
+    # streaming encode + decide keeps latents on the device and agrees with the two-step form
+    pcm = env.synth(list(range(40)), cfg.n_samples, cfg.sr)
+    detected, species, best, mu = prad.detect_chunks(enc, det, pcm, cfg, apply_rms=False)
+    pred2, best2 = det.decide(enc.session(cfg), mu)
+    assert np.array_equal(detected, pred2 >= 0) and np.array_equal(best, best2)

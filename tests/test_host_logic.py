@@ -1,0 +1,286 @@
+"""Host-side logic of the product package; no GPU needed (the library loads and its
+host-only entry points - WAV ingest - run on the CPU; no compute kernels are called)."""
+import ctypes
+import json
+import random
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from amphibian_vae_latent_detector_amd import PRESETS, SPECS, EncoderSpec
+from amphibian_vae_latent_detector_amd import _native as N
+from amphibian_vae_latent_detector_amd import encoder as penc
+from amphibian_vae_latent_detector_amd import folder as pfolder
+from amphibian_vae_latent_detector_amd import map_detector_core as core
+from amphibian_vae_latent_detector_amd import radial as prad
+from amphibian_vae_latent_detector_amd import synth, wavio
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+# ------------------------------------------------------------------ C-ABI surface
+def test_library_exports_every_declared_symbol():
+    header = (ROOT / "include" / "amph.h").read_text()
+    declared = set(re.findall(r"\b(amph_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(N.EXPORTED_SYMBOLS)
+    lib = ctypes.CDLL(str(N.LIB_PATH))
+    for name in sorted(declared):
+        assert hasattr(lib, name), name
+    assert N.lib.amph_abi_version() == 1
+
+
+def test_no_cpu_device_and_no_fallback():
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        penc._device_index("cpu")
+    src = "".join((ROOT / "amphibian_vae_latent_detector_amd" / f).read_text()
+                  for f in ("map_detector_core.py", "encoder.py", "folder.py", "radial.py", "wavio.py", "_native.py"))
+    assert "oracle" not in src                       # the product never touches the checker
+
+
+def test_create_rejects_bad_arguments_without_a_gpu():
+    ctx = ctypes.c_void_p()
+    st = N.lib.amph_create(None, None, None, 0, 0, 8, ctypes.byref(ctx))
+    assert st == N.AMPH_ERR_INVALID_ARG and not ctx.value and "amph_create" in N.last_error(None)
+
+
+# ------------------------------------------------------------------ presets / spec
+def test_presets_geometry():
+    assert (PRESETS["ref-default"].n_samples, PRESETS["ref-default"].raw_frames) == (240000, 626)
+    assert (PRESETS["ref-07cli"].n_samples, PRESETS["ref-07cli"].raw_frames) == (144000, 376)
+    b = PRESETS["bench-1s"]
+    assert (b.n_samples, b.raw_frames, b.n_bins, b.target_frames) == (22050, 58, 1025, 64)
+    assert PRESETS["bench-1s-128"].raw_frames == 87
+    t = SPECS["thesis-shape"](64, 64)
+    assert t.out_hw() == [(32, 32), (16, 16), (8, 8), (4, 4)] and t.flat == 4096 and t.latent_dim == 32
+    assert SPECS["tiny"](64, 64).flat == 16 * 16 * 16
+    assert EncoderSpec.from_dict(t.to_dict()) == t
+
+
+def test_pack_weights_layout_and_checks():
+    spec = SPECS["tiny"](64, 64)
+    st = penc.random_init_state(spec, seed=3)
+    blob = penc.pack_weights(spec, st)
+    n = sum(int(np.prod(s)) for s in penc.state_shapes(spec).values())
+    assert blob.dtype == np.float32 and blob.size == n
+    assert np.array_equal(blob[:72], st["conv.0.weight"].ravel())
+    assert np.array_equal(blob[-8:], st["fc_logvar.bias"])
+    bad = dict(st)
+    bad["fc_mu.weight"] = bad["fc_mu.weight"][:, :-1]
+    with pytest.raises(RuntimeError, match="shape"):
+        penc.pack_weights(spec, bad)
+    del bad["fc_mu.weight"]
+    with pytest.raises(RuntimeError, match="missing"):
+        penc.pack_weights(spec, bad)
+    st2 = penc.random_init_state(spec, seed=3)
+    assert all(np.array_equal(st[k], st2[k]) for k in st)
+
+
+def test_checkpoint_files_roundtrip(tmp_path):
+    spec = SPECS["tiny"](64, 64)
+    st = penc.random_init_state(spec, seed=1)
+    pt, ym = tmp_path / "model.pt", tmp_path / "enc.yaml"
+    penc.save_checkpoint(pt, ym, spec, st)
+    assert core._load_spec_yaml(ym) == spec
+    ck = torch.load(str(pt), map_location="cpu", weights_only=True)
+    assert set(ck["state_dict"]) == set(penc.state_keys(spec))
+    with pytest.raises(RuntimeError, match="no CPU path"):          # loads fine, then refuses the cpu device
+        core.load_encoder(pt, ym, tmp_path, torch.device("cpu"))
+    (tmp_path / "bad.yaml").write_text("encoder:\n  foo: 1\n")
+    with pytest.raises(RuntimeError, match="_target_"):
+        core._load_spec_yaml(tmp_path / "bad.yaml")
+    with pytest.raises(FileNotFoundError):
+        core.load_encoder(tmp_path / "nope.pt", ym, tmp_path, torch.device("cuda"))
+
+
+def test_path_helpers(tmp_path):
+    (tmp_path / "downloaded_models").mkdir()
+    (tmp_path / "latent_space_exploration" / "x" / "y").mkdir(parents=True)
+    assert core.find_project_root(tmp_path / "latent_space_exploration" / "x" / "y") == tmp_path.resolve()
+    with pytest.raises(FileNotFoundError):
+        core.resolve_default_config(tmp_path)
+    core.save_json(tmp_path / "config.json", {"species": ["a"], "ñ": 1})
+    assert core.load_json(core.resolve_default_config(tmp_path)) == {"species": ["a"], "ñ": 1}
+    (tmp_path / "list.json").write_text("[1]")
+    with pytest.raises(ValueError):
+        core.load_json(tmp_path / "list.json")
+    s = core.summarize_1d(np.arange(101, dtype=np.float64))
+    assert s == {"min": 0.0, "p05": 5.0, "p50": 50.0, "p95": 95.0, "max": 100.0}
+    assert all(np.isnan(v) for v in core.summarize_1d(np.array([])).values())
+
+
+# ------------------------------------------------------------------ golden vectors through the product's host functions
+def test_crop_or_pad_time_matches_reference(golden):
+    g = golden("crop_or_pad.npz")
+    for k in [k[3:] for k in g.files if k.startswith("in_")]:
+        assert np.array_equal(core.crop_or_pad_time(g[f"in_{k}"], int(k.split("_")[1])), g[f"out_{k}"])
+
+
+def test_output_adapter_matches_reference(golden):
+    g = golden("adapter.npz")
+    W = torch.tensor(g["W"])
+    x = torch.tensor(g["mel"]).T.unsqueeze(0).unsqueeze(0)
+    base = x.reshape(1, -1) @ W.T
+    outs = {"tensor": base, "tuple": (base, base * 2), "list_nontensor_first": ["skip", base + 1],
+            "dict_mu": {"logvar": base * 3, "mu": base}, "dict_z_over_mu": {"mu": base * 3, "z": base - 1},
+            "dict_other": {"foo": base + 5}, "ndim3": torch.stack([base, base * 3], dim=1),
+            "ndim4": base.reshape(1, 2, 2, 1)}
+    for name, out in outs.items():
+        assert np.array_equal(core._adapt_output(out), g[f"z_{name}"]), name
+    for bad in (torch.zeros(2, 4), "nope", (), {"a": 1}):
+        with pytest.raises(RuntimeError):
+            core._adapt_output(bad)
+
+
+def test_host_radial_fit_matches_reference(golden, capsys):
+    g = golden("radial_fit.npz")
+    species = json.loads(str(g["species_json"]))
+    Zs = {sp: g[f"Z_{i}"] for i, sp in enumerate(species)}
+    for q_out in (0.10, 0.25):
+        rd = prad.fit_radial_detector(Zs, 0.95, q_out)
+        for i, sp in enumerate(species):
+            assert rd["centroids"][sp] == g[f"mu_{i}_{q_out:.2f}"].tolist()
+            rk, rk_in, rk_out = g[f"rk_{i}_{q_out:.2f}"].tolist()
+            assert rd["thresholds"][sp] == rk
+            m = rd["per_species"][sp]
+            assert (m["rk_in"], m["rk_out"], m["rk_final"]) == (rk_in, rk_out, rk)
+    out = capsys.readouterr().out
+    pat = re.compile(r"✅ (\S+): rk_in=([0-9.]+) \| rk_out=([0-9.]+|nan) \| rk=([0-9.]+)")   # 9105's regex shape
+    assert len(pat.findall(out)) == 8
+
+
+def test_priority_rank_rule(golden):
+    g = golden("radial_decide.npz")
+    cfg = json.loads(str(g["cfg_json"]))
+    det = prad.RadialDetector.from_config(cfg, latent_dim=8)
+    assert det.names == list(cfg["radial_detector"]["centroids"])           # config order kept
+    # emulate the kernel's selection rule on the host with numpy distances
+    for z, want in zip(g["Z"], g["pred"]):
+        d = np.array([np.sqrt(np.sum((z - c) * (z - c))) for c in det.centroids], dtype=np.float32)
+        acc = [k for k in range(len(det.names)) if float(d[k]) <= det.thresholds[k]]
+        got = det.names[min(acc, key=lambda k: det.rank[k])] if acc else ""
+        assert got == str(want)
+    # species without threshold / with another dimension are skipped as in the reference loop
+    det2 = prad.RadialDetector({"a": np.zeros(8, np.float32), "b": np.zeros(4, np.float32), "c": np.zeros(8, np.float32)},
+                               {"a": 1.0, "b": 1.0}, latent_dim=8)
+    assert det2.names == ["a"]
+    with pytest.raises(ValueError):
+        prad.get_detector_from_config({})
+
+
+# ------------------------------------------------------------------ synthetic data + WAV ingest
+def test_synth_is_deterministic_and_shaped():
+    a = synth.synth_chunk_pcm16(7, 22050, 22050)
+    assert a.dtype == np.int16 and a.shape == (22050,) and np.array_equal(a, synth.synth_chunk_pcm16(7, 22050, 22050))
+    assert not synth.synth_chunk_pcm16(49, 22050, 22050).any() and not synth.synth_chunk_pcm16(99, 22050, 22050).any()
+    assert not np.array_equal(a, synth.synth_chunk_pcm16(8, 22050, 22050))
+
+
+def test_native_wav_reader(tmp_path):
+    q = synth.synth_chunk_pcm16(3, 22050, 22050)
+    p = tmp_path / "a.wav"
+    synth.write_wav_pcm16(p, q, 22050)
+    out, n = wavio.read_pcm16_mono(p, 22050, 22050)
+    assert n == 22050 and np.array_equal(out, q)
+    out, n = wavio.read_pcm16_mono(p, 22050, 30000)                        # longer buffer: zero filled
+    assert n == 22050 and np.array_equal(out[:22050], q) and not out[22050:].any()
+    out, n = wavio.read_pcm16_mono(p, 22050, 1000)                         # truncation
+    assert n == 1000 and np.array_equal(out, q[:1000])
+    with pytest.raises(NotImplementedError):
+        wavio.read_pcm16_mono(p, 48000, 22050)                             # wrong rate: no resampler
+    st = np.stack([q, -q], axis=1)
+    synth.write_wav_pcm16(tmp_path / "st.wav", st, 22050)
+    with pytest.raises(NotImplementedError):
+        wavio.read_pcm16_mono(tmp_path / "st.wav", 22050, 22050)
+    y = wavio.load_float_mono(tmp_path / "st.wav", 22050)                  # stereo -> channel mean, float32
+    assert y.dtype == np.float32 and np.abs(y).max() <= 1.0 / 32768 + 1e-9
+    (tmp_path / "junk.wav").write_bytes(b"not a wav at all")
+    with pytest.raises(OSError):
+        wavio.read_pcm16_mono(tmp_path / "junk.wav", 22050, 100)
+    with pytest.raises(OSError):
+        wavio.read_pcm16_mono(tmp_path / "missing.wav", 22050, 100)
+
+
+def test_native_reader_skips_extra_chunks(tmp_path):
+    q = np.arange(-50, 50, dtype="<i2")
+    body = (b"fmt " + (16).to_bytes(4, "little") + (1).to_bytes(2, "little") + (1).to_bytes(2, "little") +
+            (22050).to_bytes(4, "little") + (44100).to_bytes(4, "little") + (2).to_bytes(2, "little") + (16).to_bytes(2, "little") +
+            b"LIST" + (5).to_bytes(4, "little") + b"abcde\x00" +            # odd-sized chunk + pad byte
+            b"data" + (200).to_bytes(4, "little") + q.tobytes())
+    (tmp_path / "x.wav").write_bytes(b"RIFF" + (4 + len(body)).to_bytes(4, "little") + b"WAVE" + body)
+    out, n = wavio.read_pcm16_mono(tmp_path / "x.wav", 22050, 100)
+    assert n == 100 and np.array_equal(out, q)
+
+
+def test_read_many_flags_bad_files(tmp_path):
+    paths = []
+    for i in range(5):
+        p = tmp_path / f"c{i}.wav"
+        synth.write_wav_pcm16(p, synth.synth_chunk_pcm16(i, 2000 + 100 * i, 22050), 22050)
+        paths.append(p)
+    (tmp_path / "bad.wav").write_bytes(b"RIFFxxxxWAVEjunk")
+    paths.insert(2, tmp_path / "bad.wav")
+    pcm, lengths, status, ptr = wavio.read_many_pcm16(paths, 22050, 2200, n_threads=3)
+    assert ptr is None and pcm.shape == (6, 2200)
+    assert status.tolist() == [0, 0, N.AMPH_ERR_IO, 0, 0, 0]
+    assert lengths.tolist() == [2000, 2100, 0, 2200, 2200, 2200] and not pcm[2].any()
+    assert np.array_equal(pcm[0, :2000], synth.synth_chunk_pcm16(0, 2000, 22050)) and not pcm[0, 2000:].any()
+
+
+# ------------------------------------------------------------------ folder driver (host logic, fake encode)
+def _fake_encode(paths):
+    """Deterministic stand-in for the HIP encode: a vector derived from the file name."""
+    Z = torch.tensor([[float(int(re.findall(r"(\d+)", p.stem)[-1]) * 10 + j) for j in range(4)] for p in paths],
+                     dtype=torch.float32).reshape(len(paths), 4)
+    st = np.array([N.AMPH_ERR_IO if "bad" in p.stem else 0 for p in paths], dtype=np.int32)
+    return Z, st
+
+
+def _make_tree(root, counts):
+    for sp, n in counts.items():
+        (root / sp).mkdir(parents=True)
+        for i in range(n):
+            (root / sp / f"chunk_{i:04d}.wav").write_bytes(b"")
+    return root
+
+
+def test_plan_shards():
+    assert pfolder.plan_shards(10, 4) == ([(0, 3), (3, 6), (6, 9), (9, 10)], 3)
+    assert pfolder.plan_shards(3, 8)[0][3:] == [(3, 3)] * 5
+    assert pfolder.plan_shards(0, 2) == ([(0, 0), (0, 0)], 1)
+    assert pfolder.plan_shards(100000, 8)[1] == 12500
+
+
+def test_list_species_wavs_sampling_is_the_reference_rule(tmp_path):
+    root = _make_tree(tmp_path / "train_chunks_norm", {"b_sp": 30, "a_sp": 5, "empty_sp": 0})
+    random.seed(123)
+    got = pfolder.list_species_wavs(root, ["b_sp", "missing", "a_sp", "empty_sp"], max_per_class=10)
+    random.seed(123)
+    want_b = random.sample(sorted((root / "b_sp").resolve().glob("*.wav")), 10)
+    assert list(got) == ["b_sp", "a_sp"] and got["b_sp"] == want_b and len(got["a_sp"]) == 5
+    random.seed(123)
+    got2 = pfolder.list_species_wavs(root, ["a_sp", "b_sp"], max_per_class=10, skip=["a_sp"])
+    assert list(got2) == ["b_sp"] and got2["b_sp"] == want_b               # skipped species draw nothing
+
+
+def test_encode_folder_cache_and_failures(tmp_path, capsys):
+    cfg = PRESETS["bench-1s"]
+    root = _make_tree(tmp_path / "val_chunks_norm", {"s1": 6, "s2": 3, "s3": 2})
+    (root / "s2" / "bad_0009.wav").write_bytes(b"")
+    for p in (root / "s3").glob("*.wav"):
+        p.rename(p.with_name("bad_" + p.name))
+    cache = tmp_path / "cache_npz"
+    Z, failed = pfolder.encode_folder(None, root, ["s1", "s2", "s3", "s4"], cfg, cache_dir=cache, encode_fn=_fake_encode)
+    assert list(Z) == ["s1", "s2"] and Z["s1"].shape == (6, 4) and Z["s2"].shape == (3, 4) and failed == {"s1": 0, "s2": 1}
+    assert Z["s1"][:, 0].tolist() == [0.0, 10.0, 20.0, 30.0, 40.0, 50.0]     # name-sorted order
+    out = capsys.readouterr().out
+    assert "❌ s3" in out and "fallo bad_0009.wav" in out and "s4" in out
+    d = np.load(cache / "Z_val_chunks_norm_s2.npz")
+    assert set(d.files) == {"Z", "failed", "root"} and int(d["failed"]) == 1 and str(d["root"]) == str(root.resolve())
+    assert np.array_equal(d["Z"], Z["s2"])
+    # second call is served from the cache (encode_fn would now fail loudly)
+    Z2, failed2 = pfolder.encode_folder(None, root, ["s1", "s2"], cfg, cache_dir=cache,
+                                        encode_fn=lambda p: (_ for _ in ()).throw(AssertionError("cache miss")))
+    assert np.array_equal(Z2["s1"], Z["s1"]) and failed2 == failed

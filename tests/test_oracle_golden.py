@@ -1,0 +1,155 @@
+"""The oracle against the reference's own outputs (tests/golden/*.npz, captured by
+tests/golden/make_golden.py from the reference functions) and against known answers
+for the parts that are parity-unpinned (librosa restatement)."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import encoder as oenc
+from oracle import frontend as ofe
+from oracle import radial as orad
+
+RMS_CASES = ["noise_quiet", "noise_loud", "tone", "silent", "below_gate", "clipping", "short"]
+
+
+@pytest.mark.parametrize("case", RMS_CASES)
+def test_rms_normalize_matches_reference_bitwise(golden, case):
+    g = golden("rms_normalize.npz")
+    out, ok = ofe.rms_normalize(g[f"in_{case}"].copy())
+    assert bool(ok) == bool(g[f"ok_{case}"])
+    if str(g["numpy_version"]).split(".")[0] == np.__version__.split(".")[0]:
+        assert np.array_equal(np.asarray(out), g[f"out_{case}"])       # same numpy major: bit-exact
+    else:
+        np.testing.assert_allclose(out, g[f"out_{case}"], rtol=2e-7, atol=0)
+
+
+def test_crop_or_pad_matches_reference(golden):
+    g = golden("crop_or_pad.npz")
+    keys = [k[3:] for k in g.files if k.startswith("in_")]
+    assert len(keys) == 7
+    for k in keys:
+        target = int(k.split("_")[1])
+        assert np.array_equal(ofe.crop_or_pad_time(g[f"in_{k}"], target), g[f"out_{k}"])
+
+
+def _forms(W, D):
+    def base(x):
+        return x.reshape(1, -1) @ W.T
+    return {
+        "tensor": lambda x: base(x),
+        "tuple": lambda x: (base(x), base(x) * 2),
+        "list_nontensor_first": lambda x: ["skip", base(x) + 1],
+        "dict_mu": lambda x: {"logvar": base(x) * 3, "mu": base(x)},
+        "dict_z_over_mu": lambda x: {"mu": base(x) * 3, "z": base(x) - 1},
+        "dict_other": lambda x: {"foo": base(x) + 5},
+        "ndim3": lambda x: torch.stack([base(x), base(x) * 3], dim=1),
+        "ndim4": lambda x: (base(x).reshape(1, 2, 2, 1)),
+    }
+
+
+def test_adapter_matches_reference(golden):
+    g = golden("adapter.npz")
+    mel, W = g["mel"], torch.tensor(g["W"])
+    for name, fn in _forms(W, W.shape[0]).items():
+        z = oenc.encode_mel_to_latent(fn, mel)
+        assert np.array_equal(z, g[f"z_{name}"]), name
+        assert np.array_equal(g[f"z07_{name}"], g[f"z_{name}"])          # 07's extract_vector agrees
+    errs = json.loads(str(g["errors_json"]))
+    assert errs == {"batch2": "RuntimeError", "str": "RuntimeError", "empty_tuple": "RuntimeError",
+                    "dict_no_tensor": "RuntimeError"}
+    for bad in (lambda x: torch.zeros(2, 4), lambda x: "nope", lambda x: (), lambda x: {"a": 1}):
+        with pytest.raises(RuntimeError):
+            oenc.encode_mel_to_latent(bad, mel)
+
+
+def test_radial_fit_matches_reference(golden):
+    g = golden("radial_fit.npz")
+    species = json.loads(str(g["species_json"]))
+    Z = [g[f"Z_{i}"] for i in range(len(species))]
+    for q_out in (0.10, 0.15, 0.20, 0.25):
+        for i in range(len(species)):
+            Z_out = np.concatenate([Z[j] for j in range(len(species)) if j != i], axis=0)
+            mu, rk, rk_in, rk_out = orad.fit_species_with_fp_control(Z[i], Z_out, 0.95, q_out)
+            assert np.array_equal(mu, g[f"mu_{i}_{q_out:.2f}"])
+            assert [rk, rk_in, rk_out] == g[f"rk_{i}_{q_out:.2f}"].tolist()
+    mu, rk, rk_in, rk_out = orad.fit_species_with_fp_control(Z[0], None, 0.95, 0.1)
+    assert [rk, rk_in, rk_out] == g["rk_noout"].tolist() and rk_out == float("inf")
+
+
+def test_radial_decide_matches_reference(golden):
+    g = golden("radial_decide.npz")
+    cfg = json.loads(str(g["cfg_json"]))
+    rd = cfg["radial_detector"]
+    cents = {sp: np.array(v, dtype=np.float32) for sp, v in rd["centroids"].items()}
+    thr = {sp: float(v) for sp, v in rd["thresholds"].items()}
+    n_det = 0
+    for z, det, pred, best in zip(g["Z"], g["detected"], g["pred"], g["best_d"]):
+        d, sp, bd = orad.decide(z, cents, thr, json.loads(str(g["priority_json"])))
+        assert d == bool(det) and (sp or "") == str(pred) and bd == float(best)
+        n_det += d
+    assert 0 < n_det < len(g["Z"])                                         # both outcomes are exercised
+    assert "Zeta_extra" in set(map(str, g["pred"]))                        # sorted(accepted)[0] branch
+
+
+@pytest.mark.parametrize("n", [5, 8, 32, 33, 100, 128, 129, 1000])
+def test_pairwise_sum_emulation_is_numpy(n):
+    rng = np.random.default_rng(n)
+    for _ in range(20):
+        a = (rng.standard_normal(n) ** 2).astype(np.float32)
+        assert orad.pairwise_sum_f32(a) == np.sum(a)
+
+
+# ---- parity-unpinned part: known answers (librosa docstring values) ----
+def test_slaney_mel_scale_known_answers():
+    assert abs(float(ofe.hz_to_mel(60)) - 0.9) < 1e-12
+    np.testing.assert_allclose(ofe.hz_to_mel(np.array([110.0, 220.0, 440.0])), [1.65, 3.3, 6.6], rtol=1e-12)
+    np.testing.assert_allclose(ofe.mel_to_hz(np.array([1.0, 2, 3, 4, 5])), [66.667, 133.333, 200.0, 266.667, 333.333], atol=1e-3)
+    mf = ofe.mel_frequencies(40, 0.0, 11025.0)
+    np.testing.assert_allclose(mf[:4], [0.0, 85.317, 170.635, 255.952], atol=1e-3)
+    np.testing.assert_allclose(mf[-3:], [9246.028, 10096.408, 11025.0], atol=1e-3)
+    np.testing.assert_allclose(mf[11:14], [938.49, 1024.856, 1119.114], atol=1e-3)
+
+
+def test_mel_filterbank_structure():
+    fb = ofe.mel_filterbank(22050, 2048, 64, 150.0, 11025.0)
+    assert fb.shape == (64, 1025) and fb.dtype == np.float32 and (fb >= 0).all()
+    for row in fb:
+        nz = np.nonzero(row)[0]
+        assert nz.size and np.all(np.diff(nz) == 1)                        # one contiguous triangle
+        pk = row.argmax()
+        assert np.all(np.diff(row[nz[0]:pk + 1]) >= 0) and np.all(np.diff(row[pk:nz[-1] + 1]) <= 0)
+    # Slaney area normalisation: sum(row) * (Hz per bin) ~= 1
+    np.testing.assert_allclose(fb.sum(axis=1) * (22050 / 2048), 1.0, rtol=0.12)
+    # filters centred above Nyquist are all-zero rows (reference default fmax at 22.05 kHz)
+    fb2 = ofe.mel_filterbank(22050, 2048, 64, 150.0, 15000.0)
+    assert not fb2[-1].any() and fb2[0].any()
+
+
+def test_stft_against_scipy():
+    from scipy.signal import stft as sstft
+    rng = np.random.default_rng(0)
+    y = rng.standard_normal(22050).astype(np.float32)
+    X = ofe.stft(y, 2048, 384)
+    assert X.shape == (1025, 58) and X.dtype == np.complex64
+    yp = np.pad(y, 1024, mode="reflect").astype(np.float64)
+    _, _, Z = sstft(yp, window="hann", nperseg=2048, noverlap=2048 - 384, boundary=None, padded=False)
+    Z = Z * ofe.hann_periodic(2048).sum()
+    assert np.abs(X - Z).max() / np.abs(Z).max() < 1e-6
+
+
+def test_power_to_db_and_silence():
+    S = np.array([[1.0, 1e-3], [1e-12, 0.0]], dtype=np.float32)
+    db = ofe.power_to_db(S)
+    np.testing.assert_allclose(db, [[0.0, -30.0], [-80.0, -80.0]], atol=1e-5)
+    m = ofe.wave_to_mel(np.zeros(22050, np.float32), sr=22050, duration=1.0, n_mels=64, fmin=150.0, fmax=11025.0,
+                        hop_length=384, n_fft=2048, target_frames=64)
+    assert m.shape == (64, 64) and not m.any()                             # std == 0 path: all zeros, no NaN
+
+
+def test_pcm16_roundtrip_convention():
+    x = np.array([-1.0, -0.5, 0.0, 0.25, 1.0, 1.5 / 32767], dtype=np.float32)
+    q = ofe.float_to_pcm16(x)
+    assert q.tolist() == [-32767, -16384, 0, 8192, 32767, 2]               # x * 32767, round-half-even
+    assert ofe.pcm16_to_float(np.array([16384, -32768], np.int16)).tolist() == [0.5, -1.0]
