@@ -236,23 +236,22 @@ void launch_head_reduce(const HeadReduceParams& p, int n_rows, hipStream_t s) {
 // strided accumulators), accept if (double)d_k <= thr_k; tie -> smallest rank.
 // ----------------------------------------------------------------------------
 __device__ __forceinline__ float np_pairwise_sumsq(const float* z, const float* mu, int n) {
-    auto sq = [&](int i) { const float a = __fsub_rn(z[i], mu[i]); return __fmul_rn(a, a); };
+#pragma clang fp contract(off)   // numpy rounds a = z - mu, a * a and every add separately; no FMA
     if (n < 8) {
         float r = 0.0f;
-        for (int i = 0; i < n; ++i) r = __fadd_rn(r, sq(i));
+        for (int i = 0; i < n; ++i) { const float a = z[i] - mu[i]; r = r + a * a; }
         return r;
     }
     float r[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) r[j] = sq(j);
+    for (int j = 0; j < 8; ++j) { const float a = z[j] - mu[j]; r[j] = a * a; }
     int i = 8;
     for (; i < n - (n % 8); i += 8) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) r[j] = __fadd_rn(r[j], sq(i + j));
+        for (int j = 0; j < 8; ++j) { const float a = z[i + j] - mu[i + j]; r[j] = r[j] + a * a; }
     }
-    float res = __fadd_rn(__fadd_rn(__fadd_rn(r[0], r[1]), __fadd_rn(r[2], r[3])),
-                          __fadd_rn(__fadd_rn(r[4], r[5]), __fadd_rn(r[6], r[7])));
-    for (; i < n; ++i) res = __fadd_rn(res, sq(i));
+    float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) { const float a = z[i] - mu[i]; res = res + a * a; }
     return res;
 }
 
@@ -263,7 +262,7 @@ __global__ __launch_bounds__(256) void k_decide_radial(RadialParams p, long long
     float best = INFINITY;
     int pred = -1, pred_rank = 0x7fffffff;
     for (int k = 0; k < p.K; ++k) {
-        const float d = __fsqrt_rn(np_pairwise_sumsq(z, p.centroids + (long long)k * p.D, p.D));
+        const float d = sqrtf(np_pairwise_sumsq(z, p.centroids + (long long)k * p.D, p.D));   // IEEE-rounded (not __fsqrt_rn: raw v_sqrt_f32, 1 ulp)
         best = fminf(best, d);
         if ((double)d <= p.thresholds[k] && p.rank[k] < pred_rank) { pred = k; pred_rank = p.rank[k]; }
     }

@@ -71,63 +71,134 @@ __device__ __forceinline__ float block_max(float v, float* sh) {
 
 // ----------------------------------------------------------------------------
 // K0: per-row RMS scale.  rms = sqrt(mean(y^2)); rms < 1e-4 -> unchanged;
-// else scale = 0.05 / (rms + 1e-8) in float32 (00_normalize_dataset_rms.py:30-36).
-// PCM16 rows: sum of q^2 is exact in 64-bit integers (order independent).
+// else scale = 0.05 / (rms + 1e-8), all float32 (00_normalize_dataset_rms.py:30-36).
+//
+// The scale feeds a PCM16 re-quantisation (00 writes PCM16, 07 reads it back), which
+// is discontinuous: a last-bit difference in the scale can move every occurrence of
+// one sample value by an LSB (measured: 1.7e-4 on the latents of a quiet chunk).  So
+// mean(y^2) is evaluated in EXACTLY numpy's float32 order (tools/pairwise_model.py):
+//   the row is consumed in ufunc-buffer chunks of 8192 elements, chunk sums are
+//   accumulated sequentially; inside a chunk numpy recurses n -> (n/2 - (n/2)%8, rest)
+//   down to blocks of <= 128, each summed with 8 strided accumulators combined as
+//   ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) plus a sequential tail.
+// Mapping: 8 lanes per block (one per accumulator, xor-1/2/4 butterflies give the
+// combine order), block results into a per-chunk heap in LDS, heap levels summed
+// left+right deepest first, thread 0 folds the chunk sums in order.
 // ----------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_rms_scale_pcm16(const int16_t* __restrict__ in, long long row_stride,
-                                                         const int32_t* __restrict__ lengths, int n_in,
-                                                         float* __restrict__ scale, int32_t* __restrict__ ok) {
-    __shared__ double sh[4];
-    const int row = blockIdx.x;
-    const int16_t* x = in + (long long)row * row_stride;
-    const int n = lengths ? min(lengths[row], n_in) : n_in;
-    unsigned long long acc = 0;
-    // scalar head up to 16-byte alignment, int4 body, scalar tail
-    const int mis = (int)(((uintptr_t)x & 15u) >> 1);
-    const int head = min(n, (8 - mis) & 7);
-    if ((int)threadIdx.x < head) { int q = x[threadIdx.x]; acc += (unsigned)(q * q); }
-    const int nvec = (n - head) >> 3;
-    const int4* xv = reinterpret_cast<const int4*>(x + head);
-    for (int i = threadIdx.x; i < nvec; i += 256) {
-        const int4 v = xv[i];
-        const int w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int lo = (int)(short)(w[j] & 0xFFFF), hi = w[j] >> 16;
-            acc += (unsigned)(lo * lo);
-            acc += (unsigned)(hi * hi);
-        }
+constexpr int kNpChunk = 8192;     // numpy ufunc buffer size (elements)
+constexpr int kNpBlock = 128;      // PW_BLOCKSIZE
+constexpr int kChunksPerPass = 4;
+
+__device__ __forceinline__ int np_split(int n) { const int h = n >> 1; return h - (h & 7); }
+
+// depth of the deepest leaf of a chunk of n elements (the right child is never smaller)
+__device__ __forceinline__ int np_depth(int n) {
+    int d = 0;
+    while (n > kNpBlock) { n -= np_split(n); ++d; }
+    return d;
+}
+// node reached from the root along `path` (MSB first) after at most `level` steps
+__device__ __forceinline__ void np_walk(int n, int path, int level, int& off, int& size, int& reached) {
+    off = 0;
+    int l = 0;
+    for (; l < level && n > kNpBlock; ++l) {
+        const int n2 = np_split(n);
+        if ((path >> (level - 1 - l)) & 1) { off += n2; n -= n2; }
+        else n = n2;
     }
-    const int tail0 = head + (nvec << 3);
-    if ((int)threadIdx.x < n - tail0) { int q = x[tail0 + threadIdx.x]; acc += (unsigned)(q * q); }
-    const double tot = block_sum((double)acc, sh);   // exact: < 2^53 for any realistic row
-    if (threadIdx.x == 0) {
-        float sc = 1.0f;
-        int good = 0;
-        if (n > 0) {
-            const float rms = (float)sqrt(tot / (1073741824.0 * (double)n));   // 32768^2
-            if (!(rms < 1e-4f)) { sc = 0.05f / (rms + 1e-8f); good = 1; }
-        }
-        scale[row] = sc;
-        if (ok) ok[row] = good;
-    }
+    size = n;
+    reached = l;
 }
 
-__global__ __launch_bounds__(256) void k_rms_scale_f32(const float* __restrict__ in, long long row_stride,
-                                                       const int32_t* __restrict__ lengths, int n_in,
-                                                       float* __restrict__ scale, int32_t* __restrict__ ok) {
-    __shared__ double sh[4];
-    const int row = blockIdx.x;
-    const float* x = in + (long long)row * row_stride;
+// NOTE: `__fmul_rn` / `__fadd_rn` are device-library functions whose fmul / fadd carry the
+// library's own `contract` flag: hipcc fused them into v_fmac (seen in the ISA; 1-ulp
+// differences from numpy).  Code that must round each operation separately is written
+// with plain operators under `#pragma clang fp contract(off)` and checked in the ISA.
+template <bool PCM16>
+__device__ __forceinline__ float sq_at(const void* row, int i) {
+#pragma clang fp contract(off)
+    float y;
+    if (PCM16) y = (float)reinterpret_cast<const int16_t*>(row)[i] * (1.0f / 32768.0f);
+    else y = reinterpret_cast<const float*>(row)[i];
+    return y * y;
+}
+
+template <bool PCM16>
+__global__ __launch_bounds__(256) void k_rms_scale(const void* __restrict__ in, long long row_stride,
+                                                   const int32_t* __restrict__ lengths, int n_in,
+                                                   float* __restrict__ scale, int32_t* __restrict__ ok) {
+#pragma clang fp contract(off)
+    __shared__ float heap[kChunksPerPass][2 * 64];       // chunk depth <= 6: 64 leaves, heap of 128
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const char* x = reinterpret_cast<const char*>(in) + (long long)row * row_stride * (PCM16 ? 2 : 4);
     const int n = lengths ? min(lengths[row], n_in) : n_in;
-    double acc = 0.0;
-    for (int i = threadIdx.x; i < n; i += 256) { const float v = x[i]; const float sq = v * v; acc += (double)sq; }
-    const double tot = block_sum(acc, sh);
-    if (threadIdx.x == 0) {
+    const int n_chunks = (n + kNpChunk - 1) / kNpChunk;
+    float total = 0.0f;                                  // thread 0 only
+    for (int c0 = 0; c0 < n_chunks; c0 += kChunksPerPass) {
+        // ---- leaves: task = (chunk, leaf slot, accumulator lane)
+        for (int task = tid; task < kChunksPerPass * 64 * 8; task += 256) {
+            const int cl = task >> 9, slot = (task >> 3) & 63, j = task & 7;
+            const int chunk = c0 + cl;
+            bool owner = false;
+            int off = 0, size = 0, lvl = 0, rem = 0;
+            if (chunk < n_chunks) {
+                const int cn = min(kNpChunk, n - chunk * kNpChunk);
+                const int D = np_depth(cn);
+                if (slot < (1 << D)) {
+                    np_walk(cn, slot, D, off, size, lvl);
+                    rem = D - lvl;
+                    owner = (slot & ((1 << rem) - 1)) == 0;   // an early leaf belongs to the slot with zero low bits
+                    off += chunk * kNpChunk;
+                }
+            }
+            float r = 0.0f;
+            const int body = size - (size & 7);
+            if (owner && size >= 8) {
+                r = sq_at<PCM16>(x, off + j);
+                for (int i = 8; i < body; i += 8) r = (r + sq_at<PCM16>(x, off + i + j));
+            }
+            r = (r + dpp_xor1(r));
+            r = (r + dpp_xor2(r));
+            r = (r + __shfl_xor(r, 4));
+            if (owner && j == 0) {
+                if (size < 8) {                           // numpy: res = -0.0; res += a[i]
+                    r = -0.0f;
+                    for (int i = 0; i < size; ++i) r = (r + sq_at<PCM16>(x, off + i));
+                } else {
+                    for (int i = body; i < size; ++i) r = (r + sq_at<PCM16>(x, off + i));
+                }
+                heap[cl][(1 << lvl) + (slot >> rem)] = r;
+            }
+        }
+        __syncthreads();
+        // ---- internal nodes, deepest level first: value = left + right
+        for (int lvl = 5; lvl >= 0; --lvl) {
+            for (int t = tid; t < kChunksPerPass << lvl; t += 256) {
+                const int cl = t >> lvl, path = t & ((1 << lvl) - 1);
+                const int chunk = c0 + cl;
+                if (chunk < n_chunks) {
+                    const int cn = min(kNpChunk, n - chunk * kNpChunk);
+                    int off, size, reached;
+                    np_walk(cn, path, lvl, off, size, reached);
+                    if (reached == lvl && size > kNpBlock) {
+                        const int idx = (1 << lvl) + path;
+                        heap[cl][idx] = (heap[cl][2 * idx] + heap[cl][2 * idx + 1]);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            for (int cl = 0; cl < kChunksPerPass && c0 + cl < n_chunks; ++cl)
+                total = (c0 + cl == 0) ? heap[cl][1] : (total + heap[cl][1]);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
         float sc = 1.0f;
         int good = 0;
         if (n > 0) {
-            const float rms = sqrtf((float)(tot / (double)n));
+            const float rms = sqrtf(total / (float)n);           // np.mean = sum / n in float32; IEEE sqrt
             if (!(rms < 1e-4f)) { sc = 0.05f / (rms + 1e-8f); good = 1; }
         }
         scale[row] = sc;
@@ -407,8 +478,10 @@ void launch_stft_mel(const StftParams& p, int n_rows, int sample_is_pcm16, hipSt
 // One 256-thread block per chunk; dB values are recomputed per pass.
 // ----------------------------------------------------------------------------
 __device__ __forceinline__ float to_db(float s, float ref_db) {
+#pragma clang fp contract(off)
     // separately rounded multiply and subtract (numpy order): the max element gives exactly 0
-    return fmaxf(__fsub_rn(__fmul_rn(10.0f, log10f(fmaxf(1e-10f, s))), ref_db), -80.0f);
+    const float db = 10.0f * log10f(fmaxf(1e-10f, s));
+    return fmaxf(db - ref_db, -80.0f);
 }
 
 __global__ __launch_bounds__(256) void k_dbnorm(DbNormParams p) {
@@ -420,7 +493,7 @@ __global__ __launch_bounds__(256) void k_dbnorm(DbNormParams p) {
     float mx = -INFINITY;
     for (int i = tid; i < n; i += 256) mx = fmaxf(mx, S[i]);
     mx = block_max(mx, shf);
-    const float ref_db = __fmul_rn(10.0f, log10f(fmaxf(1e-10f, mx)));
+    const float ref_db = 10.0f * log10f(fmaxf(1e-10f, mx));             // same two operations as to_db (no FMA)
     double acc = 0.0;
     for (int i = tid; i < n; i += 256) acc += (double)to_db(S[i], ref_db);
     const float mean = (float)(block_sum(acc, shd) / (double)n);
@@ -448,11 +521,11 @@ void launch_dbnorm(const DbNormParams& p, int n_rows, hipStream_t s) {
 
 void launch_rms_scale_pcm16(const int16_t* in, long long row_stride, const int32_t* lengths, int n_in, int n_rows,
                             float* scale, int32_t* ok, hipStream_t s) {
-    hipLaunchKernelGGL(k_rms_scale_pcm16, dim3(n_rows), dim3(256), 0, s, in, row_stride, lengths, n_in, scale, ok);
+    hipLaunchKernelGGL(k_rms_scale<true>, dim3(n_rows), dim3(256), 0, s, (const void*)in, row_stride, lengths, n_in, scale, ok);
 }
 void launch_rms_scale_f32(const float* in, long long row_stride, const int32_t* lengths, int n_in, int n_rows,
                           float* scale, int32_t* ok, hipStream_t s) {
-    hipLaunchKernelGGL(k_rms_scale_f32, dim3(n_rows), dim3(256), 0, s, in, row_stride, lengths, n_in, scale, ok);
+    hipLaunchKernelGGL(k_rms_scale<false>, dim3(n_rows), dim3(256), 0, s, (const void*)in, row_stride, lengths, n_in, scale, ok);
 }
 void launch_rms_apply_f32(const float* in, int n_rows, int n, const float* scale, const int32_t* ok, float* out,
                           hipStream_t s) {
