@@ -67,6 +67,7 @@ def _load() -> C.CDLL:
                                   C.c_int, C.POINTER(vp)]),
         "amph_destroy": (None, [vp]),
         "amph_last_error": (C.c_char_p, [vp]),
+        "amph_configure": (C.c_int, [vp, C.c_char_p, C.c_int]),
         "amph_raw_frames": (C.c_int, [vp]),
         "amph_latent_dim": (C.c_int, [vp]),
         "amph_max_batch": (C.c_int, [vp]),
@@ -101,7 +102,7 @@ def _load() -> C.CDLL:
 
 
 EXPORTED_SYMBOLS = (
-    "amph_abi_version", "amph_create", "amph_destroy", "amph_last_error", "amph_raw_frames", "amph_latent_dim",
+    "amph_abi_version", "amph_create", "amph_destroy", "amph_last_error", "amph_configure", "amph_raw_frames", "amph_latent_dim",
     "amph_max_batch", "amph_get_mel_basis", "amph_rms_normalize_f32", "amph_rms_normalize_pcm16", "amph_mel_f32",
     "amph_mel_power_f32", "amph_encoder_forward", "amph_encode_pcm16", "amph_encode_f32", "amph_encode_pcm16_host",
     "amph_decide_radial", "amph_wav_read_pcm16", "amph_wav_read_many", "amph_host_alloc", "amph_host_free",

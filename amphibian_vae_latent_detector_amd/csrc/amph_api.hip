@@ -31,6 +31,20 @@ struct Stage {
     double total_ms = 0;
 };
 
+// Per-lane scratch: a lane is one HIP stream + the buffers one batch needs, so that
+// batches assigned to different lanes overlap on the GPU (VALU-bound front end of one
+// batch under the MFMA-bound convolutions of another).
+struct Workspace {
+    hipStream_t stream = nullptr;          // lane 0 uses the caller's stream
+    hipEvent_t done = nullptr;
+    float* scale = nullptr;
+    int32_t* ok = nullptr;
+    float* melpow = nullptr;
+    float* image = nullptr;
+    std::vector<float*> act;               // one per conv layer
+    float* partial = nullptr;
+};
+
 struct GemmLayer {
     ConvGemmParams prm{};   // x / y / M / splits filled per call
     int bm = 128;
@@ -52,10 +66,7 @@ struct amph_ctx {
 
     // front-end tables
     int n_frames = 0, frames_per_block = 8;
-    float* d_window = nullptr;
-    float2* d_tw_a = nullptr;
-    float2* d_tw_b = nullptr;
-    float2* d_tw_post = nullptr;
+    float* d_tables = nullptr;             // packed LDS image of the STFT tables
     int32_t *d_mel_start = nullptr, *d_mel_len = nullptr, *d_mel_wofs = nullptr;
     float* d_mel_w = nullptr;
     std::vector<float> mel_basis;          // dense [n_mels][F] for amph_get_mel_basis
@@ -68,13 +79,9 @@ struct amph_ctx {
     int head_splits = 1;
     int flat = 0, latent = 0;
 
-    // workspace (sized for max_batch)
-    float* ws_scale = nullptr;
-    int32_t* ws_ok = nullptr;
-    float* ws_melpow = nullptr;
-    float* ws_image = nullptr;
-    std::vector<float*> ws_act;            // one per conv layer
-    float* ws_partial = nullptr;
+    // workspaces (each sized for max_batch); lanes.size() >= 1
+    std::vector<Workspace> lanes;
+    hipEvent_t ev_fork = nullptr;
     // radial scratch
     float* d_centroids = nullptr;
     double* d_thr = nullptr;
@@ -215,40 +222,54 @@ int build_frontend(amph_ctx* c) {
 
     const int n_fft = f.n_fft, Nc = n_fft / 2, L = 64, TLO = 4;
     const double PI = 3.14159265358979323846;
-    std::vector<float> win(n_fft);
-    for (int n = 0; n < n_fft; ++n) win[n] = (float)(0.5 - 0.5 * std::cos(2.0 * PI * (double)n / (double)n_fft));
-    std::vector<float2> twa(16 * L), twb(16 * TLO), twp(Nc / 2 + 1);
-    for (int k1 = 0; k1 < 16; ++k1)
-        for (int t = 0; t < L; ++t) {
-            const double a = -2.0 * PI * (double)((t * k1) % Nc) / (double)Nc;
-            twa[k1 * L + t] = make_float2((float)std::cos(a), (float)std::sin(a));
+    // packed table image (layout = the kernel's LDS image): half window | tw_a (k1 = 1..15) | tw_b | tw_post
+    std::vector<float> tab(stft_mel_table_bytes() / 4, 0.0f);
+    {
+        float* win = tab.data();                                  // w[0..1024]; w[n] == w[N - n] covers the rest
+        for (int n = 0; n <= n_fft / 2; ++n) win[n] = (float)(0.5 - 0.5 * std::cos(2.0 * PI * (double)n / (double)n_fft));
+        float* twa = tab.data() + 4112 / 4;
+        for (int k1 = 1; k1 < 16; ++k1)
+            for (int t = 0; t < L; ++t) {
+                const double a = -2.0 * PI * (double)((t * k1) % Nc) / (double)Nc;
+                twa[2 * ((k1 - 1) * L + t)] = (float)std::cos(a);
+                twa[2 * ((k1 - 1) * L + t) + 1] = (float)std::sin(a);
+            }
+        float* twb = twa + 15 * 64 * 2;
+        for (int k2a = 0; k2a < 16; ++k2a)
+            for (int t = 0; t < TLO; ++t) {
+                const double a = -2.0 * PI * (double)((t * k2a) % L) / (double)L;
+                twb[2 * (k2a * TLO + t)] = (float)std::cos(a);
+                twb[2 * (k2a * TLO + t) + 1] = (float)std::sin(a);
+            }
+        float* twp = twb + 16 * 4 * 2;
+        for (int k = 0; k <= Nc / 2; ++k) {
+            const double a = -2.0 * PI * (double)k / (double)n_fft;
+            twp[2 * k] = (float)std::cos(a);
+            twp[2 * k + 1] = (float)std::sin(a);
         }
-    for (int k2a = 0; k2a < 16; ++k2a)
-        for (int t = 0; t < TLO; ++t) {
-            const double a = -2.0 * PI * (double)((t * k2a) % L) / (double)L;
-            twb[k2a * TLO + t] = make_float2((float)std::cos(a), (float)std::sin(a));
-        }
-    for (int k = 0; k <= Nc / 2; ++k) {
-        const double a = -2.0 * PI * (double)k / (double)n_fft;
-        twp[k] = make_float2((float)std::cos(a), (float)std::sin(a));
     }
-    HIP_TRY(c, upload(&c->d_window, win));
-    HIP_TRY(c, upload(&c->d_tw_a, twa));
-    HIP_TRY(c, upload(&c->d_tw_b, twb));
-    HIP_TRY(c, upload(&c->d_tw_post, twp));
+    HIP_TRY(c, upload(&c->d_tables, tab));
 
     const int F = 1 + n_fft / 2;
     c->mel_basis = mel_filterbank(f.sr, n_fft, f.n_mels, f.fmin, f.fmax);
+    // mel rows for the kernel: start bin rounded down to a multiple of 4, weights zero padded to
+    // whole 16-bin steps (4 lanes x float4), so both the weights and the power spectrum are read
+    // as aligned float4
     std::vector<int32_t> st(f.n_mels), ln(f.n_mels), wo(f.n_mels);
     std::vector<float> wv;
     for (int m = 0; m < f.n_mels; ++m) {
         int first = -1, last = -1;
         for (int k = 0; k < F; ++k)
             if (c->mel_basis[(size_t)m * F + k] != 0.0f) { if (first < 0) first = k; last = k; }
-        st[m] = first < 0 ? 0 : first;
-        ln[m] = first < 0 ? 0 : last - first + 1;
+        const int st4 = first < 0 ? 0 : (first & ~3);
+        const int steps = first < 0 ? 0 : (last - st4 + 16) / 16;
+        st[m] = st4;
+        ln[m] = steps;
         wo[m] = (int32_t)wv.size();
-        for (int k = 0; k < ln[m]; ++k) wv.push_back(c->mel_basis[(size_t)m * F + st[m] + k]);
+        for (int j = 0; j < 16 * steps; ++j) {
+            const int k = st4 + j;
+            wv.push_back(k < F ? c->mel_basis[(size_t)m * F + k] : 0.0f);
+        }
     }
     HIP_TRY(c, upload(&c->d_mel_start, st));
     HIP_TRY(c, upload(&c->d_mel_len, ln));
@@ -377,13 +398,15 @@ int build_encoder(amph_ctx* c, const float* hw, size_t n_floats) {
     return AMPH_OK;
 }
 
-int alloc_workspace(amph_ctx* c) {
+int alloc_lane(amph_ctx* c, Workspace& w, bool own_stream) {
     const int MB = c->max_batch;
     const amph_frontend_config& f = c->cfg;
-    HIP_TRY(c, hipMalloc((void**)&c->ws_scale, (size_t)MB * sizeof(float)));
-    HIP_TRY(c, hipMalloc((void**)&c->ws_ok, (size_t)MB * sizeof(int32_t)));
-    HIP_TRY(c, hipMalloc((void**)&c->ws_melpow, (size_t)MB * c->n_frames * f.n_mels * sizeof(float)));
-    HIP_TRY(c, hipMalloc((void**)&c->ws_image, (size_t)MB * f.target_frames * f.n_mels * sizeof(float)));
+    if (own_stream) HIP_TRY(c, hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+    HIP_TRY(c, hipEventCreateWithFlags(&w.done, hipEventDisableTiming));
+    HIP_TRY(c, hipMalloc((void**)&w.scale, (size_t)MB * sizeof(float)));
+    HIP_TRY(c, hipMalloc((void**)&w.ok, (size_t)MB * sizeof(int32_t)));
+    HIP_TRY(c, hipMalloc((void**)&w.melpow, (size_t)MB * c->n_frames * f.n_mels * sizeof(float)));
+    HIP_TRY(c, hipMalloc((void**)&w.image, (size_t)MB * f.target_frames * f.n_mels * sizeof(float)));
     if (c->has_encoder) {
         int H = c->spec.in_frames, W = c->spec.in_mels;
         for (int i = 0; i < c->spec.n_conv; ++i) {
@@ -392,11 +415,38 @@ int alloc_workspace(amph_ctx* c) {
             W = (W + 2 * l.pad - l.kernel) / l.stride + 1;
             float* p = nullptr;
             HIP_TRY(c, hipMalloc((void**)&p, (size_t)MB * H * W * l.c_out * sizeof(float)));
-            c->ws_act.push_back(p);
+            w.act.push_back(p);
         }
-        HIP_TRY(c, hipMalloc((void**)&c->ws_partial, (size_t)c->head_splits * MB * 2 * c->latent * sizeof(float)));
+        HIP_TRY(c, hipMalloc((void**)&w.partial, (size_t)c->head_splits * MB * 2 * c->latent * sizeof(float)));
     }
     return AMPH_OK;
+}
+
+void free_lane(Workspace& w) {
+    auto fr = [](void* p) { if (p) (void)hipFree(p); };
+    fr(w.scale); fr(w.ok); fr(w.melpow); fr(w.image);
+    for (auto p : w.act) fr(p);
+    fr(w.partial);
+    if (w.done) (void)hipEventDestroy(w.done);
+    if (w.stream) (void)hipStreamDestroy(w.stream);
+    w = Workspace();
+}
+
+int set_lanes(amph_ctx* c, int n) {
+    if (n < 1 || n > 8) return fail(c, AMPH_ERR_INVALID_ARG, "lanes must be in 1..8");
+    (void)hipDeviceSynchronize();
+    while ((int)c->lanes.size() > n) { free_lane(c->lanes.back()); c->lanes.pop_back(); }
+    while ((int)c->lanes.size() < n) {
+        c->lanes.emplace_back();
+        const int rc = alloc_lane(c, c->lanes.back(), c->lanes.size() > 1);
+        if (rc != AMPH_OK) return rc;
+    }
+    return AMPH_OK;
+}
+
+int alloc_workspace(amph_ctx* c) {
+    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    return set_lanes(c, 4);
 }
 
 void build_stages(amph_ctx* c) {
@@ -430,12 +480,12 @@ void build_stages(amph_ctx* c) {
 }
 
 // encoder on ws_image-like input; x is [nb][T][M]
-int run_encoder(amph_ctx* c, const float* d_x, int nb, float* d_mu, float* d_logvar, hipStream_t s) {
+int run_encoder(amph_ctx* c, Workspace& w, const float* d_x, int nb, float* d_mu, float* d_logvar, hipStream_t s) {
     {
         StageTimer t(c, ST_CONV0, s);
         ConvFirstParams p = c->first;
         p.x = d_x;
-        p.y = c->ws_act[0];
+        p.y = w.act[0];
         launch_conv_first(p, nb, s);
     }
     const int n_gemm = (int)c->gemm.size();
@@ -443,14 +493,14 @@ int run_encoder(amph_ctx* c, const float* d_x, int nb, float* d_mu, float* d_log
         const bool head = gi == n_gemm - 1;
         GemmLayer& gl = c->gemm[gi];
         ConvGemmParams p = gl.prm;
-        p.x = c->ws_act[gi];
+        p.x = w.act[gi];
         p.M = nb * p.OH * p.OW;
         int bm = 128;
         if (head) {
-            p.y = c->ws_partial;
+            p.y = w.partial;
             bm = 64;
         } else {
-            p.y = c->ws_act[gi + 1];
+            p.y = w.act[gi + 1];
             // keep >= ~2 workgroups per CU when the layer is small
             const long long wg128 = (long long)((p.M + 127) / 128) * ((p.N + 63) / 64);
             if (wg128 < 512) bm = 64;
@@ -461,7 +511,7 @@ int run_encoder(amph_ctx* c, const float* d_x, int nb, float* d_mu, float* d_log
     {
         StageTimer t(c, stage_head_reduce(c), s);
         HeadReduceParams p;
-        p.partial = c->ws_partial; p.bias = c->d_head_bias; p.splits = c->head_splits; p.D = c->latent;
+        p.partial = w.partial; p.bias = c->d_head_bias; p.splits = c->head_splits; p.D = c->latent;
         p.mu = d_mu; p.logvar = d_logvar;
         launch_head_reduce(p, nb, s);
     }
@@ -474,24 +524,24 @@ StftParams make_stft(amph_ctx* c, const WaveSrc& src, float* melpow) {
     p.n_samples = c->cfg.n_samples; p.n_fft = c->cfg.n_fft; p.hop = c->cfg.hop_length; p.n_frames = c->n_frames;
     p.pad_mode = c->cfg.pad_mode; p.frames_per_block = c->frames_per_block;
     p.tiles_per_row = (c->n_frames + c->frames_per_block - 1) / c->frames_per_block;
-    p.window = c->d_window; p.tw_a = c->d_tw_a; p.tw_b = c->d_tw_b; p.tw_post = c->d_tw_post;
+    p.tables = c->d_tables;
     p.n_mels = c->cfg.n_mels; p.mel_start = c->d_mel_start; p.mel_len = c->d_mel_len; p.mel_wofs = c->d_mel_wofs;
     p.mel_w = c->d_mel_w; p.melpow = melpow;
     return p;
 }
 
 // front end for one batch: wave rows -> melpow (-> image)
-int run_frontend(amph_ctx* c, const void* d_wave, bool pcm16, int nb, int n_in, const int32_t* d_len, int apply_rms,
-                 int32_t* d_rms_ok, float* melpow, hipStream_t s) {
+int run_frontend(amph_ctx* c, Workspace& w, const void* d_wave, bool pcm16, int nb, int n_in, const int32_t* d_len,
+                 int apply_rms, int32_t* d_rms_ok, float* melpow, hipStream_t s) {
     WaveSrc src{};
     src.wave = d_wave; src.row_stride = n_in; src.lengths = d_len; src.n_in = n_in;
     src.scale = nullptr; src.requant = 0;
     if (apply_rms) {
         StageTimer t(c, ST_RMS, s);
-        int32_t* okp = d_rms_ok ? d_rms_ok : c->ws_ok;
-        if (pcm16) launch_rms_scale_pcm16((const int16_t*)d_wave, n_in, d_len, n_in, nb, c->ws_scale, okp, s);
-        else launch_rms_scale_f32((const float*)d_wave, n_in, d_len, n_in, nb, c->ws_scale, okp, s);
-        src.scale = c->ws_scale;
+        int32_t* okp = d_rms_ok ? d_rms_ok : w.ok;
+        if (pcm16) launch_rms_scale_pcm16((const int16_t*)d_wave, n_in, d_len, n_in, nb, w.scale, okp, s);
+        else launch_rms_scale_f32((const float*)d_wave, n_in, d_len, n_in, nb, w.scale, okp, s);
+        src.scale = w.scale;
         src.requant = 1;
     } else if (d_rms_ok) {
         (void)hipMemsetAsync(d_rms_ok, 0, (size_t)nb * sizeof(int32_t), s);
@@ -526,13 +576,27 @@ int encode_common(amph_ctx* c, const void* d_wave, bool pcm16, int64_t n_rows, i
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t esz = pcm16 ? 2 : 4;
     const int D = c->latent;
-    for (int64_t off = 0; off < n_rows; off += c->max_batch) {
+    // fork: batches go round-robin over the lanes; lane 0 runs on the caller's stream
+    const int64_t n_batches = (n_rows + c->max_batch - 1) / c->max_batch;
+    const int L = (int)std::min<int64_t>((int64_t)c->lanes.size(), std::max<int64_t>(n_batches, 1));
+    if (L > 1) {
+        HIP_TRY(c, hipEventRecord(c->ev_fork, s));
+        for (int l = 1; l < L; ++l) HIP_TRY(c, hipStreamWaitEvent(c->lanes[l].stream, c->ev_fork, 0));
+    }
+    int64_t bi = 0;
+    for (int64_t off = 0; off < n_rows; off += c->max_batch, ++bi) {
         const int nb = (int)std::min<int64_t>(c->max_batch, n_rows - off);
-        const char* w = (const char*)d_wave + (size_t)off * n_in * esz;
-        run_frontend(c, w, pcm16, nb, n_in, d_len ? d_len + off : nullptr, apply_rms, d_rms_ok ? d_rms_ok + off : nullptr,
-                     c->ws_melpow, s);
-        run_dbnorm(c, c->ws_melpow, nb, 1, c->ws_image, s);
-        run_encoder(c, c->ws_image, nb, d_mu + off * D, d_logvar ? d_logvar + off * D : nullptr, s);
+        Workspace& w = c->lanes[bi % L];
+        hipStream_t ls = (bi % L == 0) ? s : w.stream;
+        const char* wv = (const char*)d_wave + (size_t)off * n_in * esz;
+        run_frontend(c, w, wv, pcm16, nb, n_in, d_len ? d_len + off : nullptr, apply_rms, d_rms_ok ? d_rms_ok + off : nullptr,
+                     w.melpow, ls);
+        run_dbnorm(c, w.melpow, nb, 1, w.image, ls);
+        run_encoder(c, w, w.image, nb, d_mu + off * D, d_logvar ? d_logvar + off * D : nullptr, ls);
+    }
+    for (int l = 1; l < L; ++l) {           // join
+        HIP_TRY(c, hipEventRecord(c->lanes[l].done, c->lanes[l].stream));
+        HIP_TRY(c, hipStreamWaitEvent(s, c->lanes[l].done, 0));
     }
     return check_launch(c, "encode");
 }
@@ -595,14 +659,14 @@ void amph_destroy(amph_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     auto fr = [](void* p) { if (p) (void)hipFree(p); };
-    fr(c->d_window); fr(c->d_tw_a); fr(c->d_tw_b); fr(c->d_tw_post);
+    fr(c->d_tables);
     fr(c->d_mel_start); fr(c->d_mel_len); fr(c->d_mel_wofs); fr(c->d_mel_w);
     fr(c->d_first_w); fr(c->d_first_scale); fr(c->d_first_shift);
     for (auto& g : c->gemm) { fr(g.d_w); fr(g.d_scale); fr(g.d_shift); }
     fr(c->d_head_bias);
-    fr(c->ws_scale); fr(c->ws_ok); fr(c->ws_melpow); fr(c->ws_image);
-    for (auto p : c->ws_act) fr(p);
-    fr(c->ws_partial); fr(c->d_centroids); fr(c->d_thr); fr(c->d_rank);
+    for (auto& w : c->lanes) free_lane(w);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    fr(c->d_centroids); fr(c->d_thr); fr(c->d_rank);
     for (int i = 0; i < 2; ++i) {
         if (c->pin_in[i]) (void)hipHostFree(c->pin_in[i]);
         fr(c->dev_in[i]); fr(c->dev_len[i]);
@@ -615,6 +679,21 @@ void amph_destroy(amph_ctx* c) {
         for (auto& pr : st.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     delete c;
+}
+
+int amph_configure(amph_ctx* c, const char* key, int value) {
+    if (!c || !key) return AMPH_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!std::strcmp(key, "lanes")) return set_lanes(c, value);
+    if (!std::strcmp(key, "frames_per_block")) {
+        if (value < 4 || value > 32 || (value & 3)) return fail(c, AMPH_ERR_INVALID_ARG, "frames_per_block must be a multiple of 4 in 4..32");
+        const int lds = (int)stft_mel_lds_bytes(c->cfg.n_fft, c->cfg.hop_length, value);
+        if (lds > 160 * 1024) return fail(c, AMPH_ERR_UNSUPPORTED, "frame tile needs %d bytes of LDS", lds);
+        if (amph::stft_mel_configure(lds) != hipSuccess) return fail(c, AMPH_ERR_HIP, "hipFuncSetAttribute failed");
+        c->frames_per_block = value;
+        return AMPH_OK;
+    }
+    return fail(c, AMPH_ERR_INVALID_ARG, "unknown option '%s'", key);
 }
 
 int amph_raw_frames(const amph_ctx* c) { return c ? c->n_frames : -1; }
@@ -634,9 +713,10 @@ int amph_rms_normalize_f32(amph_ctx* c, const float* d_in, int n_rows, int n, fl
     hipStream_t s = (hipStream_t)stream;
     for (int off = 0; off < n_rows; off += c->max_batch) {
         const int nb = std::min(c->max_batch, n_rows - off);
-        int32_t* okp = d_ok ? d_ok + off : c->ws_ok;
-        launch_rms_scale_f32(d_in + (size_t)off * n, n, nullptr, n, nb, c->ws_scale, okp, s);
-        launch_rms_apply_f32(d_in + (size_t)off * n, nb, n, c->ws_scale, okp, d_out + (size_t)off * n, s);
+        Workspace& w = c->lanes[0];
+        int32_t* okp = d_ok ? d_ok + off : w.ok;
+        launch_rms_scale_f32(d_in + (size_t)off * n, n, nullptr, n, nb, w.scale, okp, s);
+        launch_rms_apply_f32(d_in + (size_t)off * n, nb, n, w.scale, okp, d_out + (size_t)off * n, s);
     }
     return check_launch(c, "rms_normalize_f32");
 }
@@ -648,9 +728,10 @@ int amph_rms_normalize_pcm16(amph_ctx* c, const int16_t* d_in, int n_rows, int n
     hipStream_t s = (hipStream_t)stream;
     for (int off = 0; off < n_rows; off += c->max_batch) {
         const int nb = std::min(c->max_batch, n_rows - off);
-        int32_t* okp = d_ok ? d_ok + off : c->ws_ok;
-        launch_rms_scale_pcm16(d_in + (size_t)off * n, n, nullptr, n, nb, c->ws_scale, okp, s);
-        launch_rms_apply_pcm16(d_in + (size_t)off * n, nb, n, c->ws_scale, okp, d_out + (size_t)off * n, s);
+        Workspace& w = c->lanes[0];
+        int32_t* okp = d_ok ? d_ok + off : w.ok;
+        launch_rms_scale_pcm16(d_in + (size_t)off * n, n, nullptr, n, nb, w.scale, okp, s);
+        launch_rms_apply_pcm16(d_in + (size_t)off * n, nb, n, w.scale, okp, d_out + (size_t)off * n, s);
     }
     return check_launch(c, "rms_normalize_pcm16");
 }
@@ -664,8 +745,8 @@ int amph_mel_power_f32(amph_ctx* c, const float* d_wave, int n_rows, int n_in, c
     const size_t per = (size_t)c->n_frames * c->cfg.n_mels;
     for (int off = 0; off < n_rows; off += c->max_batch) {
         const int nb = std::min(c->max_batch, n_rows - off);
-        run_frontend(c, d_wave + (size_t)off * n_in, false, nb, n_in, d_lengths ? d_lengths + off : nullptr, 0, nullptr,
-                     d_melpow_out + (size_t)off * per, s);
+        run_frontend(c, c->lanes[0], d_wave + (size_t)off * n_in, false, nb, n_in, d_lengths ? d_lengths + off : nullptr, 0,
+                     nullptr, d_melpow_out + (size_t)off * per, s);
     }
     return check_launch(c, "mel_power_f32");
 }
@@ -680,9 +761,9 @@ int amph_mel_f32(amph_ctx* c, const float* d_wave, int n_rows, int n_in, const i
     const size_t per = (size_t)c->cfg.target_frames * c->cfg.n_mels;
     for (int off = 0; off < n_rows; off += c->max_batch) {
         const int nb = std::min(c->max_batch, n_rows - off);
-        run_frontend(c, d_wave + (size_t)off * n_in, false, nb, n_in, d_lengths ? d_lengths + off : nullptr, 0, nullptr,
-                     c->ws_melpow, s);
-        run_dbnorm(c, c->ws_melpow, nb, layout, d_mel_out + (size_t)off * per, s);
+        run_frontend(c, c->lanes[0], d_wave + (size_t)off * n_in, false, nb, n_in, d_lengths ? d_lengths + off : nullptr, 0,
+                     nullptr, c->lanes[0].melpow, s);
+        run_dbnorm(c, c->lanes[0].melpow, nb, layout, d_mel_out + (size_t)off * per, s);
     }
     return check_launch(c, "mel_f32");
 }
@@ -697,7 +778,7 @@ int amph_encoder_forward(amph_ctx* c, const float* d_x, int n_rows, float* d_mu,
     const int D = c->latent;
     for (int off = 0; off < n_rows; off += c->max_batch) {
         const int nb = std::min(c->max_batch, n_rows - off);
-        run_encoder(c, d_x + (size_t)off * per, nb, d_mu + (size_t)off * D, d_logvar ? d_logvar + (size_t)off * D : nullptr, s);
+        run_encoder(c, c->lanes[0], d_x + (size_t)off * per, nb, d_mu + (size_t)off * D, d_logvar ? d_logvar + (size_t)off * D : nullptr, s);
     }
     return check_launch(c, "encoder_forward");
 }

@@ -29,15 +29,12 @@ struct StftParams {
     int pad_mode;            // 0 reflect, 1 constant
     int frames_per_block;    // FT
     int tiles_per_row;       // ceil(n_frames / FT)
-    const float* window;     // [n_fft] periodic Hann
-    const float2* tw_a;      // [16][L]  W_Nc^(t*k1)
-    const float2* tw_b;      // [16][T_LO] W_L^(t_lo*k2a)
-    const float2* tw_post;   // [Nc/2 + 1] W_{2Nc}^k
+    const float* tables;     // packed LDS image: half window | tw_a | tw_b | tw_post (stft_mel_table_bytes())
     int n_mels;
-    const int32_t* mel_start;  // [n_mels] first FFT bin of the filter
-    const int32_t* mel_len;    // [n_mels] number of non-zero bins
-    const int32_t* mel_wofs;   // [n_mels] offset into mel_w
-    const float* mel_w;
+    const int32_t* mel_start;  // [n_mels] first FFT bin of the filter rounded down to a multiple of 4
+    const int32_t* mel_len;    // [n_mels] number of 16-bin steps covering the filter
+    const int32_t* mel_wofs;   // [n_mels] offset into mel_w (multiple of 4)
+    const float* mel_w;        // per filter 16*steps weights, zero padded, 16-byte aligned
     float* melpow;           // [B][n_frames][n_mels]
 };
 
@@ -59,6 +56,7 @@ void launch_rms_apply_pcm16(const int16_t* in, int n_rows, int n, const float* s
 // sample_is_pcm16: 1 -> src.wave is int16_t, 0 -> float
 void launch_stft_mel(const StftParams& p, int n_rows, int sample_is_pcm16, hipStream_t s);
 size_t stft_mel_lds_bytes(int n_fft, int hop, int frames_per_block);
+int stft_mel_table_bytes();
 hipError_t stft_mel_configure(int lds_bytes);   // raises the dynamic-LDS limit of the STFT kernels
 void launch_dbnorm(const DbNormParams& p, int n_rows, hipStream_t s);
 

@@ -87,7 +87,7 @@ __device__ __forceinline__ float block_max(float v, float* sh) {
 // ----------------------------------------------------------------------------
 constexpr int kNpChunk = 8192;     // numpy ufunc buffer size (elements)
 constexpr int kNpBlock = 128;      // PW_BLOCKSIZE
-constexpr int kChunksPerPass = 4;
+constexpr int kChunksPerPass = 2;  // chunks staged in LDS per pass (128 blocks -> 128 busy threads)
 
 __device__ __forceinline__ int np_split(int n) { const int h = n >> 1; return h - (h & 7); }
 
@@ -110,79 +110,127 @@ __device__ __forceinline__ void np_walk(int n, int path, int level, int& off, in
     reached = l;
 }
 
+// LDS image of a pass: element e of the pass at byte e*sizeof(T) + (e >> 7) * 16: one 16-byte pad
+// per 128-element block makes the per-block ds_read_b128 of 64 lanes conflict-free (odd slot stride)
+template <typename T>
+__device__ __forceinline__ int np_lds_off(int e) { return e * (int)sizeof(T) + ((e >> 7) << 4); }
+
 // NOTE: `__fmul_rn` / `__fadd_rn` are device-library functions whose fmul / fadd carry the
 // library's own `contract` flag: hipcc fused them into v_fmac (seen in the ISA; 1-ulp
 // differences from numpy).  Code that must round each operation separately is written
 // with plain operators under `#pragma clang fp contract(off)` and checked in the ISA.
-template <bool PCM16>
-__device__ __forceinline__ float sq_at(const void* row, int i) {
+__device__ __forceinline__ float sq_of(int16_t q) {
 #pragma clang fp contract(off)
-    float y;
-    if (PCM16) y = (float)reinterpret_cast<const int16_t*>(row)[i] * (1.0f / 32768.0f);
-    else y = reinterpret_cast<const float*>(row)[i];
+    const float y = (float)q * (1.0f / 32768.0f);
+    return y * y;
+}
+__device__ __forceinline__ float sq_of(float y) {
+#pragma clang fp contract(off)
     return y * y;
 }
 
-template <bool PCM16>
-__global__ __launch_bounds__(256) void k_rms_scale(const void* __restrict__ in, long long row_stride,
+template <typename T>
+__global__ __launch_bounds__(256) void k_rms_scale(const T* __restrict__ in, long long row_stride,
                                                    const int32_t* __restrict__ lengths, int n_in,
                                                    float* __restrict__ scale, int32_t* __restrict__ ok) {
 #pragma clang fp contract(off)
-    __shared__ float heap[kChunksPerPass][2 * 64];       // chunk depth <= 6: 64 leaves, heap of 128
+    constexpr int kPassElems = kChunksPerPass * kNpChunk;
+    constexpr int kVec = 16 / (int)sizeof(T);            // elements per 16-byte LDS read
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* heap = reinterpret_cast<float*>(smem);        // [kChunksPerPass][128]
+    char* img = smem + kChunksPerPass * 128 * 4;
     const int row = blockIdx.x, tid = threadIdx.x;
-    const char* x = reinterpret_cast<const char*>(in) + (long long)row * row_stride * (PCM16 ? 2 : 4);
+    const T* x = in + (long long)row * row_stride;
     const int n = lengths ? min(lengths[row], n_in) : n_in;
     const int n_chunks = (n + kNpChunk - 1) / kNpChunk;
     float total = 0.0f;                                  // thread 0 only
     for (int c0 = 0; c0 < n_chunks; c0 += kChunksPerPass) {
-        // ---- leaves: task = (chunk, leaf slot, accumulator lane)
-        for (int task = tid; task < kChunksPerPass * 64 * 8; task += 256) {
-            const int cl = task >> 9, slot = (task >> 3) & 63, j = task & 7;
-            const int chunk = c0 + cl;
-            bool owner = false;
-            int off = 0, size = 0, lvl = 0, rem = 0;
+        // ---- stage this pass's samples, coalesced (dword granules when the row is 4-byte aligned)
+        const int e0 = c0 * kNpChunk, ne = min(kPassElems, n - e0);
+        constexpr int U = 8;
+        if (sizeof(T) == 2 && (((uintptr_t)(x + e0)) & 3u) == 0) {
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(x + e0);
+            const int nd = ne >> 1;
+            for (int base = 0; base < nd; base += 256 * U) {
+                uint32_t v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) { const int d = base + tid + 256 * u; v[u] = d < nd ? src[d] : 0u; }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int d = base + tid + 256 * u;
+                    if (d < nd) *reinterpret_cast<uint32_t*>(img + np_lds_off<T>(2 * d)) = v[u];
+                }
+            }
+            if ((ne & 1) && tid == 0) *reinterpret_cast<T*>(img + np_lds_off<T>(ne - 1)) = x[e0 + ne - 1];
+        } else {
+            for (int base = 0; base < ne; base += 256 * U) {
+                T v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) { const int e = base + tid + 256 * u; v[u] = e < ne ? x[e0 + e] : (T)0; }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int e = base + tid + 256 * u;
+                    if (e < ne) *reinterpret_cast<T*>(img + np_lds_off<T>(e)) = v[u];
+                }
+            }
+        }
+        __syncthreads();
+        // ---- leaves: thread = (chunk of the pass, leaf slot); 8 accumulators in registers
+        if (tid < kChunksPerPass * 64) {
+            const int cl = tid >> 6, slot = tid & 63, chunk = c0 + cl;
             if (chunk < n_chunks) {
                 const int cn = min(kNpChunk, n - chunk * kNpChunk);
-                const int D = np_depth(cn);
-                if (slot < (1 << D)) {
-                    np_walk(cn, slot, D, off, size, lvl);
+                int off, size, lvl, rem = 0;
+                bool owner;
+                if (cn == kNpChunk) { off = slot * kNpBlock; size = kNpBlock; lvl = 6; owner = true; }
+                else {
+                    const int D = np_depth(cn);
+                    owner = slot < (1 << D);
+                    np_walk(cn, owner ? slot : 0, D, off, size, lvl);
                     rem = D - lvl;
-                    owner = (slot & ((1 << rem) - 1)) == 0;   // an early leaf belongs to the slot with zero low bits
-                    off += chunk * kNpChunk;
+                    owner = owner && (slot & ((1 << rem) - 1)) == 0;   // an early leaf belongs to the slot with zero low bits
                 }
-            }
-            float r = 0.0f;
-            const int body = size - (size & 7);
-            if (owner && size >= 8) {
-                r = sq_at<PCM16>(x, off + j);
-                for (int i = 8; i < body; i += 8) r = (r + sq_at<PCM16>(x, off + i + j));
-            }
-            r = (r + dpp_xor1(r));
-            r = (r + dpp_xor2(r));
-            r = (r + __shfl_xor(r, 4));
-            if (owner && j == 0) {
-                if (size < 8) {                           // numpy: res = -0.0; res += a[i]
-                    r = -0.0f;
-                    for (int i = 0; i < size; ++i) r = (r + sq_at<PCM16>(x, off + i));
-                } else {
-                    for (int i = body; i < size; ++i) r = (r + sq_at<PCM16>(x, off + i));
+                if (owner) {
+                    const int eb = cl * kNpChunk + off;                 // element index inside the pass
+                    float res;
+                    if (size < 8) {                                     // numpy: res = -0.0; res += a[i]
+                        res = -0.0f;
+                        for (int i = 0; i < size; ++i) res = res + sq_of(*reinterpret_cast<const T*>(img + np_lds_off<T>(eb + i)));
+                    } else {
+                        float r[8];
+                        const int body = size - (size & 7);
+                        for (int i = 0; i < body; i += 8) {
+                            T v[8];
+#pragma unroll
+                            for (int h = 0; h < 8 / kVec; ++h)
+                                *reinterpret_cast<int4*>(&v[h * kVec]) = *reinterpret_cast<const int4*>(img + np_lds_off<T>(eb + i + h * kVec));
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) r[j] = (i == 0) ? sq_of(v[j]) : r[j] + sq_of(v[j]);
+                        }
+                        res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+                        for (int i = body; i < size; ++i) res = res + sq_of(*reinterpret_cast<const T*>(img + np_lds_off<T>(eb + i)));
+                    }
+                    heap[cl * 128 + (1 << lvl) + (slot >> rem)] = res;
                 }
-                heap[cl][(1 << lvl) + (slot >> rem)] = r;
             }
         }
         __syncthreads();
         // ---- internal nodes, deepest level first: value = left + right
         for (int lvl = 5; lvl >= 0; --lvl) {
-            for (int t = tid; t < kChunksPerPass << lvl; t += 256) {
-                const int cl = t >> lvl, path = t & ((1 << lvl) - 1);
-                const int chunk = c0 + cl;
+            const int t = tid;
+            if (t < (kChunksPerPass << lvl)) {
+                const int cl = t >> lvl, path = t & ((1 << lvl) - 1), chunk = c0 + cl;
                 if (chunk < n_chunks) {
                     const int cn = min(kNpChunk, n - chunk * kNpChunk);
-                    int off, size, reached;
-                    np_walk(cn, path, lvl, off, size, reached);
-                    if (reached == lvl && size > kNpBlock) {
-                        const int idx = (1 << lvl) + path;
-                        heap[cl][idx] = (heap[cl][2 * idx] + heap[cl][2 * idx + 1]);
+                    bool internal = cn == kNpChunk;
+                    if (!internal) {
+                        int off, size, reached;
+                        np_walk(cn, path, lvl, off, size, reached);
+                        internal = reached == lvl && size > kNpBlock;
+                    }
+                    if (internal) {
+                        const int idx = cl * 128 + (1 << lvl) + path;
+                        heap[idx] = heap[cl * 128 + 2 * ((1 << lvl) + path)] + heap[cl * 128 + 2 * ((1 << lvl) + path) + 1];
                     }
                 }
             }
@@ -190,7 +238,7 @@ __global__ __launch_bounds__(256) void k_rms_scale(const void* __restrict__ in, 
         }
         if (tid == 0) {
             for (int cl = 0; cl < kChunksPerPass && c0 + cl < n_chunks; ++cl)
-                total = (c0 + cl == 0) ? heap[cl][1] : (total + heap[cl][1]);
+                total = (c0 + cl == 0) ? heap[cl * 128 + 1] : total + heap[cl * 128 + 1];
         }
         __syncthreads();
     }
@@ -204,6 +252,11 @@ __global__ __launch_bounds__(256) void k_rms_scale(const void* __restrict__ in, 
         scale[row] = sc;
         if (ok) ok[row] = good;
     }
+}
+
+template <typename T>
+static size_t rms_scale_lds() {
+    return (size_t)kChunksPerPass * 128 * 4 + (size_t)kChunksPerPass * kNpChunk * sizeof(T) + (size_t)kChunksPerPass * 64 * 16;
 }
 
 // y = clip(x * scale, -1, 1) for scaled rows; gated rows (scale == 1 and not ok)
@@ -282,12 +335,16 @@ __device__ __forceinline__ void dft16(float (&re)[16], float (&im)[16]) {
                    re[4 * ka + 3], im[4 * ka + 3]);
 }
 
+// sample s of a row as float32 before normalisation (0 beyond the valid length: the zero
+// pad of fix_length, map_detector_core.py:214-215)
 template <bool PCM16>
-__device__ __forceinline__ float fetch_sample(const WaveSrc& src, const void* rowp, int s, int len, float sc) {
-    if (s >= len) return 0.0f;                       // zero pad of fix_length (map_detector_core.py:214-215)
-    float x;
-    if (PCM16) x = (float)reinterpret_cast<const int16_t*>(rowp)[s] * (1.0f / 32768.0f);
-    else x = reinterpret_cast<const float*>(rowp)[s];
+__device__ __forceinline__ float load_sample(const void* rowp, int s, int len) {
+    if (s < 0 || s >= len) return 0.0f;
+    if (PCM16) return (float)reinterpret_cast<const int16_t*>(rowp)[s] * (1.0f / 32768.0f);
+    return reinterpret_cast<const float*>(rowp)[s];
+}
+// RMS scale + clip + the PCM16 write/read of 00_normalize (x*32767, rint, /32768)
+__device__ __forceinline__ float normalise_sample(const WaveSrc& src, float x, float sc) {
     if (src.scale) {
         x = fminf(fmaxf(x * sc, -1.0f), 1.0f);
         if (src.requant) x = rintf(x * 32767.0f) * (1.0f / 32768.0f);
@@ -296,9 +353,13 @@ __device__ __forceinline__ float fetch_sample(const WaveSrc& src, const void* ro
 }
 
 constexpr int kNc = 1024;                             // complex FFT length (n_fft = 2048)
-constexpr int kWaveExBytes = 16 * kExStride * 8;      // 8704: exchange tile, reused as Z[1024 + 4*kZPad]
-constexpr int kWavePBytes = 4112;                     // 1025 floats of power, rounded to 16
-constexpr int kWaveScratch = kWaveExBytes + kWavePBytes;
+constexpr int kWaveScratch = 16 * kExStride * 8;      // 8704 B per wave: exchange tile, then Z[1024 + 4*kZPad], then P[1025 + pad]
+// LDS tables (bytes, all multiples of 16), staged once per workgroup:
+constexpr int kWinHalfBytes = 4112;                   // w[0 .. 1024] of the periodic Hann window (w[n] == w[N - n])
+constexpr int kTwABytes = 15 * 64 * 8;                // W_1024^(t*k1), k1 = 1..15
+constexpr int kTwBBytes = 16 * 4 * 8;                 // W_64^(t_lo*k2a)
+constexpr int kTwPostBytes = 4112;                    // W_2048^k, k = 0..512
+constexpr int kTableBytes = kWinHalfBytes + kTwABytes + kTwBBytes + kTwPostBytes;
 
 template <bool PCM16>
 __global__ __launch_bounds__(256) void k_stft_mel(StftParams p) {
@@ -310,14 +371,26 @@ __global__ __launch_bounds__(256) void k_stft_mel(StftParams p) {
     const int f_base = tile * FT;
     const int n_fft = 2 * kNc;
     const int span_len = (FT - 1) * p.hop + n_fft;
-    float* span = reinterpret_cast<float*>(smem);
     const int span_bytes = (span_len * 4 + 15) & ~15;
-    char* wbase = smem + span_bytes + wave * kWaveScratch;
+    float* win_h = reinterpret_cast<float*>(smem);
+    float2* tw_a = reinterpret_cast<float2*>(smem + kWinHalfBytes);
+    float2* tw_b = reinterpret_cast<float2*>(smem + kWinHalfBytes + kTwABytes);
+    float2* tw_p = reinterpret_cast<float2*>(smem + kWinHalfBytes + kTwABytes + kTwBBytes);
+    float* span = reinterpret_cast<float*>(smem + kTableBytes);
+    char* wbase = smem + kTableBytes + span_bytes + wave * kWaveScratch;
     float2* ex = reinterpret_cast<float2*>(wbase);
-    float* P = reinterpret_cast<float*>(wbase + kWaveExBytes);
+    float* P = reinterpret_cast<float*>(wbase);
 
-    // ---- stage the sample span of this frame tile (decode / normalise on load)
+    // ---- stage the tables (one packed global array, same layout as the LDS image) and the
+    //      sample span of this frame tile (decode / normalise on load).  Loads are issued in
+    //      batches of independent requests so their latencies overlap instead of chaining.
     {
+        const float4* src = reinterpret_cast<const float4*>(p.tables);
+        float4* dst = reinterpret_cast<float4*>(smem);
+        constexpr int kTabVec = kTableBytes / 16;
+        float4 t[(kTabVec + 255) / 256];
+#pragma unroll
+        for (int u = 0; u < (kTabVec + 255) / 256; ++u) t[u] = src[min(tid + 256 * u, kTabVec - 1)];
         const char* rowp = reinterpret_cast<const char*>(p.src.wave) +
                            (long long)row * p.src.row_stride * (PCM16 ? 2 : 4);
         int len = p.src.lengths ? min(p.src.lengths[row], p.src.n_in) : p.src.n_in;
@@ -325,20 +398,31 @@ __global__ __launch_bounds__(256) void k_stft_mel(StftParams p) {
         const float sc = p.src.scale ? p.src.scale[row] : 1.0f;
         const int N = p.n_samples;
         const int s0 = f_base * p.hop - (n_fft >> 1);
-        for (int i = tid; i < span_len; i += 256) {
-            int s = s0 + i;
-            float v = 0.0f;
-            if (p.pad_mode == 0) {                    // reflect (np.pad mode="reflect")
-                if (s < 0) s = -s;
-                if (s >= N) s = 2 * (N - 1) - s;
+        constexpr int U = 8;
+        for (int base = 0; base < span_len; base += 256 * U) {
+            float x[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                int sidx = s0 + base + tid + 256 * u;
+                if (p.pad_mode == 0) {                // reflect (np.pad mode="reflect")
+                    if (sidx < 0) sidx = -sidx;
+                    if (sidx >= N) sidx = 2 * (N - 1) - sidx;
+                } else if (sidx >= N) sidx = -1;      // constant (zero) padding
+                x[u] = load_sample<PCM16>(rowp, sidx, len);
             }
-            if (s >= 0 && s < N) v = fetch_sample<PCM16>(p.src, rowp, s, len, sc);
-            span[i] = v;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = base + tid + 256 * u;
+                if (i < span_len) span[i] = normalise_sample(p.src, x[u], sc);
+            }
         }
+#pragma unroll
+        for (int u = 0; u < (kTabVec + 255) / 256; ++u) { const int i = tid + 256 * u; if (i < kTabVec) dst[i] = t[u]; }
     }
     __syncthreads();
 
     const int k1b = lane >> 2, t_lo = lane & 3;
+    const int k2b = ((t_lo & 1) << 1) | (t_lo >> 1);   // stage C leaves k2b bit-reversed across the quad
     for (int fl = wave; fl < FT; fl += 4) {
         const int frame = f_base + fl;
         if (frame >= p.n_frames) break;               // wave-uniform
@@ -346,13 +430,15 @@ __global__ __launch_bounds__(256) void k_stft_mel(StftParams p) {
         // ---- window + even/odd packing: z[n] = x[2n] w[2n] + i x[2n+1] w[2n+1], n = lane + 64 j
         {
             const float2* xs = reinterpret_cast<const float2*>(span + fl * p.hop);
-            const float2* wn = reinterpret_cast<const float2*>(p.window);
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const float2 x = xs[lane + 64 * j];
-                const float2 w = wn[lane + 64 * j];
-                re[j] = x.x * w.x;
-                im[j] = x.y * w.y;
+                const int n = lane + 64 * j;
+                const float2 x = xs[n];
+                float w0, w1;
+                if (j < 8) { const float2 w = reinterpret_cast<const float2*>(win_h)[n]; w0 = w.x; w1 = w.y; }
+                else { const int m = n_fft - 2 * n; w0 = win_h[m]; w1 = win_h[m - 1]; }   // w[2n] = w[N-2n], w[2n+1] = w[N-2n-1]
+                re[j] = x.x * w0;
+                im[j] = x.y * w1;
             }
         }
         // ---- stage A
@@ -361,7 +447,7 @@ __global__ __launch_bounds__(256) void k_stft_mel(StftParams p) {
         for (int k1 = 0; k1 < 16; ++k1) {
             float r = re[DFT16_POS(k1)], i = im[DFT16_POS(k1)];
             if (k1 > 0) {
-                const float2 w = p.tw_a[k1 * 64 + lane];
+                const float2 w = tw_a[(k1 - 1) * 64 + lane];
                 AMPH_CMUL(r, i, w.x, w.y);
             }
             ex[k1 * kExStride + lane] = make_float2(r, i);
@@ -375,12 +461,13 @@ __global__ __launch_bounds__(256) void k_stft_mel(StftParams p) {
             im[m] = v.y;
         }
         dft16(re, im);
-        float zr[16], zi[16];
+        wave_lds_sync();                              // the Z image below overwrites `ex`
+        float2* Z = ex;
 #pragma unroll
         for (int k2a = 0; k2a < 16; ++k2a) {
             float r = re[DFT16_POS(k2a)], i = im[DFT16_POS(k2a)];
             if (k2a > 0) {
-                const float2 w = p.tw_b[k2a * 4 + t_lo];
+                const float2 w = tw_b[k2a * 4 + t_lo];
                 AMPH_CMUL(r, i, w.x, w.y);
             }
             // ---- stage C: radix-4 over the quad's t_lo (xor-2 then xor-1 butterflies)
@@ -397,30 +484,28 @@ __global__ __launch_bounds__(256) void k_stft_mel(StftParams p) {
                 if ((t_lo & 1) == 0) { r = nr + qr; i = ni + qi; }
                 else { r = qr - nr; i = qi - ni; }
             }
-            zr[k2a] = r;
-            zi[k2a] = i;
-        }
-        wave_lds_sync();                              // all stage-B reads of `ex` are done
-        {
-            // lane holds X[k1b + 16 k2a + 256 k2b], k2b = bit-reversed t_lo
-            const int k2b = ((t_lo & 1) << 1) | (t_lo >> 1);
-            float2* Z = ex;
-#pragma unroll
-            for (int k2a = 0; k2a < 16; ++k2a)
-                Z[k1b + 16 * k2a + (256 + kZPad) * k2b] = make_float2(zr[k2a], zi[k2a]);
+            // lane holds X[k1b + 16 k2a + 256 k2b]
+            Z[k1b + 16 * k2a + (256 + kZPad) * k2b] = make_float2(r, i);
         }
         wave_lds_sync();
-        // ---- real-FFT split: bins k and 1024 - k from Z[k], Z[1024 - k]
+        // ---- real-FFT split: bins k and 1024 - k from Z[k], Z[1024 - k]; the power spectrum
+        //      is written over the Z image, so every pair is read into registers first
         {
-            const float2* Z = ex;
+            float2 za[9], zb[9];
+#pragma unroll
+            for (int it = 0; it < 9; ++it) {
+                const int k = min(lane + 64 * it, kNc / 2);
+                const int k2 = (kNc - k) & (kNc - 1);
+                za[it] = Z[k + kZPad * (k >> 8)];
+                zb[it] = Z[k2 + kZPad * (k2 >> 8)];
+            }
+            wave_lds_sync();
 #pragma unroll
             for (int it = 0; it < 9; ++it) {
                 const int k = lane + 64 * it;
                 if (k <= kNc / 2) {
-                    const int k2 = (kNc - k) & (kNc - 1);
-                    const float2 a = Z[k + kZPad * (k >> 8)];
-                    const float2 b = Z[k2 + kZPad * (k2 >> 8)];
-                    const float2 w = p.tw_post[k];
+                    const float2 a = za[it], b = zb[it];
+                    const float2 w = tw_p[k];
                     const float xer = 0.5f * (a.x + b.x), xei = 0.5f * (a.y - b.y);      // (Z[k] + conj Z[N-k]) / 2
                     const float xor_ = 0.5f * (a.y + b.y), xoi = -0.5f * (a.x - b.x);    // -i (Z[k] - conj Z[N-k]) / 2
                     const float tr = xor_ * w.x - xoi * w.y, ti = xor_ * w.y + xoi * w.x;
@@ -429,9 +514,10 @@ __global__ __launch_bounds__(256) void k_stft_mel(StftParams p) {
                     if (k != kNc - k) P[kNc - k] = mr * mr + mi * mi;
                 }
             }
+            if (lane < 32) P[kNc + 1 + lane] = 0.0f;   // zero the tail the padded mel rows may touch
         }
         wave_lds_sync();
-        // ---- mel rows: 4 lanes per filter, 16 filters per round
+        // ---- mel rows: 4 lanes per filter, each lane 4 consecutive bins per step (aligned float4)
         {
             float* out = p.melpow + ((long long)row * p.n_frames + frame) * p.n_mels;
             const int q = lane & 3;
@@ -439,26 +525,37 @@ __global__ __launch_bounds__(256) void k_stft_mel(StftParams p) {
                 const int m = m0 + (lane >> 2);
                 float acc = 0.0f;
                 if (m < p.n_mels) {
-                    const int st = p.mel_start[m], len = p.mel_len[m];
-                    const float* w = p.mel_w + p.mel_wofs[m];
-                    for (int i = q; i < len; i += 4) acc = fmaf(w[i], P[st + i], acc);
+                    const int st4 = p.mel_start[m], iters = p.mel_len[m];
+                    const float4* w = reinterpret_cast<const float4*>(p.mel_w + p.mel_wofs[m]) + q;
+                    const float4* pp = reinterpret_cast<const float4*>(P + st4) + q;
+                    for (int i = 0; i < iters; ++i) {
+                        const float4 wv = w[4 * i], pv = pp[4 * i];
+                        acc = fmaf(wv.x, pv.x, acc);
+                        acc = fmaf(wv.y, pv.y, acc);
+                        acc = fmaf(wv.z, pv.z, acc);
+                        acc = fmaf(wv.w, pv.w, acc);
+                    }
                 }
                 acc += dpp_xor1(acc);
                 acc += dpp_xor2(acc);
                 if (q == 0 && m < p.n_mels) out[m] = acc;
             }
         }
-        wave_lds_sync();                              // P / ex are rewritten by the next frame
+        wave_lds_sync();                              // the scratch is rewritten by the next frame
     }
 }
 
 size_t stft_mel_lds_bytes(int n_fft, int hop, int frames_per_block) {
     const size_t span = (((size_t)(frames_per_block - 1) * hop + n_fft) * 4 + 15) & ~(size_t)15;
-    return span + 4 * (size_t)kWaveScratch;
+    return (size_t)kTableBytes + span + 4 * (size_t)kWaveScratch;
 }
+int stft_mel_table_bytes() { return kTableBytes; }
 
 hipError_t stft_mel_configure(int lds_bytes) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stft_mel<true>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rms_scale<float>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)rms_scale_lds<float>());
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stft_mel<true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stft_mel<false>),
@@ -484,48 +581,93 @@ __device__ __forceinline__ float to_db(float s, float ref_db) {
     return fmaxf(db - ref_db, -80.0f);
 }
 
+// kCache > 0: every thread keeps its kCache dB values in registers (one log10f per element);
+// kCache == 0: values are recomputed per pass (any size).
+template <int kCache>
 __global__ __launch_bounds__(256) void k_dbnorm(DbNormParams p) {
     __shared__ double shd[4];
     __shared__ float shf[4];
     const int row = blockIdx.x, tid = threadIdx.x;
     const int n = p.n_frames * p.n_mels;
     const float* S = p.melpow + (long long)row * n;
+    constexpr int C = kCache > 0 ? kCache : 1;
+    float v[C];
     float mx = -INFINITY;
-    for (int i = tid; i < n; i += 256) mx = fmaxf(mx, S[i]);
+    if (kCache > 0) {
+#pragma unroll
+        for (int j = 0; j < C; ++j) { const int i = tid + 256 * j; v[j] = i < n ? S[i] : -INFINITY; mx = fmaxf(mx, v[j]); }
+    } else {
+        for (int i = tid; i < n; i += 256) mx = fmaxf(mx, S[i]);
+    }
     mx = block_max(mx, shf);
     const float ref_db = 10.0f * log10f(fmaxf(1e-10f, mx));             // same two operations as to_db (no FMA)
     double acc = 0.0;
-    for (int i = tid; i < n; i += 256) acc += (double)to_db(S[i], ref_db);
+    if (kCache > 0) {
+#pragma unroll
+        for (int j = 0; j < C; ++j) if (tid + 256 * j < n) { v[j] = to_db(v[j], ref_db); acc += (double)v[j]; }
+    } else {
+        for (int i = tid; i < n; i += 256) acc += (double)to_db(S[i], ref_db);
+    }
     const float mean = (float)(block_sum(acc, shd) / (double)n);
     acc = 0.0;
-    for (int i = tid; i < n; i += 256) { const float d = to_db(S[i], ref_db) - mean; acc += (double)(d * d); }
+    if (kCache > 0) {
+#pragma unroll
+        for (int j = 0; j < C; ++j) if (tid + 256 * j < n) { const float d = v[j] - mean; acc += (double)(d * d); }
+    } else {
+        for (int i = tid; i < n; i += 256) { const float d = to_db(S[i], ref_db) - mean; acc += (double)(d * d); }
+    }
     const float sd = sqrtf((float)(block_sum(acc, shd) / (double)n));
     const float den = sd + 1e-8f;
-    // crop_or_pad_time (map_detector_core.py:185-195)
+    // crop_or_pad_time (map_detector_core.py:185-195): destination frame = source frame - shift
     const int T = p.n_frames, TT = p.target_frames, M = p.n_mels;
-    const int shift = (T >= TT) ? (T - TT) / 2 : -((TT - T) / 2);   // source frame = tt + shift
+    const int shift = (T >= TT) ? (T - TT) / 2 : -((TT - T) / 2);
     float* out = p.out + (long long)row * TT * M;
-    for (int i = tid; i < TT * M; i += 256) {
-        const int tt = i / M, m = i - tt * M;
-        const int src = tt + shift;
-        float v = 0.0f;
-        if (src >= 0 && src < T) v = (to_db(S[src * M + m], ref_db) - mean) / den;
-        if (p.layout == 1) out[i] = v;
-        else out[m * TT + tt] = v;
+    if (kCache > 0) {
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            const int i = tid + 256 * j;
+            if (i < n) {
+                const int fr = i / M, m = i - fr * M, tt = fr - shift;
+                if (tt >= 0 && tt < TT) {
+                    const float z = (v[j] - mean) / den;
+                    if (p.layout == 1) out[tt * M + m] = z;
+                    else out[m * TT + tt] = z;
+                }
+            }
+        }
+        if (T < TT) {                                   // literal zero padding, left then right
+            const int left = -shift, right0 = left + T;
+            for (int i = tid; i < (TT - T) * M; i += 256) {
+                const int fr = i / M, m = i - fr * M;
+                const int tt = fr < left ? fr : right0 + (fr - left);
+                if (p.layout == 1) out[tt * M + m] = 0.0f;
+                else out[m * TT + tt] = 0.0f;
+            }
+        }
+    } else {
+        for (int i = tid; i < TT * M; i += 256) {
+            const int tt = i / M, m = i - tt * M;
+            const int src = tt + shift;
+            float z = 0.0f;
+            if (src >= 0 && src < T) z = (to_db(S[src * M + m], ref_db) - mean) / den;
+            if (p.layout == 1) out[i] = z;
+            else out[m * TT + tt] = z;
+        }
     }
 }
 
 void launch_dbnorm(const DbNormParams& p, int n_rows, hipStream_t s) {
-    hipLaunchKernelGGL(k_dbnorm, dim3(n_rows), dim3(256), 0, s, p);
+    if (p.n_frames * p.n_mels <= 256 * 16) hipLaunchKernelGGL(k_dbnorm<16>, dim3(n_rows), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(k_dbnorm<0>, dim3(n_rows), dim3(256), 0, s, p);
 }
 
 void launch_rms_scale_pcm16(const int16_t* in, long long row_stride, const int32_t* lengths, int n_in, int n_rows,
                             float* scale, int32_t* ok, hipStream_t s) {
-    hipLaunchKernelGGL(k_rms_scale<true>, dim3(n_rows), dim3(256), 0, s, (const void*)in, row_stride, lengths, n_in, scale, ok);
+    hipLaunchKernelGGL(k_rms_scale<int16_t>, dim3(n_rows), dim3(256), rms_scale_lds<int16_t>(), s, in, row_stride, lengths, n_in, scale, ok);
 }
 void launch_rms_scale_f32(const float* in, long long row_stride, const int32_t* lengths, int n_in, int n_rows,
                           float* scale, int32_t* ok, hipStream_t s) {
-    hipLaunchKernelGGL(k_rms_scale<false>, dim3(n_rows), dim3(256), 0, s, (const void*)in, row_stride, lengths, n_in, scale, ok);
+    hipLaunchKernelGGL(k_rms_scale<float>, dim3(n_rows), dim3(256), rms_scale_lds<float>(), s, in, row_stride, lengths, n_in, scale, ok);
 }
 void launch_rms_apply_f32(const float* in, int n_rows, int n, const float* scale, const int32_t* ok, float* out,
                           hipStream_t s) {

@@ -262,6 +262,10 @@ class AmphSession:
             torch.cuda.current_stream(self.device).synchronize()   # host arrays above must outlive the async copies
         return pred, best
 
+    def configure(self, key: str, value: int):
+        """Tuning knobs of include/amph.h's amph_configure ("lanes", "frames_per_block")."""
+        self._chk(N.lib.amph_configure(self._ctx, key.encode(), int(value)))
+
     # -- profiling
     def profile_enable(self, on, only_stage: Optional[int] = None):
         """on=False: off; on=True: every stage; only_stage=i: bracket stage i alone."""

@@ -87,6 +87,13 @@ int amph_create(const amph_frontend_config* cfg, const amph_encoder_spec* spec,
 void amph_destroy(amph_ctx* ctx);
 const char* amph_last_error(const amph_ctx* ctx);   /* ctx may be NULL: create-time error */
 
+/* Tuning knobs (all have working defaults):
+ *   "lanes"            1..8  HIP streams + workspaces the encode entry points spread their
+ *                            batches over (default 2; lane 0 is the caller's stream, the
+ *                            others are forked from / joined to it with events)
+ *   "frames_per_block" 4..32 STFT frames per workgroup (multiple of 4, default 8) */
+int amph_configure(amph_ctx* ctx, const char* key, int value);
+
 /* Geometry derived from the configuration. */
 int amph_raw_frames(const amph_ctx* ctx);     /* T_raw = 1 + n_samples / hop_length */
 int amph_latent_dim(const amph_ctx* ctx);
