@@ -67,6 +67,8 @@ struct amph_ctx {
     // front-end tables
     int n_frames = 0, frames_per_block = 8;
     float* d_tables = nullptr;             // packed LDS image of the STFT tables
+    float2* d_tw_a = nullptr;              // stage-A twiddles (global memory)
+    int mel_w_floats = 0, mel_p_tail = 0;
     int32_t *d_mel_start = nullptr, *d_mel_len = nullptr, *d_mel_wofs = nullptr;
     float* d_mel_w = nullptr;
     std::vector<float> mel_basis;          // dense [n_mels][F] for amph_get_mel_basis
@@ -82,6 +84,8 @@ struct amph_ctx {
     // workspaces (each sized for max_batch); lanes.size() >= 1
     std::vector<Workspace> lanes;
     hipEvent_t ev_fork = nullptr;
+    unsigned long long* d_stamps = nullptr;   // AMPH_STAMPS builds only
+    bool fuse_conv12 = true;               // recompute layer 1 inside layer 2's A staging when the tiling allows
     // radial scratch
     float* d_centroids = nullptr;
     double* d_thr = nullptr;
@@ -222,19 +226,18 @@ int build_frontend(amph_ctx* c) {
 
     const int n_fft = f.n_fft, Nc = n_fft / 2, L = 64, TLO = 4;
     const double PI = 3.14159265358979323846;
-    // packed table image (layout = the kernel's LDS image): half window | tw_a (k1 = 1..15) | tw_b | tw_post
+    // packed table image (layout = the kernel's LDS image): half window | tw_b | tw_post; tw_a separately
     std::vector<float> tab(stft_mel_table_bytes() / 4, 0.0f);
+    std::vector<float2> twa(15 * L);
     {
         float* win = tab.data();                                  // w[0..1024]; w[n] == w[N - n] covers the rest
         for (int n = 0; n <= n_fft / 2; ++n) win[n] = (float)(0.5 - 0.5 * std::cos(2.0 * PI * (double)n / (double)n_fft));
-        float* twa = tab.data() + 4112 / 4;
         for (int k1 = 1; k1 < 16; ++k1)
             for (int t = 0; t < L; ++t) {
                 const double a = -2.0 * PI * (double)((t * k1) % Nc) / (double)Nc;
-                twa[2 * ((k1 - 1) * L + t)] = (float)std::cos(a);
-                twa[2 * ((k1 - 1) * L + t) + 1] = (float)std::sin(a);
+                twa[(k1 - 1) * L + t] = make_float2((float)std::cos(a), (float)std::sin(a));
             }
-        float* twb = twa + 15 * 64 * 2;
+        float* twb = tab.data() + 4112 / 4;
         for (int k2a = 0; k2a < 16; ++k2a)
             for (int t = 0; t < TLO; ++t) {
                 const double a = -2.0 * PI * (double)((t * k2a) % L) / (double)L;
@@ -248,32 +251,44 @@ int build_frontend(amph_ctx* c) {
             twp[2 * k + 1] = (float)std::sin(a);
         }
     }
+    HIP_TRY(c, upload(&c->d_tw_a, twa));
     HIP_TRY(c, upload(&c->d_tables, tab));
 
     const int F = 1 + n_fft / 2;
     c->mel_basis = mel_filterbank(f.sr, n_fft, f.n_mels, f.fmin, f.fmax);
-    // mel rows for the kernel: start bin rounded down to a multiple of 4, weights zero padded to
-    // whole 16-bin steps (4 lanes x float4), so both the weights and the power spectrum are read
-    // as aligned float4
+    // mel rows for the kernel: start bin rounded down to a multiple of 4, weights zero padded to whole
+    // 16-bin steps (4 lanes x float4) and to the longest row of the filter's round of 16 (so the
+    // step count is uniform across a wave); weights and power spectrum are read as aligned float4
     std::vector<int32_t> st(f.n_mels), ln(f.n_mels), wo(f.n_mels);
     std::vector<float> wv;
-    for (int m = 0; m < f.n_mels; ++m) {
-        int first = -1, last = -1;
-        for (int k = 0; k < F; ++k)
-            if (c->mel_basis[(size_t)m * F + k] != 0.0f) { if (first < 0) first = k; last = k; }
-        const int st4 = first < 0 ? 0 : (first & ~3);
-        const int steps = first < 0 ? 0 : (last - st4 + 16) / 16;
-        st[m] = st4;
-        ln[m] = steps;
-        wo[m] = (int32_t)wv.size();
-        for (int j = 0; j < 16 * steps; ++j) {
-            const int k = st4 + j;
-            wv.push_back(k < F ? c->mel_basis[(size_t)m * F + k] : 0.0f);
+    int p_tail = 0;
+    for (int m0 = 0; m0 < f.n_mels; m0 += 16) {
+        int first[16], last[16], round_steps = 0;
+        for (int j = 0; j < 16 && m0 + j < f.n_mels; ++j) {
+            first[j] = last[j] = -1;
+            for (int k = 0; k < F; ++k)
+                if (c->mel_basis[(size_t)(m0 + j) * F + k] != 0.0f) { if (first[j] < 0) first[j] = k; last[j] = k; }
+            if (first[j] >= 0) round_steps = std::max(round_steps, (last[j] - (first[j] & ~3) + 16) / 16);
+        }
+        for (int j = 0; j < 16 && m0 + j < f.n_mels; ++j) {
+            const int m = m0 + j;
+            const int st4 = first[j] < 0 ? 0 : (first[j] & ~3);
+            st[m] = st4;
+            ln[m] = round_steps;
+            wo[m] = (int32_t)wv.size();
+            for (int e = 0; e < 16 * round_steps; ++e) {
+                const int k = st4 + e;
+                wv.push_back(k < F ? c->mel_basis[(size_t)m * F + k] : 0.0f);
+            }
+            p_tail = std::max(p_tail, st4 + 16 * round_steps - F);
         }
     }
+    c->mel_p_tail = std::max(p_tail, 0);
+    if (F + c->mel_p_tail > 2176) return fail(c, AMPH_ERR_UNSUPPORTED, "mel rows reach past the per-wave scratch");
     HIP_TRY(c, upload(&c->d_mel_start, st));
     HIP_TRY(c, upload(&c->d_mel_len, ln));
     HIP_TRY(c, upload(&c->d_mel_wofs, wo));
+    c->mel_w_floats = (int)wv.size();
     HIP_TRY(c, upload(&c->d_mel_w, wv));
     return AMPH_OK;
 }
@@ -481,32 +496,47 @@ void build_stages(amph_ctx* c) {
 
 // encoder on ws_image-like input; x is [nb][T][M]
 int run_encoder(amph_ctx* c, Workspace& w, const float* d_x, int nb, float* d_mu, float* d_logvar, hipStream_t s) {
-    {
+    const int n_gemm = (int)c->gemm.size();
+    // tile height per GEMM layer, then: can layer 2 recompute layer 1 on the fly?
+    std::vector<ConvGemmParams> prm(n_gemm);
+    std::vector<int> bms(n_gemm);
+    for (int gi = 0; gi < n_gemm; ++gi) {
+        const bool head = gi == n_gemm - 1;
+        ConvGemmParams& p = prm[gi];
+        p = c->gemm[gi].prm;
+        p.x = w.act[gi];
+        p.M = nb * p.OH * p.OW;
+        p.img = nullptr;
+        int bm = 128;
+        if (head) { p.y = w.partial; bm = 64; }
+        else {
+            p.y = w.act[gi + 1];
+            // keep >= ~2 workgroups per CU when the layer is small
+            const long long wg128 = (long long)((p.M + 127) / 128) * ((p.N + 63) / 64);
+            if (wg128 < 512) bm = 64;
+        }
+        bms[gi] = bm;
+    }
+    bool fuse = false;
+    if (c->fuse_conv12 && n_gemm >= 2) {
+        ConvGemmParams& p = prm[0];
+        p.img = d_x; p.w1 = c->first.w; p.scale1 = c->first.scale; p.shift1 = c->first.shift;
+        p.H0 = c->first.H; p.W0 = c->first.W; p.k1 = c->first.k; p.s1 = c->first.stride; p.p1 = c->first.pad;
+        fuse = conv_gemm_can_fuse(p, bms[0]);
+        if (!fuse && bms[0] == 128 && conv_gemm_can_fuse(p, 64)) { bms[0] = 64; fuse = true; }
+        if (!fuse) p.img = nullptr;
+    }
+    if (!fuse) {
         StageTimer t(c, ST_CONV0, s);
         ConvFirstParams p = c->first;
         p.x = d_x;
         p.y = w.act[0];
         launch_conv_first(p, nb, s);
     }
-    const int n_gemm = (int)c->gemm.size();
     for (int gi = 0; gi < n_gemm; ++gi) {
         const bool head = gi == n_gemm - 1;
-        GemmLayer& gl = c->gemm[gi];
-        ConvGemmParams p = gl.prm;
-        p.x = w.act[gi];
-        p.M = nb * p.OH * p.OW;
-        int bm = 128;
-        if (head) {
-            p.y = w.partial;
-            bm = 64;
-        } else {
-            p.y = w.act[gi + 1];
-            // keep >= ~2 workgroups per CU when the layer is small
-            const long long wg128 = (long long)((p.M + 127) / 128) * ((p.N + 63) / 64);
-            if (wg128 < 512) bm = 64;
-        }
         StageTimer t(c, head ? stage_head_gemm(c) : ST_CONV0 + 1 + gi, s);
-        launch_conv_gemm(p, bm, s);
+        launch_conv_gemm(prm[gi], bms[gi], fuse && gi == 0, s);
     }
     {
         StageTimer t(c, stage_head_reduce(c), s);
@@ -524,9 +554,13 @@ StftParams make_stft(amph_ctx* c, const WaveSrc& src, float* melpow) {
     p.n_samples = c->cfg.n_samples; p.n_fft = c->cfg.n_fft; p.hop = c->cfg.hop_length; p.n_frames = c->n_frames;
     p.pad_mode = c->cfg.pad_mode; p.frames_per_block = c->frames_per_block;
     p.tiles_per_row = (c->n_frames + c->frames_per_block - 1) / c->frames_per_block;
-    p.tables = c->d_tables;
+    p.tables = c->d_tables; p.tw_a = c->d_tw_a; p.mel_w_floats = c->mel_w_floats; p.p_tail = c->mel_p_tail;
     p.n_mels = c->cfg.n_mels; p.mel_start = c->d_mel_start; p.mel_len = c->d_mel_len; p.mel_wofs = c->d_mel_wofs;
     p.mel_w = c->d_mel_w; p.melpow = melpow;
+#ifdef AMPH_STAMPS
+    if (!c->d_stamps) (void)hipMalloc((void**)&c->d_stamps, (size_t)c->max_batch * 64 * 16 * 8);
+    p.stamps = c->d_stamps;
+#endif
     return p;
 }
 
@@ -641,7 +675,7 @@ int amph_create(const amph_frontend_config* cfg, const amph_encoder_spec* spec, 
     if (rc == AMPH_OK) rc = alloc_workspace(c);
     if (rc == AMPH_OK) {
         build_stages(c);
-        const int lds = (int)stft_mel_lds_bytes(c->cfg.n_fft, c->cfg.hop_length, c->frames_per_block);
+        const int lds = (int)stft_mel_lds_bytes(c->cfg.n_fft, c->cfg.hop_length, c->frames_per_block, c->cfg.n_mels, c->mel_w_floats);
         if (lds > 160 * 1024) rc = fail(c, AMPH_ERR_UNSUPPORTED, "frame tile needs %d bytes of LDS", lds);
         else rc = amph::stft_mel_configure(lds) == hipSuccess ? AMPH_OK : fail(c, AMPH_ERR_HIP, "hipFuncSetAttribute failed");
     }
@@ -659,7 +693,7 @@ void amph_destroy(amph_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     auto fr = [](void* p) { if (p) (void)hipFree(p); };
-    fr(c->d_tables);
+    fr(c->d_tables); fr(c->d_tw_a);
     fr(c->d_mel_start); fr(c->d_mel_len); fr(c->d_mel_wofs); fr(c->d_mel_w);
     fr(c->d_first_w); fr(c->d_first_scale); fr(c->d_first_shift);
     for (auto& g : c->gemm) { fr(g.d_w); fr(g.d_scale); fr(g.d_shift); }
@@ -685,9 +719,32 @@ int amph_configure(amph_ctx* c, const char* key, int value) {
     if (!c || !key) return AMPH_ERR_INVALID_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     if (!std::strcmp(key, "lanes")) return set_lanes(c, value);
+    if (!std::strcmp(key, "fuse_conv12")) { c->fuse_conv12 = value != 0; return AMPH_OK; }
+#ifdef AMPH_STAMPS
+    if (!std::strcmp(key, "dump_stamps")) {      // value = number of workgroups of the last stft launch
+        (void)hipDeviceSynchronize();
+        std::vector<unsigned long long> h((size_t)value * 16);
+        (void)hipMemcpy(h.data(), c->d_stamps, h.size() * 8, hipMemcpyDeviceToHost);
+        double sum[16] = {0};
+        for (int b = 0; b < value; ++b) for (int k = 1; k < 10; ++k) sum[k] += (double)(h[(size_t)b * 16 + k] - h[(size_t)b * 16 + k - 1]);
+        const char* nm[10] = {"", "staging+sync", "window+pack", "stageA+exwrite", "exread", "dft16B", "stageC+Zwrite", "Zread", "post+Pwrite", "mel"};
+        for (int k = 1; k < 10; ++k) fprintf(stderr, "  stamp %-16s %9.0f cycles (mean over %d workgroups, first frame of wave 0)\n", nm[k], sum[k] / value, value);
+        return AMPH_OK;
+    }
+#endif
+    if (!std::strcmp(key, "stft_grid")) {
+        if (value < 1 || value > 65536) return fail(c, AMPH_ERR_INVALID_ARG, "stft_grid must be in 1..65536");
+        amph::g_stft_grid = value;
+        return AMPH_OK;
+    }
+    if (!std::strcmp(key, "gemm_min_lds")) {
+        if (value < 0 || value > 64 * 1024) return fail(c, AMPH_ERR_INVALID_ARG, "gemm_min_lds must be in 0..65536");
+        amph::g_gemm_min_lds = value;
+        return AMPH_OK;
+    }
     if (!std::strcmp(key, "frames_per_block")) {
         if (value < 4 || value > 32 || (value & 3)) return fail(c, AMPH_ERR_INVALID_ARG, "frames_per_block must be a multiple of 4 in 4..32");
-        const int lds = (int)stft_mel_lds_bytes(c->cfg.n_fft, c->cfg.hop_length, value);
+        const int lds = (int)stft_mel_lds_bytes(c->cfg.n_fft, c->cfg.hop_length, value, c->cfg.n_mels, c->mel_w_floats);
         if (lds > 160 * 1024) return fail(c, AMPH_ERR_UNSUPPORTED, "frame tile needs %d bytes of LDS", lds);
         if (amph::stft_mel_configure(lds) != hipSuccess) return fail(c, AMPH_ERR_HIP, "hipFuncSetAttribute failed");
         c->frames_per_block = value;

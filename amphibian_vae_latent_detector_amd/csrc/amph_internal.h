@@ -29,13 +29,19 @@ struct StftParams {
     int pad_mode;            // 0 reflect, 1 constant
     int frames_per_block;    // FT
     int tiles_per_row;       // ceil(n_frames / FT)
-    const float* tables;     // packed LDS image: half window | tw_a | tw_b | tw_post (stft_mel_table_bytes())
+    const float* tables;     // packed LDS image: half window | tw_b | tw_post (stft_mel_table_bytes())
+    const float2* tw_a;      // [15][64] W_1024^(t*k1), k1 = 1..15 (read from global memory)
     int n_mels;
     const int32_t* mel_start;  // [n_mels] first FFT bin of the filter rounded down to a multiple of 4
-    const int32_t* mel_len;    // [n_mels] number of 16-bin steps covering the filter
+    const int32_t* mel_len;    // [n_mels] 16-bin steps of the filter's ROUND (16 consecutive filters share it)
     const int32_t* mel_wofs;   // [n_mels] offset into mel_w (multiple of 4)
-    const float* mel_w;        // per filter 16*steps weights, zero padded, 16-byte aligned
+    const float* mel_w;        // per filter 16*steps weights, zero padded, 16-byte aligned (staged into LDS)
+    int mel_w_floats;          // total, a multiple of 16
+    int p_tail;                // floats past bin n_fft/2 the padded rows may read (zeroed per frame)
     float* melpow;           // [B][n_frames][n_mels]
+#ifdef AMPH_STAMPS
+    unsigned long long* stamps;   // diagnostic build: [grid][16] s_memtime stamps
+#endif
 };
 
 struct DbNormParams {
@@ -55,7 +61,7 @@ void launch_rms_apply_pcm16(const int16_t* in, int n_rows, int n, const float* s
                             hipStream_t s);
 // sample_is_pcm16: 1 -> src.wave is int16_t, 0 -> float
 void launch_stft_mel(const StftParams& p, int n_rows, int sample_is_pcm16, hipStream_t s);
-size_t stft_mel_lds_bytes(int n_fft, int hop, int frames_per_block);
+size_t stft_mel_lds_bytes(int n_fft, int hop, int frames_per_block, int n_mels, int mel_w_floats);
 int stft_mel_table_bytes();
 hipError_t stft_mel_configure(int lds_bytes);   // raises the dynamic-LDS limit of the STFT kernels
 void launch_dbnorm(const DbNormParams& p, int n_rows, hipStream_t s);
@@ -83,6 +89,12 @@ struct ConvGemmParams {      // implicit GEMM: M = B*OH*OW, N = C_out, K = k*k*C
     int M;                   // B*OH*OW
     int epilogue;            // 0: y = relu(acc*scale + shift); 1: raw partial sums (split-K)
     int splits;              // gridDim.z; each split reduces K_pad/32/splits slices
+    // fused first layer (FUSE1 launches only): x is unused, the input is recomputed from `img`
+    const float* img;        // [B][H0][W0] standardised mel image
+    const float* w1;         // first layer [k1*k1][C_in] (tap-major)
+    const float* scale1;     // [C_in]
+    const float* shift1;     // [C_in]
+    int H0, W0, k1, s1, p1;
 };
 
 struct HeadReduceParams {    // mu/logvar = sum_s partial[s] + bias
@@ -94,7 +106,10 @@ struct HeadReduceParams {    // mu/logvar = sum_s partial[s] + bias
 };
 
 void launch_conv_first(const ConvFirstParams& p, int n_rows, hipStream_t s);
-void launch_conv_gemm(const ConvGemmParams& p, int bm, hipStream_t s);
+extern int g_gemm_min_lds;
+extern int g_stft_grid;
+bool conv_gemm_can_fuse(const ConvGemmParams& p, int bm);
+void launch_conv_gemm(const ConvGemmParams& p, int bm, bool fuse_first, hipStream_t s);
 void launch_head_reduce(const HeadReduceParams& p, int n_rows, hipStream_t s);
 
 // ----------------------------------------------------------------------------

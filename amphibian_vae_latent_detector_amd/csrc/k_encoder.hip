@@ -14,6 +14,8 @@
 // (one rounding per product), so precision equals a VALU fp32 convolution.
 #include "amph_internal.h"
 
+#include <algorithm>
+
 namespace amph {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -79,13 +81,28 @@ void launch_conv_first(const ConvFirstParams& p, int n_rows, hipStream_t s) {
 // ----------------------------------------------------------------------------
 constexpr int kBN = 64, kBK = 32, kLdsRow = 36;
 
-template <int BM>
+// FUSE1: the layer's input is not read from HBM.  It is the output of the FIRST layer
+// (C_in == 1 direct 3x3 conv + BN + ReLU), recomputed per A-tile element from an image patch
+// held in LDS, with exactly k_conv_first's FMA order (so fused == unfused bitwise).  The
+// first layer's 128 KB/chunk activation is then never written nor re-read 2.25x; its VALU
+// work is interleaved with this kernel's MFMAs.  Requires the BM-row tile to be whole output
+// rows of one chunk (host checks (OH*OW) % BM == 0 and BM % OW == 0).
+//
+// Pipeline: a 3-stage REGISTER ring.  Global loads for slice ks+3 are issued while slice ks
+// is multiplied; the ring stage holding slice ks+1 is written to the spare LDS buffer at the
+// end of the iteration (the compiler's counted vmcnt wait then leaves two slices in flight),
+// one barrier per slice.  With a prefetch distance of one slice the loop was bound by the
+// L2 -> register latency (measured 4.7k cycles per slice for 1k cycles of MFMA).
+template <int BM, bool FUSE1>
 __global__ __launch_bounds__(256) void k_conv_gemm(ConvGemmParams p) {
     constexpr int A_ROWS = BM / 32;            // rows of the A tile each thread stages
     constexpr int NT = (BM == 128) ? 2 : 1;    // 32x32 tiles per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* As = reinterpret_cast<float*>(smem);                       // [2][BM][36]
     float* Bs = As + 2 * BM * kLdsRow;                                // [2][64][36]
+    // FUSE1 only: first-layer tables and the image patch of this tile
+    float* w1s = Bs + 2 * kBN * kLdsRow;                              // [9][C_in] then scale1, shift1 [C_in]
+    float* patch = w1s + 11 * p.C_in;                                 // [patch_rows][W0 + 2 p1]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c4 = tid & 7, r0 = tid >> 3;
@@ -107,6 +124,25 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvGemmParams p) {
         iw0[i] = ow * p.stride - p.pad;
         boff[i] = (long long)b * p.H * p.W * p.C_in;
     }
+    const int PW = p.W0 + 2 * p.p1;
+    int patch_lo = 0;                          // image row held in patch row 0
+    if (FUSE1) {
+        const int b = m_blk / ohw, oh_first = (m_blk - b * ohw) / p.OW, n_oh = BM / p.OW;
+        const int r1_lo = oh_first * p.stride - p.pad;
+        const int r1_cnt = (n_oh - 1) * p.stride + p.k;
+        patch_lo = r1_lo * p.s1 - p.p1;
+        const int rows = (r1_cnt - 1) * p.s1 + 3;
+        const float* img = p.img + (long long)b * p.H0 * p.W0;
+        for (int i = tid; i < rows * PW; i += 256) {
+            const int r = i / PW, cc = i - r * PW;
+            const int ir = patch_lo + r, ic = cc - p.p1;
+            patch[i] = (ir >= 0 && ir < p.H0 && ic >= 0 && ic < p.W0) ? img[ir * p.W0 + ic] : 0.0f;
+        }
+        const int nw = 9 * p.C_in;
+        for (int i = tid; i < nw + 2 * p.C_in; i += 256)
+            w1s[i] = i < nw ? p.w1[i] : (i < nw + p.C_in ? p.scale1[i - nw] : p.shift1[i - nw - p.C_in]);
+        __syncthreads();
+    }
     const float* wrow0 = p.w + (long long)(n_blk + r0) * p.K_pad + 4 * c4;
     const float* wrow1 = p.w + (long long)(n_blk + r0 + 32) * p.K_pad + 4 * c4;
 
@@ -114,33 +150,81 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvGemmParams p) {
     const int sps = n_slices / p.splits;
     const int ks_begin = blockIdx.z * sps, ks_end = ks_begin + sps;
 
-    // staging registers (named scalars / fully unrolled arrays so they stay in VGPRs)
-    float4 ra[A_ROWS];
-    float4 rb0, rb1;
-#define AMPH_LOAD_SLICE(ks_)                                                                              \
+    // ---- register ring: stage q holds the A rows / B rows of one K slice
+    float4 sa0[A_ROWS], sa1[A_ROWS], sa2[A_ROWS];
+    float4 sb0a, sb0b, sb1a, sb1b, sb2a, sb2b;
+    // decoded position of this thread's float4 inside a slice
+#define AMPH_DECODE(ks_, kval_, kh_, kw_, ci_)                                                            \
+    const int kflat_ = min((ks_), ks_end - 1) * kBK + 4 * c4;                                             \
+    const bool kval_ = kflat_ < p.K;                                                                      \
+    const int kpos_ = kflat_ / p.C_in, ci_ = kflat_ - kpos_ * p.C_in;                                     \
+    const int kh_ = kpos_ / p.k, kw_ = kpos_ - kh_ * p.k;
+    // issue the global loads of slice ks_ into ring stage q (slices past the end re-load the last one)
+#define AMPH_LOAD_B(q, ks_)                                                                               \
     {                                                                                                     \
-        const int kflat_ = (ks_) * kBK + 4 * c4;                                                          \
-        const bool kval_ = kflat_ < p.K;                                                                  \
-        const int kpos_ = kflat_ / p.C_in, ci_ = kflat_ - kpos_ * p.C_in;                                 \
-        const int kh_ = kpos_ / p.k, kw_ = kpos_ - kh_ * p.k;                                             \
+        const int kc_ = min((ks_), ks_end - 1) * kBK;                                                     \
+        sb##q##a = *reinterpret_cast<const float4*>(wrow0 + kc_);                                         \
+        sb##q##b = *reinterpret_cast<const float4*>(wrow1 + kc_);                                         \
+    }
+#define AMPH_LOAD_A(q, ks_)                                                                               \
+    {                                                                                                     \
+        AMPH_DECODE(ks_, kval_, kh_, kw_, ci_)                                                            \
         _Pragma("unroll") for (int i = 0; i < A_ROWS; ++i) {                                              \
             const int ih_ = ih0[i] + kh_, iw_ = iw0[i] + kw_;                                             \
-            float4 v_ = make_float4(0.f, 0.f, 0.f, 0.f);                                                  \
+            float4 a_ = make_float4(0.f, 0.f, 0.f, 0.f);                                                  \
             if (kval_ && mval[i] && ih_ >= 0 && ih_ < p.H && iw_ >= 0 && iw_ < p.W)                       \
-                v_ = *reinterpret_cast<const float4*>(p.x + boff[i] + ((long long)ih_ * p.W + iw_) * p.C_in + ci_); \
-            ra[i] = v_;                                                                                   \
+                a_ = *reinterpret_cast<const float4*>(p.x + boff[i] + ((long long)ih_ * p.W + iw_) * p.C_in + ci_); \
+            sa##q[i] = a_;                                                                                \
         }                                                                                                 \
-        rb0 = *reinterpret_cast<const float4*>(wrow0 + (ks_) * kBK);                                      \
-        rb1 = *reinterpret_cast<const float4*>(wrow1 + (ks_) * kBK);                                      \
     }
-#define AMPH_STORE_SLICE(buf_)                                                                            \
+#define AMPH_STORE(q, buf_)                                                                               \
     {                                                                                                     \
         float* a_ = As + (buf_) * BM * kLdsRow;                                                           \
         float* b_ = Bs + (buf_) * kBN * kLdsRow;                                                          \
         _Pragma("unroll") for (int i = 0; i < A_ROWS; ++i)                                                \
-            *reinterpret_cast<float4*>(a_ + (r0 + 32 * i) * kLdsRow + 4 * c4) = ra[i];                    \
-        *reinterpret_cast<float4*>(b_ + r0 * kLdsRow + 4 * c4) = rb0;                                     \
-        *reinterpret_cast<float4*>(b_ + (r0 + 32) * kLdsRow + 4 * c4) = rb1;                              \
+            *reinterpret_cast<float4*>(a_ + (r0 + 32 * i) * kLdsRow + 4 * c4) = sa##q[i];                 \
+        *reinterpret_cast<float4*>(b_ + r0 * kLdsRow + 4 * c4) = sb##q##a;                                \
+        *reinterpret_cast<float4*>(b_ + (r0 + 32) * kLdsRow + 4 * c4) = sb##q##b;                         \
+    }
+    // FUSE1, software pipelined across the k-groups of one slice: F_DECODE fetches the slice's 9 tap
+    // weights + BN, F_PATCH(i) the 3x3 image window of row i, F_ROW(q, i) turns the window fetched one
+    // k-group earlier into layer-1 output (conv + BN + ReLU) in ring stage q
+    float4 sc1 = make_float4(0.f, 0.f, 0.f, 0.f), sh1 = sc1, w1r[9];
+    float pv[9];
+    bool pok = false, f_kval = false;
+    int f_kh = 0, f_kw = 0;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) { w1r[t] = sc1; pv[t] = 0.0f; }
+#define AMPH_F_DECODE(ks_)                                                                                \
+    {                                                                                                     \
+        AMPH_DECODE(ks_, kval_, kh_, kw_, ci_)                                                            \
+        f_kval = kval_; f_kh = kh_; f_kw = kw_;                                                           \
+        const float* wt_ = w1s + (kval_ ? ci_ : 0);                                                       \
+        _Pragma("unroll") for (int t = 0; t < 9; ++t) w1r[t] = *reinterpret_cast<const float4*>(wt_ + t * p.C_in); \
+        sc1 = *reinterpret_cast<const float4*>(wt_ + 9 * p.C_in);                                         \
+        sh1 = *reinterpret_cast<const float4*>(wt_ + 10 * p.C_in);                                        \
+    }
+#define AMPH_F_PATCH(i)                                                                                   \
+    {                                                                                                     \
+        const int ih_ = ih0[i] + f_kh, iw_ = iw0[i] + f_kw;                                               \
+        pok = f_kval && mval[i] && ih_ >= 0 && ih_ < p.H && iw_ >= 0 && iw_ < p.W;                        \
+        const float* pp_ = patch + (pok ? (ih_ * p.s1 - p.p1 - patch_lo) * PW + iw_ * p.s1 : 0);          \
+        _Pragma("unroll") for (int t = 0; t < 9; ++t) pv[t] = pp_[(t / 3) * PW + (t % 3)];                \
+    }
+#define AMPH_F_ROW(q, i)                                                                                  \
+    {                                                                                                     \
+        float4 a_ = make_float4(0.f, 0.f, 0.f, 0.f);                                                      \
+        _Pragma("unroll") for (int t = 0; t < 9; ++t) {                                                   \
+            a_.x = fmaf(pv[t], w1r[t].x, a_.x);                                                           \
+            a_.y = fmaf(pv[t], w1r[t].y, a_.y);                                                           \
+            a_.z = fmaf(pv[t], w1r[t].z, a_.z);                                                           \
+            a_.w = fmaf(pv[t], w1r[t].w, a_.w);                                                           \
+        }                                                                                                 \
+        a_.x = pok ? fmaxf(fmaf(a_.x, sc1.x, sh1.x), 0.0f) : 0.0f;                                        \
+        a_.y = pok ? fmaxf(fmaf(a_.y, sc1.y, sh1.y), 0.0f) : 0.0f;                                        \
+        a_.z = pok ? fmaxf(fmaf(a_.z, sc1.z, sh1.z), 0.0f) : 0.0f;                                        \
+        a_.w = pok ? fmaxf(fmaf(a_.w, sc1.w, sh1.w), 0.0f) : 0.0f;                                        \
+        sa##q[i] = a_;                                                                                    \
     }
 
     f32x16 acc[NT];
@@ -154,32 +238,64 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvGemmParams p) {
     const int a_off = (row_tile * 32 + (lane & 31)) * kLdsRow + 4 * (lane >> 5);
     const int b_off = (col_tile0 * 32 + (lane & 31)) * kLdsRow + 4 * (lane >> 5);
 
-    AMPH_LOAD_SLICE(ks_begin);
-    AMPH_STORE_SLICE(0);
+    // one slice: multiply LDS buffer `buf_` (slice ks_), load slice ks_+3 into stage qload_,
+    // stage slice ks_+1 (ring stage qstore_) into the other buffer
+#define AMPH_STEP(ks_, buf_, qload_, qstore_)                                                             \
+    {                                                                                                     \
+        AMPH_LOAD_B(qload_, (ks_) + 3);                                                                   \
+        if (!FUSE1) AMPH_LOAD_A(qload_, (ks_) + 3)                                                        \
+        else { AMPH_F_DECODE((ks_) + 1); AMPH_F_PATCH(0); }                                               \
+        const float* a = As + (buf_) * BM * kLdsRow + a_off;                                              \
+        const float* b = Bs + (buf_) * kBN * kLdsRow + b_off;                                             \
+        _Pragma("unroll") for (int kg = 0; kg < kBK / 8; ++kg) {                                          \
+            const float4 fa = *reinterpret_cast<const float4*>(a + 8 * kg);                               \
+            float4 fb[NT];                                                                                \
+            _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                \
+                fb[t] = *reinterpret_cast<const float4*>(b + t * 32 * kLdsRow + 8 * kg);                  \
+            const float fav[4] = {fa.x, fa.y, fa.z, fa.w};                                                \
+            _Pragma("unroll") for (int st = 0; st < 4; ++st)                                              \
+                _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                          \
+                    const float fbv = st == 0 ? fb[t].x : st == 1 ? fb[t].y : st == 2 ? fb[t].z : fb[t].w; \
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fav[st], fbv, acc[t], 0, 0, 0);         \
+                }                                                                                         \
+            if (FUSE1 && kg < A_ROWS) {                                                                   \
+                AMPH_F_ROW(qstore_, kg);                                                                  \
+                if (kg + 1 < A_ROWS) AMPH_F_PATCH(kg + 1);                                                \
+                _Pragma("unroll") for (int g = 0; g < 4 * NT; ++g) {                                      \
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
+                    __builtin_amdgcn_sched_group_barrier(0x002, 96 / (4 * NT), 0);                        \
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                    \
+                }                                                                                         \
+            }                                                                                             \
+        }                                                                                                 \
+        AMPH_STORE(qstore_, (buf_) ^ 1);                                                                  \
+        __syncthreads();                                                                                  \
+    }
+
+    // prologue: slices 0, 1, 2 into the ring (B always; A gathered, or slice 0 recomputed), slice 0 to LDS
+    AMPH_LOAD_B(0, ks_begin);
+    AMPH_LOAD_B(1, ks_begin + 1);
+    AMPH_LOAD_B(2, ks_begin + 2);
+    if (!FUSE1) {
+        AMPH_LOAD_A(0, ks_begin)
+        AMPH_LOAD_A(1, ks_begin + 1)
+        AMPH_LOAD_A(2, ks_begin + 2)
+    } else {
+        AMPH_F_DECODE(ks_begin);
+#pragma unroll
+        for (int i = 0; i < A_ROWS; ++i) { AMPH_F_PATCH(i); AMPH_F_ROW(0, i); }
+    }
+    AMPH_STORE(0, 0);
     __syncthreads();
-    int buf = 0;
-    for (int ks = ks_begin; ks < ks_end; ++ks) {
-        const bool more = ks + 1 < ks_end;
-        if (more) AMPH_LOAD_SLICE(ks + 1);
-        const float* a = As + buf * BM * kLdsRow + a_off;
-        const float* b = Bs + buf * kBN * kLdsRow + b_off;
-#pragma unroll
-        for (int kg = 0; kg < kBK / 8; ++kg) {
-            const float4 fa = *reinterpret_cast<const float4*>(a + 8 * kg);
-            float4 fb[NT];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) fb[t] = *reinterpret_cast<const float4*>(b + t * 32 * kLdsRow + 8 * kg);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb[t].x, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb[t].y, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb[t].z, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb[t].w, acc[t], 0, 0, 0);
-            }
-        }
-        if (more) AMPH_STORE_SLICE(buf ^ 1);
-        __syncthreads();
-        buf ^= 1;
+    // main loop, unrolled by the ring length so that every stage index is static; the LDS buffer
+    // parity alternates 0,1,0 / 1,0,1 across the two halves of a 6-slice period
+    for (int ks = ks_begin; ks < ks_end; ks += 6) {
+        AMPH_STEP(ks, 0, 0, 1)
+        if (ks + 1 < ks_end) AMPH_STEP(ks + 1, 1, 1, 2)
+        if (ks + 2 < ks_end) AMPH_STEP(ks + 2, 0, 2, 0)
+        if (ks + 3 < ks_end) AMPH_STEP(ks + 3, 1, 0, 1)
+        if (ks + 4 < ks_end) AMPH_STEP(ks + 4, 0, 1, 2)
+        if (ks + 5 < ks_end) AMPH_STEP(ks + 5, 1, 2, 0)
     }
 
     // epilogue: C/D map of the 32x32 tile: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
@@ -202,12 +318,34 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvGemmParams p) {
     }
 }
 
-static size_t conv_gemm_lds(int bm) { return (size_t)2 * (bm + kBN) * kLdsRow * sizeof(float); }
+static size_t conv_gemm_lds(const ConvGemmParams& p, int bm, bool fuse) {
+    size_t b = (size_t)2 * (bm + kBN) * kLdsRow * sizeof(float);
+    if (fuse) {
+        const int n_oh = bm / p.OW;
+        const int rows = ((n_oh - 1) * p.stride + p.k - 1) * p.s1 + p.k1;
+        b += ((size_t)11 * p.C_in + (size_t)rows * (p.W0 + 2 * p.p1)) * sizeof(float);
+    }
+    return b;
+}
 
-void launch_conv_gemm(const ConvGemmParams& p, int bm, hipStream_t s) {
+bool conv_gemm_can_fuse(const ConvGemmParams& p, int bm) {
+    const int ohw = p.OH * p.OW;
+    return p.img != nullptr && p.k1 == 3 && ohw % bm == 0 && bm % p.OW == 0 && (p.C_in % 4) == 0 &&
+           conv_gemm_lds(p, bm, true) <= 64 * 1024;
+}
+
+int g_gemm_min_lds = 0;   // experiment knob: request at least this much LDS (limits workgroups per CU)
+
+void launch_conv_gemm(const ConvGemmParams& p, int bm, bool fuse, hipStream_t s) {
     const dim3 grid((unsigned)((p.M + bm - 1) / bm), (unsigned)((p.N + kBN - 1) / kBN), (unsigned)p.splits);
-    if (bm == 128) hipLaunchKernelGGL(k_conv_gemm<128>, grid, dim3(256), conv_gemm_lds(128), s, p);
-    else hipLaunchKernelGGL(k_conv_gemm<64>, grid, dim3(256), conv_gemm_lds(64), s, p);
+    const size_t lds = std::max(conv_gemm_lds(p, bm, fuse), (size_t)g_gemm_min_lds);
+    if (fuse) {
+        if (bm == 128) hipLaunchKernelGGL((k_conv_gemm<128, true>), grid, dim3(256), lds, s, p);
+        else hipLaunchKernelGGL((k_conv_gemm<64, true>), grid, dim3(256), lds, s, p);
+    } else {
+        if (bm == 128) hipLaunchKernelGGL((k_conv_gemm<128, false>), grid, dim3(256), lds, s, p);
+        else hipLaunchKernelGGL((k_conv_gemm<64, false>), grid, dim3(256), lds, s, p);
+    }
 }
 
 // ----------------------------------------------------------------------------

@@ -22,6 +22,8 @@
 //   applying PCM16 decode, RMS scale, clip and the PCM16 re-quantisation on load.
 #include "amph_internal.h"
 
+#include <algorithm>
+
 namespace amph {
 
 // ----------------------------------------------------------------------------
@@ -352,80 +354,160 @@ __device__ __forceinline__ float normalise_sample(const WaveSrc& src, float x, f
     return x;
 }
 
+// Diagnostic build only (-DAMPH_STAMPS, `make stamps`): wave 0 of every workgroup stamps s_memtime at
+// the phase boundaries of its first frame; the stamps go to a buffer nothing else reads.  Never timed.
+#ifdef AMPH_STAMPS
+#define AMPH_STAMP(k)                                                                       \
+    if (wave == 0 && fl == 0) {                                                             \
+        unsigned long long t_;                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");          \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+        if (lane == 0) p.stamps[(size_t)blockIdx.x * 16 + (k)] = t_;                        \
+    }
+#else
+#define AMPH_STAMP(k)
+#endif
+
 constexpr int kNc = 1024;                             // complex FFT length (n_fft = 2048)
 constexpr int kWaveScratch = 16 * kExStride * 8;      // 8704 B per wave: exchange tile, then Z[1024 + 4*kZPad], then P[1025 + pad]
 // LDS tables (bytes, all multiples of 16), staged once per workgroup:
 constexpr int kWinHalfBytes = 4112;                   // w[0 .. 1024] of the periodic Hann window (w[n] == w[N - n])
-constexpr int kTwABytes = 15 * 64 * 8;                // W_1024^(t*k1), k1 = 1..15
 constexpr int kTwBBytes = 16 * 4 * 8;                 // W_64^(t_lo*k2a)
 constexpr int kTwPostBytes = 4112;                    // W_2048^k, k = 0..512
-constexpr int kTableBytes = kWinHalfBytes + kTwABytes + kTwBBytes + kTwPostBytes;
+constexpr int kTableBytes = kWinHalfBytes + kTwBBytes + kTwPostBytes;
+// W_1024^(t*k1), k1 = 1..15, [15][64] float2 stays in global memory (L1/L2 resident): its 15 loads per
+// frame are independent of everything and are issued at the top of the frame, under the first DFT.
+// The mel weights, whose loads sat on the critical path of every frame, live in LDS instead.
 
+// Persistent: gridDim.x workgroups (2 per CU) walk the (row, frame tile) list with stride gridDim.x.
+// The tables and mel rows are staged into LDS once per workgroup (staged per tile they were 37 MB of
+// L2 traffic per launch, fetched by every workgroup at the same moment); the next tile's samples are
+// prefetched into registers while the current tile's FFTs run.
 template <bool PCM16>
-__global__ __launch_bounds__(256) void k_stft_mel(StftParams p) {
+__global__ __launch_bounds__(256) void k_stft_mel(StftParams p, int n_tiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int row = blockIdx.x / p.tiles_per_row;
-    const int tile = blockIdx.x - row * p.tiles_per_row;
     const int FT = p.frames_per_block;
-    const int f_base = tile * FT;
+#ifdef AMPH_STAMPS
+    { const int fl = 0; AMPH_STAMP(0) }
+#endif
     const int n_fft = 2 * kNc;
     const int span_len = (FT - 1) * p.hop + n_fft;
     const int span_bytes = (span_len * 4 + 15) & ~15;
     float* win_h = reinterpret_cast<float*>(smem);
-    float2* tw_a = reinterpret_cast<float2*>(smem + kWinHalfBytes);
-    float2* tw_b = reinterpret_cast<float2*>(smem + kWinHalfBytes + kTwABytes);
-    float2* tw_p = reinterpret_cast<float2*>(smem + kWinHalfBytes + kTwABytes + kTwBBytes);
-    float* span = reinterpret_cast<float*>(smem + kTableBytes);
-    char* wbase = smem + kTableBytes + span_bytes + wave * kWaveScratch;
+    float2* tw_b = reinterpret_cast<float2*>(smem + kWinHalfBytes);
+    float2* tw_p = reinterpret_cast<float2*>(smem + kWinHalfBytes + kTwBBytes);
+    const float2* tw_a = p.tw_a;
+    const int meta_bytes = (p.n_mels * 12 + 15) & ~15;
+    const int melw_bytes = p.mel_w_floats * 4;                             // multiple of 64
+    int3* mel_meta = reinterpret_cast<int3*>(smem + kTableBytes);          // (start4, steps, wofs) per filter
+    float* mel_w = reinterpret_cast<float*>(smem + kTableBytes + meta_bytes);
+    float* span = reinterpret_cast<float*>(smem + kTableBytes + meta_bytes + melw_bytes);
+    char* wbase = smem + kTableBytes + meta_bytes + melw_bytes + span_bytes + wave * kWaveScratch;
     float2* ex = reinterpret_cast<float2*>(wbase);
     float* P = reinterpret_cast<float*>(wbase);
 
-    // ---- stage the tables (one packed global array, same layout as the LDS image) and the
-    //      sample span of this frame tile (decode / normalise on load).  Loads are issued in
-    //      batches of independent requests so their latencies overlap instead of chaining.
+    // ---- once per workgroup: tables (one packed global array = the LDS image) and the mel rows
     {
         const float4* src = reinterpret_cast<const float4*>(p.tables);
         float4* dst = reinterpret_cast<float4*>(smem);
-        constexpr int kTabVec = kTableBytes / 16;
-        float4 t[(kTabVec + 255) / 256];
+        for (int i = tid; i < kTableBytes / 16; i += 256) dst[i] = src[i];
+        for (int m = tid; m < p.n_mels; m += 256) mel_meta[m] = make_int3(p.mel_start[m], p.mel_len[m], p.mel_wofs[m]);
+        const float4* wsrc = reinterpret_cast<const float4*>(p.mel_w);
+        float4* wdst = reinterpret_cast<float4*>(mel_w);
+        for (int i = tid; i < (p.mel_w_floats >> 2); i += 256) wdst[i] = wsrc[i];
+    }
+
+    // per-tile source description
+    struct TileSrc { const char* rowp; int len, s0; float sc; bool fast; };
+    auto describe = [&](int t) {
+        TileSrc d;
+        const int r = t / p.tiles_per_row, tl = t - r * p.tiles_per_row;
+        d.rowp = reinterpret_cast<const char*>(p.src.wave) + (long long)r * p.src.row_stride * (PCM16 ? 2 : 4);
+        int len = p.src.lengths ? min(p.src.lengths[r], p.src.n_in) : p.src.n_in;
+        d.len = min(len, p.n_samples);               // truncation of fix_length (:217)
+        d.sc = p.src.scale ? p.src.scale[r] : 1.0f;
+        d.s0 = tl * FT * p.hop - (n_fft >> 1);
+        // interior tile of a PCM16 row: one contiguous, 4-byte aligned run -> dword loads
+        d.fast = PCM16 && d.s0 >= 0 && d.s0 + span_len <= d.len && (span_len & 1) == 0 &&
+                 ((reinterpret_cast<uintptr_t>(d.rowp) + 2 * (size_t)d.s0) & 3u) == 0;
+        return d;
+    };
+    constexpr int U = 10;                              // dwords per thread per batch (FT = 8: one batch)
+    uint32_t pre[U];                                   // next tile's samples, prefetched (fast tiles only)
 #pragma unroll
-        for (int u = 0; u < (kTabVec + 255) / 256; ++u) t[u] = src[min(tid + 256 * u, kTabVec - 1)];
-        const char* rowp = reinterpret_cast<const char*>(p.src.wave) +
-                           (long long)row * p.src.row_stride * (PCM16 ? 2 : 4);
-        int len = p.src.lengths ? min(p.src.lengths[row], p.src.n_in) : p.src.n_in;
-        len = min(len, p.n_samples);                 // truncation of fix_length (:217)
-        const float sc = p.src.scale ? p.src.scale[row] : 1.0f;
-        const int N = p.n_samples;
-        const int s0 = f_base * p.hop - (n_fft >> 1);
-        constexpr int U = 8;
-        for (int base = 0; base < span_len; base += 256 * U) {
-            float x[U];
+    for (int u = 0; u < U; ++u) pre[u] = 0;
+    bool have_pre = false;
+    const int nd = span_len >> 1;
+    const bool pre_fits = nd <= 256 * U;
+
+    for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const TileSrc d = describe(t);
+        const int row = t / p.tiles_per_row;
+        const int f_base = (t - row * p.tiles_per_row) * FT;
+        // ---- stage this tile's sample span (decode / normalise on the way into LDS)
+        if (d.fast) {
+            const uint32_t* src32 = reinterpret_cast<const uint32_t*>(d.rowp + 2 * (size_t)d.s0);
+            for (int base = 0; base < nd; base += 256 * U) {
+                uint32_t v[U];
+                if (have_pre) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                int sidx = s0 + base + tid + 256 * u;
-                if (p.pad_mode == 0) {                // reflect (np.pad mode="reflect")
-                    if (sidx < 0) sidx = -sidx;
-                    if (sidx >= N) sidx = 2 * (N - 1) - sidx;
-                } else if (sidx >= N) sidx = -1;      // constant (zero) padding
-                x[u] = load_sample<PCM16>(rowp, sidx, len);
+                    for (int u = 0; u < U; ++u) v[u] = pre[u];
+                } else {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) v[u] = src32[min(base + tid + 256 * u, nd - 1)];
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int e = base + tid + 256 * u;
+                    if (e < nd) {
+                        const float lo = (float)(short)(v[u] & 0xFFFFu) * (1.0f / 32768.0f);
+                        const float hi = (float)((int)v[u] >> 16) * (1.0f / 32768.0f);
+                        *reinterpret_cast<float2*>(span + 2 * e) =
+                            make_float2(normalise_sample(p.src, lo, d.sc), normalise_sample(p.src, hi, d.sc));
+                    }
+                }
             }
+        } else {
+            const int N = p.n_samples;
+            for (int base = 0; base < span_len; base += 256 * U) {
+                float x[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int i = base + tid + 256 * u;
-                if (i < span_len) span[i] = normalise_sample(p.src, x[u], sc);
+                for (int u = 0; u < U; ++u) {
+                    int sidx = d.s0 + base + tid + 256 * u;
+                    if (p.pad_mode == 0) {                // reflect (np.pad mode="reflect")
+                        if (sidx < 0) sidx = -sidx;
+                        if (sidx >= N) sidx = 2 * (N - 1) - sidx;
+                    } else if (sidx >= N) sidx = -1;      // constant (zero) padding
+                    x[u] = load_sample<PCM16>(d.rowp, sidx, d.len);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int i = base + tid + 256 * u;
+                    if (i < span_len) span[i] = normalise_sample(p.src, x[u], d.sc);
+                }
             }
         }
+        __syncthreads();
+        // ---- prefetch the next tile's samples; they land while this tile's frames are transformed
+        have_pre = false;
+        if (t + (int)gridDim.x < n_tiles && pre_fits) {
+            const TileSrc dn = describe(t + gridDim.x);
+            if (dn.fast) {
+                const uint32_t* src32 = reinterpret_cast<const uint32_t*>(dn.rowp + 2 * (size_t)dn.s0);
 #pragma unroll
-        for (int u = 0; u < (kTabVec + 255) / 256; ++u) { const int i = tid + 256 * u; if (i < kTabVec) dst[i] = t[u]; }
-    }
-    __syncthreads();
+                for (int u = 0; u < U; ++u) pre[u] = src32[min(tid + 256 * u, nd - 1)];
+                have_pre = true;
+            }
+        }
 
     const int k1b = lane >> 2, t_lo = lane & 3;
     const int k2b = ((t_lo & 1) << 1) | (t_lo >> 1);   // stage C leaves k2b bit-reversed across the quad
     for (int fl = wave; fl < FT; fl += 4) {
         const int frame = f_base + fl;
         if (frame >= p.n_frames) break;               // wave-uniform
+        AMPH_STAMP(1)
         float re[16], im[16];
         // ---- window + even/odd packing: z[n] = x[2n] w[2n] + i x[2n+1] w[2n+1], n = lane + 64 j
         {
@@ -441,6 +523,7 @@ __global__ __launch_bounds__(256) void k_stft_mel(StftParams p) {
                 im[j] = x.y * w1;
             }
         }
+        AMPH_STAMP(2)
         // ---- stage A
         dft16(re, im);
 #pragma unroll
@@ -453,6 +536,7 @@ __global__ __launch_bounds__(256) void k_stft_mel(StftParams p) {
             ex[k1 * kExStride + lane] = make_float2(r, i);
         }
         wave_lds_sync();
+        AMPH_STAMP(3)
         // ---- stage B: lane (k1b, t_lo) gathers t = t_lo + 4 m
 #pragma unroll
         for (int m = 0; m < 16; ++m) {
@@ -460,7 +544,9 @@ __global__ __launch_bounds__(256) void k_stft_mel(StftParams p) {
             re[m] = v.x;
             im[m] = v.y;
         }
+        AMPH_STAMP(4)
         dft16(re, im);
+        AMPH_STAMP(5)
         wave_lds_sync();                              // the Z image below overwrites `ex`
         float2* Z = ex;
 #pragma unroll
@@ -488,6 +574,7 @@ __global__ __launch_bounds__(256) void k_stft_mel(StftParams p) {
             Z[k1b + 16 * k2a + (256 + kZPad) * k2b] = make_float2(r, i);
         }
         wave_lds_sync();
+        AMPH_STAMP(6)
         // ---- real-FFT split: bins k and 1024 - k from Z[k], Z[1024 - k]; the power spectrum
         //      is written over the Z image, so every pair is read into registers first
         {
@@ -500,6 +587,7 @@ __global__ __launch_bounds__(256) void k_stft_mel(StftParams p) {
                 zb[it] = Z[k2 + kZPad * (k2 >> 8)];
             }
             wave_lds_sync();
+            AMPH_STAMP(7)
 #pragma unroll
             for (int it = 0; it < 9; ++it) {
                 const int k = lane + 64 * it;
@@ -514,40 +602,55 @@ __global__ __launch_bounds__(256) void k_stft_mel(StftParams p) {
                     if (k != kNc - k) P[kNc - k] = mr * mr + mi * mi;
                 }
             }
-            if (lane < 32) P[kNc + 1 + lane] = 0.0f;   // zero the tail the padded mel rows may touch
+            for (int i = lane; i < p.p_tail; i += 64) P[kNc + 1 + i] = 0.0f;   // zero the tail the padded mel rows touch
         }
         wave_lds_sync();
-        // ---- mel rows: 4 lanes per filter, each lane 4 consecutive bins per step (aligned float4)
+        AMPH_STAMP(8)
+        // ---- mel rows: 4 lanes per filter, each lane 4 consecutive bins per step (aligned float4).
+        //      The host pads every filter of a 16-filter round to the round's longest row (zero
+        //      weights), so the step count is wave-uniform: no per-lane predication, no branches.
         {
             float* out = p.melpow + ((long long)row * p.n_frames + frame) * p.n_mels;
             const int q = lane & 3;
             for (int m0 = 0; m0 < p.n_mels; m0 += 16) {
-                const int m = m0 + (lane >> 2);
-                float acc = 0.0f;
-                if (m < p.n_mels) {
-                    const int st4 = p.mel_start[m], iters = p.mel_len[m];
-                    const float4* w = reinterpret_cast<const float4*>(p.mel_w + p.mel_wofs[m]) + q;
-                    const float4* pp = reinterpret_cast<const float4*>(P + st4) + q;
-                    for (int i = 0; i < iters; ++i) {
-                        const float4 wv = w[4 * i], pv = pp[4 * i];
-                        acc = fmaf(wv.x, pv.x, acc);
-                        acc = fmaf(wv.y, pv.y, acc);
-                        acc = fmaf(wv.z, pv.z, acc);
-                        acc = fmaf(wv.w, pv.w, acc);
-                    }
+                const int m = min(m0 + (lane >> 2), p.n_mels - 1);
+                const int3 meta = mel_meta[m];                                // (start4, steps of the round, wofs)
+                const int steps = __builtin_amdgcn_readfirstlane(meta.y);
+                const float4* w = reinterpret_cast<const float4*>(mel_w + meta.z) + q;
+                const float4* pp = reinterpret_cast<const float4*>(P + meta.x) + q;
+                float acc0 = 0.0f, acc1 = 0.0f;
+                int i = 0;
+                for (; i + 1 < steps; i += 2) {
+                    const float4 a0 = w[4 * i], b0 = pp[4 * i], a1 = w[4 * i + 4], b1 = pp[4 * i + 4];
+                    acc0 = fmaf(a0.x, b0.x, acc0); acc1 = fmaf(a1.x, b1.x, acc1);
+                    acc0 = fmaf(a0.y, b0.y, acc0); acc1 = fmaf(a1.y, b1.y, acc1);
+                    acc0 = fmaf(a0.z, b0.z, acc0); acc1 = fmaf(a1.z, b1.z, acc1);
+                    acc0 = fmaf(a0.w, b0.w, acc0); acc1 = fmaf(a1.w, b1.w, acc1);
                 }
+                if (i < steps) {
+                    const float4 a0 = w[4 * i], b0 = pp[4 * i];
+                    acc0 = fmaf(a0.x, b0.x, acc0);
+                    acc0 = fmaf(a0.y, b0.y, acc0);
+                    acc0 = fmaf(a0.z, b0.z, acc0);
+                    acc0 = fmaf(a0.w, b0.w, acc0);
+                }
+                float acc = acc0 + acc1;
                 acc += dpp_xor1(acc);
                 acc += dpp_xor2(acc);
-                if (q == 0 && m < p.n_mels) out[m] = acc;
+                if (q == 0 && m0 + (lane >> 2) < p.n_mels) out[m] = acc;
             }
         }
         wave_lds_sync();                              // the scratch is rewritten by the next frame
+        AMPH_STAMP(9)
+    }
+        __syncthreads();                              // every wave is done with `span` before it is restaged
     }
 }
 
-size_t stft_mel_lds_bytes(int n_fft, int hop, int frames_per_block) {
+size_t stft_mel_lds_bytes(int n_fft, int hop, int frames_per_block, int n_mels, int mel_w_floats) {
     const size_t span = (((size_t)(frames_per_block - 1) * hop + n_fft) * 4 + 15) & ~(size_t)15;
-    return (size_t)kTableBytes + span + 4 * (size_t)kWaveScratch;
+    const size_t meta = ((size_t)n_mels * 12 + 15) & ~(size_t)15;
+    return (size_t)kTableBytes + meta + (size_t)mel_w_floats * 4 + span + 4 * (size_t)kWaveScratch;
 }
 int stft_mel_table_bytes() { return kTableBytes; }
 
@@ -562,11 +665,15 @@ hipError_t stft_mel_configure(int lds_bytes) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
 }
 
+int g_stft_grid = 512;   // persistent workgroups (2 per CU x 256 CUs); tuning knob
+
 void launch_stft_mel(const StftParams& p, int n_rows, int sample_is_pcm16, hipStream_t s) {
-    const size_t lds = stft_mel_lds_bytes(p.n_fft, p.hop, p.frames_per_block);
-    const dim3 grid((unsigned)(n_rows * p.tiles_per_row));
-    if (sample_is_pcm16) hipLaunchKernelGGL(k_stft_mel<true>, grid, dim3(256), lds, s, p);
-    else hipLaunchKernelGGL(k_stft_mel<false>, grid, dim3(256), lds, s, p);
+    const size_t lds = stft_mel_lds_bytes(p.n_fft, p.hop, p.frames_per_block, p.n_mels, p.mel_w_floats);
+    const int n_tiles = n_rows * p.tiles_per_row;
+    if (n_tiles <= 0) return;
+    const dim3 grid((unsigned)std::min(n_tiles, g_stft_grid));
+    if (sample_is_pcm16) hipLaunchKernelGGL(k_stft_mel<true>, grid, dim3(256), lds, s, p, n_tiles);
+    else hipLaunchKernelGGL(k_stft_mel<false>, grid, dim3(256), lds, s, p, n_tiles);
 }
 
 // ----------------------------------------------------------------------------

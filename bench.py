@@ -95,8 +95,10 @@ def main():
         sys.exit("bench.py needs an MI355X; there is no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ          # under torch.distributed.run: always take the RCCL path
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
 
     from amphibian_vae_latent_detector_amd import PRESETS, SPECS
@@ -115,15 +117,15 @@ def main():
     pcm_host = synth_batch_pcm16(idx, cfg.n_samples, cfg.sr)
     pcm = torch.from_numpy(pcm_host).to(dev)
     mu = torch.empty((args.chunks, D), dtype=torch.float32, device=dev)
-    gathered = torch.empty((world * args.chunks, D), dtype=torch.float32, device=dev) if world > 1 else None
+    gathered = torch.empty((world * args.chunks, D), dtype=torch.float32, device=dev) if use_dist else None
 
     def step():
         sess.encode(pcm, apply_rms=True, out_mu=mu)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, mu)
+        if use_dist:
+            dist.all_gather_into_tensor(gathered, mu)   # the one exchange step: concatenate the latent matrix
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -151,10 +153,12 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        if rank == 0 and not torch.equal(gathered[:args.chunks], mu):
+            sys.exit("all-gather did not return this rank's latents in place 0")
     prof = sess.profile_read()[dom]
     sess.profile_enable(False)
 
@@ -203,7 +207,7 @@ def main():
         if world == 1 and args.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(cfg, spec, state, pcm_host[:4000], args.cpu_seconds)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -91,7 +91,9 @@ const char* amph_last_error(const amph_ctx* ctx);   /* ctx may be NULL: create-t
  *   "lanes"            1..8  HIP streams + workspaces the encode entry points spread their
  *                            batches over (default 2; lane 0 is the caller's stream, the
  *                            others are forked from / joined to it with events)
- *   "frames_per_block" 4..32 STFT frames per workgroup (multiple of 4, default 8) */
+ *   "frames_per_block" 4..32 STFT frames per workgroup (multiple of 4, default 8)
+ *   "fuse_conv12"      0/1   recompute conv layer 1 inside layer 2's operand staging instead of
+ *                            materialising it (default 1; results are bit-identical either way) */
 int amph_configure(amph_ctx* ctx, const char* key, int value);
 
 /* Geometry derived from the configuration. */

@@ -204,6 +204,23 @@ def test_encoder_forward_against_torch_cpu(env, name):
         enc(torch.zeros(1, 1, 32, 64))
 
 
+@pytest.mark.parametrize("name", ["tiny", "thesis-shape"])
+def test_fused_first_two_layers_equal_unfused_bitwise(env, name):
+    """Layer 1 recomputed inside layer 2's operand staging (no 128 KB/chunk activation in HBM)
+    must give the same bits as the materialised path, for full and ragged batches."""
+    enc, tenc, spec = _encoders(env, name, max_batch=16)
+    sess = enc.session(env.cfg)
+    x = torch.from_numpy(np.random.default_rng(7).standard_normal((37, 1, 64, 64)).astype(np.float32))
+    sess.configure("fuse_conv12", 1)
+    mu1, lv1 = sess.encoder_forward(x)
+    sess.configure("fuse_conv12", 0)
+    mu0, lv0 = sess.encoder_forward(x)
+    sess.configure("fuse_conv12", 1)
+    assert torch.equal(mu1, mu0) and torch.equal(lv1, lv0)
+    with torch.no_grad():
+        _assert_latents(mu1.cpu().numpy(), tenc(x)[0].numpy(), 1e-5)
+
+
 def test_encoder_odd_shapes_generic_path(env):
     """Non power-of-two geometry: 5x5 stride-1 first layer, C_out not a multiple of 64, K padded to 32."""
     from amphibian_vae_latent_detector_amd import EncoderSpec

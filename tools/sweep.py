@@ -51,6 +51,16 @@ def main():
                 ref = mu.clone()
             elif not torch.equal(ref, mu):
                 print("!! result changed with", dict(zip(keys, c)))
+    if "stages" in opts:
+        for c in combos:
+            for k, v in zip(keys, c):
+                sess.configure(k, v)
+            sess.configure("lanes", 1)
+            sess.profile_reset(); sess.profile_enable(True)
+            sess.encode(pcm, apply_rms=True, out_mu=mu)
+            torch.cuda.synchronize()
+            print("  isolated us/launch", dict(zip(keys, c)), {st["stage"]: round(1e3 * st["total_ms"] / st["launches"], 1) for st in sess.profile_read() if st["launches"]})
+            sess.profile_enable(False); sess.profile_reset()
     print(f"batch={batch} chunks={chunks} steps={steps} rounds={rounds}")
     for c in combos:
         v = res[c]
