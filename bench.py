@@ -29,8 +29,14 @@ import sys
 import time
 from pathlib import Path
 
-import numpy as np
-import torch
+# The encode spreads its batches over 4 HIP streams ("lanes").  A process gets 4 hardware queues by
+# default and streams are mapped onto them in creation order, so once RCCL has created its own
+# streams the lanes would share queues and serialise (measured: 7.3 instead of 6.1 ms/step).  Must be
+# set before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
