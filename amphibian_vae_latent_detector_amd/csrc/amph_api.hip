@@ -85,6 +85,9 @@ struct amph_ctx {
     std::vector<Workspace> lanes;
     hipEvent_t ev_fork = nullptr;
     unsigned long long* d_stamps = nullptr;   // AMPH_STAMPS builds only
+    unsigned long long* d_gstamps = nullptr;
+    int gstamp_wgs[16] = {0};
+    int gemm_min_wg128 = 512;
     bool fuse_conv12 = true;               // recompute layer 1 inside layer 2's A staging when the tiling allows
     // radial scratch
     float* d_centroids = nullptr;
@@ -511,9 +514,10 @@ int run_encoder(amph_ctx* c, Workspace& w, const float* d_x, int nb, float* d_mu
         if (head) { p.y = w.partial; bm = 64; }
         else {
             p.y = w.act[gi + 1];
-            // keep >= ~2 workgroups per CU when the layer is small
+            // 128-row tiles move 25 % fewer operand bytes than 64-row ones (the kernels are bound by
+            // operand delivery) as long as they still give every CU a workgroup
             const long long wg128 = (long long)((p.M + 127) / 128) * ((p.N + 63) / 64);
-            if (wg128 < 512) bm = 64;
+            if (wg128 < c->gemm_min_wg128) bm = 64;
         }
         bms[gi] = bm;
     }
@@ -535,6 +539,11 @@ int run_encoder(amph_ctx* c, Workspace& w, const float* d_x, int nb, float* d_mu
     }
     for (int gi = 0; gi < n_gemm; ++gi) {
         const bool head = gi == n_gemm - 1;
+#ifdef AMPH_STAMPS
+        if (!c->d_gstamps) (void)hipMalloc((void**)&c->d_gstamps, (size_t)n_gemm * 8192 * 8 * 8);
+        prm[gi].stamps = c->d_gstamps + (size_t)gi * 8192 * 8;
+        c->gstamp_wgs[gi] = ((prm[gi].M + bms[gi] - 1) / bms[gi]) * ((prm[gi].N + 63) / 64) * prm[gi].splits;
+#endif
         StageTimer t(c, head ? stage_head_gemm(c) : ST_CONV0 + 1 + gi, s);
         launch_conv_gemm(prm[gi], bms[gi], fuse && gi == 0, s);
     }
@@ -721,6 +730,19 @@ int amph_configure(amph_ctx* c, const char* key, int value) {
     if (!std::strcmp(key, "lanes")) return set_lanes(c, value);
     if (!std::strcmp(key, "fuse_conv12")) { c->fuse_conv12 = value != 0; return AMPH_OK; }
 #ifdef AMPH_STAMPS
+    if (!std::strcmp(key, "dump_gemm_stamps")) {
+        (void)hipDeviceSynchronize();
+        for (int gi = 0; gi < (int)c->gemm.size(); ++gi) {
+            const int nwg = std::min(c->gstamp_wgs[gi], 8192);
+            std::vector<unsigned long long> h((size_t)nwg * 8);
+            (void)hipMemcpy(h.data(), c->d_gstamps + (size_t)gi * 8192 * 8, h.size() * 8, hipMemcpyDeviceToHost);
+            double s[2][3] = {{0}};
+            for (int w = 0; w < nwg; ++w) for (int r = 0; r < 2; ++r) for (int k = 0; k < 3; ++k) s[r][k] += (double)h[(size_t)w * 8 + r * 4 + k];
+            fprintf(stderr, "  gemm %d (%d workgroups): consumer work %7.0f wait %7.0f total %7.0f | loader work %7.0f wait %7.0f total %7.0f cycles\n",
+                    gi, nwg, s[0][0] / nwg, s[0][1] / nwg, s[0][2] / nwg, s[1][0] / nwg, s[1][1] / nwg, s[1][2] / nwg);
+        }
+        return AMPH_OK;
+    }
     if (!std::strcmp(key, "dump_stamps")) {      // value = number of workgroups of the last stft launch
         (void)hipDeviceSynchronize();
         std::vector<unsigned long long> h((size_t)value * 16);
@@ -732,6 +754,7 @@ int amph_configure(amph_ctx* c, const char* key, int value) {
         return AMPH_OK;
     }
 #endif
+    if (!std::strcmp(key, "gemm_min_wg128")) { c->gemm_min_wg128 = value; return AMPH_OK; }
     if (!std::strcmp(key, "stft_grid")) {
         if (value < 1 || value > 65536) return fail(c, AMPH_ERR_INVALID_ARG, "stft_grid must be in 1..65536");
         amph::g_stft_grid = value;

@@ -95,6 +95,9 @@ struct ConvGemmParams {      // implicit GEMM: M = B*OH*OW, N = C_out, K = k*k*C
     const float* scale1;     // [C_in]
     const float* shift1;     // [C_in]
     int H0, W0, k1, s1, p1;
+#ifdef AMPH_STAMPS
+    unsigned long long* stamps;   // diagnostic build: [workgroup][role][4]
+#endif
 };
 
 struct HeadReduceParams {    // mu/logvar = sum_s partial[s] + bias

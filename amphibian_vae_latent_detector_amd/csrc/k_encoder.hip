@@ -88,11 +88,17 @@ constexpr int kBN = 64, kBK = 32, kLdsRow = 36;
 // work is interleaved with this kernel's MFMAs.  Requires the BM-row tile to be whole output
 // rows of one chunk (host checks (OH*OW) % BM == 0 and BM % OW == 0).
 //
-// Pipeline: a 3-stage REGISTER ring.  Global loads for slice ks+3 are issued while slice ks
-// is multiplied; the ring stage holding slice ks+1 is written to the spare LDS buffer at the
-// end of the iteration (the compiler's counted vmcnt wait then leaves two slices in flight),
-// one barrier per slice.  With a prefetch distance of one slice the loop was bound by the
-// L2 -> register latency (measured 4.7k cycles per slice for 1k cycles of MFMA).
+// Pipeline: a 3-stage REGISTER ring.  Global loads for slice ks+3 are issued while slice ks is
+// multiplied; the ring stage holding slice ks+1 is written to the spare LDS buffer at the end of
+// the iteration (the compiler's counted vmcnt wait leaves two slices in flight), one barrier per
+// slice, double-buffered LDS.
+//
+// What bounds it (profiles/r01_gemm_*; DESIGN.md "K4"): operand delivery.  In-kernel stamps of a
+// wave-specialised variant (4 loader + 4 MFMA waves) showed the loaders busy 44k of 53k cycles and
+// never waiting, the MFMA waves waiting 19k: per launch the 64x64 tiles pull 150 MB (im2col repeats
+// every input 2.25x, every A tile is re-read per N tile, the weights per M tile) = 13 B/clk/CU,
+// the fabric rate.  Prefetch depth, address-math trimming and wave roles therefore did not move it;
+// the roles variant was dropped again (it starved the fused layer-1 recompute of issue slots).
 template <int BM, bool FUSE1>
 __global__ __launch_bounds__(256) void k_conv_gemm(ConvGemmParams p) {
     constexpr int A_ROWS = BM / 32;            // rows of the A tile each thread stages
@@ -108,21 +114,28 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvGemmParams p) {
     const int c4 = tid & 7, r0 = tid >> 3;
     const int m_blk = blockIdx.x * BM, n_blk = blockIdx.y * kBN;
 
-    // per-thread A rows: output pixel -> input window origin
+    // per-thread A rows: output pixel -> input window origin, base pointer of the window in the
+    // NHWC input (never dereferenced for padded taps) and a bitmask of the k*k taps that are in range
     int ih0[A_ROWS], iw0[A_ROWS];
-    long long boff[A_ROWS];
-    bool mval[A_ROWS];
+    const float* pa[A_ROWS];
+    unsigned vmask[A_ROWS];
     const int ohw = p.OH * p.OW;
 #pragma unroll
     for (int i = 0; i < A_ROWS; ++i) {
         const int m = m_blk + r0 + 32 * i;
-        mval[i] = m < p.M;
-        const int mm = mval[i] ? m : 0;
+        const bool mv = m < p.M;
+        const int mm = mv ? m : 0;
         const int b = mm / ohw, rem = mm - b * ohw;
         const int oh = rem / p.OW, ow = rem - oh * p.OW;
         ih0[i] = oh * p.stride - p.pad;
         iw0[i] = ow * p.stride - p.pad;
-        boff[i] = (long long)b * p.H * p.W * p.C_in;
+        pa[i] = p.x + (long long)b * p.H * p.W * p.C_in + ((long long)ih0[i] * p.W + iw0[i]) * p.C_in;
+        unsigned vm = 0;
+        for (int kh = 0; kh < p.k; ++kh)
+            for (int kw = 0; kw < p.k; ++kw)
+                if (mv && ih0[i] + kh >= 0 && ih0[i] + kh < p.H && iw0[i] + kw >= 0 && iw0[i] + kw < p.W)
+                    vm |= 1u << (kh * p.k + kw);
+        vmask[i] = vm;
     }
     const int PW = p.W0 + 2 * p.p1;
     int patch_lo = 0;                          // image row held in patch row 0
@@ -153,30 +166,60 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvGemmParams p) {
     // ---- register ring: stage q holds the A rows / B rows of one K slice
     float4 sa0[A_ROWS], sa1[A_ROWS], sa2[A_ROWS];
     float4 sb0a, sb0b, sb1a, sb1b, sb2a, sb2b;
-    // decoded position of this thread's float4 inside a slice
-#define AMPH_DECODE(ks_, kval_, kh_, kw_, ci_)                                                            \
-    const int kflat_ = min((ks_), ks_end - 1) * kBK + 4 * c4;                                             \
-    const bool kval_ = kflat_ < p.K;                                                                      \
-    const int kpos_ = kflat_ / p.C_in, ci_ = kflat_ - kpos_ * p.C_in;                                     \
-    const int kh_ = kpos_ / p.k, kw_ = kpos_ - kh_ * p.k;
-    // issue the global loads of slice ks_ into ring stage q (slices past the end re-load the last one)
-#define AMPH_LOAD_B(q, ks_)                                                                               \
+    // position of this thread's float4 inside the K slices, advanced slice by slice without divisions:
+    // flat k = (kh*k + kw)*C_in + ci.  `ld` is the state of the next slice the ring will LOAD (plain
+    // path), `fd` of the next slice the fused path will recompute.
+    struct KPos { int kflat, kpos, kh, kw, ci; };
+    auto kpos_init = [&](int ks) {
+        KPos d;
+        d.kflat = ks * kBK + 4 * c4;
+        d.kpos = d.kflat / p.C_in;
+        d.ci = d.kflat - d.kpos * p.C_in;
+        d.kh = d.kpos / p.k;
+        d.kw = d.kpos - d.kh * p.k;
+        return d;
+    };
+    auto kpos_next = [&](KPos& d) {
+        d.kflat += kBK;
+        d.ci += kBK;
+        while (d.ci >= p.C_in) {
+            d.ci -= p.C_in;
+            ++d.kpos;
+            if (++d.kw == p.k) { d.kw = 0; ++d.kh; }
+        }
+    };
+    KPos ld = kpos_init(ks_begin), fd = ld;
+    int ld_left = ks_end - ks_begin, fd_left = ld_left;     // slices not yet consumed by each state
+    const float* wp0 = wrow0 + ks_begin * kBK;
+    const float* wp1 = wrow1 + ks_begin * kBK;
+#ifdef AMPH_ABL_NOLOAD
+#define AMPH_A_FETCH(ptr_) make_float4((float)koff_, 1.f, 1.f, 1.f)
+#else
+#define AMPH_A_FETCH(ptr_) (*reinterpret_cast<const float4*>(ptr_))
+#endif
+    // issue the global loads of the NEXT slice into ring stage q (past the end: reload the last slice)
+#ifdef AMPH_ABL_NOLOAD   /* timing-only diagnostic build: no global operand loads */
+#define AMPH_LOAD_B(q) { sb##q##a = make_float4(1.f, 1.f, 1.f, 1.f); sb##q##b = sb##q##a; }
+#else
+#define AMPH_LOAD_B(q)                                                                                    \
     {                                                                                                     \
-        const int kc_ = min((ks_), ks_end - 1) * kBK;                                                     \
-        sb##q##a = *reinterpret_cast<const float4*>(wrow0 + kc_);                                         \
-        sb##q##b = *reinterpret_cast<const float4*>(wrow1 + kc_);                                         \
+        sb##q##a = *reinterpret_cast<const float4*>(wp0);                                                 \
+        sb##q##b = *reinterpret_cast<const float4*>(wp1);                                                 \
     }
-#define AMPH_LOAD_A(q, ks_)                                                                               \
+#endif
+#define AMPH_LOAD_A(q)                                                                                    \
     {                                                                                                     \
-        AMPH_DECODE(ks_, kval_, kh_, kw_, ci_)                                                            \
+        const bool kval_ = ld.kflat < p.K;                                                                \
+        const int koff_ = (ld.kh * p.W + ld.kw) * p.C_in + ld.ci;                                         \
         _Pragma("unroll") for (int i = 0; i < A_ROWS; ++i) {                                              \
-            const int ih_ = ih0[i] + kh_, iw_ = iw0[i] + kw_;                                             \
             float4 a_ = make_float4(0.f, 0.f, 0.f, 0.f);                                                  \
-            if (kval_ && mval[i] && ih_ >= 0 && ih_ < p.H && iw_ >= 0 && iw_ < p.W)                       \
-                a_ = *reinterpret_cast<const float4*>(p.x + boff[i] + ((long long)ih_ * p.W + iw_) * p.C_in + ci_); \
+            if (kval_ && ((vmask[i] >> ld.kpos) & 1u)) a_ = AMPH_A_FETCH(pa[i] + koff_);                  \
             sa##q[i] = a_;                                                                                \
         }                                                                                                 \
     }
+    // advance the load state by one slice (stays on the last slice once the end is reached)
+#define AMPH_LOAD_ADVANCE()                                                                               \
+    { if (--ld_left > 0) { kpos_next(ld); wp0 += kBK; wp1 += kBK; } else { ld_left = 1; } }
 #define AMPH_STORE(q, buf_)                                                                               \
     {                                                                                                     \
         float* a_ = As + (buf_) * BM * kLdsRow;                                                           \
@@ -195,19 +238,20 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvGemmParams p) {
     int f_kh = 0, f_kw = 0;
 #pragma unroll
     for (int t = 0; t < 9; ++t) { w1r[t] = sc1; pv[t] = 0.0f; }
-#define AMPH_F_DECODE(ks_)                                                                                \
+#define AMPH_F_DECODE()                                                                                   \
     {                                                                                                     \
-        AMPH_DECODE(ks_, kval_, kh_, kw_, ci_)                                                            \
-        f_kval = kval_; f_kh = kh_; f_kw = kw_;                                                           \
-        const float* wt_ = w1s + (kval_ ? ci_ : 0);                                                       \
+        f_kval = fd.kflat < p.K; f_kh = fd.kh; f_kw = fd.kw;                                              \
+        const float* wt_ = w1s + (f_kval ? fd.ci : 0);                                                    \
         _Pragma("unroll") for (int t = 0; t < 9; ++t) w1r[t] = *reinterpret_cast<const float4*>(wt_ + t * p.C_in); \
         sc1 = *reinterpret_cast<const float4*>(wt_ + 9 * p.C_in);                                         \
         sh1 = *reinterpret_cast<const float4*>(wt_ + 10 * p.C_in);                                        \
     }
+#define AMPH_F_ADVANCE()                                                                                  \
+    { if (--fd_left > 0) { kpos_next(fd); } else { fd_left = 1; } }
 #define AMPH_F_PATCH(i)                                                                                   \
     {                                                                                                     \
         const int ih_ = ih0[i] + f_kh, iw_ = iw0[i] + f_kw;                                               \
-        pok = f_kval && mval[i] && ih_ >= 0 && ih_ < p.H && iw_ >= 0 && iw_ < p.W;                        \
+        pok = f_kval && ((vmask[i] >> (f_kh * p.k + f_kw)) & 1u);                                         \
         const float* pp_ = patch + (pok ? (ih_ * p.s1 - p.p1 - patch_lo) * PW + iw_ * p.s1 : 0);          \
         _Pragma("unroll") for (int t = 0; t < 9; ++t) pv[t] = pp_[(t / 3) * PW + (t % 3)];                \
     }
@@ -238,13 +282,32 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvGemmParams p) {
     const int a_off = (row_tile * 32 + (lane & 31)) * kLdsRow + 4 * (lane >> 5);
     const int b_off = (col_tile0 * 32 + (lane & 31)) * kLdsRow + 4 * (lane >> 5);
 
+#ifdef AMPH_ABL_NOMFMA   /* timing-only diagnostic build: operands stay live, no matrix instruction */
+#define AMPH_MFMA(acc_, a_, b_) { asm volatile("" ::"v"(a_), "v"(b_)); }
+#else
+#define AMPH_MFMA(acc_, a_, b_) acc_ = __builtin_amdgcn_mfma_f32_32x32x2f32(a_, b_, acc_, 0, 0, 0);
+#endif
     // one slice: multiply LDS buffer `buf_` (slice ks_), load slice ks_+3 into stage qload_,
     // stage slice ks_+1 (ring stage qstore_) into the other buffer
-#define AMPH_STEP(ks_, buf_, qload_, qstore_)                                                             \
+#ifdef AMPH_STAMPS
+#define AMPH_GSTAMP(v_)                                                                                   \
     {                                                                                                     \
-        AMPH_LOAD_B(qload_, (ks_) + 3);                                                                   \
-        if (!FUSE1) AMPH_LOAD_A(qload_, (ks_) + 3)                                                        \
-        else { AMPH_F_DECODE((ks_) + 1); AMPH_F_PATCH(0); }                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v_)::"memory");                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+    }
+    unsigned long long t_a = 0, t_b = 0, t_c = 0, sum_work = 0, sum_wait = 0, t_start = 0;
+    AMPH_GSTAMP(t_start)
+#else
+#define AMPH_GSTAMP(v_)
+#endif
+#define AMPH_STEP(buf_, qload_, qstore_)                                                                  \
+    {                                                                                                     \
+        AMPH_GSTAMP(t_a)                                                                                  \
+        AMPH_LOAD_B(qload_);                                                                              \
+        if (!FUSE1) AMPH_LOAD_A(qload_)                                                                   \
+        else { AMPH_F_DECODE(); AMPH_F_PATCH(0); }                                                        \
+        AMPH_LOAD_ADVANCE()                                                                               \
         const float* a = As + (buf_) * BM * kLdsRow + a_off;                                              \
         const float* b = Bs + (buf_) * kBN * kLdsRow + b_off;                                             \
         _Pragma("unroll") for (int kg = 0; kg < kBK / 8; ++kg) {                                          \
@@ -256,9 +319,12 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvGemmParams p) {
             _Pragma("unroll") for (int st = 0; st < 4; ++st)                                              \
                 _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                          \
                     const float fbv = st == 0 ? fb[t].x : st == 1 ? fb[t].y : st == 2 ? fb[t].z : fb[t].w; \
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fav[st], fbv, acc[t], 0, 0, 0);         \
+                    AMPH_MFMA(acc[t], fav[st], fbv)                                                       \
                 }                                                                                         \
             if (FUSE1 && kg < A_ROWS) {                                                                   \
+                /* layer-1 output of A row kg of the NEXT slice from the window read one k-group       */ \
+                /* earlier, and the window of row kg + 1; the group barriers spread this VALU / LDS    */ \
+                /* work between this k-group's MFMAs (a wave issues in order)                          */ \
                 AMPH_F_ROW(qstore_, kg);                                                                  \
                 if (kg + 1 < A_ROWS) AMPH_F_PATCH(kg + 1);                                                \
                 _Pragma("unroll") for (int g = 0; g < 4 * NT; ++g) {                                      \
@@ -268,35 +334,58 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvGemmParams p) {
                 }                                                                                         \
             }                                                                                             \
         }                                                                                                 \
+        if (FUSE1) AMPH_F_ADVANCE()                                                                       \
         AMPH_STORE(qstore_, (buf_) ^ 1);                                                                  \
+        AMPH_GSTAMP(t_b)                                                                                  \
         __syncthreads();                                                                                  \
+        AMPH_GSTAMP(t_c)                                                                                  \
+        AMPH_GACC()                                                                                       \
     }
+#ifdef AMPH_STAMPS
+#define AMPH_GACC() { sum_work += t_b - t_a; sum_wait += t_c - t_b; }
+#else
+#define AMPH_GACC()
+#endif
 
-    // prologue: slices 0, 1, 2 into the ring (B always; A gathered, or slice 0 recomputed), slice 0 to LDS
-    AMPH_LOAD_B(0, ks_begin);
-    AMPH_LOAD_B(1, ks_begin + 1);
-    AMPH_LOAD_B(2, ks_begin + 2);
-    if (!FUSE1) {
-        AMPH_LOAD_A(0, ks_begin)
-        AMPH_LOAD_A(1, ks_begin + 1)
-        AMPH_LOAD_A(2, ks_begin + 2)
-    } else {
-        AMPH_F_DECODE(ks_begin);
+    // prologue: slices 0, 1, 2 into the ring (B always; A gathered, or slice 0 recomputed), slice 0 to LDS.
+    // Plain path: the load state runs three slices ahead of the multiply.  Fused path: B runs three
+    // ahead, the recompute state `fd` one ahead (it fills the ring stage that is stored next).
+    AMPH_LOAD_B(0);
+    if (!FUSE1) AMPH_LOAD_A(0)
+    AMPH_LOAD_ADVANCE()
+    AMPH_LOAD_B(1);
+    if (!FUSE1) AMPH_LOAD_A(1)
+    AMPH_LOAD_ADVANCE()
+    AMPH_LOAD_B(2);
+    if (!FUSE1) AMPH_LOAD_A(2)
+    AMPH_LOAD_ADVANCE()
+    if (FUSE1) {
+        AMPH_F_DECODE();
 #pragma unroll
         for (int i = 0; i < A_ROWS; ++i) { AMPH_F_PATCH(i); AMPH_F_ROW(0, i); }
+        AMPH_F_ADVANCE()
     }
     AMPH_STORE(0, 0);
     __syncthreads();
     // main loop, unrolled by the ring length so that every stage index is static; the LDS buffer
     // parity alternates 0,1,0 / 1,0,1 across the two halves of a 6-slice period
     for (int ks = ks_begin; ks < ks_end; ks += 6) {
-        AMPH_STEP(ks, 0, 0, 1)
-        if (ks + 1 < ks_end) AMPH_STEP(ks + 1, 1, 1, 2)
-        if (ks + 2 < ks_end) AMPH_STEP(ks + 2, 0, 2, 0)
-        if (ks + 3 < ks_end) AMPH_STEP(ks + 3, 1, 0, 1)
-        if (ks + 4 < ks_end) AMPH_STEP(ks + 4, 0, 1, 2)
-        if (ks + 5 < ks_end) AMPH_STEP(ks + 5, 1, 2, 0)
+        AMPH_STEP(0, 0, 1)
+        if (ks + 1 < ks_end) AMPH_STEP(1, 1, 2)
+        if (ks + 2 < ks_end) AMPH_STEP(0, 2, 0)
+        if (ks + 3 < ks_end) AMPH_STEP(1, 0, 1)
+        if (ks + 4 < ks_end) AMPH_STEP(0, 1, 2)
+        if (ks + 5 < ks_end) AMPH_STEP(1, 2, 0)
     }
+#ifdef AMPH_STAMPS
+    if (tid == 0 && p.stamps) {
+        unsigned long long t_end;
+        AMPH_GSTAMP(t_end)
+        unsigned long long* o = p.stamps + (size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8;
+        o[0] = sum_work; o[1] = sum_wait; o[2] = t_end - t_start; o[3] = 1;
+        o[4] = o[5] = o[6] = o[7] = 0;
+    }
+#endif
 
     // epilogue: C/D map of the 32x32 tile: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
 #pragma unroll
@@ -330,7 +419,7 @@ static size_t conv_gemm_lds(const ConvGemmParams& p, int bm, bool fuse) {
 
 bool conv_gemm_can_fuse(const ConvGemmParams& p, int bm) {
     const int ohw = p.OH * p.OW;
-    return p.img != nullptr && p.k1 == 3 && ohw % bm == 0 && bm % p.OW == 0 && (p.C_in % 4) == 0 &&
+    return p.img != nullptr && p.k1 == 3 && p.k * p.k <= 32 && ohw % bm == 0 && bm % p.OW == 0 && (p.C_in % 4) == 0 &&
            conv_gemm_lds(p, bm, true) <= 64 * 1024;
 }
 
