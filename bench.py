@@ -188,6 +188,16 @@ def main():
         iso_cpl = args.chunks / max(1, stages[dom]["launches"])
         iso = (prof["flops_per_chunk"] * iso_cpl / (iso_ms * 1e-3) / 1e12 if is_mfma
                else prof["bytes_per_chunk"] * iso_cpl / (iso_ms * 1e-3) / 1e9)
+        # HBM-side bytes per launch of that kernel from the committed PMC profile of this same configuration
+        # (bench.py cannot run rocprofv3 on itself); null when the profile has no entry for the kernel
+        try:
+            tr = json.load(open(ROOT / "profiles" / "r01_traffic.json"))["kernels"].get(prof["stage"])
+            if tr and args.batch == 256 and args.preset == "bench-1s" and args.spec == "thesis-shape":
+                roof["traffic"] = tr["traffic_bytes"]
+                roof["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+                roof["algorithmic_bytes_per_launch"] = int(prof["bytes_per_chunk"] * args.batch)
+        except (OSError, ValueError, KeyError):
+            pass
         roof.update({"avg_launch_ms": round(ms, 5), "launches": int(prof["launches"]),
                      "chunks_per_launch": round(chunks_per_launch, 1), "concurrent_lanes": n_lanes,
                      "isolated": {"avg_launch_ms": round(iso_ms, 5), "achieved": round(iso, 3),
