@@ -217,7 +217,8 @@ int stage_head_reduce(const amph_ctx* c) { return ST_CONV0 + c->spec.n_conv + 1;
 
 int build_frontend(amph_ctx* c) {
     const amph_frontend_config& f = c->cfg;
-    if (f.n_fft != 2048) return fail(c, AMPH_ERR_UNSUPPORTED, "n_fft=%d: this build implements n_fft=2048 only", f.n_fft);
+    if (f.n_fft != 2048 && f.n_fft != 1024)
+        return fail(c, AMPH_ERR_UNSUPPORTED, "n_fft=%d: this build implements n_fft = 1024 and 2048", f.n_fft);
     if (f.hop_length <= 0 || (f.hop_length & 1)) return fail(c, AMPH_ERR_UNSUPPORTED, "hop_length must be positive and even");
     if (f.n_samples <= 0 || f.n_mels <= 0 || f.target_frames <= 0 || f.sr <= 0)
         return fail(c, AMPH_ERR_INVALID_ARG, "non-positive front-end parameter");
@@ -227,10 +228,10 @@ int build_frontend(amph_ctx* c) {
     c->n_frames = 1 + f.n_samples / f.hop_length;
     c->frames_per_block = 8;
 
-    const int n_fft = f.n_fft, Nc = n_fft / 2, L = 64, TLO = 4;
+    const int n_fft = f.n_fft, Nc = n_fft / 2, TLO = Nc / 256, L = 16 * TLO;
     const double PI = 3.14159265358979323846;
     // packed table image (layout = the kernel's LDS image): half window | tw_b | tw_post; tw_a separately
-    std::vector<float> tab(stft_mel_table_bytes() / 4, 0.0f);
+    std::vector<float> tab(stft_mel_table_bytes(n_fft) / 4, 0.0f);
     std::vector<float2> twa(15 * L);
     {
         float* win = tab.data();                                  // w[0..1024]; w[n] == w[N - n] covers the rest
@@ -240,14 +241,14 @@ int build_frontend(amph_ctx* c) {
                 const double a = -2.0 * PI * (double)((t * k1) % Nc) / (double)Nc;
                 twa[(k1 - 1) * L + t] = make_float2((float)std::cos(a), (float)std::sin(a));
             }
-        float* twb = tab.data() + 4112 / 4;
+        float* twb = tab.data() + ((((Nc + 1) * 4 + 15) & ~15) / 4);
         for (int k2a = 0; k2a < 16; ++k2a)
             for (int t = 0; t < TLO; ++t) {
                 const double a = -2.0 * PI * (double)((t * k2a) % L) / (double)L;
                 twb[2 * (k2a * TLO + t)] = (float)std::cos(a);
                 twb[2 * (k2a * TLO + t) + 1] = (float)std::sin(a);
             }
-        float* twp = twb + 16 * 4 * 2;
+        float* twp = twb + 16 * TLO * 2;
         for (int k = 0; k <= Nc / 2; ++k) {
             const double a = -2.0 * PI * (double)k / (double)n_fft;
             twp[2 * k] = (float)std::cos(a);
@@ -287,7 +288,8 @@ int build_frontend(amph_ctx* c) {
         }
     }
     c->mel_p_tail = std::max(p_tail, 0);
-    if (F + c->mel_p_tail > 2176) return fail(c, AMPH_ERR_UNSUPPORTED, "mel rows reach past the per-wave scratch");
+    if (F + c->mel_p_tail > stft_mel_scratch_floats(n_fft))
+        return fail(c, AMPH_ERR_UNSUPPORTED, "mel rows reach past the per-frame scratch");
     HIP_TRY(c, upload(&c->d_mel_start, st));
     HIP_TRY(c, upload(&c->d_mel_len, ln));
     HIP_TRY(c, upload(&c->d_mel_wofs, wo));

@@ -10,7 +10,6 @@ namespace amph {
 // Front end
 // ----------------------------------------------------------------------------
 constexpr int kFrontThreads = 256;      // 4 waves per workgroup
-constexpr int kExStride = 68;           // exchange row stride in float2 (64 + 4 pad)
 constexpr int kZPad = 4;                // float2 of padding per 256-point block of Z
 
 struct WaveSrc {
@@ -62,7 +61,8 @@ void launch_rms_apply_pcm16(const int16_t* in, int n_rows, int n, const float* s
 // sample_is_pcm16: 1 -> src.wave is int16_t, 0 -> float
 void launch_stft_mel(const StftParams& p, int n_rows, int sample_is_pcm16, hipStream_t s);
 size_t stft_mel_lds_bytes(int n_fft, int hop, int frames_per_block, int n_mels, int mel_w_floats);
-int stft_mel_table_bytes();
+int stft_mel_table_bytes(int n_fft);
+int stft_mel_scratch_floats(int n_fft);   // floats of per-frame scratch the power spectrum + tail may use
 hipError_t stft_mel_configure(int lds_bytes);   // raises the dynamic-LDS limit of the STFT kernels
 void launch_dbnorm(const DbNormParams& p, int n_rows, hipStream_t s);
 

@@ -369,14 +369,23 @@ __device__ __forceinline__ float normalise_sample(const WaveSrc& src, float x, f
 #define AMPH_STAMP(k)
 #endif
 
-constexpr int kNc = 1024;                             // complex FFT length (n_fft = 2048)
-constexpr int kWaveScratch = 16 * kExStride * 8;      // 8704 B per wave: exchange tile, then Z[1024 + 4*kZPad], then P[1025 + pad]
-// LDS tables (bytes, all multiples of 16), staged once per workgroup:
-constexpr int kWinHalfBytes = 4112;                   // w[0 .. 1024] of the periodic Hann window (w[n] == w[N - n])
-constexpr int kTwBBytes = 16 * 4 * 8;                 // W_64^(t_lo*k2a)
-constexpr int kTwPostBytes = 4112;                    // W_2048^k, k = 0..512
-constexpr int kTableBytes = kWinHalfBytes + kTwBBytes + kTwPostBytes;
-// W_1024^(t*k1), k1 = 1..15, [15][64] float2 stays in global memory (L1/L2 resident): its 15 loads per
+// Geometry of the wave FFT for n_fft = 512 * T_LO (tools/fft_lane_model.py): NC = 256 * T_LO complex
+// points per frame on L = 16 * T_LO lanes, so a wave transforms 64 / L frames at once (T_LO = 4: one
+// frame per wave; T_LO = 2: one frame per half-wave).  The last stage is a radix-T_LO across adjacent lanes.
+template <int T_LO>
+struct FftGeo {
+    static constexpr int L = 16 * T_LO;
+    static constexpr int NC = 256 * T_LO;
+    static constexpr int SLOTS = 64 / L;                       // frames per wave per iteration
+    static constexpr int EXS = T_LO == 4 ? 68 : 34;            // exchange row stride (float2): conflict-free both ways
+    static constexpr int SLOT_BYTES = 16 * EXS * 8;            // exchange tile, then Z[NC + pads], then P[NC + 1 + tail]
+    static constexpr int WIN_BYTES = ((NC + 1) * 4 + 15) & ~15;        // w[0 .. NC] of the periodic Hann window (w[n] == w[N - n])
+    static constexpr int TWB_BYTES = 16 * T_LO * 8;                    // W_L^(t_lo*k2a)
+    static constexpr int TWP_BYTES = ((NC / 2 + 1) * 8 + 15) & ~15;    // W_{2NC}^k, k = 0 .. NC/2
+    static constexpr int TABLE_BYTES = WIN_BYTES + TWB_BYTES + TWP_BYTES;
+};
+constexpr int kWaveScratch = 8704;                    // = SLOTS * SLOT_BYTES for both geometries
+// W_NC^(t*k1), k1 = 1..15, [15][L] float2 stays in global memory (L1/L2 resident): its 15 loads per
 // frame are independent of everything and are issued at the top of the frame, under the first DFT.
 // The mel weights, whose loads sat on the critical path of every frame, live in LDS instead.
 
@@ -384,15 +393,19 @@ constexpr int kTableBytes = kWinHalfBytes + kTwBBytes + kTwPostBytes;
 // The tables and mel rows are staged into LDS once per workgroup (staged per tile they were 37 MB of
 // L2 traffic per launch, fetched by every workgroup at the same moment); the next tile's samples are
 // prefetched into registers while the current tile's FFTs run.
-template <bool PCM16>
+template <bool PCM16, int T_LO>
 __global__ __launch_bounds__(256) void k_stft_mel(StftParams p, int n_tiles) {
+    using G = FftGeo<T_LO>;
+    constexpr int kNc = G::NC, L = G::L, SLOTS = G::SLOTS, EXS = G::EXS;
+    constexpr int kWinHalfBytes = G::WIN_BYTES, kTwBBytes = G::TWB_BYTES, kTableBytes = G::TABLE_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lane_f = lane & (L - 1), slot = lane / L;       // lane inside its frame, frame slot of the wave
     const int FT = p.frames_per_block;
 #ifdef AMPH_STAMPS
     { const int fl = 0; AMPH_STAMP(0) }
 #endif
-    const int n_fft = 2 * kNc;
+    constexpr int n_fft = 2 * kNc;
     const int span_len = (FT - 1) * p.hop + n_fft;
     const int span_bytes = (span_len * 4 + 15) & ~15;
     float* win_h = reinterpret_cast<float*>(smem);
@@ -405,8 +418,8 @@ __global__ __launch_bounds__(256) void k_stft_mel(StftParams p, int n_tiles) {
     float* mel_w = reinterpret_cast<float*>(smem + kTableBytes + meta_bytes);
     float* span = reinterpret_cast<float*>(smem + kTableBytes + meta_bytes + melw_bytes);
     char* wbase = smem + kTableBytes + meta_bytes + melw_bytes + span_bytes + wave * kWaveScratch;
-    float2* ex = reinterpret_cast<float2*>(wbase);
-    float* P = reinterpret_cast<float*>(wbase);
+    float2* ex = reinterpret_cast<float2*>(wbase + slot * G::SLOT_BYTES);   // this frame slot's scratch
+    float* P = reinterpret_cast<float*>(wbase + slot * G::SLOT_BYTES);
 
     // ---- once per workgroup: tables (one packed global array = the LDS image) and the mel rows
     {
@@ -502,19 +515,22 @@ __global__ __launch_bounds__(256) void k_stft_mel(StftParams p, int n_tiles) {
             }
         }
 
-    const int k1b = lane >> 2, t_lo = lane & 3;
-    const int k2b = ((t_lo & 1) << 1) | (t_lo >> 1);   // stage C leaves k2b bit-reversed across the quad
-    for (int fl = wave; fl < FT; fl += 4) {
+    const int k1b = lane_f / T_LO, t_lo = lane_f % T_LO;
+    // stage C leaves k2b bit-reversed across the quad (radix-4); the radix-2 form is in order
+    const int k2b = T_LO == 4 ? (((t_lo & 1) << 1) | (t_lo >> 1)) : t_lo;
+    for (int fl0 = wave * SLOTS; fl0 < FT; fl0 += 4 * SLOTS) {
+        if (f_base + fl0 >= p.n_frames) break;        // wave-uniform: the wave's first frame slot is past the end
+        const int fl = fl0 + slot;
         const int frame = f_base + fl;
-        if (frame >= p.n_frames) break;               // wave-uniform
+        const bool fvalid = fl < FT && frame < p.n_frames;    // the second half-wave may hold no frame
         AMPH_STAMP(1)
         float re[16], im[16];
-        // ---- window + even/odd packing: z[n] = x[2n] w[2n] + i x[2n+1] w[2n+1], n = lane + 64 j
+        // ---- window + even/odd packing: z[n] = x[2n] w[2n] + i x[2n+1] w[2n+1], n = lane_f + L j
         {
-            const float2* xs = reinterpret_cast<const float2*>(span + fl * p.hop);
+            const float2* xs = reinterpret_cast<const float2*>(span + min(fl, FT - 1) * p.hop);
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const int n = lane + 64 * j;
+                const int n = lane_f + L * j;
                 const float2 x = xs[n];
                 float w0, w1;
                 if (j < 8) { const float2 w = reinterpret_cast<const float2*>(win_h)[n]; w0 = w.x; w1 = w.y; }
@@ -530,17 +546,17 @@ __global__ __launch_bounds__(256) void k_stft_mel(StftParams p, int n_tiles) {
         for (int k1 = 0; k1 < 16; ++k1) {
             float r = re[DFT16_POS(k1)], i = im[DFT16_POS(k1)];
             if (k1 > 0) {
-                const float2 w = tw_a[(k1 - 1) * 64 + lane];
+                const float2 w = tw_a[(k1 - 1) * L + lane_f];
                 AMPH_CMUL(r, i, w.x, w.y);
             }
-            ex[k1 * kExStride + lane] = make_float2(r, i);
+            ex[k1 * EXS + lane_f] = make_float2(r, i);
         }
         wave_lds_sync();
         AMPH_STAMP(3)
-        // ---- stage B: lane (k1b, t_lo) gathers t = t_lo + 4 m
+        // ---- stage B: lane (k1b, t_lo) gathers t = t_lo + T_LO m
 #pragma unroll
         for (int m = 0; m < 16; ++m) {
-            const float2 v = ex[k1b * kExStride + t_lo + 4 * m];
+            const float2 v = ex[k1b * EXS + t_lo + T_LO * m];
             re[m] = v.x;
             im[m] = v.y;
         }
@@ -553,11 +569,11 @@ __global__ __launch_bounds__(256) void k_stft_mel(StftParams p, int n_tiles) {
         for (int k2a = 0; k2a < 16; ++k2a) {
             float r = re[DFT16_POS(k2a)], i = im[DFT16_POS(k2a)];
             if (k2a > 0) {
-                const float2 w = tw_b[k2a * 4 + t_lo];
+                const float2 w = tw_b[k2a * T_LO + t_lo];
                 AMPH_CMUL(r, i, w.x, w.y);
             }
-            // ---- stage C: radix-4 over the quad's t_lo (xor-2 then xor-1 butterflies)
-            {
+            // ---- stage C: radix-T_LO over adjacent lanes (DPP xor butterflies)
+            if (T_LO == 4) {
                 const float pr = dpp_xor2(r), pi = dpp_xor2(i);
                 float nr, ni;
                 if (t_lo < 2) { nr = r + pr; ni = i + pi; }
@@ -569,19 +585,23 @@ __global__ __launch_bounds__(256) void k_stft_mel(StftParams p, int n_tiles) {
                 const float qr = dpp_xor1(nr), qi = dpp_xor1(ni);
                 if ((t_lo & 1) == 0) { r = nr + qr; i = ni + qi; }
                 else { r = qr - nr; i = qi - ni; }
+            } else {
+                const float pr = dpp_xor1(r), pi = dpp_xor1(i);
+                if (t_lo == 0) { r = r + pr; i = i + pi; }
+                else { r = pr - r; i = pi - i; }
             }
             // lane holds X[k1b + 16 k2a + 256 k2b]
             Z[k1b + 16 * k2a + (256 + kZPad) * k2b] = make_float2(r, i);
         }
         wave_lds_sync();
         AMPH_STAMP(6)
-        // ---- real-FFT split: bins k and 1024 - k from Z[k], Z[1024 - k]; the power spectrum
+        // ---- real-FFT split: bins k and NC - k from Z[k], Z[NC - k]; the power spectrum
         //      is written over the Z image, so every pair is read into registers first
         {
             float2 za[9], zb[9];
 #pragma unroll
             for (int it = 0; it < 9; ++it) {
-                const int k = min(lane + 64 * it, kNc / 2);
+                const int k = min(lane_f + L * it, kNc / 2);
                 const int k2 = (kNc - k) & (kNc - 1);
                 za[it] = Z[k + kZPad * (k >> 8)];
                 zb[it] = Z[k2 + kZPad * (k2 >> 8)];
@@ -590,7 +610,7 @@ __global__ __launch_bounds__(256) void k_stft_mel(StftParams p, int n_tiles) {
             AMPH_STAMP(7)
 #pragma unroll
             for (int it = 0; it < 9; ++it) {
-                const int k = lane + 64 * it;
+                const int k = lane_f + L * it;
                 if (k <= kNc / 2) {
                     const float2 a = za[it], b = zb[it];
                     const float2 w = tw_p[k];
@@ -602,22 +622,25 @@ __global__ __launch_bounds__(256) void k_stft_mel(StftParams p, int n_tiles) {
                     if (k != kNc - k) P[kNc - k] = mr * mr + mi * mi;
                 }
             }
-            for (int i = lane; i < p.p_tail; i += 64) P[kNc + 1 + i] = 0.0f;   // zero the tail the padded mel rows touch
+            for (int i = lane_f; i < p.p_tail; i += L) P[kNc + 1 + i] = 0.0f;   // zero the tail the padded mel rows touch
         }
         wave_lds_sync();
         AMPH_STAMP(8)
         // ---- mel rows: 4 lanes per filter, each lane 4 consecutive bins per step (aligned float4).
         //      The host pads every filter of a 16-filter round to the round's longest row (zero
         //      weights), so the step count is wave-uniform: no per-lane predication, no branches.
-        {
-            float* out = p.melpow + ((long long)row * p.n_frames + frame) * p.n_mels;
+        for (int sl = 0; sl < SLOTS; ++sl) {            // all 64 lanes work on one frame slot at a time
+            const int fr = f_base + fl0 + sl;
+            if (fl0 + sl >= FT || fr >= p.n_frames) break;    // wave-uniform
+            float* out = p.melpow + ((long long)row * p.n_frames + fr) * p.n_mels;
+            const float* Ps = reinterpret_cast<const float*>(wbase + sl * G::SLOT_BYTES);
             const int q = lane & 3;
             for (int m0 = 0; m0 < p.n_mels; m0 += 16) {
                 const int m = min(m0 + (lane >> 2), p.n_mels - 1);
                 const int3 meta = mel_meta[m];                                // (start4, steps of the round, wofs)
                 const int steps = __builtin_amdgcn_readfirstlane(meta.y);
                 const float4* w = reinterpret_cast<const float4*>(mel_w + meta.z) + q;
-                const float4* pp = reinterpret_cast<const float4*>(P + meta.x) + q;
+                const float4* pp = reinterpret_cast<const float4*>(Ps + meta.x) + q;
                 float acc0 = 0.0f, acc1 = 0.0f;
                 int i = 0;
                 for (; i + 1 < steps; i += 2) {
@@ -640,6 +663,7 @@ __global__ __launch_bounds__(256) void k_stft_mel(StftParams p, int n_tiles) {
                 if (q == 0 && m0 + (lane >> 2) < p.n_mels) out[m] = acc;
             }
         }
+        (void)fvalid;
         wave_lds_sync();                              // the scratch is rewritten by the next frame
         AMPH_STAMP(9)
     }
@@ -647,22 +671,27 @@ __global__ __launch_bounds__(256) void k_stft_mel(StftParams p, int n_tiles) {
     }
 }
 
+static int table_bytes_for(int n_fft) { return n_fft == 2048 ? FftGeo<4>::TABLE_BYTES : FftGeo<2>::TABLE_BYTES; }
+
 size_t stft_mel_lds_bytes(int n_fft, int hop, int frames_per_block, int n_mels, int mel_w_floats) {
     const size_t span = (((size_t)(frames_per_block - 1) * hop + n_fft) * 4 + 15) & ~(size_t)15;
     const size_t meta = ((size_t)n_mels * 12 + 15) & ~(size_t)15;
-    return (size_t)kTableBytes + meta + (size_t)mel_w_floats * 4 + span + 4 * (size_t)kWaveScratch;
+    return (size_t)table_bytes_for(n_fft) + meta + (size_t)mel_w_floats * 4 + span + 4 * (size_t)kWaveScratch;
 }
-int stft_mel_table_bytes() { return kTableBytes; }
+int stft_mel_table_bytes(int n_fft) { return table_bytes_for(n_fft); }
+int stft_mel_scratch_floats(int n_fft) { return (n_fft == 2048 ? FftGeo<4>::SLOT_BYTES : FftGeo<2>::SLOT_BYTES) / 4; }
 
 hipError_t stft_mel_configure(int lds_bytes) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rms_scale<float>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)rms_scale_lds<float>());
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stft_mel<true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stft_mel<false>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    const void* fns[4] = {reinterpret_cast<const void*>(&k_stft_mel<true, 4>), reinterpret_cast<const void*>(&k_stft_mel<false, 4>),
+                          reinterpret_cast<const void*>(&k_stft_mel<true, 2>), reinterpret_cast<const void*>(&k_stft_mel<false, 2>)};
+    for (const void* f : fns) {
+        e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 int g_stft_grid = 512;   // persistent workgroups (2 per CU x 256 CUs); tuning knob
@@ -672,8 +701,13 @@ void launch_stft_mel(const StftParams& p, int n_rows, int sample_is_pcm16, hipSt
     const int n_tiles = n_rows * p.tiles_per_row;
     if (n_tiles <= 0) return;
     const dim3 grid((unsigned)std::min(n_tiles, g_stft_grid));
-    if (sample_is_pcm16) hipLaunchKernelGGL(k_stft_mel<true>, grid, dim3(256), lds, s, p, n_tiles);
-    else hipLaunchKernelGGL(k_stft_mel<false>, grid, dim3(256), lds, s, p, n_tiles);
+    if (p.n_fft == 2048) {
+        if (sample_is_pcm16) hipLaunchKernelGGL((k_stft_mel<true, 4>), grid, dim3(256), lds, s, p, n_tiles);
+        else hipLaunchKernelGGL((k_stft_mel<false, 4>), grid, dim3(256), lds, s, p, n_tiles);
+    } else {
+        if (sample_is_pcm16) hipLaunchKernelGGL((k_stft_mel<true, 2>), grid, dim3(256), lds, s, p, n_tiles);
+        else hipLaunchKernelGGL((k_stft_mel<false, 2>), grid, dim3(256), lds, s, p, n_tiles);
+    }
 }
 
 // ----------------------------------------------------------------------------

@@ -324,10 +324,35 @@ def test_reference_default_preset_crop_path(env):
     _assert_latents(mu.cpu().numpy(), _oracle_latents(env, tenc, pcm, cfg))
 
 
+def test_n_fft_1024_preset_128_mels(env):
+    """BASELINE.json configs[3] front end: n_fft = 1024, hop 256, 128 mel bins (preset bench-1s-128):
+    half-wave FFT geometry (two frames per wave), 87 raw frames zero-padded 4 left / 5 right to 96."""
+    cfg = env.PRESETS["bench-1s-128"]
+    sess = env.AmphSession(cfg, None, None, DEV, max_batch=4)
+    assert sess.raw_frames == 87
+    pcm = env.synth([0, 1, 2, 3, 4, 49, 6], cfg.n_samples, cfg.sr)
+    y = env.ofe.pcm16_to_float(pcm)
+    want_basis = env.ofe.mel_filterbank(cfg.sr, cfg.n_fft, cfg.n_mels, cfg.fmin, cfg.fmax)
+    np.testing.assert_allclose(sess.mel_basis(), want_basis, rtol=2e-7, atol=0)
+    mp = sess.mel_power(y).cpu().numpy()
+    assert mp.shape == (7, 87, 128)
+    for r in range(7):
+        want = env.ofe.melspectrogram(y[r], cfg.sr, cfg.n_fft, cfg.hop_length, cfg.n_mels, cfg.fmin, cfg.fmax).T
+        assert rel_l2(mp[r], want) <= 1e-5 and np.abs(mp[r] - want).max() <= 3e-6 * max(want.max(), 1e-30), r
+    mel = sess.mel(y, layout=0).cpu().numpy()
+    want = np.stack([env.ofe.wave_to_mel(v, **cfg.mel_kwargs()) for v in y])
+    assert mel.shape == (7, 128, 96) and np.abs(mel - want).max() <= 1e-4
+    assert not mel[:, :, :4].any() and not mel[:, :, 91:].any()
+    sess.close()
+    enc, tenc, spec = _encoders(env, "thesis-shape", cfg=cfg, max_batch=4)
+    mu, _, _ = enc.session(cfg).encode(pcm, apply_rms=True)
+    _assert_latents(mu.cpu().numpy(), _oracle_latents(env, tenc, pcm, cfg))
+
+
 def test_unsupported_and_invalid_configurations_raise(env):
     from dataclasses import replace
     with pytest.raises(env.N.AmphError, match="AMPH_ERR_UNSUPPORTED"):
-        env.AmphSession(replace(env.cfg, n_fft=1024), None, None, DEV)
+        env.AmphSession(replace(env.cfg, n_fft=4096), None, None, DEV)
     with pytest.raises(env.N.AmphError, match="AMPH_ERR_UNSUPPORTED"):
         env.AmphSession(replace(env.cfg, duration=0.02), None, None, DEV)        # reflect pad longer than the chunk
     spec = env.SPECS["tiny"](64, 64)
