@@ -11,6 +11,7 @@ Tolerances (fp32 path; BASELINE.json north_star: latents within 1e-4 relative):
   latents: per-vector ||dz||2/||z||2 <= 1e-4 and |dz| <= 1e-4*max(1,|z|)   
 """
 import json
+import re
 from pathlib import Path
 
 import numpy as np
@@ -473,3 +474,57 @@ def test_folder_encode_fit_and_decisions_match_cpu(env, tmp_path):
     detected, species, best, mu = prad.detect_chunks(enc, det, pcm, cfg, apply_rms=False)
     pred2, best2 = det.decide(enc.session(cfg), mu)
     assert np.array_equal(detected, pred2 >= 0) and np.array_equal(best, best2)
+
+
+def test_qout_grid_pipeline_on_resident_latents(env, tmp_path, capsys):
+    """BASELINE.json configs[4] workload (run_qout_grid.sh: q_in 0.95, q_out in {.10,.15,.20,.25}, max_per_class,
+    seed 123): fit (08) + folder benchmark (10) per grid point from latents encoded once; reference-format
+    outputs; decisions equal to the CPU rule on CPU latents wherever the margin to a threshold exceeds 1e-4."""
+    from amphibian_vae_latent_detector_amd import map_detector_core as core
+    from amphibian_vae_latent_detector_amd import pipeline as ppipe
+    from amphibian_vae_latent_detector_amd import synth
+    cfg = env.cfg
+    enc, tenc, spec = _encoders(env, "tiny", max_batch=32)
+    train, val = tmp_path / "train_chunks", tmp_path / "val_chunks"
+    synth.write_synth_folder(train, 120, cfg.n_samples, cfg.sr)
+    for sp in synth.SPECIES:
+        (val / sp).mkdir(parents=True)
+    for i in range(200, 240):
+        synth.write_wav_pcm16(val / synth.SPECIES[i % 4] / f"chunk_{i:06d}.wav", synth.synth_chunk_pcm16(i, cfg.n_samples, cfg.sr), cfg.sr)
+    (val / synth.SPECIES[0] / "chunk_999999.wav").write_bytes(b"RIFFjunk")
+    cfgp = tmp_path / "config.json"
+    core.save_json(cfgp, {"species": list(synth.SPECIES), "chunk_seconds": 1.0})
+    out = ppipe.run_qout_grid(enc, train, val, cfgp, cfg, tmp_path / "qout_grid", max_per_class=25, seed=123)
+    assert sorted(out) == [0.10, 0.15, 0.20, 0.25]
+    log = capsys.readouterr().out
+    assert len(re.findall(r"✅\s+[\w_]+:\s+rk_in=[0-9.]+\s+\|\s+rk_out=[0-9.]+\s+\|\s+rk=[0-9.]+", log)) == 16   # 9105's RK_LINE
+    # CPU side: same sampled training files, oracle latents, reference fit + decision rule
+    import random
+    random.seed(123)
+    Zc = {}
+    for sp in synth.SPECIES:
+        wavs = random.sample(sorted((train / sp).resolve().glob("*.wav")), 25)
+        Zc[sp] = np.stack([env.oenc.encode_mel_to_latent(tenc, env.ofe.wav_to_mel(w, **cfg.mel_kwargs())) for w in wavs])
+    ev_files = [w for sp in sorted(synth.SPECIES) for w in sorted((val / sp).glob("*.wav")) if w.stat().st_size > 100]
+    Zev = np.stack([env.oenc.encode_mel_to_latent(tenc, env.ofe.wav_to_mel(w, **cfg.mel_kwargs())) for w in ev_files])
+    for q_out, res in out.items():
+        run = tmp_path / "qout_grid" / f"qout_{q_out:.2f}"
+        assert {p.name for p in run.iterdir()} == {"results.csv", "summary.txt", "config_used.json", "config_snapshot.json"}
+        used = core.load_json(run / "config_used.json")
+        assert used["radial_detector"]["meta_fit"]["q_out"] == q_out and used["radial_detector"]["meta_fit"]["max_per_class"] == 25
+        snap = core.load_json(run / "config_snapshot.json")
+        cents, thr = {}, {}
+        for sp in synth.SPECIES:
+            others = np.concatenate([Zc[o] for o in synth.SPECIES if o != sp])
+            mu, rk, rk_in, rk_out = env.orad.fit_species_with_fp_control(Zc[sp], others, 0.95, q_out)
+            cents[sp], thr[sp] = mu, rk
+            assert abs(res["radial_detector"]["thresholds"][sp] - rk) <= 1e-4 * rk
+            assert abs(snap["rk_per_species"][sp] - rk) <= 1e-4 * rk + 1e-6
+        rows = [r for r in res["rows"] if r["pred_species"] != "ERROR"]
+        assert len(rows) == len(ev_files) == 40 and sum(r["pred_species"] == "ERROR" for r in res["rows"]) == 1
+        for r, z in zip(rows, Zev):
+            d, sp, bd = env.orad.decide(z, cents, thr)
+            margin = min(abs(env.orad.l2(z - cents[s]) - thr[s]) / thr[s] for s in synth.SPECIES)
+            if margin > 1e-3:
+                assert r["pred_species"] == (sp or "NO_DETECT"), (q_out, r["file"], margin)
+            assert abs(r["best_distance"] - bd) <= 1e-4 * max(1.0, bd)

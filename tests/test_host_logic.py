@@ -15,6 +15,7 @@ from amphibian_vae_latent_detector_amd import _native as N
 from amphibian_vae_latent_detector_amd import encoder as penc
 from amphibian_vae_latent_detector_amd import folder as pfolder
 from amphibian_vae_latent_detector_amd import map_detector_core as core
+from amphibian_vae_latent_detector_amd import pipeline as ppipe
 from amphibian_vae_latent_detector_amd import radial as prad
 from amphibian_vae_latent_detector_amd import synth, wavio
 
@@ -284,3 +285,61 @@ def test_encode_folder_cache_and_failures(tmp_path, capsys):
     Z2, failed2 = pfolder.encode_folder(None, root, ["s1", "s2"], cfg, cache_dir=cache,
                                         encode_fn=lambda p: (_ for _ in ()).throw(AssertionError("cache miss")))
     assert np.array_equal(Z2["s1"], Z["s1"]) and failed2 == failed
+
+
+# ------------------------------------------------------------------ reference-format outputs (08 / 10 / 9100 / 9105)
+def test_write_radial_config_keys_and_backup(tmp_path, golden):
+    g = golden("radial_fit.npz")
+    species = json.loads(str(g["species_json"]))
+    Zs = {sp: g[f"Z_{i}"] for i, sp in enumerate(species)}
+    cfgp = tmp_path / "config.json"
+    core.save_json(cfgp, {"species": species, "chunk_seconds": 1.0, "other": {"keep": True}})
+    rd = prad.fit_radial_detector(Zs, 0.95, 0.15, failed={species[0]: 2}, verbose=False)
+    fe = PRESETS["bench-1s"]
+    bak = ppipe.write_radial_config(cfgp, rd, chunks_dir=tmp_path / "train_chunks", q_in=0.95, q_out=0.15,
+                                    chunk_seconds=1.0, fe=fe, max_per_class=400, seed=123)
+    assert bak.name == "config.json.bak" and "radial_detector" not in core.load_json(bak)   # backup = previous file
+    out = core.load_json(cfgp)
+    assert out["other"] == {"keep": True} and set(out["radial_detector"]) == {"centroids", "thresholds", "meta_fit"}
+    mf = out["radial_detector"]["meta_fit"]                              # 08_fit_radial_detector.py:568-583
+    assert list(mf) == ["chunks_dir", "chunks_name", "q_in", "q_out", "chunk_seconds", "sr", "n_mels", "target_frames",
+                        "fmin", "fmax", "hop_length", "n_fft", "max_per_class", "seed", "per_species"]
+    assert mf["chunks_name"] == "train_chunks" and mf["max_per_class"] == 400 and mf["n_fft"] == 2048
+    ps = mf["per_species"][species[0]]
+    assert set(ps) == {"N_in", "N_out", "rk_in", "rk_out", "rk_final", "failed", "used", "rho_in_summary", "rho_out_summary"}
+    assert ps["failed"] == 2 and set(ps["rho_in_summary"]) == {"min", "p50", "p90", "max"}
+    # the written detector is what 09's get_detector_from_config reads back
+    cents, thr, dur = prad.get_detector_from_config(out)
+    assert list(cents) == species and thr == out["radial_detector"]["thresholds"] and dur == 1.0
+    assert cents[species[1]].dtype == np.float32
+
+
+def test_results_csv_and_summary_are_parseable_by_the_reference_scripts(tmp_path):
+    files = [("a_sp", Path("/x/a_sp/1.wav")), ("a_sp", Path("/x/a_sp/2.wav")), ("a_sp", Path("/x/a_sp/3.wav")),
+             ("b_sp", Path("/x/b_sp/1.wav")), ("b_sp", Path("/x/b_sp/2.wav"))]
+    status = np.array([0, 0, 4, 0, 0])
+    rows = ppipe.rows_from_decisions(files, status, ["a_sp", None, None, "b_sp", "a_sp"], np.array([1.5, 9.0, 0.0, 0.25, 2.0], np.float32))
+    assert [r["pred_species"] for r in rows] == ["a_sp", "NO_DETECT", "ERROR", "b_sp", "a_sp"]
+    assert [r["correct"] for r in rows] == [True, False, False, True, False] and "error" in rows[2]
+    csv_path, summary_path = ppipe.write_results(rows, tmp_path / "detection_benchmark")
+    import pandas as pd
+    df = pd.read_csv(csv_path)
+    assert list(df.columns) == ["file", "true_species", "pred_species", "detected", "correct", "best_distance", "error"]
+    assert df["detected"].tolist() == [True, False, False, True, True] and np.isnan(df["best_distance"][2])
+    assert df["best_distance"][3] == 0.25
+    txt = summary_path.read_text(encoding="utf-8")
+    # the three patterns 9100_spearman_rk_analysis.py:53-58 applies to summary.txt
+    g = re.search(r"Correct:\s*\d+\s*\|\s*Accuracy:\s*([0-9.]+)%", txt)
+    n = re.search(r"NO_DETECT:\s*\d+\s*\|\s*Rate:\s*([0-9.]+)%", txt)
+    cls = re.compile(r"^\-\s*(?P<sp>.+?)\s+n=\s*(?P<n>\d+)\s+acc=\s*(?P<acc>[0-9.]+)%\s+no_detect=\s*(?P<nd>[0-9.]+)%", re.I | re.M)
+    assert float(g.group(1)) == 50.0 and float(n.group(1)) == 25.0          # ERROR rows are left out of the summary
+    per = {m.group("sp"): (int(m.group("n")), float(m.group("acc")), float(m.group("nd"))) for m in cls.finditer(txt)}
+    assert per == {"a_sp": (2, 50.0, 50.0), "b_sp": (2, 50.0, 0.0)}
+    assert txt.splitlines()[0] == "=== Detection Benchmark Summary ===" and "Total files: 4" in txt
+
+
+def test_list_audio_files_is_recursive_and_sorted(tmp_path):
+    for rel in ("sp/b.wav", "sp/sub/a.WAV", "sp/c.txt", "sp/a.wav"):
+        (tmp_path / rel).parent.mkdir(parents=True, exist_ok=True)
+        (tmp_path / rel).write_bytes(b"")
+    assert [p.name for p in ppipe.list_audio_files(tmp_path / "sp")] == ["a.wav", "b.wav", "a.WAV"]
