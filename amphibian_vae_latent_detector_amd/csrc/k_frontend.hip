@@ -89,7 +89,9 @@ __device__ __forceinline__ float block_max(float v, float* sh) {
 // ----------------------------------------------------------------------------
 constexpr int kNpChunk = 8192;     // numpy ufunc buffer size (elements)
 constexpr int kNpBlock = 128;      // PW_BLOCKSIZE
-constexpr int kChunksPerPass = 2;  // chunks staged in LDS per pass (128 blocks -> 128 busy threads)
+// chunks staged in LDS per pass: 4 for PCM16 (64 KB: 256 blocks, every thread owns one; a 1 s / 22.05 kHz
+// row is a single pass), 2 for float32 (the same 64 KB)
+template <typename T> struct NpPass { static constexpr int kChunks = sizeof(T) == 2 ? 4 : 2; };
 
 __device__ __forceinline__ int np_split(int n) { const int h = n >> 1; return h - (h & 7); }
 
@@ -136,6 +138,7 @@ __global__ __launch_bounds__(256) void k_rms_scale(const T* __restrict__ in, lon
                                                    const int32_t* __restrict__ lengths, int n_in,
                                                    float* __restrict__ scale, int32_t* __restrict__ ok) {
 #pragma clang fp contract(off)
+    constexpr int kChunksPerPass = NpPass<T>::kChunks;
     constexpr int kPassElems = kChunksPerPass * kNpChunk;
     constexpr int kVec = 16 / (int)sizeof(T);            // elements per 16-byte LDS read
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -258,6 +261,7 @@ __global__ __launch_bounds__(256) void k_rms_scale(const T* __restrict__ in, lon
 
 template <typename T>
 static size_t rms_scale_lds() {
+    constexpr int kChunksPerPass = NpPass<T>::kChunks;
     return (size_t)kChunksPerPass * 128 * 4 + (size_t)kChunksPerPass * kNpChunk * sizeof(T) + (size_t)kChunksPerPass * 64 * 16;
 }
 
@@ -684,6 +688,9 @@ int stft_mel_scratch_floats(int n_fft) { return (n_fft == 2048 ? FftGeo<4>::SLOT
 hipError_t stft_mel_configure(int lds_bytes) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rms_scale<float>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)rms_scale_lds<float>());
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rms_scale<int16_t>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)rms_scale_lds<int16_t>());
     if (e != hipSuccess) return e;
     const void* fns[4] = {reinterpret_cast<const void*>(&k_stft_mel<true, 4>), reinterpret_cast<const void*>(&k_stft_mel<false, 4>),
                           reinterpret_cast<const void*>(&k_stft_mel<true, 2>), reinterpret_cast<const void*>(&k_stft_mel<false, 2>)};
