@@ -49,6 +49,8 @@ struct GemmLayer {
     ConvGemmParams prm{};   // x / y / M / splits filled per call
     int bm = 128;
     float* d_w = nullptr;
+    uint16_t* d_w_bf16 = nullptr;   // bf16 copy [n_pad][K_pad_b] for the bf16 encoder path
+    int K_pad_b = 0;                // K rounded up to 64 elements
     float* d_scale = nullptr;
     float* d_shift = nullptr;
     int n_pad = 0;
@@ -88,6 +90,7 @@ struct amph_ctx {
     unsigned long long* d_gstamps = nullptr;
     int gstamp_wgs[16] = {0};
     int gemm_min_wg128 = 512;
+    bool bf16_encoder = false;             // BASELINE config 4: bf16 weights/activations, bf16 MFMA, fp32 accumulate
     bool fuse_conv12 = true;               // recompute layer 1 inside layer 2's A staging when the tiling allows
     // radial scratch
     float* d_centroids = nullptr;
@@ -171,6 +174,23 @@ std::vector<float> mel_filterbank(int sr, int n_fft, int n_mels, double fmin, do
         }
     }
     return w;
+}
+
+// float -> bf16, round to nearest even (NaN stays NaN)
+uint16_t f32_to_bf16_host(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+// bf16 copy of a [n_pad][K_pad] fp32 GEMM weight matrix, rows re-padded to a multiple of 64 elements
+hipError_t upload_bf16(uint16_t** dptr, const std::vector<float>& w, int n_pad, int K_pad, int K_pad_b) {
+    std::vector<uint16_t> h((size_t)n_pad * K_pad_b, 0);
+    for (int n = 0; n < n_pad; ++n)
+        for (int k = 0; k < K_pad; ++k) h[(size_t)n * K_pad_b + k] = f32_to_bf16_host(w[(size_t)n * K_pad + k]);
+    return upload(dptr, h);
 }
 
 int pick_head_splits(int n_slices) {
@@ -372,6 +392,8 @@ int build_encoder(amph_ctx* c, const float* hw, size_t n_floats) {
                     for (int t = 0; t < kk; ++t)
                         wg[(size_t)o * K_pad + (size_t)t * l.c_in + ci] = w[((size_t)o * l.c_in + ci) * kk + t];
             HIP_TRY(c, upload(&gl.d_w, wg));
+            gl.K_pad_b = (K + 63) / 64 * 64;
+            HIP_TRY(c, upload_bf16(&gl.d_w_bf16, wg, n_pad, K_pad, gl.K_pad_b));
             HIP_TRY(c, upload(&gl.d_scale, alpha));
             HIP_TRY(c, upload(&gl.d_shift, shift));
             gl.n_pad = n_pad;
@@ -404,6 +426,8 @@ int build_encoder(amph_ctx* c, const float* hw, size_t n_floats) {
         }
         GemmLayer gl;
         HIP_TRY(c, upload(&gl.d_w, wg));
+        gl.K_pad_b = (flat + 63) / 64 * 64;
+        HIP_TRY(c, upload_bf16(&gl.d_w_bf16, wg, n_pad, K_pad, gl.K_pad_b));
         HIP_TRY(c, upload(&c->d_head_bias, bias));
         gl.n_pad = n_pad;
         ConvGemmParams& p = gl.prm;
@@ -502,6 +526,46 @@ void build_stages(amph_ctx* c) {
 // encoder on ws_image-like input; x is [nb][T][M]
 int run_encoder(amph_ctx* c, Workspace& w, const float* d_x, int nb, float* d_mu, float* d_logvar, hipStream_t s) {
     const int n_gemm = (int)c->gemm.size();
+    if (c->bf16_encoder) {
+        {
+            StageTimer t(c, ST_CONV0, s);
+            ConvFirstParams p = c->first;
+            p.x = d_x;
+            p.y = w.act[0];                            // bf16 NHWC in the (fp32-sized) activation buffer
+            launch_conv_first_bf16(p, nb, s);
+        }
+        for (int gi = 0; gi < n_gemm; ++gi) {
+            const bool head = gi == n_gemm - 1;
+            ConvGemmParams p = c->gemm[gi].prm;
+            p.x = w.act[gi];
+            p.w = reinterpret_cast<const float*>(c->gemm[gi].d_w_bf16);
+            p.K_pad = c->gemm[gi].K_pad_b;
+            p.M = nb * p.OH * p.OW;
+            p.img = nullptr;
+            int bm = 128;
+            if (head) {
+                p.y = w.partial;
+                bm = 64;
+                int sp = 1;                            // split-K over 64-element slices, at most the fp32 path's count
+                for (int q = 1; q <= c->head_splits; ++q) if ((p.K_pad / 64) % q == 0) sp = q;
+                p.splits = sp;
+            } else {
+                p.y = w.act[gi + 1];
+                const long long wg128 = (long long)((p.M + 127) / 128) * ((p.N + 63) / 64);
+                if (wg128 < c->gemm_min_wg128) bm = 64;
+            }
+            StageTimer t(c, head ? stage_head_gemm(c) : ST_CONV0 + 1 + gi, s);
+            launch_conv_gemm_bf16(p, bm, s);
+            if (head) {
+                StageTimer t2(c, stage_head_reduce(c), s);
+                HeadReduceParams hp;
+                hp.partial = w.partial; hp.bias = c->d_head_bias; hp.splits = p.splits; hp.D = c->latent;
+                hp.mu = d_mu; hp.logvar = d_logvar;
+                launch_head_reduce(hp, nb, s);
+            }
+        }
+        return AMPH_OK;
+    }
     // tile height per GEMM layer, then: can layer 2 recompute layer 1 on the fly?
     std::vector<ConvGemmParams> prm(n_gemm);
     std::vector<int> bms(n_gemm);
@@ -707,7 +771,7 @@ void amph_destroy(amph_ctx* c) {
     fr(c->d_tables); fr(c->d_tw_a);
     fr(c->d_mel_start); fr(c->d_mel_len); fr(c->d_mel_wofs); fr(c->d_mel_w);
     fr(c->d_first_w); fr(c->d_first_scale); fr(c->d_first_shift);
-    for (auto& g : c->gemm) { fr(g.d_w); fr(g.d_scale); fr(g.d_shift); }
+    for (auto& g : c->gemm) { fr(g.d_w); fr(g.d_w_bf16); fr(g.d_scale); fr(g.d_shift); }
     fr(c->d_head_bias);
     for (auto& w : c->lanes) free_lane(w);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -757,6 +821,15 @@ int amph_configure(amph_ctx* c, const char* key, int value) {
     }
 #endif
     if (!std::strcmp(key, "gemm_min_wg128")) { c->gemm_min_wg128 = value; return AMPH_OK; }
+    if (!std::strcmp(key, "bf16_encoder")) {
+        if (value) {
+            if (!c->has_encoder) return fail(c, AMPH_ERR_INVALID_ARG, "no encoder in this context");
+            for (auto& g : c->gemm)
+                if (g.prm.C_in % 8) return fail(c, AMPH_ERR_UNSUPPORTED, "bf16 path needs every GEMM layer's c_in to be a multiple of 8");
+        }
+        c->bf16_encoder = value != 0;
+        return AMPH_OK;
+    }
     if (!std::strcmp(key, "stft_grid")) {
         if (value < 1 || value > 65536) return fail(c, AMPH_ERR_INVALID_ARG, "stft_grid must be in 1..65536");
         amph::g_stft_grid = value;

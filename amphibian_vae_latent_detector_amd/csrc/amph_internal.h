@@ -114,6 +114,10 @@ extern int g_stft_grid;
 bool conv_gemm_can_fuse(const ConvGemmParams& p, int bm);
 void launch_conv_gemm(const ConvGemmParams& p, int bm, bool fuse_first, hipStream_t s);
 void launch_head_reduce(const HeadReduceParams& p, int n_rows, hipStream_t s);
+// bf16 encoder path (k_encoder_bf16.hip): x / w are bf16, y bf16 (epilogue 0) or fp32 partials (epilogue 1);
+// K, K_pad and C_in count bf16 elements, K_pad % 64 == 0, C_in % 8 == 0
+void launch_conv_first_bf16(const ConvFirstParams& p, int n_rows, hipStream_t s);
+void launch_conv_gemm_bf16(const ConvGemmParams& p, int bm, hipStream_t s);
 
 // ----------------------------------------------------------------------------
 // Radial decision

@@ -805,8 +805,10 @@ __global__ __launch_bounds__(256) void k_dbnorm(DbNormParams p) {
 }
 
 void launch_dbnorm(const DbNormParams& p, int n_rows, hipStream_t s) {
-    if (p.n_frames * p.n_mels <= 256 * 16) hipLaunchKernelGGL(k_dbnorm<16>, dim3(n_rows), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(k_dbnorm<0>, dim3(n_rows), dim3(256), 0, s, p);
+    const int n = p.n_frames * p.n_mels;
+    if (n <= 256 * 16) hipLaunchKernelGGL(k_dbnorm<16>, dim3(n_rows), dim3(256), 0, s, p);          // 1 s chunks, 64 mels
+    else if (n <= 256 * 48) hipLaunchKernelGGL(k_dbnorm<48>, dim3(n_rows), dim3(256), 0, s, p);     // e.g. 87 frames x 128 mels
+    else hipLaunchKernelGGL(k_dbnorm<0>, dim3(n_rows), dim3(256), 0, s, p);                          // 5 s chunks: recompute per pass
 }
 
 void launch_rms_scale_pcm16(const int16_t* in, long long row_stride, const int32_t* lengths, int n_in, int n_rows,

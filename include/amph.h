@@ -92,6 +92,9 @@ const char* amph_last_error(const amph_ctx* ctx);   /* ctx may be NULL: create-t
  *                            batches over (default 2; lane 0 is the caller's stream, the
  *                            others are forked from / joined to it with events)
  *   "frames_per_block" 4..32 STFT frames per workgroup (multiple of 4, default 8)
+ *   "bf16_encoder"     0/1   encoder in bf16 (weights, activations, v_mfma_f32_32x32x16_bf16) with fp32
+ *                            accumulation, BN/ReLU and latents (default 0 = fp32, the path the 1e-4 parity
+ *                            bar applies to); the front end is always fp32
  *   "fuse_conv12"      0/1   recompute conv layer 1 inside layer 2's operand staging instead of
  *                            materialising it (default 1; results are bit-identical either way) */
 int amph_configure(amph_ctx* ctx, const char* key, int value);

@@ -350,6 +350,42 @@ def test_n_fft_1024_preset_128_mels(env):
     _assert_latents(mu.cpu().numpy(), _oracle_latents(env, tenc, pcm, cfg))
 
 
+@pytest.mark.parametrize("preset,name", [("bench-1s", "tiny"), ("bench-1s-128", "thesis-shape")])
+def test_bf16_encoder_path(env, preset, name, capsys):
+    """BASELINE.json configs[3]: bf16 encoder (weights + activations, bf16 MFMA, fp32 accumulate / BN / latents).
+    Checked two ways: tightly against a torch-CPU emulation that rounds weights and every layer's output to
+    bf16 (kernel correctness), and loosely against the fp32 oracle (the price of bf16, reported)."""
+    cfg = env.PRESETS[preset]
+    enc, tenc, spec = _encoders(env, name, cfg=cfg, max_batch=8)
+    sess = enc.session(cfg)
+    pcm = env.synth(list(range(11)), cfg.n_samples, cfg.sr)
+    mel = np.stack([env.ofe.wave_to_mel(env.ofe.normalize_pcm16_chunk(q, True)[0], **cfg.mel_kwargs()) for q in pcm])
+    x = torch.from_numpy(mel).transpose(1, 2).unsqueeze(1).contiguous()
+    bf = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    with torch.no_grad():
+        mu32, _ = tenc(x)
+        h = x
+        for conv, bn in zip(tenc.conv, tenc.bn):
+            y = torch.nn.functional.conv2d(h, bf(conv.weight) if conv is not tenc.conv[0] else conv.weight, conv.bias,
+                                           stride=conv.stride, padding=conv.padding)
+            h = bf(torch.relu(bn(y)))
+        flat = h.flatten(1)
+        mu_emu = flat @ bf(tenc.fc_mu.weight).T + tenc.fc_mu.bias
+    sess.configure("bf16_encoder", 1)
+    mu_b, lv_b = sess.encoder_forward(x)
+    mu_f, _, _ = sess.encode(pcm, apply_rms=True)                    # fused path end to end in bf16 mode
+    sess.configure("bf16_encoder", 0)
+    mu_fp32, _ = sess.encoder_forward(x)
+    mu_b = mu_b.cpu().numpy()
+    err_emu = max(rel_l2(mu_b[r], mu_emu[r].numpy()) for r in range(11))
+    err_f32 = max(rel_l2(mu_b[r], mu32[r].numpy()) for r in range(11))
+    with capsys.disabled():
+        print(f"\n[bf16 encoder, {preset}/{name}] max rel L2 vs bf16-emulating torch: {err_emu:.2e}; vs fp32 oracle: {err_f32:.2e}")
+    assert err_emu <= 5e-3 and err_f32 <= 5e-2
+    assert max(rel_l2(mu_f.cpu().numpy()[r], mu_b[r]) for r in range(11)) <= 5e-3   # HIP mel vs oracle mel in front
+    _assert_latents(mu_fp32.cpu().numpy(), mu32.numpy(), 1e-5)       # switching back restores the fp32 path
+
+
 def test_unsupported_and_invalid_configurations_raise(env):
     from dataclasses import replace
     with pytest.raises(env.N.AmphError, match="AMPH_ERR_UNSUPPORTED"):

@@ -24,7 +24,7 @@ def main():
     chunks = int(opts.get("chunks", 10000))
     rounds = int(opts.get("rounds", 3))
     steps = int(opts.get("steps", 3))
-    cfg = PRESETS["bench-1s"]
+    cfg = PRESETS[opts.get("preset", "bench-1s")]
     spec = SPECS["thesis-shape"](cfg.target_frames, cfg.n_mels)
     enc = HipEncoder(spec, random_init_state(spec, 0), "cuda:0", max_batch=batch)
     sess = enc.session(cfg)
