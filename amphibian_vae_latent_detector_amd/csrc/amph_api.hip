@@ -68,6 +68,7 @@ struct amph_ctx {
 
     // front-end tables
     int n_frames = 0, frames_per_block = 8;
+    int stft_waves = 4;                    // waves per STFT workgroup: 4 (two workgroups per CU) or 12 (one)
     float* d_tables = nullptr;             // packed LDS image of the STFT tables
     float2* d_tw_a = nullptr;              // stage-A twiddles (global memory)
     int mel_w_floats = 0, mel_p_tail = 0;
@@ -80,6 +81,7 @@ struct amph_ctx {
     float *d_first_w = nullptr, *d_first_scale = nullptr, *d_first_shift = nullptr;
     std::vector<GemmLayer> gemm;           // conv layers 2.. then the head GEMM last
     float* d_head_bias = nullptr;
+    float* d_zeros = nullptr;              // 256 bytes of zeros: the source of padded taps (k_conv_gemm_p3)
     int head_splits = 1;
     int flat = 0, latent = 0;
 
@@ -429,6 +431,7 @@ int build_encoder(amph_ctx* c, const float* hw, size_t n_floats) {
         gl.K_pad_b = (flat + 63) / 64 * 64;
         HIP_TRY(c, upload_bf16(&gl.d_w_bf16, wg, n_pad, K_pad, gl.K_pad_b));
         HIP_TRY(c, upload(&c->d_head_bias, bias));
+        HIP_TRY(c, upload(&c->d_zeros, std::vector<float>(64, 0.0f)));
         gl.n_pad = n_pad;
         ConvGemmParams& p = gl.prm;
         p.w = gl.d_w; p.scale = nullptr; p.shift = nullptr;
@@ -576,6 +579,7 @@ int run_encoder(amph_ctx* c, Workspace& w, const float* d_x, int nb, float* d_mu
         p.x = w.act[gi];
         p.M = nb * p.OH * p.OW;
         p.img = nullptr;
+        p.zeros = c->d_zeros;
         int bm = 128;
         if (head) { p.y = w.partial; bm = 64; }
         else {
@@ -657,7 +661,7 @@ int run_frontend(amph_ctx* c, Workspace& w, const void* d_wave, bool pcm16, int 
     }
     {
         StageTimer t(c, ST_STFT, s);
-        launch_stft_mel(make_stft(c, src, melpow), nb, pcm16 ? 1 : 0, s);
+        launch_stft_mel(make_stft(c, src, melpow), nb, pcm16 ? 1 : 0, c->stft_waves, s);
     }
     return AMPH_OK;
 }
@@ -750,7 +754,16 @@ int amph_create(const amph_frontend_config* cfg, const amph_encoder_spec* spec, 
     if (rc == AMPH_OK) rc = alloc_workspace(c);
     if (rc == AMPH_OK) {
         build_stages(c);
-        const int lds = (int)stft_mel_lds_bytes(c->cfg.n_fft, c->cfg.hop_length, c->frames_per_block, c->cfg.n_mels, c->mel_w_floats);
+        // STFT workgroup shape: 12 waves (one 768-thread workgroup per CU, three waves per SIMD) with one
+        // wave-iteration of frames per tile when that fits the 160 KB of LDS, else 4 waves x 8 frames.
+        // The kernel is bound by the LDS round trips of a frame, so the third wave per SIMD is worth
+        // 73 -> 52 us per 256 one-second chunks (tools/sweep.py frames_per_block=8,12 stft_waves=4,12).
+        {
+            const int slots = c->cfg.n_fft == 2048 ? 1 : 2;
+            const size_t l12 = stft_mel_lds_bytes(c->cfg.n_fft, c->cfg.hop_length, 12 * slots, c->cfg.n_mels, c->mel_w_floats, 12);
+            if (l12 <= 160 * 1024) { c->stft_waves = 12; c->frames_per_block = 12 * slots; }
+        }
+        const int lds = (int)stft_mel_lds_bytes(c->cfg.n_fft, c->cfg.hop_length, c->frames_per_block, c->cfg.n_mels, c->mel_w_floats, c->stft_waves);
         if (lds > 160 * 1024) rc = fail(c, AMPH_ERR_UNSUPPORTED, "frame tile needs %d bytes of LDS", lds);
         else rc = amph::stft_mel_configure(lds) == hipSuccess ? AMPH_OK : fail(c, AMPH_ERR_HIP, "hipFuncSetAttribute failed");
     }
@@ -772,7 +785,7 @@ void amph_destroy(amph_ctx* c) {
     fr(c->d_mel_start); fr(c->d_mel_len); fr(c->d_mel_wofs); fr(c->d_mel_w);
     fr(c->d_first_w); fr(c->d_first_scale); fr(c->d_first_shift);
     for (auto& g : c->gemm) { fr(g.d_w); fr(g.d_w_bf16); fr(g.d_scale); fr(g.d_shift); }
-    fr(c->d_head_bias);
+    fr(c->d_head_bias); fr(c->d_zeros);
     for (auto& w : c->lanes) free_lane(w);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     fr(c->d_centroids); fr(c->d_thr); fr(c->d_rank);
@@ -831,18 +844,27 @@ int amph_configure(amph_ctx* c, const char* key, int value) {
         return AMPH_OK;
     }
     if (!std::strcmp(key, "stft_grid")) {
-        if (value < 1 || value > 65536) return fail(c, AMPH_ERR_INVALID_ARG, "stft_grid must be in 1..65536");
+        if (value < 0 || value > 65536) return fail(c, AMPH_ERR_INVALID_ARG, "stft_grid must be in 0..65536 (0 = fill the chip)");
         amph::g_stft_grid = value;
         return AMPH_OK;
     }
+    if (!std::strcmp(key, "gemm_flags")) { amph::g_gemm_flags = value; return AMPH_OK; }
     if (!std::strcmp(key, "gemm_min_lds")) {
         if (value < 0 || value > 64 * 1024) return fail(c, AMPH_ERR_INVALID_ARG, "gemm_min_lds must be in 0..65536");
         amph::g_gemm_min_lds = value;
         return AMPH_OK;
     }
+    if (!std::strcmp(key, "stft_waves")) {
+        if (value != 4 && value != 12) return fail(c, AMPH_ERR_INVALID_ARG, "stft_waves must be 4 or 12");
+        const int lds = (int)stft_mel_lds_bytes(c->cfg.n_fft, c->cfg.hop_length, c->frames_per_block, c->cfg.n_mels, c->mel_w_floats, value);
+        if (lds > 160 * 1024) return fail(c, AMPH_ERR_UNSUPPORTED, "%d waves x %d frames need %d bytes of LDS", value, c->frames_per_block, lds);
+        if (amph::stft_mel_configure(lds) != hipSuccess) return fail(c, AMPH_ERR_HIP, "hipFuncSetAttribute failed");
+        c->stft_waves = value;
+        return AMPH_OK;
+    }
     if (!std::strcmp(key, "frames_per_block")) {
         if (value < 4 || value > 32 || (value & 3)) return fail(c, AMPH_ERR_INVALID_ARG, "frames_per_block must be a multiple of 4 in 4..32");
-        const int lds = (int)stft_mel_lds_bytes(c->cfg.n_fft, c->cfg.hop_length, value, c->cfg.n_mels, c->mel_w_floats);
+        const int lds = (int)stft_mel_lds_bytes(c->cfg.n_fft, c->cfg.hop_length, value, c->cfg.n_mels, c->mel_w_floats, c->stft_waves);
         if (lds > 160 * 1024) return fail(c, AMPH_ERR_UNSUPPORTED, "frame tile needs %d bytes of LDS", lds);
         if (amph::stft_mel_configure(lds) != hipSuccess) return fail(c, AMPH_ERR_HIP, "hipFuncSetAttribute failed");
         c->frames_per_block = value;

@@ -59,8 +59,8 @@ void launch_rms_apply_f32(const float* in, int n_rows, int n, const float* scale
 void launch_rms_apply_pcm16(const int16_t* in, int n_rows, int n, const float* scale, const int32_t* ok, int16_t* out,
                             hipStream_t s);
 // sample_is_pcm16: 1 -> src.wave is int16_t, 0 -> float
-void launch_stft_mel(const StftParams& p, int n_rows, int sample_is_pcm16, hipStream_t s);
-size_t stft_mel_lds_bytes(int n_fft, int hop, int frames_per_block, int n_mels, int mel_w_floats);
+void launch_stft_mel(const StftParams& p, int n_rows, int sample_is_pcm16, int n_waves, hipStream_t s);
+size_t stft_mel_lds_bytes(int n_fft, int hop, int frames_per_block, int n_mels, int mel_w_floats, int n_waves);
 int stft_mel_table_bytes(int n_fft);
 int stft_mel_scratch_floats(int n_fft);   // floats of per-frame scratch the power spectrum + tail may use
 hipError_t stft_mel_configure(int lds_bytes);   // raises the dynamic-LDS limit of the STFT kernels
@@ -95,6 +95,8 @@ struct ConvGemmParams {      // implicit GEMM: M = B*OH*OW, N = C_out, K = k*k*C
     const float* scale1;     // [C_in]
     const float* shift1;     // [C_in]
     int H0, W0, k1, s1, p1;
+    const float* zeros;      // >= 16 bytes of zeros (16-byte aligned): source of padded taps in k_conv_gemm_p3
+    int flags;               // bit 1: use the first-generation kernel; bit 0: static issue priority from the wave's slot on its SIMD (see k_conv_gemm)
 #ifdef AMPH_STAMPS
     unsigned long long* stamps;   // diagnostic build: [workgroup][role][4]
 #endif
@@ -110,6 +112,7 @@ struct HeadReduceParams {    // mu/logvar = sum_s partial[s] + bias
 
 void launch_conv_first(const ConvFirstParams& p, int n_rows, hipStream_t s);
 extern int g_gemm_min_lds;
+extern int g_gemm_flags;
 extern int g_stft_grid;
 bool conv_gemm_can_fuse(const ConvGemmParams& p, int bm);
 void launch_conv_gemm(const ConvGemmParams& p, int bm, bool fuse_first, hipStream_t s);

@@ -113,6 +113,18 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvGemmParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c4 = tid & 7, r0 = tid >> 3;
     const int m_blk = blockIdx.x * BM, n_blk = blockIdx.y * kBN;
+    // Co-resident waves of a SIMD run this same loop and fall into lockstep: with equal priority they
+    // alternate MFMAs, finish their 16 together and then do their loads / address math / barrier
+    // together with the matrix pipe idle (PMC: issue-stall = 2x the wave's own MFMA time).  A static
+    // priority taken from the wave's slot on its SIMD (HW_ID[3:0]; the waves of one workgroup
+    // normally hold the same slot on all four SIMDs) lets one wave run its MFMAs while the other
+    // is in its non-matrix phase.
+    if (p.flags & 1) {
+        const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | 4) & 3u;
+        if (slot == 1) __builtin_amdgcn_s_setprio(1);
+        else if (slot == 2) __builtin_amdgcn_s_setprio(2);
+        else if (slot == 3) __builtin_amdgcn_s_setprio(3);
+    }
 
     // per-thread A rows: output pixel -> input window origin, base pointer of the window in the
     // NHWC input (never dereferenced for padded taps) and a bitmask of the k*k taps that are in range
@@ -407,6 +419,207 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvGemmParams p) {
     }
 }
 
+// ----------------------------------------------------------------------------
+// Second-generation plain (non-fused) implicit GEMM, used when C_in % 32 == 0 (then a 32-deep K slice
+// lies inside ONE tap (kh, kw), the tap state is wave-uniform scalar work and K needs no padding).
+//
+// What the first kernel lost (PMC, profiles/r01_pmc_sq_v1.txt): its waves spent 55 % of their life
+// stalled at MFMA issue and 23 % at waits, because the compiler clusters the 16 MFMAs of a slice and
+// puts every load / address / LDS instruction, the vmcnt wait, the LDS stores and the barrier in one
+// block between the clusters - with the matrix pipe idle meanwhile - and the co-resident waves of a
+// SIMD run the same program in phase.  Here the instruction order is pinned (sched_barrier) so that
+// all of that issues in the 64-cycle shadows of the MFMAs:
+//   * THREE LDS slice buffers: slice s+2 is stored in the middle of iteration s (its global loads were
+//     issued at the top of iteration s-1), so no store sits in front of the barrier;
+//   * the first fragments of slice s+1 (stored in iteration s-1, published by the previous barrier)
+//     are read BEFORE the barrier that ends iteration s, under the last MFMAs: the matrix pipe does
+//     not wait for an LDS round trip after the barrier;
+//   * A loads are unconditional (padded taps read a zero line), so the loop body is one basic block
+//     and the compiler's vmcnt counts are exact.
+// Same MFMA k order as k_conv_gemm (step s of a k-group of 8 consumes k = {s, 4 + s}) => bit-identical.
+// ----------------------------------------------------------------------------
+#define AMPH_SB() __builtin_amdgcn_sched_barrier(0)
+
+template <int BM>
+__global__ __launch_bounds__(256) void k_conv_gemm_p3(ConvGemmParams p) {
+    static_assert(BM == 64, "one 32x32 tile per wave");
+    constexpr int A_ROWS = BM / 32;
+    constexpr int kABuf = BM * kLdsRow, kBBuf = kBN * kLdsRow;          // floats per slice buffer
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* As = reinterpret_cast<float*>(smem);                         // [3][BM][36]
+    float* Bs = As + 3 * kABuf;                                         // [3][64][36]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c4 = tid & 7, r0 = tid >> 3;
+    const int m_blk = blockIdx.x * BM, n_blk = blockIdx.y * kBN;
+
+    // per-thread A rows: pointer to (window origin, channel 4*c4) of the NHWC input (never dereferenced
+    // for padded taps) and the bitmask of the taps that are in range
+    const float* pa[A_ROWS];
+    unsigned vmask[A_ROWS];
+    const int ohw = p.OH * p.OW;
+#pragma unroll
+    for (int i = 0; i < A_ROWS; ++i) {
+        const int m = m_blk + r0 + 32 * i;
+        const bool mv = m < p.M;
+        const int mm = mv ? m : 0;
+        const int b = mm / ohw, rem = mm - b * ohw;
+        const int oh = rem / p.OW, ow = rem - oh * p.OW;
+        const int ih0 = oh * p.stride - p.pad, iw0 = ow * p.stride - p.pad;
+        pa[i] = p.x + (long long)b * p.H * p.W * p.C_in + ((long long)ih0 * p.W + iw0) * p.C_in + 4 * c4;
+        unsigned vm = 0;
+        for (int kh = 0; kh < p.k; ++kh)
+            for (int kw = 0; kw < p.k; ++kw)
+                if (mv && ih0 + kh >= 0 && ih0 + kh < p.H && iw0 + kw >= 0 && iw0 + kw < p.W) vm |= 1u << (kh * p.k + kw);
+        vmask[i] = vm;
+    }
+    const float *pa0 = pa[0], *pa1 = pa[1];
+    const unsigned vmask0 = vmask[0], vmask1 = vmask[1];
+    const int n_slices = p.K_pad / kBK;
+    const int sps = n_slices / p.splits;
+    const int ks_begin = blockIdx.z * sps, ks_end = ks_begin + sps;
+    const float* wp0 = p.w + (long long)(n_blk + r0) * p.K_pad + 4 * c4 + ks_begin * kBK;
+    const float* wp1 = wp0 + 32ll * p.K_pad;
+
+    // wave-uniform position of the next slice to LOAD: tap (kh, kw) = kpos, first channel ci0
+    int l_kpos = (ks_begin * kBK) / p.C_in;
+    int l_ci0 = ks_begin * kBK - l_kpos * p.C_in;
+    int l_kh = l_kpos / p.k, l_kw = l_kpos - l_kh * p.k;
+    int l_left = sps;                                   // slices not yet loaded (stays on the last one at the end)
+
+    // register stages (plain named variables: a struct passed to a lambda ends up in scratch memory)
+    float4 sa0x, sa0y, sa1x, sa1y, sa2x, sa2y;           // A rows r0 and r0 + 32 of the three stages
+    float4 sb0a, sb0b, sb1a, sb1b, sb2a, sb2b;
+#define AMPH_P3_LOAD(q)                                                                    \
+    {                                                                                      \
+        const int koff_ = (l_kh * p.W + l_kw) * p.C_in + l_ci0;                            \
+        sa##q##x = *reinterpret_cast<const float4*>(((vmask0 >> l_kpos) & 1u) ? pa0 + koff_ : p.zeros); \
+        sa##q##y = *reinterpret_cast<const float4*>(((vmask1 >> l_kpos) & 1u) ? pa1 + koff_ : p.zeros); \
+        sb##q##a = *reinterpret_cast<const float4*>(wp0);                                  \
+        sb##q##b = *reinterpret_cast<const float4*>(wp1);                                  \
+        /* advance with selects only: the loop body stays one basic block */               \
+        const int adv_ = l_left > 1 ? 1 : 0;                                               \
+        l_left -= adv_;                                                                    \
+        wp0 += kBK * adv_;                                                                 \
+        wp1 += kBK * adv_;                                                                 \
+        l_ci0 += kBK * adv_;                                                               \
+        const int wrap_ = l_ci0 >= p.C_in ? 1 : 0;                                         \
+        l_ci0 -= wrap_ * p.C_in;                                                           \
+        l_kpos += wrap_;                                                                   \
+        l_kw += wrap_;                                                                     \
+        const int wrap2_ = l_kw >= p.k ? 1 : 0;                                            \
+        l_kw -= wrap2_ * p.k;                                                              \
+        l_kh += wrap2_;                                                                    \
+    }
+    const int st_off = r0 * kLdsRow + 4 * c4;
+#define AMPH_P3_STORE(q, buf_)                                                             \
+    {                                                                                      \
+        float* a_ = As + (buf_) * kABuf + st_off;                                          \
+        float* b_ = Bs + (buf_) * kBBuf + st_off;                                          \
+        *reinterpret_cast<float4*>(a_) = sa##q##x;                                         \
+        *reinterpret_cast<float4*>(a_ + 32 * kLdsRow) = sa##q##y;                          \
+        *reinterpret_cast<float4*>(b_) = sb##q##a;                                         \
+        *reinterpret_cast<float4*>(b_ + 32 * kLdsRow) = sb##q##b;                          \
+    }
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    const int row_tile = wave >> 1, col_tile = wave & 1;
+    const float* a_rd = As + (row_tile * 32 + (lane & 31)) * kLdsRow + 4 * (lane >> 5);
+    const float* b_rd = Bs + (col_tile * 32 + (lane & 31)) * kLdsRow + 4 * (lane >> 5);
+
+#define AMPH_P3_READ(fa_, fb_, buf_, kg_)                                                  \
+    fa_ = *reinterpret_cast<const float4*>(a_rd + (buf_) * kABuf + 8 * (kg_));            \
+    fb_ = *reinterpret_cast<const float4*>(b_rd + (buf_) * kBBuf + 8 * (kg_));
+#define AMPH_P3_MFMA(x_, y_) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x_, y_, acc, 0, 0, 0);
+    // one slice from LDS buffer R; stage R receives slice s+3, stage (R+2)%3 goes to buffer (R+2)%3
+#define AMPH_P3_STEP(R, QL, QS)                                                 \
+    {                                                                                      \
+        float4 f1a, f1b, f2a, f2b, f3a, f3b, n0a, n0b;                                     \
+        AMPH_P3_READ(f1a, f1b, R, 1)                                                       \
+        AMPH_SB();                                                                         \
+        AMPH_P3_MFMA(f0a.x, f0b.x)                                                         \
+        AMPH_SB();                                                                         \
+        AMPH_P3_LOAD(QL)                                                                   \
+        AMPH_SB();                                                                         \
+        AMPH_P3_MFMA(f0a.y, f0b.y)                                                         \
+        AMPH_SB();                                                                         \
+        AMPH_P3_READ(f2a, f2b, R, 2)                                                       \
+        AMPH_SB();                                                                         \
+        AMPH_P3_MFMA(f0a.z, f0b.z)                                                         \
+        AMPH_P3_MFMA(f0a.w, f0b.w)                                                         \
+        AMPH_P3_MFMA(f1a.x, f1b.x)                                                         \
+        AMPH_SB();                                                                         \
+        AMPH_P3_READ(f3a, f3b, R, 3)                                                       \
+        AMPH_SB();                                                                         \
+        AMPH_P3_MFMA(f1a.y, f1b.y)                                                         \
+        AMPH_P3_MFMA(f1a.z, f1b.z)                                                         \
+        AMPH_P3_MFMA(f1a.w, f1b.w)                                                         \
+        AMPH_P3_MFMA(f2a.x, f2b.x)                                                         \
+        AMPH_SB();                                                                         \
+        AMPH_P3_STORE(QS, (R + 2) % 3)                                                     \
+        AMPH_SB();                                                                         \
+        AMPH_P3_MFMA(f2a.y, f2b.y)                                                         \
+        AMPH_P3_MFMA(f2a.z, f2b.z)                                                         \
+        AMPH_P3_MFMA(f2a.w, f2b.w)                                                         \
+        AMPH_P3_MFMA(f3a.x, f3b.x)                                                         \
+        AMPH_SB();                                                                         \
+        AMPH_P3_READ(n0a, n0b, (R + 1) % 3, 0)                                             \
+        AMPH_SB();                                                                         \
+        AMPH_P3_MFMA(f3a.y, f3b.y)                                                         \
+        AMPH_P3_MFMA(f3a.z, f3b.z)                                                         \
+        AMPH_P3_MFMA(f3a.w, f3b.w)                                                         \
+        AMPH_SB();                                                                         \
+        __syncthreads();                                                                   \
+        f0a = n0a; f0b = n0b;                                                              \
+    }
+
+    // prologue: slices 0, 1, 2 into the register stages, 0 and 1 on to LDS
+    AMPH_P3_LOAD(0)
+    AMPH_P3_LOAD(1)
+    AMPH_P3_LOAD(2)
+    AMPH_P3_STORE(0, 0)
+    AMPH_P3_STORE(1, 1)
+    __syncthreads();
+    float4 f0a, f0b;
+    AMPH_P3_READ(f0a, f0b, 0, 0)
+    // three slices per trip in ONE basic block (the compiler's waitcnt scoreboard is exact inside a block;
+    // across the block boundaries of a conditionally executed step it merges conservatively and drains
+    // the load ring early), then the 0..2 remaining slices
+    int ks = ks_begin;
+    for (; ks + 3 <= ks_end; ks += 3) {
+        AMPH_P3_STEP(0, 0, 2)
+        AMPH_P3_STEP(1, 1, 0)
+        AMPH_P3_STEP(2, 2, 1)
+    }
+    if (ks < ks_end) {
+        AMPH_P3_STEP(0, 0, 2)
+        if (ks + 1 < ks_end) AMPH_P3_STEP(1, 1, 0)
+    }
+
+    // epilogue: C/D map of the 32x32 tile: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    const int n = n_blk + col_tile * 32 + (lane & 31);
+    if (n < p.N) {
+        float sc = 1.0f, sh = 0.0f;
+        if (p.epilogue == 0) { sc = p.scale[n]; sh = p.shift[n]; }
+        float* ybase = p.y + (p.epilogue == 1 ? (long long)blockIdx.z * p.M * p.N : 0ll);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m_blk + row_tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (m < p.M) {
+                float v = acc[r];
+                if (p.epilogue == 0) v = fmaxf(fmaf(v, sc, sh), 0.0f);
+                ybase[(long long)m * p.N + n] = v;
+            }
+        }
+    }
+}
+
+bool conv_gemm_p3_ok(const ConvGemmParams& p, int bm) {
+    return bm == 64 && (p.C_in % kBK) == 0 && p.K == p.K_pad && p.k * p.k <= 32 && p.zeros != nullptr;
+}
+
 static size_t conv_gemm_lds(const ConvGemmParams& p, int bm, bool fuse) {
     size_t b = (size_t)2 * (bm + kBN) * kLdsRow * sizeof(float);
     if (fuse) {
@@ -423,11 +636,19 @@ bool conv_gemm_can_fuse(const ConvGemmParams& p, int bm) {
            conv_gemm_lds(p, bm, true) <= 64 * 1024;
 }
 
+int g_gemm_flags = 0;     // experiment knob: ConvGemmParams::flags of every launch
 int g_gemm_min_lds = 0;   // experiment knob: request at least this much LDS (limits workgroups per CU)
 
-void launch_conv_gemm(const ConvGemmParams& p, int bm, bool fuse, hipStream_t s) {
+void launch_conv_gemm(const ConvGemmParams& p_in, int bm, bool fuse, hipStream_t s) {
+    ConvGemmParams p = p_in;
+    p.flags = g_gemm_flags;
     const dim3 grid((unsigned)((p.M + bm - 1) / bm), (unsigned)((p.N + kBN - 1) / kBN), (unsigned)p.splits);
     const size_t lds = std::max(conv_gemm_lds(p, bm, fuse), (size_t)g_gemm_min_lds);
+    if (!fuse && (g_gemm_flags & 2) == 0 && conv_gemm_p3_ok(p, bm)) {
+        const size_t lds3 = std::max((size_t)3 * (bm + kBN) * kLdsRow * sizeof(float), (size_t)g_gemm_min_lds);
+        hipLaunchKernelGGL((k_conv_gemm_p3<64>), grid, dim3(256), lds3, s, p);
+        return;
+    }
     if (fuse) {
         if (bm == 128) hipLaunchKernelGGL((k_conv_gemm<128, true>), grid, dim3(256), lds, s, p);
         else hipLaunchKernelGGL((k_conv_gemm<64, true>), grid, dim3(256), lds, s, p);

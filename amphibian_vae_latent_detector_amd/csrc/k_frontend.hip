@@ -397,8 +397,9 @@ constexpr int kWaveScratch = 8704;                    // = SLOTS * SLOT_BYTES fo
 // The tables and mel rows are staged into LDS once per workgroup (staged per tile they were 37 MB of
 // L2 traffic per launch, fetched by every workgroup at the same moment); the next tile's samples are
 // prefetched into registers while the current tile's FFTs run.
-template <bool PCM16, int T_LO>
-__global__ __launch_bounds__(256) void k_stft_mel(StftParams p, int n_tiles) {
+template <bool PCM16, int T_LO, int NW>
+__global__ __launch_bounds__(64 * NW) void k_stft_mel(StftParams p, int n_tiles) {
+    constexpr int kThreads = 64 * NW;                  // NW waves per workgroup
     using G = FftGeo<T_LO>;
     constexpr int kNc = G::NC, L = G::L, SLOTS = G::SLOTS, EXS = G::EXS;
     constexpr int kWinHalfBytes = G::WIN_BYTES, kTwBBytes = G::TWB_BYTES, kTableBytes = G::TABLE_BYTES;
@@ -429,11 +430,11 @@ __global__ __launch_bounds__(256) void k_stft_mel(StftParams p, int n_tiles) {
     {
         const float4* src = reinterpret_cast<const float4*>(p.tables);
         float4* dst = reinterpret_cast<float4*>(smem);
-        for (int i = tid; i < kTableBytes / 16; i += 256) dst[i] = src[i];
-        for (int m = tid; m < p.n_mels; m += 256) mel_meta[m] = make_int3(p.mel_start[m], p.mel_len[m], p.mel_wofs[m]);
+        for (int i = tid; i < kTableBytes / 16; i += kThreads) dst[i] = src[i];
+        for (int m = tid; m < p.n_mels; m += kThreads) mel_meta[m] = make_int3(p.mel_start[m], p.mel_len[m], p.mel_wofs[m]);
         const float4* wsrc = reinterpret_cast<const float4*>(p.mel_w);
         float4* wdst = reinterpret_cast<float4*>(mel_w);
-        for (int i = tid; i < (p.mel_w_floats >> 2); i += 256) wdst[i] = wsrc[i];
+        for (int i = tid; i < (p.mel_w_floats >> 2); i += kThreads) wdst[i] = wsrc[i];
     }
 
     // per-tile source description
@@ -451,13 +452,13 @@ __global__ __launch_bounds__(256) void k_stft_mel(StftParams p, int n_tiles) {
                  ((reinterpret_cast<uintptr_t>(d.rowp) + 2 * (size_t)d.s0) & 3u) == 0;
         return d;
     };
-    constexpr int U = 10;                              // dwords per thread per batch (FT = 8: one batch)
+    constexpr int U = NW == 4 ? 10 : 5;                // dwords per thread per batch (one batch for FT = 8 / 12)
     uint32_t pre[U];                                   // next tile's samples, prefetched (fast tiles only)
 #pragma unroll
     for (int u = 0; u < U; ++u) pre[u] = 0;
     bool have_pre = false;
     const int nd = span_len >> 1;
-    const bool pre_fits = nd <= 256 * U;
+    const bool pre_fits = nd <= kThreads * U;
 
     for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         const TileSrc d = describe(t);
@@ -466,18 +467,18 @@ __global__ __launch_bounds__(256) void k_stft_mel(StftParams p, int n_tiles) {
         // ---- stage this tile's sample span (decode / normalise on the way into LDS)
         if (d.fast) {
             const uint32_t* src32 = reinterpret_cast<const uint32_t*>(d.rowp + 2 * (size_t)d.s0);
-            for (int base = 0; base < nd; base += 256 * U) {
+            for (int base = 0; base < nd; base += kThreads * U) {
                 uint32_t v[U];
                 if (have_pre) {
 #pragma unroll
                     for (int u = 0; u < U; ++u) v[u] = pre[u];
                 } else {
 #pragma unroll
-                    for (int u = 0; u < U; ++u) v[u] = src32[min(base + tid + 256 * u, nd - 1)];
+                    for (int u = 0; u < U; ++u) v[u] = src32[min(base + tid + kThreads * u, nd - 1)];
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    const int e = base + tid + 256 * u;
+                    const int e = base + tid + kThreads * u;
                     if (e < nd) {
                         const float lo = (float)(short)(v[u] & 0xFFFFu) * (1.0f / 32768.0f);
                         const float hi = (float)((int)v[u] >> 16) * (1.0f / 32768.0f);
@@ -488,11 +489,11 @@ __global__ __launch_bounds__(256) void k_stft_mel(StftParams p, int n_tiles) {
             }
         } else {
             const int N = p.n_samples;
-            for (int base = 0; base < span_len; base += 256 * U) {
+            for (int base = 0; base < span_len; base += kThreads * U) {
                 float x[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    int sidx = d.s0 + base + tid + 256 * u;
+                    int sidx = d.s0 + base + tid + kThreads * u;
                     if (p.pad_mode == 0) {                // reflect (np.pad mode="reflect")
                         if (sidx < 0) sidx = -sidx;
                         if (sidx >= N) sidx = 2 * (N - 1) - sidx;
@@ -501,7 +502,7 @@ __global__ __launch_bounds__(256) void k_stft_mel(StftParams p, int n_tiles) {
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    const int i = base + tid + 256 * u;
+                    const int i = base + tid + kThreads * u;
                     if (i < span_len) span[i] = normalise_sample(p.src, x[u], d.sc);
                 }
             }
@@ -514,7 +515,7 @@ __global__ __launch_bounds__(256) void k_stft_mel(StftParams p, int n_tiles) {
             if (dn.fast) {
                 const uint32_t* src32 = reinterpret_cast<const uint32_t*>(dn.rowp + 2 * (size_t)dn.s0);
 #pragma unroll
-                for (int u = 0; u < U; ++u) pre[u] = src32[min(tid + 256 * u, nd - 1)];
+                for (int u = 0; u < U; ++u) pre[u] = src32[min(tid + kThreads * u, nd - 1)];
                 have_pre = true;
             }
         }
@@ -522,7 +523,7 @@ __global__ __launch_bounds__(256) void k_stft_mel(StftParams p, int n_tiles) {
     const int k1b = lane_f / T_LO, t_lo = lane_f % T_LO;
     // stage C leaves k2b bit-reversed across the quad (radix-4); the radix-2 form is in order
     const int k2b = T_LO == 4 ? (((t_lo & 1) << 1) | (t_lo >> 1)) : t_lo;
-    for (int fl0 = wave * SLOTS; fl0 < FT; fl0 += 4 * SLOTS) {
+    for (int fl0 = wave * SLOTS; fl0 < FT; fl0 += NW * SLOTS) {
         if (f_base + fl0 >= p.n_frames) break;        // wave-uniform: the wave's first frame slot is past the end
         const int fl = fl0 + slot;
         const int frame = f_base + fl;
@@ -677,10 +678,10 @@ __global__ __launch_bounds__(256) void k_stft_mel(StftParams p, int n_tiles) {
 
 static int table_bytes_for(int n_fft) { return n_fft == 2048 ? FftGeo<4>::TABLE_BYTES : FftGeo<2>::TABLE_BYTES; }
 
-size_t stft_mel_lds_bytes(int n_fft, int hop, int frames_per_block, int n_mels, int mel_w_floats) {
+size_t stft_mel_lds_bytes(int n_fft, int hop, int frames_per_block, int n_mels, int mel_w_floats, int n_waves) {
     const size_t span = (((size_t)(frames_per_block - 1) * hop + n_fft) * 4 + 15) & ~(size_t)15;
     const size_t meta = ((size_t)n_mels * 12 + 15) & ~(size_t)15;
-    return (size_t)table_bytes_for(n_fft) + meta + (size_t)mel_w_floats * 4 + span + 4 * (size_t)kWaveScratch;
+    return (size_t)table_bytes_for(n_fft) + meta + (size_t)mel_w_floats * 4 + span + (size_t)n_waves * kWaveScratch;
 }
 int stft_mel_table_bytes(int n_fft) { return table_bytes_for(n_fft); }
 int stft_mel_scratch_floats(int n_fft) { return (n_fft == 2048 ? FftGeo<4>::SLOT_BYTES : FftGeo<2>::SLOT_BYTES) / 4; }
@@ -692,8 +693,10 @@ hipError_t stft_mel_configure(int lds_bytes) {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rms_scale<int16_t>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)rms_scale_lds<int16_t>());
     if (e != hipSuccess) return e;
-    const void* fns[4] = {reinterpret_cast<const void*>(&k_stft_mel<true, 4>), reinterpret_cast<const void*>(&k_stft_mel<false, 4>),
-                          reinterpret_cast<const void*>(&k_stft_mel<true, 2>), reinterpret_cast<const void*>(&k_stft_mel<false, 2>)};
+    const void* fns[8] = {reinterpret_cast<const void*>(&k_stft_mel<true, 4, 4>), reinterpret_cast<const void*>(&k_stft_mel<false, 4, 4>),
+                          reinterpret_cast<const void*>(&k_stft_mel<true, 2, 4>), reinterpret_cast<const void*>(&k_stft_mel<false, 2, 4>),
+                          reinterpret_cast<const void*>(&k_stft_mel<true, 4, 12>), reinterpret_cast<const void*>(&k_stft_mel<false, 4, 12>),
+                          reinterpret_cast<const void*>(&k_stft_mel<true, 2, 12>), reinterpret_cast<const void*>(&k_stft_mel<false, 2, 12>)};
     for (const void* f : fns) {
         e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
@@ -701,20 +704,29 @@ hipError_t stft_mel_configure(int lds_bytes) {
     return hipSuccess;
 }
 
-int g_stft_grid = 512;   // persistent workgroups (2 per CU x 256 CUs); tuning knob
+int g_stft_grid = 0;     // persistent workgroups; 0 = fill the chip (2 per CU with 4 waves, 1 per CU with 12)
 
-void launch_stft_mel(const StftParams& p, int n_rows, int sample_is_pcm16, hipStream_t s) {
-    const size_t lds = stft_mel_lds_bytes(p.n_fft, p.hop, p.frames_per_block, p.n_mels, p.mel_w_floats);
+template <int NW>
+static void launch_stft_mel_nw(const StftParams& p, int n_tiles, int sample_is_pcm16, hipStream_t s) {
+    const size_t lds = stft_mel_lds_bytes(p.n_fft, p.hop, p.frames_per_block, p.n_mels, p.mel_w_floats, NW);
+    const int fill = NW == 4 ? 512 : 256;
+    const dim3 grid((unsigned)std::min(n_tiles, g_stft_grid > 0 ? g_stft_grid : fill)), block(64 * NW);
+    if (p.n_fft == 2048) {
+        if (sample_is_pcm16) hipLaunchKernelGGL((k_stft_mel<true, 4, NW>), grid, block, lds, s, p, n_tiles);
+        else hipLaunchKernelGGL((k_stft_mel<false, 4, NW>), grid, block, lds, s, p, n_tiles);
+    } else {
+        if (sample_is_pcm16) hipLaunchKernelGGL((k_stft_mel<true, 2, NW>), grid, block, lds, s, p, n_tiles);
+        else hipLaunchKernelGGL((k_stft_mel<false, 2, NW>), grid, block, lds, s, p, n_tiles);
+    }
+}
+
+// n_waves: 4 (256-thread workgroups, two per CU) or 12 (768 threads, one per CU: three waves per SIMD hide
+// more of the LDS round trips of a frame; needs frames_per_block * ... to fit 160 KB, checked by the caller)
+void launch_stft_mel(const StftParams& p, int n_rows, int sample_is_pcm16, int n_waves, hipStream_t s) {
     const int n_tiles = n_rows * p.tiles_per_row;
     if (n_tiles <= 0) return;
-    const dim3 grid((unsigned)std::min(n_tiles, g_stft_grid));
-    if (p.n_fft == 2048) {
-        if (sample_is_pcm16) hipLaunchKernelGGL((k_stft_mel<true, 4>), grid, dim3(256), lds, s, p, n_tiles);
-        else hipLaunchKernelGGL((k_stft_mel<false, 4>), grid, dim3(256), lds, s, p, n_tiles);
-    } else {
-        if (sample_is_pcm16) hipLaunchKernelGGL((k_stft_mel<true, 2>), grid, dim3(256), lds, s, p, n_tiles);
-        else hipLaunchKernelGGL((k_stft_mel<false, 2>), grid, dim3(256), lds, s, p, n_tiles);
-    }
+    if (n_waves == 12) launch_stft_mel_nw<12>(p, n_tiles, sample_is_pcm16, s);
+    else launch_stft_mel_nw<4>(p, n_tiles, sample_is_pcm16, s);
 }
 
 // ----------------------------------------------------------------------------

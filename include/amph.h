@@ -91,7 +91,11 @@ const char* amph_last_error(const amph_ctx* ctx);   /* ctx may be NULL: create-t
  *   "lanes"            1..8  HIP streams + workspaces the encode entry points spread their
  *                            batches over (default 2; lane 0 is the caller's stream, the
  *                            others are forked from / joined to it with events)
- *   "frames_per_block" 4..32 STFT frames per workgroup (multiple of 4, default 8)
+ *   "stft_waves"       4/12  waves per STFT workgroup: 12 = one 768-thread workgroup per CU (three waves
+ *                            per SIMD; the default when its LDS image fits 160 KB), 4 = two 256-thread ones
+ *   "frames_per_block" 4..32 STFT frames per workgroup tile (multiple of 4; default 12 with 12 waves
+ *                            at n_fft = 2048, 24 at n_fft = 1024, 8 with 4 waves)
+ *   "stft_grid"        0..   persistent STFT workgroups (0 = fill the chip)
  *   "bf16_encoder"     0/1   encoder in bf16 (weights, activations, v_mfma_f32_32x32x16_bf16) with fp32
  *                            accumulation, BN/ReLU and latents (default 0 = fp32, the path the 1e-4 parity
  *                            bar applies to); the front end is always fp32
