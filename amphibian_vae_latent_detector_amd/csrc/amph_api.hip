@@ -596,8 +596,11 @@ int run_encoder(amph_ctx* c, Workspace& w, const float* d_x, int nb, float* d_mu
         ConvGemmParams& p = prm[0];
         p.img = d_x; p.w1 = c->first.w; p.scale1 = c->first.scale; p.shift1 = c->first.shift;
         p.H0 = c->first.H; p.W0 = c->first.W; p.k1 = c->first.k; p.s1 = c->first.stride; p.p1 = c->first.pad;
-        fuse = conv_gemm_can_fuse(p, bms[0]);
-        if (!fuse && bms[0] == 128 && conv_gemm_can_fuse(p, 64)) { bms[0] = 64; fuse = true; }
+        if (conv_gemm_f3_ok(p, 64)) { bms[0] = 64; fuse = true; }      // second-generation fused kernel
+        else {
+            fuse = conv_gemm_can_fuse(p, bms[0]);
+            if (!fuse && bms[0] == 128 && conv_gemm_can_fuse(p, 64)) { bms[0] = 64; fuse = true; }
+        }
         if (!fuse) p.img = nullptr;
     }
     if (!fuse) {
@@ -815,10 +818,11 @@ int amph_configure(amph_ctx* c, const char* key, int value) {
             const int nwg = std::min(c->gstamp_wgs[gi], 8192);
             std::vector<unsigned long long> h((size_t)nwg * 8);
             (void)hipMemcpy(h.data(), c->d_gstamps + (size_t)gi * 8192 * 8, h.size() * 8, hipMemcpyDeviceToHost);
-            double s[2][3] = {{0}};
-            for (int w = 0; w < nwg; ++w) for (int r = 0; r < 2; ++r) for (int k = 0; k < 3; ++k) s[r][k] += (double)h[(size_t)w * 8 + r * 4 + k];
-            fprintf(stderr, "  gemm %d (%d workgroups): consumer work %7.0f wait %7.0f total %7.0f | loader work %7.0f wait %7.0f total %7.0f cycles\n",
-                    gi, nwg, s[0][0] / nwg, s[0][1] / nwg, s[0][2] / nwg, s[1][0] / nwg, s[1][1] / nwg, s[1][2] / nwg);
+            double s8[8] = {0};
+            for (int w = 0; w < nwg; ++w) for (int k = 0; k < 8; ++k) s8[k] += (double)h[(size_t)w * 8 + k];
+            fprintf(stderr, "  gemm %d (%d workgroups) mean cycles per workgroup:", gi, nwg);
+            for (int k = 0; k < 8; ++k) fprintf(stderr, " %8.0f", s8[k] / nwg);
+            fprintf(stderr, "\n");
         }
         return AMPH_OK;
     }

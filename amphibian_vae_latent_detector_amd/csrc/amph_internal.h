@@ -115,6 +115,7 @@ extern int g_gemm_min_lds;
 extern int g_gemm_flags;
 extern int g_stft_grid;
 bool conv_gemm_can_fuse(const ConvGemmParams& p, int bm);
+bool conv_gemm_f3_ok(const ConvGemmParams& p, int bm);   // second-generation fused kernel (64-row tiles, 32 first-layer channels)
 void launch_conv_gemm(const ConvGemmParams& p, int bm, bool fuse_first, hipStream_t s);
 void launch_head_reduce(const HeadReduceParams& p, int n_rows, hipStream_t s);
 // bf16 encoder path (k_encoder_bf16.hip): x / w are bf16, y bf16 (epilogue 0) or fp32 partials (epilogue 1);

@@ -533,10 +533,23 @@ __global__ __launch_bounds__(256) void k_conv_gemm_p3(ConvGemmParams p) {
     fa_ = *reinterpret_cast<const float4*>(a_rd + (buf_) * kABuf + 8 * (kg_));            \
     fb_ = *reinterpret_cast<const float4*>(b_rd + (buf_) * kBBuf + 8 * (kg_));
 #define AMPH_P3_MFMA(x_, y_) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x_, y_, acc, 0, 0, 0);
+#ifdef AMPH_STAMPS
+#define AMPH_P3_T(v_) AMPH_GSTAMP(v_)
+#define AMPH_P3_WAITLOADS() asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+#define AMPH_P3_ACC() { q_p1 += ts1 - ts0; q_ld += ts2 - ts1; q_p2 += ts3 - ts2; q_bar += ts4 - ts3; }
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, q_p1 = 0, q_ld = 0, q_p2 = 0, q_bar = 0, q_begin = 0;
+    AMPH_GSTAMP(q_begin)
+    const unsigned long long q_rt0 = __builtin_amdgcn_s_memrealtime();
+#else
+#define AMPH_P3_T(v_)
+#define AMPH_P3_WAITLOADS()
+#define AMPH_P3_ACC()
+#endif
     // one slice from LDS buffer R; stage R receives slice s+3, stage (R+2)%3 goes to buffer (R+2)%3
 #define AMPH_P3_STEP(R, QL, QS)                                                 \
     {                                                                                      \
         float4 f1a, f1b, f2a, f2b, f3a, f3b, n0a, n0b;                                     \
+        AMPH_P3_T(ts0)                                                                     \
         AMPH_P3_READ(f1a, f1b, R, 1)                                                       \
         AMPH_SB();                                                                         \
         AMPH_P3_MFMA(f0a.x, f0b.x)                                                         \
@@ -558,6 +571,9 @@ __global__ __launch_bounds__(256) void k_conv_gemm_p3(ConvGemmParams p) {
         AMPH_P3_MFMA(f1a.w, f1b.w)                                                         \
         AMPH_P3_MFMA(f2a.x, f2b.x)                                                         \
         AMPH_SB();                                                                         \
+        AMPH_P3_T(ts1)                                                                     \
+        AMPH_P3_WAITLOADS()                                                                \
+        AMPH_P3_T(ts2)                                                                     \
         AMPH_P3_STORE(QS, (R + 2) % 3)                                                     \
         AMPH_SB();                                                                         \
         AMPH_P3_MFMA(f2a.y, f2b.y)                                                         \
@@ -571,7 +587,10 @@ __global__ __launch_bounds__(256) void k_conv_gemm_p3(ConvGemmParams p) {
         AMPH_P3_MFMA(f3a.z, f3b.z)                                                         \
         AMPH_P3_MFMA(f3a.w, f3b.w)                                                         \
         AMPH_SB();                                                                         \
+        AMPH_P3_T(ts3)                                                                     \
         __syncthreads();                                                                   \
+        AMPH_P3_T(ts4)                                                                     \
+        AMPH_P3_ACC()                                                                      \
         f0a = n0a; f0b = n0b;                                                              \
     }
 
@@ -598,6 +617,16 @@ __global__ __launch_bounds__(256) void k_conv_gemm_p3(ConvGemmParams p) {
         if (ks + 1 < ks_end) AMPH_P3_STEP(1, 1, 0)
     }
 
+#ifdef AMPH_STAMPS
+    if (tid == 0 && p.stamps) {
+        unsigned long long q_end;
+        AMPH_GSTAMP(q_end)
+        unsigned long long* o = p.stamps + (size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8;
+        o[0] = q_p1; o[1] = q_ld; o[2] = q_p2; o[3] = q_bar; o[4] = q_end - q_begin;
+        o[5] = __builtin_amdgcn_s_memrealtime() - q_rt0;   // 100 MHz ticks: clock = o[4] / o[5] * 100 MHz
+        o[6] = o[7] = 0;
+    }
+#endif
     // epilogue: C/D map of the 32x32 tile: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
     const int n = n_blk + col_tile * 32 + (lane & 31);
     if (n < p.N) {
@@ -616,9 +645,275 @@ __global__ __launch_bounds__(256) void k_conv_gemm_p3(ConvGemmParams p) {
     }
 }
 
+// ----------------------------------------------------------------------------
+// Fused conv1 -> conv2 in the second-generation structure ("f3"): k_conv_gemm_p3 whose A stage is not
+// loaded but RECOMPUTED - layer 1 (C_in == 1 direct 3x3 conv + BN + ReLU, exactly k_conv_first's FMA
+// order, so fused == unfused bitwise) evaluated from an image patch in LDS for the 2 x 4 A-tile values
+// a thread stages per slice.  Requires layer 1 to have 32 channels (= one K slice per conv2 tap: the
+// thread's 4 channels, hence its 9 x 4 tap weights + BN constants, are the same for every slice and
+// live in registers) and a 3x3 first layer.  The ~100 VALU + 18 LDS reads per slice are placed in the
+// shadows of MFMAs 1..10, the LDS store of the finished stage after MFMA 11.
+// LDS 3 x 36.9 KB + patch = 62 KB: two workgroups per CU, so the 1024 workgroups of a 256-chunk batch
+// run as two full rounds (the first-generation fused kernel: 43 KB, three per CU, 768 + 256).
+// ----------------------------------------------------------------------------
+template <int BM>
+__global__ __launch_bounds__(256) void k_conv_gemm_f3(ConvGemmParams p) {
+    static_assert(BM == 64, "one 32x32 tile per wave");
+    constexpr int kABuf = BM * kLdsRow, kBBuf = kBN * kLdsRow;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* As = reinterpret_cast<float*>(smem);                         // [3][BM][36]
+    float* Bs = As + 3 * kABuf;                                         // [3][64][36]
+    float* patch = Bs + 3 * kBBuf;                                      // [rows][W0 + 2 p1]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c4 = tid & 7, r0 = tid >> 3;
+    const int m_blk = blockIdx.x * BM, n_blk = blockIdx.y * kBN;
+    const int ohw = p.OH * p.OW;
+    const int PW = p.W0 + 2 * p.p1;
+
+    // ---- image patch of this tile (whole output rows of one chunk)
+    const int b = m_blk / ohw, oh_first = (m_blk - b * ohw) / p.OW, n_oh = BM / p.OW;
+    const int r1_lo = oh_first * p.stride - p.pad;
+    const int r1_cnt = (n_oh - 1) * p.stride + p.k;
+    const int patch_lo = r1_lo * p.s1 - p.p1;
+    {
+        const int rows = (r1_cnt - 1) * p.s1 + 3;
+        const float* img = p.img + (long long)b * p.H0 * p.W0;
+        for (int i = tid; i < rows * PW; i += 256) {
+            const int r = i / PW, cc = i - r * PW;
+            const int ir = patch_lo + r, ic = cc - p.p1;
+            patch[i] = (ir >= 0 && ir < p.H0 && ic >= 0 && ic < p.W0) ? img[ir * p.W0 + ic] : 0.0f;
+        }
+    }
+    // ---- this thread's 4 first-layer channels: 9 tap weights + BN constants, in registers for the whole kernel
+    float4 w1_0, w1_1, w1_2, w1_3, w1_4, w1_5, w1_6, w1_7, w1_8, sc1, sh1;
+    {
+        const float* wt = p.w1 + 4 * c4;
+        w1_0 = *reinterpret_cast<const float4*>(wt + 0 * p.C_in); w1_1 = *reinterpret_cast<const float4*>(wt + 1 * p.C_in);
+        w1_2 = *reinterpret_cast<const float4*>(wt + 2 * p.C_in); w1_3 = *reinterpret_cast<const float4*>(wt + 3 * p.C_in);
+        w1_4 = *reinterpret_cast<const float4*>(wt + 4 * p.C_in); w1_5 = *reinterpret_cast<const float4*>(wt + 5 * p.C_in);
+        w1_6 = *reinterpret_cast<const float4*>(wt + 6 * p.C_in); w1_7 = *reinterpret_cast<const float4*>(wt + 7 * p.C_in);
+        w1_8 = *reinterpret_cast<const float4*>(wt + 8 * p.C_in);
+        sc1 = *reinterpret_cast<const float4*>(p.scale1 + 4 * c4);
+        sh1 = *reinterpret_cast<const float4*>(p.shift1 + 4 * c4);
+    }
+    // ---- per-thread A rows r0 and r0 + 32: window origin in the patch for tap (0, 0), valid-tap masks
+    int rowbase0, rowbase1;
+    unsigned vmask0, vmask1;
+    {
+        int rb[2];
+        unsigned vm[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = m_blk + r0 + 32 * i;
+            const bool mv = m < p.M;
+            const int rem = (mv ? m : m_blk) - b * ohw;
+            const int oh = rem / p.OW, ow = rem - oh * p.OW;
+            const int ih0 = oh * p.stride - p.pad, iw0 = ow * p.stride - p.pad;     // layer-1 output coordinates
+            rb[i] = (ih0 * p.s1 - p.p1 - patch_lo) * PW + iw0 * p.s1;
+            unsigned v = 0;
+            for (int kh = 0; kh < p.k; ++kh)
+                for (int kw = 0; kw < p.k; ++kw)
+                    if (mv && ih0 + kh >= 0 && ih0 + kh < p.H && iw0 + kw >= 0 && iw0 + kw < p.W) v |= 1u << (kh * p.k + kw);
+            vm[i] = v;
+        }
+        rowbase0 = rb[0]; rowbase1 = rb[1]; vmask0 = vm[0]; vmask1 = vm[1];
+    }
+    const int n_slices = p.K_pad / kBK;                  // == k * k taps (C_in == 32), splits == 1
+    const float* wp0 = p.w + (long long)(n_blk + r0) * p.K_pad + 4 * c4;
+    const float* wp1 = wp0 + 32ll * p.K_pad;
+    int l_left = n_slices;                               // B slices not yet loaded
+    int c_kpos = 0, c_kh = 0, c_kw = 0;                  // tap of the next slice to COMPUTE (wave-uniform)
+
+    float4 sb0a, sb0b, sb1a, sb1b, sb2a, sb2b;           // B register stages
+    float4 a0, a1;                                       // the A stage being computed (rows r0, r0 + 32)
+    float pv0_0, pv0_1, pv0_2, pv0_3, pv0_4, pv0_5, pv0_6, pv0_7, pv0_8;
+    float pv1_0, pv1_1, pv1_2, pv1_3, pv1_4, pv1_5, pv1_6, pv1_7, pv1_8;
+    bool ok0 = false, ok1 = false;
+#define AMPH_F3_LOADB(q)                                                                   \
+    {                                                                                      \
+        sb##q##a = *reinterpret_cast<const float4*>(wp0);                                  \
+        sb##q##b = *reinterpret_cast<const float4*>(wp1);                                  \
+        const int adv_ = l_left > 1 ? 1 : 0;                                               \
+        l_left -= adv_;                                                                    \
+        wp0 += kBK * adv_;                                                                 \
+        wp1 += kBK * adv_;                                                                 \
+    }
+    // window of row i for the tap being computed (taps past the end have no mask bit: all zero)
+#define AMPH_F3_WINDOW(i)                                                                  \
+    {                                                                                      \
+        ok##i = (vmask##i >> c_kpos) & 1u;                                                 \
+        const float* pp_ = patch + (ok##i ? rowbase##i + (c_kh * p.s1 * PW + c_kw * p.s1) : 0); \
+        pv##i##_0 = pp_[0]; pv##i##_1 = pp_[1]; pv##i##_2 = pp_[2];                        \
+        pv##i##_3 = pp_[PW]; pv##i##_4 = pp_[PW + 1]; pv##i##_5 = pp_[PW + 2];             \
+        pv##i##_6 = pp_[2 * PW]; pv##i##_7 = pp_[2 * PW + 1]; pv##i##_8 = pp_[2 * PW + 2]; \
+    }
+#define AMPH_F3_TAP(i, t)                                                                  \
+    a##i.x = fmaf(pv##i##_##t, w1_##t.x, a##i.x); a##i.y = fmaf(pv##i##_##t, w1_##t.y, a##i.y); \
+    a##i.z = fmaf(pv##i##_##t, w1_##t.z, a##i.z); a##i.w = fmaf(pv##i##_##t, w1_##t.w, a##i.w);
+#define AMPH_F3_ZERO(i) a##i = make_float4(0.f, 0.f, 0.f, 0.f);
+#define AMPH_F3_FIN(i)                                                                     \
+    a##i.x = ok##i ? fmaxf(fmaf(a##i.x, sc1.x, sh1.x), 0.0f) : 0.0f;                       \
+    a##i.y = ok##i ? fmaxf(fmaf(a##i.y, sc1.y, sh1.y), 0.0f) : 0.0f;                       \
+    a##i.z = ok##i ? fmaxf(fmaf(a##i.z, sc1.z, sh1.z), 0.0f) : 0.0f;                       \
+    a##i.w = ok##i ? fmaxf(fmaf(a##i.w, sc1.w, sh1.w), 0.0f) : 0.0f;
+#define AMPH_F3_NEXT_TAP()                                                                 \
+    {                                                                                      \
+        ++c_kpos; ++c_kw;                                                                  \
+        const int wrap_ = c_kw >= p.k ? 1 : 0;                                             \
+        c_kw -= wrap_ * p.k;                                                               \
+        c_kh += wrap_;                                                                     \
+    }
+    const int st_off = r0 * kLdsRow + 4 * c4;
+#define AMPH_F3_STORE(q, buf_)                                                             \
+    {                                                                                      \
+        float* a_ = As + (buf_) * kABuf + st_off;                                          \
+        float* b_ = Bs + (buf_) * kBBuf + st_off;                                          \
+        *reinterpret_cast<float4*>(a_) = a0;                                               \
+        *reinterpret_cast<float4*>(a_ + 32 * kLdsRow) = a1;                                \
+        *reinterpret_cast<float4*>(b_) = sb##q##a;                                         \
+        *reinterpret_cast<float4*>(b_ + 32 * kLdsRow) = sb##q##b;                          \
+    }
+#define AMPH_F3_COMPUTE_ALL()                                                              \
+    {                                                                                      \
+        AMPH_F3_WINDOW(0) AMPH_F3_WINDOW(1)                                                \
+        AMPH_F3_ZERO(0) AMPH_F3_ZERO(1)                                                    \
+        AMPH_F3_TAP(0, 0) AMPH_F3_TAP(0, 1) AMPH_F3_TAP(0, 2) AMPH_F3_TAP(0, 3) AMPH_F3_TAP(0, 4) \
+        AMPH_F3_TAP(0, 5) AMPH_F3_TAP(0, 6) AMPH_F3_TAP(0, 7) AMPH_F3_TAP(0, 8) AMPH_F3_FIN(0) \
+        AMPH_F3_TAP(1, 0) AMPH_F3_TAP(1, 1) AMPH_F3_TAP(1, 2) AMPH_F3_TAP(1, 3) AMPH_F3_TAP(1, 4) \
+        AMPH_F3_TAP(1, 5) AMPH_F3_TAP(1, 6) AMPH_F3_TAP(1, 7) AMPH_F3_TAP(1, 8) AMPH_F3_FIN(1) \
+        AMPH_F3_NEXT_TAP()                                                                 \
+    }
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    const int row_tile = wave >> 1, col_tile = wave & 1;
+    const float* a_rd = As + (row_tile * 32 + (lane & 31)) * kLdsRow + 4 * (lane >> 5);
+    const float* b_rd = Bs + (col_tile * 32 + (lane & 31)) * kLdsRow + 4 * (lane >> 5);
+
+    // one slice from LDS buffer R: B stage QL receives slice s+3; slice s+2 (A computed here, B stage QS) goes
+    // to buffer (R+2)%3
+#define AMPH_F3_STEP(R, QL, QS)                                                            \
+    {                                                                                      \
+        float4 f1a, f1b, f2a, f2b, f3a, f3b, n0a, n0b;                                     \
+        AMPH_P3_READ(f1a, f1b, R, 1)                                                       \
+        AMPH_SB();                                                                         \
+        AMPH_P3_MFMA(f0a.x, f0b.x)                                                         \
+        AMPH_SB();                                                                         \
+        AMPH_F3_LOADB(QL)                                                                  \
+        AMPH_F3_WINDOW(0)                                                                  \
+        AMPH_SB();                                                                         \
+        AMPH_P3_MFMA(f0a.y, f0b.y)                                                         \
+        AMPH_SB();                                                                         \
+        AMPH_P3_READ(f2a, f2b, R, 2)                                                       \
+        AMPH_F3_WINDOW(1)                                                                  \
+        AMPH_SB();                                                                         \
+        AMPH_P3_MFMA(f0a.z, f0b.z)                                                         \
+        AMPH_SB();                                                                         \
+        AMPH_F3_ZERO(0) AMPH_F3_TAP(0, 0) AMPH_F3_TAP(0, 1) AMPH_F3_TAP(0, 2)              \
+        AMPH_SB();                                                                         \
+        AMPH_P3_MFMA(f0a.w, f0b.w)                                                         \
+        AMPH_SB();                                                                         \
+        AMPH_F3_TAP(0, 3) AMPH_F3_TAP(0, 4) AMPH_F3_TAP(0, 5)                              \
+        AMPH_SB();                                                                         \
+        AMPH_P3_MFMA(f1a.x, f1b.x)                                                         \
+        AMPH_SB();                                                                         \
+        AMPH_P3_READ(f3a, f3b, R, 3)                                                       \
+        AMPH_F3_TAP(0, 6) AMPH_F3_TAP(0, 7) AMPH_F3_TAP(0, 8)                              \
+        AMPH_SB();                                                                         \
+        AMPH_P3_MFMA(f1a.y, f1b.y)                                                         \
+        AMPH_SB();                                                                         \
+        AMPH_F3_FIN(0)                                                                     \
+        AMPH_SB();                                                                         \
+        AMPH_P3_MFMA(f1a.z, f1b.z)                                                         \
+        AMPH_SB();                                                                         \
+        AMPH_F3_ZERO(1) AMPH_F3_TAP(1, 0) AMPH_F3_TAP(1, 1) AMPH_F3_TAP(1, 2)              \
+        AMPH_SB();                                                                         \
+        AMPH_P3_MFMA(f1a.w, f1b.w)                                                         \
+        AMPH_SB();                                                                         \
+        AMPH_F3_TAP(1, 3) AMPH_F3_TAP(1, 4) AMPH_F3_TAP(1, 5)                              \
+        AMPH_SB();                                                                         \
+        AMPH_P3_MFMA(f2a.x, f2b.x)                                                         \
+        AMPH_SB();                                                                         \
+        AMPH_F3_TAP(1, 6) AMPH_F3_TAP(1, 7) AMPH_F3_TAP(1, 8)                              \
+        AMPH_SB();                                                                         \
+        AMPH_P3_MFMA(f2a.y, f2b.y)                                                         \
+        AMPH_SB();                                                                         \
+        AMPH_F3_FIN(1)                                                                     \
+        AMPH_F3_NEXT_TAP()                                                                 \
+        AMPH_SB();                                                                         \
+        AMPH_P3_MFMA(f2a.z, f2b.z)                                                         \
+        AMPH_SB();                                                                         \
+        AMPH_F3_STORE(QS, (R + 2) % 3)                                                     \
+        AMPH_SB();                                                                         \
+        AMPH_P3_MFMA(f2a.w, f2b.w)                                                         \
+        AMPH_P3_MFMA(f3a.x, f3b.x)                                                         \
+        AMPH_SB();                                                                         \
+        AMPH_P3_READ(n0a, n0b, (R + 1) % 3, 0)                                             \
+        AMPH_SB();                                                                         \
+        AMPH_P3_MFMA(f3a.y, f3b.y)                                                         \
+        AMPH_P3_MFMA(f3a.z, f3b.z)                                                         \
+        AMPH_P3_MFMA(f3a.w, f3b.w)                                                         \
+        AMPH_SB();                                                                         \
+        __syncthreads();                                                                   \
+        f0a = n0a; f0b = n0b;                                                              \
+    }
+
+    // prologue: B of slices 0, 1, 2 into the register stages; A of slices 0 and 1 computed; 0 and 1 on to LDS
+    AMPH_F3_LOADB(0)
+    AMPH_F3_LOADB(1)
+    AMPH_F3_LOADB(2)
+    __syncthreads();                                     // the patch is staged
+    AMPH_F3_COMPUTE_ALL()
+    AMPH_F3_STORE(0, 0)
+    AMPH_F3_COMPUTE_ALL()
+    AMPH_F3_STORE(1, 1)
+    __syncthreads();
+    float4 f0a, f0b;
+    AMPH_P3_READ(f0a, f0b, 0, 0)
+    int ks = 0;
+    for (; ks + 3 <= n_slices; ks += 3) {
+        AMPH_F3_STEP(0, 0, 2)
+        AMPH_F3_STEP(1, 1, 0)
+        AMPH_F3_STEP(2, 2, 1)
+    }
+    if (ks < n_slices) {
+        AMPH_F3_STEP(0, 0, 2)
+        if (ks + 1 < n_slices) AMPH_F3_STEP(1, 1, 0)
+    }
+
+    // epilogue: C/D map of the 32x32 tile: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    const int n = n_blk + col_tile * 32 + (lane & 31);
+    if (n < p.N) {
+        const float sc = p.scale[n], sh = p.shift[n];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m_blk + row_tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (m < p.M) p.y[(long long)m * p.N + n] = fmaxf(fmaf(acc[r], sc, sh), 0.0f);
+        }
+    }
+}
+
+static size_t conv_gemm_f3_lds(const ConvGemmParams& p, int bm) {
+    const int n_oh = bm / p.OW;
+    const int rows = ((n_oh - 1) * p.stride + p.k - 1) * p.s1 + p.k1;
+    return ((size_t)3 * (bm + kBN) * kLdsRow + (size_t)rows * (p.W0 + 2 * p.p1)) * sizeof(float);
+}
+bool conv_gemm_f3_ok(const ConvGemmParams& p, int bm) {
+    const int ohw = p.OH * p.OW;
+    return bm == 64 && p.img != nullptr && p.k1 == 3 && p.C_in == kBK && p.K == p.K_pad && p.k * p.k <= 32 && p.splits == 1 &&
+           p.epilogue == 0 && ohw % bm == 0 && bm % p.OW == 0 && conv_gemm_f3_lds(p, bm) <= 80 * 1024;
+}
+
 bool conv_gemm_p3_ok(const ConvGemmParams& p, int bm) {
     return bm == 64 && (p.C_in % kBK) == 0 && p.K == p.K_pad && p.k * p.k <= 32 && p.zeros != nullptr;
 }
+
+// first-generation fused tile: the 64-row tile needs 43 KB (three workgroups per CU: 768 of a 256-chunk batch's 1024
+// workgroups are resident, a second, one-third-full round follows); the 128-row tile (66 KB, one round of 512) was
+// measured no faster (48.4 vs 49.1 us) and stays excluded
+constexpr size_t kFuseLdsMax = 64 * 1024;
 
 static size_t conv_gemm_lds(const ConvGemmParams& p, int bm, bool fuse) {
     size_t b = (size_t)2 * (bm + kBN) * kLdsRow * sizeof(float);
@@ -633,7 +928,7 @@ static size_t conv_gemm_lds(const ConvGemmParams& p, int bm, bool fuse) {
 bool conv_gemm_can_fuse(const ConvGemmParams& p, int bm) {
     const int ohw = p.OH * p.OW;
     return p.img != nullptr && p.k1 == 3 && p.k * p.k <= 32 && ohw % bm == 0 && bm % p.OW == 0 && (p.C_in % 4) == 0 &&
-           conv_gemm_lds(p, bm, true) <= 64 * 1024;
+           conv_gemm_lds(p, bm, true) <= kFuseLdsMax;
 }
 
 int g_gemm_flags = 0;     // experiment knob: ConvGemmParams::flags of every launch
@@ -649,7 +944,26 @@ void launch_conv_gemm(const ConvGemmParams& p_in, int bm, bool fuse, hipStream_t
         hipLaunchKernelGGL((k_conv_gemm_p3<64>), grid, dim3(256), lds3, s, p);
         return;
     }
+    if (fuse && (g_gemm_flags & 4) == 0 && conv_gemm_f3_ok(p, bm)) {
+        static bool raised3[64] = {false};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev >= 0 && dev < 64 && !raised3[dev]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_gemm_f3<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            raised3[dev] = true;
+        }
+        hipLaunchKernelGGL((k_conv_gemm_f3<64>), grid, dim3(256), std::max(conv_gemm_f3_lds(p, bm), (size_t)g_gemm_min_lds), s, p);
+        return;
+    }
     if (fuse) {
+        static bool raised[64] = {false};          // per device: dynamic LDS above the 64 KB default
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev >= 0 && dev < 64 && !raised[dev]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_gemm<128, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFuseLdsMax);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_gemm<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFuseLdsMax);
+            raised[dev] = true;
+        }
         if (bm == 128) hipLaunchKernelGGL((k_conv_gemm<128, true>), grid, dim3(256), lds, s, p);
         else hipLaunchKernelGGL((k_conv_gemm<64, true>), grid, dim3(256), lds, s, p);
     } else {
