@@ -81,6 +81,9 @@ struct amph_ctx {
     float *d_first_w = nullptr, *d_first_scale = nullptr, *d_first_shift = nullptr;
     std::vector<GemmLayer> gemm;           // conv layers 2.. then the head GEMM last
     float* d_head_bias = nullptr;
+    float *d_map_means = nullptr, *d_map_prec = nullptr;   // Gaussian-MAP parameters (amph_decide_map)
+    double *d_map_logdet = nullptr, *d_map_lprior = nullptr;
+    size_t map_prec_cap = 0;
     float* d_zeros = nullptr;              // 256 bytes of zeros: the source of padded taps (k_conv_gemm_p3)
     int head_splits = 1;
     int flat = 0, latent = 0;
@@ -792,6 +795,7 @@ void amph_destroy(amph_ctx* c) {
     for (auto& w : c->lanes) free_lane(w);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     fr(c->d_centroids); fr(c->d_thr); fr(c->d_rank);
+    fr(c->d_map_means); fr(c->d_map_prec); fr(c->d_map_logdet); fr(c->d_map_lprior);
     for (int i = 0; i < 2; ++i) {
         if (c->pin_in[i]) (void)hipHostFree(c->pin_in[i]);
         fr(c->dev_in[i]); fr(c->dev_len[i]);
@@ -1063,6 +1067,44 @@ int amph_decide_radial(amph_ctx* c, const float* d_z, int64_t n_rows, int dim, c
     p.pred = d_pred; p.best_d = d_best_d;
     if (n_rows > 0) launch_decide_radial(p, n_rows, s);
     return check_launch(c, "decide_radial");
+}
+
+int amph_decide_map(amph_ctx* c, const float* d_z, int64_t n_rows, int dim, const float* h_means, const float* h_precision,
+                    const double* h_logdet, const double* h_log_prior, int n_species, int has_tau, double tau,
+                    int32_t* d_pred, double* d_best_score, double* d_scores, void* stream) {
+    if (!c) return AMPH_ERR_INVALID_ARG;
+    if (n_rows < 0 || dim < 1 || dim > kMaxRadialDim || n_species < 0 || n_species > kMaxSpecies ||
+        (n_species > 0 && (!h_means || !h_precision || !h_logdet || !h_log_prior)) ||
+        (n_rows > 0 && (!d_z || !d_pred || !d_best_score)))
+        return fail(c, AMPH_ERR_INVALID_ARG, "bad MAP arguments (dim <= %d, species <= %d)", kMaxRadialDim, kMaxSpecies);
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    if (!c->d_map_means) {
+        HIP_TRY(c, hipMalloc((void**)&c->d_map_means, (size_t)kMaxSpecies * kMaxRadialDim * sizeof(float)));
+        HIP_TRY(c, hipMalloc((void**)&c->d_map_logdet, kMaxSpecies * sizeof(double)));
+        HIP_TRY(c, hipMalloc((void**)&c->d_map_lprior, kMaxSpecies * sizeof(double)));
+    }
+    const size_t need = (size_t)std::max(n_species, 1) * dim * dim * sizeof(float);
+    if (need > c->map_prec_cap) {
+        HIP_TRY(c, hipStreamSynchronize(s));                 // an earlier launch may still read the old buffer
+        if (c->d_map_prec) (void)hipFree(c->d_map_prec);
+        c->d_map_prec = nullptr; c->map_prec_cap = 0;
+        HIP_TRY(c, hipMalloc((void**)&c->d_map_prec, need));
+        c->map_prec_cap = need;
+    }
+    if (n_species > 0) {
+        HIP_TRY(c, hipMemcpyAsync(c->d_map_means, h_means, (size_t)n_species * dim * sizeof(float), hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(c->d_map_prec, h_precision, (size_t)n_species * dim * dim * sizeof(float), hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(c->d_map_logdet, h_logdet, (size_t)n_species * sizeof(double), hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(c->d_map_lprior, h_log_prior, (size_t)n_species * sizeof(double), hipMemcpyHostToDevice, s));
+    }
+    MapParams p;
+    p.z = d_z; p.means = c->d_map_means; p.prec = c->d_map_prec; p.logdet = c->d_map_logdet; p.log_prior = c->d_map_lprior;
+    p.d_log2pi = (double)dim * 1.8378770664093453;          // d * float(np.log(2.0 * np.pi)), map_detector_core.py:323
+    p.K = n_species; p.D = dim; p.has_tau = has_tau; p.tau = tau;
+    p.pred = d_pred; p.best_score = d_best_score; p.scores = d_scores;
+    if (n_rows > 0) launch_score_map(p, n_rows, s);
+    return check_launch(c, "decide_map");
 }
 
 // ---------------------------------------------------------------------------- WAV ingest

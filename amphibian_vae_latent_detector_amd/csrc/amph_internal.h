@@ -139,4 +139,23 @@ struct RadialParams {
 };
 void launch_decide_radial(const RadialParams& p, long long n_rows, hipStream_t s);
 
+// ----------------------------------------------------------------------------
+// Gaussian-MAP decision
+// ----------------------------------------------------------------------------
+struct MapParams {
+    const float* z;          // [B][D]
+    const float* means;      // device [K][D]
+    const float* prec;       // device [K][D][D] precision matrices (row-major, float32 as the reference reads them)
+    const double* logdet;    // device [K] log det of the covariance
+    const double* log_prior; // device [K] log(prior + 1e-12)
+    double d_log2pi;         // D * log(2 pi)
+    int K, D;
+    int has_tau;
+    double tau;
+    int32_t* pred;           // [B] species index, -1 = NO_DETECT
+    double* best_score;      // [B]
+    double* scores;          // nullable [B][K]
+};
+void launch_score_map(const MapParams& p, long long n_rows, hipStream_t s);
+
 }  // namespace amph

@@ -1036,4 +1036,65 @@ void launch_decide_radial(const RadialParams& p, long long n_rows, hipStream_t s
     hipLaunchKernelGGL(k_decide_radial, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, s, p, n_rows);
 }
 
+// ----------------------------------------------------------------------------
+// K7: Gaussian-MAP scoring + decision (10b_benchmark_folder_detection_map.py:143-169 with
+// gaussian_logpdf_from_precision, map_detector_core.py:319-323):
+//   diff = z - mu_k (float32);  quad = diff^T P_k diff (float32; the reference's is numpy / BLAS
+//   sgemv + sdot, whose summation order is the library's own);  in float64:
+//   score_k = -0.5 * ((quad + logdet_k) + D log 2pi) + log(prior_k + 1e-12)
+//   pred = first k with the largest score (strict >), NO_DETECT (-1) if best < tau.
+// A group of Dp = pow2 >= D threads owns one chunk: thread j forms y_j = sum_i diff_i P[i][j] (fma
+// chain, i ascending), the products y_j diff_j are summed by a fixed LDS tree: deterministic and
+// independent of the batch composition.
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_score_map(MapParams p, long long n_rows, int Dp) {
+#pragma clang fp contract(off)
+    __shared__ float sh_diff[256];
+    __shared__ float sh_part[256];
+    const int tid = threadIdx.x;
+    const int cpb = 256 / Dp;                               // chunks per block
+    const int cl = tid / Dp, j = tid - cl * Dp;
+    const long long row = (long long)blockIdx.x * cpb + cl;
+    const bool rv = row < n_rows, jv = j < p.D;
+    const float zj = (rv && jv) ? p.z[row * p.D + j] : 0.0f;
+    double best = -INFINITY;
+    int pred = -1;
+    for (int k = 0; k < p.K; ++k) {
+        const float dj = jv ? zj - p.means[(long long)k * p.D + j] : 0.0f;
+        __syncthreads();                                    // previous species' tree is done with sh_part / sh_diff
+        sh_diff[tid] = dj;
+        __syncthreads();
+        float y = 0.0f;
+        if (jv) {
+            const float* P = p.prec + (long long)k * p.D * p.D + j;
+            const float* df = sh_diff + cl * Dp;
+            for (int i = 0; i < p.D; ++i) y = __builtin_fmaf(df[i], P[(long long)i * p.D], y);
+        }
+        sh_part[tid] = y * dj;
+        __syncthreads();
+        for (int o = Dp >> 1; o > 0; o >>= 1) {
+            if (j < o) sh_part[tid] = sh_part[tid] + sh_part[tid + o];
+            __syncthreads();
+        }
+        if (j == 0 && rv) {
+            const double quad = (double)sh_part[tid];
+            const double sc = -0.5 * ((quad + p.logdet[k]) + p.d_log2pi) + p.log_prior[k];
+            if (p.scores) p.scores[row * p.K + k] = sc;
+            if (sc > best) { best = sc; pred = k; }
+        }
+    }
+    if (j == 0 && rv) {
+        if (pred >= 0 && p.has_tau && best < p.tau) pred = -1;
+        p.pred[row] = pred;
+        p.best_score[row] = best;
+    }
+}
+
+void launch_score_map(const MapParams& p, long long n_rows, hipStream_t s) {
+    int Dp = 8;
+    while (Dp < p.D) Dp <<= 1;
+    const int cpb = 256 / Dp;
+    hipLaunchKernelGGL(k_score_map, dim3((unsigned)((n_rows + cpb - 1) / cpb)), dim3(256), 0, s, p, n_rows, Dp);
+}
+
 }  // namespace amph

@@ -262,6 +262,29 @@ class AmphSession:
             torch.cuda.current_stream(self.device).synchronize()   # host arrays above must outlive the async copies
         return pred, best
 
+    def decide_map(self, z: torch.Tensor, means: np.ndarray, precisions: np.ndarray, logdets: np.ndarray,
+                   log_priors: np.ndarray, tau: Optional[float] = None, want_scores: bool = False):
+        """Gaussian-MAP scoring + decision (K7, include/amph.h amph_decide_map).
+        -> (pred int32 [B] (-1 = NO_DETECT), best_score float64 [B], scores float64 [B, K] or None)."""
+        z = self._dev(z, torch.float32)
+        B, D = z.shape
+        mu = np.ascontiguousarray(means, dtype=np.float32).reshape(-1, D)
+        K = mu.shape[0]
+        pr = np.ascontiguousarray(precisions, dtype=np.float32).reshape(K, D, D)
+        ld = np.ascontiguousarray(logdets, dtype=np.float64).reshape(K)
+        lp = np.ascontiguousarray(log_priors, dtype=np.float64).reshape(K)
+        pred = torch.empty(B, dtype=torch.int32, device=self.device)
+        best = torch.empty(B, dtype=torch.float64, device=self.device)
+        scores = torch.empty((B, K), dtype=torch.float64, device=self.device) if want_scores else None
+        with torch.cuda.device(self.device):
+            self._chk(N.lib.amph_decide_map(self._ctx, _ptr(z), B, D, mu.ctypes.data_as(C.c_void_p),
+                                            pr.ctypes.data_as(C.c_void_p), ld.ctypes.data_as(C.c_void_p),
+                                            lp.ctypes.data_as(C.c_void_p), K, 0 if tau is None else 1,
+                                            0.0 if tau is None else float(tau), _ptr(pred), _ptr(best), _ptr(scores),
+                                            self._stream()))
+            torch.cuda.current_stream(self.device).synchronize()   # host arrays above must outlive the async copies
+        return pred, best, scores
+
     def configure(self, key: str, value: int):
         """Tuning knobs of include/amph.h's amph_configure ("lanes", "frames_per_block")."""
         self._chk(N.lib.amph_configure(self._ctx, key.encode(), int(value)))

@@ -9,6 +9,8 @@ Same names, keyword sets, return types and error behaviour:
   encode_wav_to_latent(encoder, wav_path, device, *, ...) -> np f32 [D]   ref :240-300
   crop_or_pad_time(mel, target_frames)                               ref :185-195
   find_project_root / resolve_default_* / load_json / save_json / summarize_1d   ref :48-101
+  inv_and_logdet / gaussian_logpdf_from_precision / get_priors_from_map_meta /
+  get_chunk_seconds_for_map / read_map_detector_params (host numpy, as in the reference)   ref :306-420
 
 plus the batched form the reference lacks (it loops batch-1,
 08_fit_radial_detector.py:488-503): `encode_chunks`.
@@ -243,3 +245,93 @@ def encode_chunks(encoder: HipEncoder, chunks, device: Optional[torch.device] = 
     cfg = _config(sr, duration, n_mels, fmin, fmax, hop_length, n_fft, target_frames)
     mu, _, _ = encoder.session(cfg).encode(chunks, lengths=lengths, apply_rms=apply_rms)
     return mu if return_tensor else mu.cpu().numpy()
+
+
+# ---------------------------------------------------------------------------
+# MAP helpers (host numpy, ref :306-420).  The batched on-GPU form of the scoring
+# is map_detector.MapDetector.decide -> HIP kernel K7 (amph_decide_map).
+# ---------------------------------------------------------------------------
+def inv_and_logdet(cov: np.ndarray):
+    sign, ld = np.linalg.slogdet(cov)
+    if sign <= 0:
+        d = cov.shape[0]
+        cov2 = cov + (1e-3 * np.eye(d, dtype=cov.dtype))
+        sign, ld = np.linalg.slogdet(cov2)
+        if sign <= 0:
+            raise RuntimeError("Covarianza no PD incluso tras regularización.")
+        cov = cov2
+    prec = np.linalg.inv(cov).astype(np.float32)
+    return prec, float(ld)
+
+
+def gaussian_logpdf_from_precision(z: np.ndarray, mu: np.ndarray, prec: np.ndarray, logdet_cov: float) -> float:
+    d = int(z.shape[0])
+    diff = (z - mu).astype(np.float32)
+    quad = float(diff.T @ prec @ diff)
+    return -0.5 * (quad + float(logdet_cov) + d * float(np.log(2.0 * np.pi)))
+
+
+def get_priors_from_map_meta(cfg: Dict[str, Any], species) -> Dict[str, float]:
+    """cfg["map_detector"]["meta_fit"]["per_species"][sp]["prior"], normalised; fallback uniform."""
+    priors: Dict[str, float] = {}
+    md = cfg.get("map_detector", {})
+    meta = md.get("meta_fit", {}) if isinstance(md, dict) else {}
+    per = meta.get("per_species", {}) if isinstance(meta, dict) else {}
+    ok = True
+    for sp in species:
+        try:
+            priors[sp] = float(per.get(sp, {}).get("prior"))
+        except Exception:  # noqa: BLE001
+            ok = False
+            break
+    if ok and priors:
+        s = sum(max(0.0, v) for v in priors.values())
+        if s > 0:
+            priors = {k: max(0.0, v) / s for k, v in priors.items()}
+        return priors
+    K = len(species)
+    if K == 0:
+        return {}
+    return {sp: 1.0 / K for sp in species}
+
+
+def get_chunk_seconds_for_map(cfg: Dict[str, Any]) -> float:
+    md = cfg.get("map_detector", {})
+    if isinstance(md, dict):
+        meta = md.get("meta_fit", {})
+        if isinstance(meta, dict) and "chunk_seconds" in meta:
+            try:
+                return float(meta["chunk_seconds"])
+            except Exception:  # noqa: BLE001
+                pass
+    try:
+        return float(cfg.get("chunk_seconds", 5.0))
+    except Exception:  # noqa: BLE001
+        return 5.0
+
+
+def read_map_detector_params(cfg: Dict[str, Any]):
+    """-> (means {sp: f32[D]}, precisions {sp: f32[D,D]}, logdets {sp: float}, tau float|None) as 08b stores them."""
+    md = cfg.get("map_detector", None)
+    if not isinstance(md, dict):
+        raise ValueError("config.json no contiene map_detector (dict). Ejecuta antes 08b_fit_map_detector.py")
+    if md.get("model", "") != "gaussian_map":
+        raise ValueError(f"map_detector.model inesperado: {md.get('model')}")
+    means_raw, prec_raw, logdet_raw = md.get("means", None), md.get("precision", None), md.get("logdet_cov", None)
+    if not isinstance(means_raw, dict) or not isinstance(prec_raw, dict) or not isinstance(logdet_raw, dict):
+        raise ValueError("map_detector debe contener 'means', 'precision' y 'logdet_cov' como dicts.")
+    means = {sp: np.array(v, dtype=np.float32) for sp, v in means_raw.items()
+             if isinstance(sp, str) and isinstance(v, list) and len(v) > 0}
+    precisions: Dict[str, np.ndarray] = {}
+    for sp, mat in prec_raw.items():
+        if isinstance(sp, str) and isinstance(mat, list) and len(mat) > 0:
+            P = np.array(mat, dtype=np.float32)
+            if P.ndim != 2 or P.shape[0] != P.shape[1]:
+                raise ValueError(f"precision[{sp}] debe ser matriz cuadrada, obtuve shape={P.shape}")
+            precisions[sp] = P
+    logdets = {sp: float(v) for sp, v in logdet_raw.items() if isinstance(sp, str)}
+    tau = md.get("tau", None)
+    tau_f = float(tau) if tau is not None else None
+    if not means or not precisions or not logdets:
+        raise ValueError("means/precision/logdet_cov vacíos o mal formateados en config.json.")
+    return means, precisions, logdets, tau_f

@@ -181,6 +181,24 @@ int amph_decide_radial(amph_ctx* ctx, const float* d_z, int64_t n_rows, int dim,
                        int32_t* d_pred, float* d_best_d, void* stream);
 
 /* -------------------------------------------------------------------------
+ * Gaussian-MAP decision - MapDetectorSession.predict_one,
+ * 10b_benchmark_folder_detection_map.py:143-169, with gaussian_logpdf_from_precision
+ * (map_detector_core.py:319-323).  K species in the caller's order (the reference
+ * iterates sorted(names), 10b:113); for each:
+ *   score_k = -0.5 * (diff^T P_k diff + logdet_k + D log 2pi) + h_log_prior[k],
+ *   diff = z - mu_k and the quadratic form in float32, the rest in float64;
+ * h_log_prior[k] = log(prior_k + 1e-12) (10b:156).  d_pred[b] = first k with the
+ * largest score (strict >), or -1 (NO_DETECT) when has_tau and best < tau (10b:166);
+ * d_best_score[b] = that score; d_scores (nullable) receives all [n_rows][K] scores
+ * (what 08b_fit_map_detector.py:302-306 evaluates for the true class when it sets tau).
+ * ------------------------------------------------------------------------- */
+int amph_decide_map(amph_ctx* ctx, const float* d_z, int64_t n_rows, int dim,
+                    const float* h_means, const float* h_precision,
+                    const double* h_logdet, const double* h_log_prior, int n_species,
+                    int has_tau, double tau,
+                    int32_t* d_pred, double* d_best_score, double* d_scores, void* stream);
+
+/* -------------------------------------------------------------------------
  * WAV ingest — the libsndfile decode inside librosa.load
  * (map_detector_core.py:210) for mono PCM16 RIFF files already at `sr`.
  * Reads up to max_samples int16 samples into h_out (zero-filled beyond the

@@ -424,6 +424,75 @@ def test_radial_decisions_bit_identical_to_reference(env, fe, golden):
             assert (det.names[pred[r]] if pred[r] >= 0 else None) == sp and float(best[r]) == bd
 
 
+# ----------------------------------------------------------------------------- K7: Gaussian-MAP decision
+def test_map_scores_and_decisions_against_reference(env, fe, golden):
+    """Scores within 1e-5 relative of the reference's (its quadratic form is float32 BLAS with an unspecified
+    summation order; the kernel's order is fixed), decisions equal wherever the reference's margin is not
+    within that tolerance of a tie or of tau."""
+    from amphibian_vae_latent_detector_amd.map_detector import MapDetector
+    from oracle import map_score as omap
+    g = golden("map_decide.npz")
+    cfg = json.loads(str(g["cfg_json"]))
+    det = MapDetector.from_config(cfg, latent_dim=8)
+    assert det.names == json.loads(str(g["species_json"]))
+    sc = det.scores(fe, g["Z"])
+    ref = g["scores"]
+    tol = 1e-5 * np.maximum(1.0, np.abs(ref))
+    assert np.all(np.abs(sc - ref) <= tol), float(np.max(np.abs(sc - ref) / np.maximum(1.0, np.abs(ref))))
+    pred, best = det.decide(fe, g["Z"])
+    srt = np.sort(ref, axis=1)
+    margin = np.minimum(srt[:, -1] - srt[:, -2], np.abs(srt[:, -1] - det.tau))
+    safe = margin > 2e-5 * np.maximum(1.0, np.abs(srt[:, -1]))
+    assert safe.mean() > 0.95
+    got = np.array([det.names[i] if i >= 0 else "" for i in pred.tolist()])
+    assert np.array_equal(got[safe], np.array([str(s) for s in g["pred"]])[safe])
+    assert np.array_equal((pred >= 0)[safe], g["detected"][safe])
+    assert np.all(np.abs(best - g["best_score"]) <= 1e-5 * np.maximum(1.0, np.abs(g["best_score"])))
+    assert (pred < 0).sum() > 0 and (pred >= 0).sum() > 0
+    # tau = None: nothing is rejected; K = 1, D not a power of two, D = 128 (two waves per chunk), empty batch
+    g2 = golden("map_decide_notau.npz")
+    det.tau = None
+    det.log_priors[:] = np.log(0.2 + 1e-12)
+    pred2, best2 = det.decide(fe, g["Z"])
+    assert (pred2 >= 0).all()
+    assert np.array_equal(np.array([det.names[i] for i in pred2.tolist()])[safe], np.array([str(s) for s in g2["pred"]])[safe])
+    rng = np.random.default_rng(9)
+    for D, K in ((5, 1), (32, 4), (100, 3), (128, 2)):
+        names = [f"s{k}" for k in range(K)]
+        means = {sp: rng.standard_normal(D).astype(np.float32) for sp in names}
+        precs, lds = {}, {}
+        for sp in names:
+            A = (rng.standard_normal((D, D)) * 0.2 + np.eye(D)).astype(np.float32)
+            precs[sp], lds[sp] = omap.inv_and_logdet((A @ A.T + 0.1 * np.eye(D)).astype(np.float32))
+        pri = {sp: 1.0 / K for sp in names}
+        d = MapDetector(means, precs, lds, pri, -1e9, D)
+        Z = (rng.standard_normal((257, D)) * 1.5).astype(np.float32)
+        sc = d.scores(fe, Z)
+        want = np.stack([omap.scores(z, names, means, precs, lds, pri) for z in Z])
+        assert np.all(np.abs(sc - want) <= 2e-5 * np.maximum(1.0, np.abs(want))), (D, K)
+        pred, best = d.decide(fe, Z)
+        assert np.array_equal(pred, np.argmax(sc, axis=1).astype(np.int32)) and np.array_equal(best, sc.max(axis=1))
+    pred0, best0 = d.decide(fe, np.zeros((0, D), np.float32))
+    assert pred0.shape == (0,) and best0.shape == (0,)
+    with pytest.raises(RuntimeError):
+        fe.decide_map(np.zeros((4, 200), np.float32), np.zeros((1, 200)), np.zeros((1, 200, 200)), np.zeros(1), np.zeros(1))
+
+
+def test_map_fit_scores_through_the_kernel(env, fe, golden):
+    """fit_map_detector(session=...) evaluates the true-class scores of the tau quantile on the GPU: tau within 1e-5
+    relative of the reference's."""
+    from amphibian_vae_latent_detector_amd.map_detector import fit_map_detector
+    g = golden("map_fit.npz")
+    species = json.loads(str(g["species_json"]))
+    Z = {sp: g[f"Z_{i}"] for i, sp in enumerate(species)}
+    for vi in (0, 3):
+        prm = json.loads(str(g[f"v{vi}_params_json"]))
+        md = fit_map_detector(Z, cov_type=prm["cov_type"], cov_structure=prm["cov_structure"], priors=prm["priors"],
+                              eps=prm["eps"], shrink=prm["shrink"], set_tau_q=prm["tau_q"], session=fe, verbose=False)
+        tau = float(g[f"v{vi}_tau"])
+        assert abs(md["tau"] - tau) <= 1e-4 * max(1.0, abs(tau))
+
+
 # ----------------------------------------------------------------------------- the drop-in Python surface
 def test_map_detector_core_surface(env, tmp_path):
     from amphibian_vae_latent_detector_amd import map_detector_core as core

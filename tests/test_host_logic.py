@@ -171,6 +171,62 @@ def test_priority_rank_rule(golden):
         prad.get_detector_from_config({})
 
 
+
+# ------------------------------------------------------------------ Gaussian-MAP detector: host fit + config readers
+def test_host_map_fit_matches_reference(golden, capsys):
+    from amphibian_vae_latent_detector_amd import map_detector as pmap
+    g = golden("map_fit.npz")
+    species = json.loads(str(g["species_json"]))
+    Z = {sp: g[f"Z_{i}"] for i, sp in enumerate(species)}
+    same = str(g["numpy_version"]) == np.__version__
+    for vi in range(4):
+        prm = json.loads(str(g[f"v{vi}_params_json"]))
+        md = pmap.fit_map_detector(Z, cov_type=prm["cov_type"], cov_structure=prm["cov_structure"], priors=prm["priors"],
+                                   eps=prm["eps"], shrink=prm["shrink"], set_tau_q=prm["tau_q"], meta={"chunk_seconds": 1.0})
+        assert md["model"] == "gaussian_map" and sorted(md["means"]) == sorted(species)
+        assert set(md) == {"model", "cov_type", "cov_structure", "priors", "means", "cov", "precision", "logdet_cov", "tau",
+                           "meta_fit"}                                               # the keys 08b writes (:322-351)
+        for i, sp in enumerate(species):
+            assert md["means"][sp] == g[f"v{vi}_mean_{i}"].astype(float).tolist()
+            assert md["meta_fit"]["per_species"][sp]["prior"] == float(g[f"v{vi}_prior_{i}"])
+            if same:
+                assert md["precision"][sp] == g[f"v{vi}_prec_{i}"].astype(float).tolist()
+                assert md["logdet_cov"][sp] == float(g[f"v{vi}_logdet_{i}"])
+            else:
+                np.testing.assert_allclose(md["logdet_cov"][sp], float(g[f"v{vi}_logdet_{i}"]), rtol=1e-5)
+        if prm["tau_q"] is None:
+            assert md["tau"] is None
+        else:
+            np.testing.assert_allclose(md["tau"], float(g[f"v{vi}_tau"]), rtol=0 if same else 1e-4)
+    assert "tau fijado desde train" in capsys.readouterr().out
+    with pytest.raises(ValueError):
+        pmap.fit_map_detector(Z, shrink=1.5)
+
+
+def test_map_config_readers_match_reference(golden):
+    from amphibian_vae_latent_detector_amd import map_detector as pmap
+    from amphibian_vae_latent_detector_amd import map_detector_core as core
+    g = golden("map_decide.npz")
+    cfg = json.loads(str(g["cfg_json"]))
+    means, precs, logdets, tau = core.read_map_detector_params(cfg)
+    species = sorted(set(means) & set(precs) & set(logdets))
+    assert species == json.loads(str(g["species_json"])) and tau == -14.0
+    assert core.get_priors_from_map_meta(cfg, species) == json.loads(str(g["priors_json"]))
+    assert core.get_chunk_seconds_for_map(cfg) == float(g["duration"]) == 1.0     # meta_fit wins over chunk_seconds
+    det = pmap.MapDetector.from_config(cfg, latent_dim=8)
+    assert det.names == species and det.precisions.shape == (5, 8, 8) and det.tau == -14.0
+    # host scores with the mirrored core function reproduce the reference's
+    z = g["Z"][3]
+    sc = [core.gaussian_logpdf_from_precision(z, means[sp], precs[sp], logdets[sp]) + det.log_priors[k]
+          for k, sp in enumerate(species)]
+    np.testing.assert_allclose(sc, g["scores"][3], rtol=1e-6, atol=1e-6)
+    for bad in ({}, {"map_detector": {"model": "other"}}, {"map_detector": {"model": "gaussian_map", "means": []}}):
+        with pytest.raises(ValueError):
+            core.read_map_detector_params(bad)
+    det2 = pmap.MapDetector({"a": np.zeros(8), "b": np.zeros(4)}, {"a": np.eye(8), "b": np.eye(4)}, {"a": 0.0, "b": 0.0},
+                            {}, None, latent_dim=8)
+    assert det2.names == ["a"]                                     # another dimension: skipped (10b:153-154)
+
 # ------------------------------------------------------------------ synthetic data + WAV ingest
 def test_synth_is_deterministic_and_shaped():
     a = synth.synth_chunk_pcm16(7, 22050, 22050)

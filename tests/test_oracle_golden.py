@@ -9,6 +9,7 @@ import torch
 
 from oracle import encoder as oenc
 from oracle import frontend as ofe
+from oracle import map_score as omap
 from oracle import radial as orad
 
 RMS_CASES = ["noise_quiet", "noise_loud", "tone", "silent", "below_gate", "clipping", "short"]
@@ -153,3 +154,72 @@ def test_pcm16_roundtrip_convention():
     q = ofe.float_to_pcm16(x)
     assert q.tolist() == [-32767, -16384, 0, 8192, 32767, 2]               # x * 32767, round-half-even
     assert ofe.pcm16_to_float(np.array([16384, -32768], np.int16)).tolist() == [0.5, -1.0]
+
+
+# ----------------------------------------------------------------------------- Gaussian-MAP detector (pinned)
+def _same_numpy(g):
+    return str(g["numpy_version"]) == np.__version__
+
+
+def test_map_fit_matches_reference(golden):
+    g = golden("map_fit.npz")
+    species = json.loads(str(g["species_json"]))
+    Z = {sp: g[f"Z_{i}"] for i, sp in enumerate(species)}
+    for vi in range(4):
+        prm = json.loads(str(g[f"v{vi}_params_json"]))
+        fit = omap.fit_map(Z, cov_type=prm["cov_type"], cov_structure=prm["cov_structure"], priors=prm["priors"],
+                           eps=prm["eps"], shrink=prm["shrink"], tau_q=prm["tau_q"])
+        assert fit["species"] == sorted(species)
+        for i, sp in enumerate(species):
+            assert fit["priors"][sp] == float(g[f"v{vi}_prior_{i}"])
+            assert np.array_equal(fit["means"][sp], g[f"v{vi}_mean_{i}"])
+            if _same_numpy(g):                                       # same numpy / LAPACK build: bit-exact
+                assert np.array_equal(fit["covs"][sp], g[f"v{vi}_cov_{i}"])
+                assert np.array_equal(fit["precs"][sp], g[f"v{vi}_prec_{i}"])
+                assert fit["logdets"][sp] == float(g[f"v{vi}_logdet_{i}"])
+                assert np.array_equal(fit["scores_true"][sp], g[f"v{vi}_scores_{i}"])
+            else:
+                np.testing.assert_allclose(fit["covs"][sp], g[f"v{vi}_cov_{i}"], rtol=1e-5, atol=1e-7)
+                np.testing.assert_allclose(fit["precs"][sp], g[f"v{vi}_prec_{i}"], rtol=1e-3, atol=1e-4)
+                np.testing.assert_allclose(fit["logdets"][sp], float(g[f"v{vi}_logdet_{i}"]), rtol=1e-5)
+                np.testing.assert_allclose(fit["scores_true"][sp], g[f"v{vi}_scores_{i}"], rtol=1e-4, atol=1e-3)
+        tau = float(g[f"v{vi}_tau"])
+        if prm["tau_q"] is None:
+            assert fit["tau"] is None and np.isnan(tau)
+        else:
+            np.testing.assert_allclose(fit["tau"], tau, rtol=0 if _same_numpy(g) else 1e-4)
+    # edge cases: a single row, and a singular covariance (1e-3 regularisation branch)
+    assert np.array_equal(omap.estimate_cov(np.zeros((1, 5), np.float32), 1e-6, 0.0, "full"), g["edge_cov_n1"])
+    prec, ld = omap.inv_and_logdet(g["edge_singular_in"].copy())
+    np.testing.assert_allclose(prec, g["edge_singular_prec"], rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(ld, float(g["edge_singular_logdet"]), rtol=1e-6)
+
+
+def test_map_decision_matches_reference(golden):
+    g = golden("map_decide.npz")
+    cfg = json.loads(str(g["cfg_json"]))
+    md = cfg["map_detector"]
+    species = json.loads(str(g["species_json"]))
+    assert species == sorted(md["means"])
+    means = {sp: np.array(md["means"][sp], np.float32) for sp in species}
+    precs = {sp: np.array(md["precision"][sp], np.float32) for sp in species}
+    logdets = {sp: float(md["logdet_cov"][sp]) for sp in species}
+    priors = omap.get_priors({sp: md["meta_fit"]["per_species"][sp]["prior"] for sp in species}, species)
+    assert priors == json.loads(str(g["priors_json"]))
+    n_no = 0
+    for r, z in enumerate(g["Z"]):
+        det, sp, best = omap.decide(z, species, means, precs, logdets, priors, md["tau"])
+        sc = omap.scores(z, species, means, precs, logdets, priors)
+        np.testing.assert_allclose(sc, g["scores"][r], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(best, g["best_score"][r], rtol=1e-6, atol=1e-6)
+        assert det == bool(g["detected"][r]) and (sp or "") == str(g["pred"][r])
+        n_no += not det
+    assert 0 < n_no < len(g["Z"])                                  # both outcomes are exercised
+    # tau = None and no per-species priors -> uniform priors, nothing rejected
+    g2 = golden("map_decide_notau.npz")
+    pri2 = omap.get_priors({}, species)
+    assert pri2 == json.loads(str(g2["priors_json"])) and all(abs(v - 0.2) < 1e-15 for v in pri2.values())
+    for r, z in enumerate(g["Z"]):
+        det, sp, best = omap.decide(z, species, means, precs, logdets, pri2, None)
+        assert det and sp == str(g2["pred"][r])
+        np.testing.assert_allclose(best, g2["best_score"][r], rtol=1e-6, atol=1e-6)
