@@ -9,6 +9,10 @@
                              -> summary.txt in the layout 9100_spearman_rk_analysis.py:53-58 parses
   run_qout_grid            = latent_space_exploration/run_qout_grid.sh (08 then 10 per q_out, outputs per run):
                              the train / eval folders are encoded ONCE and the latents stay resident.
+  fit_map_from_folder      = latent_space_exploration/08b_fit_map_detector.py main() (:129-360)
+                             -> config.json:map_detector {model, cov_type, ..., means, cov, precision, logdet_cov, tau, meta_fit}
+  benchmark_folder_map     = latent_space_exploration/10b_benchmark_folder_detection_map.py main() (:286-407)
+                             -> results.csv (…, best_score[, error]) + summary.txt ("… Summary (MAP)")
 
 Plots are not produced (reporting, out of scope).  Fit arithmetic stays numpy on the host
 (O(N*D), once per grid point); encode and decide run in the HIP kernels.
@@ -25,6 +29,7 @@ from typing import Any, Dict, List, Optional, Sequence, Tuple
 import numpy as np
 
 from . import folder as _folder
+from . import map_detector as _map
 from . import radial as _radial
 from .config import FrontendConfig
 from .map_detector_core import load_json, save_json
@@ -109,13 +114,14 @@ def _class_files(root: Path) -> List[Tuple[str, Path]]:
     return [(d.name, w) for d in dirs for w in list_audio_files(d)]
 
 
-def summary_text(rows: Sequence[Dict[str, Any]]) -> str:
-    """write_summary of 10_benchmark_folder_detection.py:278-301 for the non-ERROR rows."""
+def summary_text(rows: Sequence[Dict[str, Any]], title: str = "=== Detection Benchmark Summary ===") -> str:
+    """write_summary of 10_benchmark_folder_detection.py:278-301 (10b:243-267 with the "(MAP)" title) for the
+    non-ERROR rows."""
     ok = [r for r in rows if r["pred_species"] != "ERROR"]
     total = len(ok)
     correct = sum(bool(r["correct"]) for r in ok)
     no_det = sum(r["pred_species"] == "NO_DETECT" for r in ok)
-    lines = ["=== Detection Benchmark Summary ===", f"Total files: {total}",
+    lines = [title, f"Total files: {total}",
              f"Correct: {correct}  | Accuracy: {(correct / total if total else 0.0) * 100:.2f}%",
              f"NO_DETECT: {no_det} | Rate: {(no_det / total if total else 0.0) * 100:.2f}%", "", "=== Per-class ==="]
     per: Dict[str, List[Dict[str, Any]]] = {}
@@ -128,10 +134,11 @@ def summary_text(rows: Sequence[Dict[str, Any]]) -> str:
     return "\n".join(lines)
 
 
-def write_results(rows: Sequence[Dict[str, Any]], out_dir: Path) -> Tuple[Path, Path]:
+def write_results(rows: Sequence[Dict[str, Any]], out_dir: Path, value_col: str = "best_distance",
+                  title: str = "=== Detection Benchmark Summary ===") -> Tuple[Path, Path]:
     out_dir = Path(out_dir)
     out_dir.mkdir(parents=True, exist_ok=True)
-    cols = ["file", "true_species", "pred_species", "detected", "correct", "best_distance"]
+    cols = ["file", "true_species", "pred_species", "detected", "correct", value_col]
     if any("error" in r for r in rows):
         cols.append("error")
     csv_path = out_dir / "results.csv"
@@ -139,27 +146,27 @@ def write_results(rows: Sequence[Dict[str, Any]], out_dir: Path) -> Tuple[Path, 
         w = csv.writer(fh, lineterminator="\n")
         w.writerow(cols)
         for r in rows:
-            bd = r["best_distance"]
+            bd = r[value_col]
             w.writerow([r["file"], r["true_species"], r["pred_species"], bool(r["detected"]), bool(r["correct"]),
                         "" if (isinstance(bd, float) and math.isnan(bd)) else repr(float(bd))] +
                        ([r.get("error", "")] if "error" in cols else []))
     summary_path = out_dir / "summary.txt"
-    summary_path.write_text(summary_text(rows), encoding="utf-8")
+    summary_path.write_text(summary_text(rows, title), encoding="utf-8")
     return csv_path, summary_path
 
 
 def rows_from_decisions(files: Sequence[Tuple[str, Path]], status: np.ndarray, species: Sequence[Optional[str]],
-                        best_d: np.ndarray) -> List[Dict[str, Any]]:
-    """One results.csv row per file (10:401-418); files the ingest flagged become ERROR rows."""
+                        best_d: np.ndarray, value_col: str = "best_distance") -> List[Dict[str, Any]]:
+    """One results.csv row per file (10:401-418, 10b:354-375); files the ingest flagged become ERROR rows."""
     rows = []
     for (true_sp, wav), st, pred, bd in zip(files, status, species, best_d):
         if st != 0:
             rows.append({"file": str(wav), "true_species": true_sp, "pred_species": "ERROR", "detected": False,
-                         "correct": False, "best_distance": float("nan"), "error": f"WAV ingest status {int(st)}"})
+                         "correct": False, value_col: float("nan"), "error": f"WAV ingest status {int(st)}"})
             continue
         pred_species = pred if pred is not None else "NO_DETECT"
         rows.append({"file": str(wav), "true_species": true_sp, "pred_species": pred_species,
-                     "detected": pred is not None, "correct": pred_species == true_sp, "best_distance": float(bd)})
+                     "detected": pred is not None, "correct": pred_species == true_sp, value_col: float(bd)})
     return rows
 
 
@@ -220,3 +227,65 @@ def run_qout_grid(encoder, train_dir: Path, eval_dir: Path, config_path: Path, f
                 "source_log": "resident latents (no log file: fit and benchmark ran in one process)"})
         out[float(q_out)] = {"radial_detector": rd, "rows": rows}
     return out
+
+
+# ---------------------------------------------------------------------------- 08b / 10b: Gaussian-MAP detector
+def fit_map_from_folder(encoder, chunks_dir: Path, config_path: Path, fe: FrontendConfig, *, cov_type: str = "lda",
+                        cov_structure: str = "full", priors: str = "empirical", eps: float = 1e-6, shrink: float = 0.0,
+                        set_tau_q: Optional[float] = None, max_per_class: int = 0, seed: int = 123,
+                        cache_dir: Optional[Path] = None, apply_rms: bool = False, group=None,
+                        latents: Optional[Tuple[Dict[str, np.ndarray], Dict[str, int]]] = None,
+                        verbose: bool = True) -> Dict[str, Any]:
+    """08b's main(): encode `chunks_dir/<species>/*.wav` (same loop, sampling and cache files as 08), fit the
+    Gaussian-MAP parameters on the host (the tau quantile's N x K score evaluations on the GPU), write the
+    `map_detector` block into config.json after copying the previous file to config.json.bak."""
+    config_path = Path(config_path)
+    config = load_json(config_path)
+    species = config.get("species")
+    if not isinstance(species, list) or not all(isinstance(s, str) for s in species):
+        raise ValueError("config.json debe tener un campo 'species' (lista de strings).")
+    fe2, chunk_seconds = _frontend_from(config, fe)
+    if latents is None:
+        latents = _folder.encode_folder(encoder, chunks_dir, species, fe2, max_per_class=max_per_class, seed=seed,
+                                        cache_dir=cache_dir, apply_rms=apply_rms, group=group, verbose=verbose)
+    Z_by, failed = latents
+    if not Z_by:
+        raise RuntimeError("No se codificó ninguna especie. Revisa root y/o pipeline.")
+    rank = _folder._dist_info(group)[0]
+    meta = {"chunks_dir": str(Path(chunks_dir).resolve()), "chunks_name": Path(chunks_dir).name,
+            "chunk_seconds": float(chunk_seconds), "sr": int(fe2.sr), "n_mels": int(fe2.n_mels),
+            "target_frames": int(fe2.target_frames), "fmin": float(fe2.fmin), "fmax": float(fe2.fmax),
+            "hop_length": int(fe2.hop_length), "n_fft": int(fe2.n_fft), "max_per_class": int(max_per_class), "seed": int(seed)}
+    md = _map.fit_map_detector(Z_by, cov_type=cov_type, cov_structure=cov_structure, priors=priors, eps=eps, shrink=shrink,
+                               set_tau_q=set_tau_q, failed=failed, session=encoder.session(fe2), meta=meta,
+                               verbose=verbose and rank == 0)
+    if rank == 0:
+        config["map_detector"] = md
+        shutil.copy2(config_path, config_path.with_suffix(config_path.suffix + ".bak"))
+        save_json(config_path, config)
+    return md
+
+
+def benchmark_folder_map(encoder, root: Path, config_path: Path, fe: FrontendConfig, out_dir: Optional[Path] = None, *,
+                         apply_rms: bool = False, group=None,
+                         latents: Optional[Tuple[List[Tuple[str, Path]], np.ndarray, np.ndarray]] = None
+                         ) -> List[Dict[str, Any]]:
+    """10b's main() without the plots: encode every WAV under `root/<class>/`, score + decide on the GPU with the
+    `map_detector` of config.json (duration from its meta_fit.chunk_seconds, map_detector_core.py:359-371)."""
+    config = load_json(Path(config_path))
+    dur = _map.get_chunk_seconds_for_map(config)
+    fe2 = FrontendConfig(sr=fe.sr, duration=dur, n_fft=fe.n_fft, hop_length=fe.hop_length, n_mels=fe.n_mels, fmin=fe.fmin,
+                         fmax=fe.fmax, target_frames=fe.target_frames, pad_mode=fe.pad_mode)
+    if latents is None:
+        files = _class_files(Path(root).expanduser().resolve())
+        if not files:
+            raise RuntimeError("No se procesó ningún archivo (rows vacío).")
+        Z, status = _folder.encode_file_list(encoder, [w for _, w in files], fe2, apply_rms=apply_rms, group=group)
+    else:
+        files, Z, status = latents
+    det = _map.MapDetector.from_config(config, latent_dim=Z.shape[1])
+    pred, best = det.decide(encoder.session(fe2), Z)
+    rows = rows_from_decisions(files, status, det.species(pred), best, value_col="best_score")
+    if out_dir is not None and _folder._dist_info(group)[0] == 0:
+        write_results(rows, out_dir, value_col="best_score", title="=== Detection Benchmark Summary (MAP) ===")
+    return rows
