@@ -619,6 +619,7 @@ int run_encoder(amph_ctx* c, Workspace& w, const float* d_x, int nb, float* d_mu
         if (!c->d_gstamps) (void)hipMalloc((void**)&c->d_gstamps, (size_t)n_gemm * 8192 * 8 * 8);
         prm[gi].stamps = c->d_gstamps + (size_t)gi * 8192 * 8;
         c->gstamp_wgs[gi] = ((prm[gi].M + bms[gi] - 1) / bms[gi]) * ((prm[gi].N + 63) / 64) * prm[gi].splits;
+        if (fuse && gi == 0 && conv_gemm_f3_ok(prm[gi], bms[gi])) c->gstamp_wgs[gi] = std::min(c->gstamp_wgs[gi], 2 * amph::g_num_cus);
 #endif
         StageTimer t(c, head ? stage_head_gemm(c) : ST_CONV0 + 1 + gi, s);
         launch_conv_gemm(prm[gi], bms[gi], fuse && gi == 0, s);
@@ -743,6 +744,7 @@ int amph_create(const amph_frontend_config* cfg, const amph_encoder_spec* spec, 
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return fail(nullptr, AMPH_ERR_NO_DEVICE, "hipGetDeviceProperties failed");
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(nullptr, AMPH_ERR_NO_DEVICE, "device %d is %s; libamph is built for gfx950 only", device, prop.gcnArchName);
+    if (prop.multiProcessorCount > 0) amph::g_num_cus = prop.multiProcessorCount;
 
     amph_ctx* c = new amph_ctx();
     c->device = device;
@@ -826,7 +828,25 @@ int amph_configure(amph_ctx* c, const char* key, int value) {
             for (int w = 0; w < nwg; ++w) for (int k = 0; k < 8; ++k) s8[k] += (double)h[(size_t)w * 8 + k];
             fprintf(stderr, "  gemm %d (%d workgroups) mean cycles per workgroup:", gi, nwg);
             for (int k = 0; k < 8; ++k) fprintf(stderr, " %8.0f", s8[k] / nwg);
-            fprintf(stderr, "\n");
+            unsigned long long t0 = ~0ull, t1 = 0, l0 = ~0ull, l1 = 0;
+            for (int w = 0; w < nwg; ++w) {
+                t0 = std::min(t0, h[(size_t)w * 8 + 7]); t1 = std::max(t1, h[(size_t)w * 8 + 7]);
+                l0 = std::min(l0, h[(size_t)w * 8 + 5]); l1 = std::max(l1, h[(size_t)w * 8 + 5]);
+            }
+            fprintf(stderr, "   | lifetime ticks min %llu max %llu, start spread %llu ticks (100 MHz)\n", l0, l1, t1 - t0);
+            if (t1 > t0 && t1 - t0 < 100000) {                 // start-time histogram, 2 us bins; end = start + lifetime
+                int hist[40] = {0}, hend[40] = {0};
+                for (int w = 0; w < nwg; ++w) {
+                    const unsigned long long st = h[(size_t)w * 8 + 7] - t0, en = st + h[(size_t)w * 8 + 5];
+                    hist[std::min<unsigned long long>(st / 200, 39)]++;
+                    hend[std::min<unsigned long long>(en / 200, 39)]++;
+                }
+                fprintf(stderr, "      starts per 2 us:");
+                for (int b = 0; b < 40; ++b) if (hist[b]) fprintf(stderr, " [%d]=%d", 2 * b, hist[b]);
+                fprintf(stderr, "\n      ends   per 2 us:");
+                for (int b = 0; b < 40; ++b) if (hend[b]) fprintf(stderr, " [%d]=%d", 2 * b, hend[b]);
+                fprintf(stderr, "\n");
+            }
         }
         return AMPH_OK;
     }

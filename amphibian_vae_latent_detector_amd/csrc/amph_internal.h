@@ -113,6 +113,7 @@ struct HeadReduceParams {    // mu/logvar = sum_s partial[s] + bias
 void launch_conv_first(const ConvFirstParams& p, int n_rows, hipStream_t s);
 extern int g_gemm_min_lds;
 extern int g_gemm_flags;
+extern int g_num_cus;
 extern int g_stft_grid;
 bool conv_gemm_can_fuse(const ConvGemmParams& p, int bm);
 bool conv_gemm_f3_ok(const ConvGemmParams& p, int bm);   // second-generation fused kernel (64-row tiles, 32 first-layer channels)

@@ -532,7 +532,10 @@ __global__ __launch_bounds__(256) void k_conv_gemm_p3(ConvGemmParams p) {
 #define AMPH_P3_READ(fa_, fb_, buf_, kg_)                                                  \
     fa_ = *reinterpret_cast<const float4*>(a_rd + (buf_) * kABuf + 8 * (kg_));            \
     fb_ = *reinterpret_cast<const float4*>(b_rd + (buf_) * kBBuf + 8 * (kg_));
-#define AMPH_P3_MFMA(x_, y_) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x_, y_, acc, 0, 0, 0);
+// The B fragment goes in as the MFMA's FIRST operand: the accumulator then holds the TRANSPOSED tile (lane = output
+// row m, registers 4g..4g+3 = four consecutive channels n), so the epilogue is 4 x 16-byte stores per lane instead of
+// 16 dword stores (store issue was ~7k cycles per tile).  Products commute: the sums are bit-identical.
+#define AMPH_P3_MFMA(x_, y_) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(y_, x_, acc, 0, 0, 0);
 #ifdef AMPH_STAMPS
 #define AMPH_P3_T(v_) AMPH_GSTAMP(v_)
 #define AMPH_P3_WAITLOADS() asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -627,19 +630,24 @@ __global__ __launch_bounds__(256) void k_conv_gemm_p3(ConvGemmParams p) {
         o[6] = o[7] = 0;
     }
 #endif
-    // epilogue: C/D map of the 32x32 tile: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-    const int n = n_blk + col_tile * 32 + (lane & 31);
-    if (n < p.N) {
-        float sc = 1.0f, sh = 0.0f;
-        if (p.epilogue == 0) { sc = p.scale[n]; sh = p.shift[n]; }
+    // epilogue on the transposed accumulator: lane = row m, register group g = channels n0 .. n0 + 3
+    {
+        const int m = m_blk + row_tile * 32 + (lane & 31);
         float* ybase = p.y + (p.epilogue == 1 ? (long long)blockIdx.z * p.M * p.N : 0ll);
+        if (m < p.M) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m_blk + row_tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (m < p.M) {
-                float v = acc[r];
-                if (p.epilogue == 0) v = fmaxf(fmaf(v, sc, sh), 0.0f);
-                ybase[(long long)m * p.N + n] = v;
+            for (int g = 0; g < 4; ++g) {
+                const int n0 = n_blk + col_tile * 32 + 8 * g + 4 * (lane >> 5);
+                if (n0 < p.N) {                                                      // N % 4 == 0 (host check)
+                    float4 v = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+                    if (p.epilogue == 0) {
+                        const float4 sc = *reinterpret_cast<const float4*>(p.scale + n0);
+                        const float4 sh = *reinterpret_cast<const float4*>(p.shift + n0);
+                        v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.0f); v.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.0f);
+                        v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.0f); v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.0f);
+                    }
+                    *reinterpret_cast<float4*>(ybase + (long long)m * p.N + n0) = v;
+                }
             }
         }
     }
@@ -667,25 +675,17 @@ __global__ __launch_bounds__(256) void k_conv_gemm_f3(ConvGemmParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c4 = tid & 7, r0 = tid >> 3;
-    const int m_blk = blockIdx.x * BM, n_blk = blockIdx.y * kBN;
+    const int n_blk = blockIdx.y * kBN;
     const int ohw = p.OH * p.OW;
     const int PW = p.W0 + 2 * p.p1;
-
-    // ---- image patch of this tile (whole output rows of one chunk)
-    const int b = m_blk / ohw, oh_first = (m_blk - b * ohw) / p.OW, n_oh = BM / p.OW;
-    const int r1_lo = oh_first * p.stride - p.pad;
-    const int r1_cnt = (n_oh - 1) * p.stride + p.k;
-    const int patch_lo = r1_lo * p.s1 - p.p1;
-    {
-        const int rows = (r1_cnt - 1) * p.s1 + 3;
-        const float* img = p.img + (long long)b * p.H0 * p.W0;
-        for (int i = tid; i < rows * PW; i += 256) {
-            const int r = i / PW, cc = i - r * PW;
-            const int ir = patch_lo + r, ic = cc - p.p1;
-            patch[i] = (ir >= 0 && ir < p.H0 && ic >= 0 && ic < p.W0) ? img[ir * p.W0 + ic] : 0.0f;
-        }
-    }
-    // ---- this thread's 4 first-layer channels: 9 tap weights + BN constants, in registers for the whole kernel
+    const int n_tiles = (p.M + BM - 1) / BM;
+#ifdef AMPH_STAMPS
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, q_p1 = 0, q_ld = 0, q_p2 = 0, q_bar = 0, q_begin = 0, q_loop = 0,
+                       q_tile = 0, q_pro = 0, q_main = 0;
+    AMPH_GSTAMP(q_begin)
+    const unsigned long long q_rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    // this thread's 4 first-layer channels: 9 tap weights + BN constants, in registers for the whole kernel
     float4 w1_0, w1_1, w1_2, w1_3, w1_4, w1_5, w1_6, w1_7, w1_8, sc1, sh1;
     {
         const float* wt = p.w1 + 4 * c4;
@@ -697,27 +697,73 @@ __global__ __launch_bounds__(256) void k_conv_gemm_f3(ConvGemmParams p) {
         sc1 = *reinterpret_cast<const float4*>(p.scale1 + 4 * c4);
         sh1 = *reinterpret_cast<const float4*>(p.shift1 + 4 * c4);
     }
-    // ---- per-thread A rows r0 and r0 + 32: window origin in the patch for tap (0, 0), valid-tap masks
-    int rowbase0, rowbase1;
-    unsigned vmask0, vmask1;
-    {
-        int rb[2];
-        unsigned vm[2];
+    // PERSISTENT over the M tiles (grid.x = two workgroups per CU): a second dispatch round of this kernel started
+    // 5-8 us after the workgroups it replaced had ended (start / end histograms of the stamps build); one resident
+    // round that walks its tiles has no such gap
+    // patch slots of this thread (the same for every tile): element i = tid + 256 u of the [rows][PW] patch
+    constexpr int PU = 8;
+    const int n_oh = BM / p.OW;
+    const int r1_cnt = (n_oh - 1) * p.stride + p.k;
+    const int n_patch = ((r1_cnt - 1) * p.s1 + 3) * PW;            // <= 256 * PU (host check)
+    int p_r[PU], p_ic[PU];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int m = m_blk + r0 + 32 * i;
-            const bool mv = m < p.M;
-            const int rem = (mv ? m : m_blk) - b * ohw;
-            const int oh = rem / p.OW, ow = rem - oh * p.OW;
-            const int ih0 = oh * p.stride - p.pad, iw0 = ow * p.stride - p.pad;     // layer-1 output coordinates
-            rb[i] = (ih0 * p.s1 - p.p1 - patch_lo) * PW + iw0 * p.s1;
-            unsigned v = 0;
-            for (int kh = 0; kh < p.k; ++kh)
-                for (int kw = 0; kw < p.k; ++kw)
-                    if (mv && ih0 + kh >= 0 && ih0 + kh < p.H && iw0 + kw >= 0 && iw0 + kw < p.W) v |= 1u << (kh * p.k + kw);
-            vm[i] = v;
+    for (int u = 0; u < PU; ++u) {
+        const int i = tid + 256 * u;
+        const int r = i / PW, ic = i - r * PW - p.p1;
+        p_r[u] = i < n_patch ? r : -(1 << 20);                       // out-of-patch slots never pass the row test
+        p_ic[u] = (ic >= 0 && ic < p.W0) ? ic : -1;
+    }
+    float pf[PU];                                                    // the NEXT tile's patch values, prefetched
+#define AMPH_F3_FETCH_PATCH(tile_)                                                         \
+    {                                                                                      \
+        const int mb_ = (tile_) * BM;                                                      \
+        const int b_ = mb_ / ohw, ohf_ = (mb_ - b_ * ohw) / p.OW;                          \
+        const int plo_ = (ohf_ * p.stride - p.pad) * p.s1 - p.p1;                          \
+        const float* img_ = p.img + (long long)b_ * p.H0 * p.W0;                           \
+        _Pragma("unroll") for (int u = 0; u < PU; ++u) {                                   \
+            const int ir_ = plo_ + p_r[u];                                                 \
+            pf[u] = (ir_ >= 0 && ir_ < p.H0 && p_ic[u] >= 0) ? img_[ir_ * p.W0 + p_ic[u]] : 0.0f; \
+        }                                                                                  \
+    }
+    // per-thread A rows r0 and r0 + 32 inside a tile (whole output rows of one chunk, so tile-independent): local output
+    // row / column, window origin in the patch for tap (0, 0) and the horizontally valid taps
+    const int ohl0 = r0 / p.OW, owl0 = r0 - ohl0 * p.OW, ohl1 = (r0 + 32) / p.OW, owl1 = (r0 + 32) - ohl1 * p.OW;
+    const int rowbase0 = (ohl0 * p.stride * p.s1) * PW + (owl0 * p.stride - p.pad) * p.s1;
+    const int rowbase1 = (ohl1 * p.stride * p.s1) * PW + (owl1 * p.stride - p.pad) * p.s1;
+    unsigned hm0 = 0, hm1 = 0;
+    for (int kw = 0; kw < p.k; ++kw) {
+        const int iwA = owl0 * p.stride - p.pad + kw, iwB = owl1 * p.stride - p.pad + kw;
+        for (int kh = 0; kh < p.k; ++kh) {
+            if (iwA >= 0 && iwA < p.W) hm0 |= 1u << (kh * p.k + kw);
+            if (iwB >= 0 && iwB < p.W) hm1 |= 1u << (kh * p.k + kw);
         }
-        rowbase0 = rb[0]; rowbase1 = rb[1]; vmask0 = vm[0]; vmask1 = vm[1];
+    }
+    if ((int)blockIdx.x < n_tiles) AMPH_F3_FETCH_PATCH(blockIdx.x)
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int m_blk = tile * BM;
+#ifdef AMPH_STAMPS
+    AMPH_GSTAMP(q_tile)
+#endif
+
+    // ---- image patch of this tile (whole output rows of one chunk): fetched one tile ahead (all loads of a fetch are
+    //      issued together and land under the previous tile's main loop; staged per element with a load -> LDS write
+    //      per trip it was ~4 us of serialised round trips per tile)
+    const int b = m_blk / ohw, oh_first = (m_blk - b * ohw) / p.OW;
+    const int r1_lo = oh_first * p.stride - p.pad;
+    const int patch_lo = r1_lo * p.s1 - p.p1;
+#pragma unroll
+    for (int u = 0; u < PU; ++u)
+        if (tid + 256 * u < n_patch) patch[tid + 256 * u] = pf[u];
+    // ---- valid-tap masks of the two A rows: horizontal validity is tile-independent (hm*), the vertical one depends on
+    //      the tile's first output row only
+    unsigned vmask0 = 0, vmask1 = 0;
+    {
+        const int ihA = (oh_first + ohl0) * p.stride - p.pad, ihB = (oh_first + ohl1) * p.stride - p.pad;
+        for (int kh = 0; kh < p.k; ++kh) {
+            const unsigned rowbits = ((1u << p.k) - 1u) << (kh * p.k);
+            if (m_blk + r0 < p.M && ihA + kh >= 0 && ihA + kh < p.H) vmask0 |= hm0 & rowbits;
+            if (m_blk + r0 + 32 < p.M && ihB + kh >= 0 && ihB + kh < p.H) vmask1 |= hm1 & rowbits;
+        }
     }
     const int n_slices = p.K_pad / kBK;                  // == k * k taps (C_in == 32), splits == 1
     const float* wp0 = p.w + (long long)(n_blk + r0) * p.K_pad + 4 * c4;
@@ -797,6 +843,7 @@ __global__ __launch_bounds__(256) void k_conv_gemm_f3(ConvGemmParams p) {
 #define AMPH_F3_STEP(R, QL, QS)                                                            \
     {                                                                                      \
         float4 f1a, f1b, f2a, f2b, f3a, f3b, n0a, n0b;                                     \
+        AMPH_P3_T(ts0)                                                                     \
         AMPH_P3_READ(f1a, f1b, R, 1)                                                       \
         AMPH_SB();                                                                         \
         AMPH_P3_MFMA(f0a.x, f0b.x)                                                         \
@@ -845,6 +892,8 @@ __global__ __launch_bounds__(256) void k_conv_gemm_f3(ConvGemmParams p) {
         AMPH_SB();                                                                         \
         AMPH_P3_MFMA(f2a.z, f2b.z)                                                         \
         AMPH_SB();                                                                         \
+        AMPH_P3_T(ts1)                                                                     \
+        AMPH_P3_T(ts2)                                                                     \
         AMPH_F3_STORE(QS, (R + 2) % 3)                                                     \
         AMPH_SB();                                                                         \
         AMPH_P3_MFMA(f2a.w, f2b.w)                                                         \
@@ -856,7 +905,10 @@ __global__ __launch_bounds__(256) void k_conv_gemm_f3(ConvGemmParams p) {
         AMPH_P3_MFMA(f3a.z, f3b.z)                                                         \
         AMPH_P3_MFMA(f3a.w, f3b.w)                                                         \
         AMPH_SB();                                                                         \
+        AMPH_P3_T(ts3)                                                                     \
         __syncthreads();                                                                   \
+        AMPH_P3_T(ts4)                                                                     \
+        AMPH_P3_ACC()                                                                      \
         f0a = n0a; f0b = n0b;                                                              \
     }
 
@@ -865,6 +917,7 @@ __global__ __launch_bounds__(256) void k_conv_gemm_f3(ConvGemmParams p) {
     AMPH_F3_LOADB(1)
     AMPH_F3_LOADB(2)
     __syncthreads();                                     // the patch is staged
+    if (tile + (int)gridDim.x < n_tiles) AMPH_F3_FETCH_PATCH(tile + gridDim.x)
     AMPH_F3_COMPUTE_ALL()
     AMPH_F3_STORE(0, 0)
     AMPH_F3_COMPUTE_ALL()
@@ -872,6 +925,10 @@ __global__ __launch_bounds__(256) void k_conv_gemm_f3(ConvGemmParams p) {
     __syncthreads();
     float4 f0a, f0b;
     AMPH_P3_READ(f0a, f0b, 0, 0)
+#ifdef AMPH_STAMPS
+    AMPH_GSTAMP(q_loop)
+    q_pro += q_loop - q_tile;
+#endif
     int ks = 0;
     for (; ks + 3 <= n_slices; ks += 3) {
         AMPH_F3_STEP(0, 0, 2)
@@ -883,16 +940,39 @@ __global__ __launch_bounds__(256) void k_conv_gemm_f3(ConvGemmParams p) {
         if (ks + 1 < n_slices) AMPH_F3_STEP(1, 1, 0)
     }
 
-    // epilogue: C/D map of the 32x32 tile: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-    const int n = n_blk + col_tile * 32 + (lane & 31);
-    if (n < p.N) {
-        const float sc = p.scale[n], sh = p.shift[n];
+#ifdef AMPH_STAMPS
+    { unsigned long long q_e; AMPH_GSTAMP(q_e) q_main += q_e - q_loop; }
+#endif
+    // epilogue on the transposed accumulator: lane = row m, register group g = channels n0 .. n0 + 3
+    {
+        const int m = m_blk + row_tile * 32 + (lane & 31);
+        if (m < p.M) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m_blk + row_tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (m < p.M) p.y[(long long)m * p.N + n] = fmaxf(fmaf(acc[r], sc, sh), 0.0f);
+            for (int g = 0; g < 4; ++g) {
+                const int n0 = n_blk + col_tile * 32 + 8 * g + 4 * (lane >> 5);
+                if (n0 < p.N) {
+                    const float4 sc = *reinterpret_cast<const float4*>(p.scale + n0);
+                    const float4 sh = *reinterpret_cast<const float4*>(p.shift + n0);
+                    float4 v;
+                    v.x = fmaxf(fmaf(acc[4 * g], sc.x, sh.x), 0.0f); v.y = fmaxf(fmaf(acc[4 * g + 1], sc.y, sh.y), 0.0f);
+                    v.z = fmaxf(fmaf(acc[4 * g + 2], sc.z, sh.z), 0.0f); v.w = fmaxf(fmaf(acc[4 * g + 3], sc.w, sh.w), 0.0f);
+                    *reinterpret_cast<float4*>(p.y + (long long)m * p.N + n0) = v;
+                }
+            }
         }
     }
+    }   // tile loop (the last step's barrier has retired every LDS read of this tile)
+#ifdef AMPH_STAMPS
+    if (tid == 0 && p.stamps) {
+        unsigned long long q_end;
+        AMPH_GSTAMP(q_end)
+        unsigned long long* o = p.stamps + (size_t)blockIdx.x * 8;
+        o[0] = q_p1; o[1] = q_pro; o[2] = q_p2; o[3] = q_bar; o[4] = q_end - q_begin;   // sums over this workgroup's tiles
+        o[5] = __builtin_amdgcn_s_memrealtime() - q_rt0;
+        o[6] = q_main;                                 // main-loop cycles (all tiles)
+        o[7] = q_rt0 & 0xffffffffull;
+    }
+#endif
 }
 
 static size_t conv_gemm_f3_lds(const ConvGemmParams& p, int bm) {
@@ -902,12 +982,13 @@ static size_t conv_gemm_f3_lds(const ConvGemmParams& p, int bm) {
 }
 bool conv_gemm_f3_ok(const ConvGemmParams& p, int bm) {
     const int ohw = p.OH * p.OW;
-    return bm == 64 && p.img != nullptr && p.k1 == 3 && p.C_in == kBK && p.K == p.K_pad && p.k * p.k <= 32 && p.splits == 1 &&
-           p.epilogue == 0 && ohw % bm == 0 && bm % p.OW == 0 && conv_gemm_f3_lds(p, bm) <= 80 * 1024;
+    return bm == 64 && p.img != nullptr && p.k1 == 3 && p.C_in == kBK && p.K == p.K_pad && p.k * p.k <= 32 && p.splits == 1 && (p.N % 4) == 0 &&
+           p.epilogue == 0 && ohw % bm == 0 && bm % p.OW == 0 && conv_gemm_f3_lds(p, bm) <= 80 * 1024 &&
+           (((bm / p.OW - 1) * p.stride + p.k - 1) * p.s1 + 3) * (p.W0 + 2 * p.p1) <= 256 * 8;
 }
 
 bool conv_gemm_p3_ok(const ConvGemmParams& p, int bm) {
-    return bm == 64 && (p.C_in % kBK) == 0 && p.K == p.K_pad && p.k * p.k <= 32 && p.zeros != nullptr;
+    return bm == 64 && (p.C_in % kBK) == 0 && p.K == p.K_pad && p.k * p.k <= 32 && p.zeros != nullptr && (p.N % 4) == 0;
 }
 
 // first-generation fused tile: the 64-row tile needs 43 KB (three workgroups per CU: 768 of a 256-chunk batch's 1024
@@ -931,6 +1012,7 @@ bool conv_gemm_can_fuse(const ConvGemmParams& p, int bm) {
            conv_gemm_lds(p, bm, true) <= kFuseLdsMax;
 }
 
+int g_num_cus = 256;      // compute units of the device (amph_create sets it)
 int g_gemm_flags = 0;     // experiment knob: ConvGemmParams::flags of every launch
 int g_gemm_min_lds = 0;   // experiment knob: request at least this much LDS (limits workgroups per CU)
 
@@ -952,7 +1034,8 @@ void launch_conv_gemm(const ConvGemmParams& p_in, int bm, bool fuse, hipStream_t
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_gemm_f3<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
             raised3[dev] = true;
         }
-        hipLaunchKernelGGL((k_conv_gemm_f3<64>), grid, dim3(256), std::max(conv_gemm_f3_lds(p, bm), (size_t)g_gemm_min_lds), s, p);
+        const dim3 pgrid(std::min(grid.x, (unsigned)(2 * g_num_cus)), grid.y, 1);      // persistent: one resident round
+        hipLaunchKernelGGL((k_conv_gemm_f3<64>), pgrid, dim3(256), std::max(conv_gemm_f3_lds(p, bm), (size_t)g_gemm_min_lds), s, p);
         return;
     }
     if (fuse) {

@@ -152,7 +152,9 @@ __global__ __launch_bounds__(256) void k_rms_scale(const T* __restrict__ in, lon
     for (int c0 = 0; c0 < n_chunks; c0 += kChunksPerPass) {
         // ---- stage this pass's samples, coalesced (dword granules when the row is 4-byte aligned)
         const int e0 = c0 * kNpChunk, ne = min(kPassElems, n - e0);
-        constexpr int U = 8;
+        // every load of a batch is issued before the first LDS write: a 1 s / 22.05 kHz row (11 025 dwords) is ONE batch,
+        // i.e. one global round trip (batches of 8 loads per thread were six serialised round trips: 16 -> 10 us)
+        constexpr int U = sizeof(T) == 2 ? 44 : 32;
         if (sizeof(T) == 2 && (((uintptr_t)(x + e0)) & 3u) == 0) {
             const uint32_t* src = reinterpret_cast<const uint32_t*>(x + e0);
             const int nd = ne >> 1;

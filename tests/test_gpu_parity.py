@@ -680,3 +680,31 @@ def test_map_folder_pipeline_fit_and_benchmark(env, tmp_path, capsys):
         if min(srt[-1] - srt[-2], abs(srt[-1] - tau)) > 2e-2 * max(1.0, abs(srt[-1])):
             det, sp, _ = omap.decide(z, species, means, precs, logdets, priors, tau)
             assert r["pred_species"] == (sp or "NO_DETECT")
+
+def test_cli_07_single_wav_jsonl(env, tmp_path, capsys):
+    """BASELINE configs[0] / SURVEY 8(d) config 1: the 07-style CLI (--wav ... --jsonl) on chunk 0."""
+    from amphibian_vae_latent_detector_amd import encode_wav_to_latent as cli
+    from amphibian_vae_latent_detector_amd import synth
+    from amphibian_vae_latent_detector_amd.encoder import save_checkpoint
+    cfg = env.cfg
+    spec = env.SPECS["tiny"](cfg.target_frames, cfg.n_mels)
+    state = env.random_init_state(spec, seed=0)
+    pt, ym, wav = tmp_path / "model.pt", tmp_path / "enc.yaml", tmp_path / "chunk_000000.wav"
+    save_checkpoint(pt, ym, spec, state)
+    synth.write_wav_pcm16(wav, synth.synth_chunk_pcm16(0, cfg.n_samples, cfg.sr), cfg.sr)
+    argv = ["--wav", str(wav), "--encoder", str(pt), "--encoder-config", str(ym), "--sr", str(cfg.sr), "--duration", "1.0",
+            "--n-mels", "64", "--fmin", "150", "--fmax", str(cfg.fmax), "--hop-length", "384", "--n-fft", "2048",
+            "--target-frames", "64"]
+    cli.main(argv + ["--jsonl"])
+    out = capsys.readouterr().out
+    rec = json.loads(out.strip().splitlines()[-1])
+    assert rec["wav"] == str(wav) and rec["latent_dim"] == 8 and len(rec["vector"]) == 8
+    tenc = env.oenc.build_torch_encoder(spec.to_dict(), state)
+    want = env.oenc.encode_mel_to_latent(tenc, env.ofe.wav_to_mel(wav, **cfg.mel_kwargs()))
+    _assert_latents(np.array(rec["vector"], np.float32)[None], want[None])
+    assert "✅ target_frames usado: 64" in out
+    cli.main(argv + ["--precision", "3"])
+    out = capsys.readouterr().out
+    assert "✅ Latent dim: 8" in out
+    with pytest.raises(SystemExit):
+        cli.main(["--wav", str(wav), "--encoder", str(tmp_path / "missing.pt")])

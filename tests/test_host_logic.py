@@ -227,6 +227,19 @@ def test_map_config_readers_match_reference(golden):
                             {}, None, latent_dim=8)
     assert det2.names == ["a"]                                     # another dimension: skipped (10b:153-154)
 
+
+def test_cli_flags_are_the_reference_07_flags():
+    """07_encode_wav_to_latent.py:416-441: same flag names and defaults (device excepted: no CPU path)."""
+    from amphibian_vae_latent_detector_amd.encode_wav_to_latent import parse_args
+    a = parse_args(["--wav", "x.wav"])
+    assert (a.sr, a.duration, a.n_mels, a.fmin, a.fmax, a.hop_length, a.n_fft, a.target_frames) == \
+        (48000, 3.0, 64, 150.0, 15000.0, 384, 2048, 192)
+    assert (a.jsonl, a.precision, a.auto_frames, a.auto_max_frames, a.auto_step, a.encoder, a.encoder_config) == \
+        (False, 6, False, 512, 8, None, None)
+    assert a.device == "cuda"
+    with pytest.raises(SystemExit):
+        parse_args([])                                             # --wav is required
+
 # ------------------------------------------------------------------ synthetic data + WAV ingest
 def test_synth_is_deterministic_and_shaped():
     a = synth.synth_chunk_pcm16(7, 22050, 22050)
