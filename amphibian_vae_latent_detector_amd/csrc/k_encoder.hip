@@ -749,8 +749,6 @@ __global__ __launch_bounds__(256) void k_conv_gemm_f3(ConvGemmParams p) {
     //      issued together and land under the previous tile's main loop; staged per element with a load -> LDS write
     //      per trip it was ~4 us of serialised round trips per tile)
     const int b = m_blk / ohw, oh_first = (m_blk - b * ohw) / p.OW;
-    const int r1_lo = oh_first * p.stride - p.pad;
-    const int patch_lo = r1_lo * p.s1 - p.p1;
 #pragma unroll
     for (int u = 0; u < PU; ++u)
         if (tid + 256 * u < n_patch) patch[tid + 256 * u] = pf[u];

@@ -411,6 +411,17 @@ __global__ __launch_bounds__(64 * NW) void k_stft_mel(StftParams p, int n_tiles)
     const int FT = p.frames_per_block;
 #ifdef AMPH_STAMPS
     { const int fl = 0; AMPH_STAMP(0) }
+    unsigned long long w_t0 = 0, w_t1 = 0, w_t2 = 0, w_t3 = 0, w_stage = 0, w_frames = 0, w_endbar = 0, w_begin = 0;
+    const unsigned long long w_rt0 = __builtin_amdgcn_s_memrealtime();
+#define AMPH_WSTAMP(v_)                                                                     \
+    {                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v_)::"memory");          \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+    }
+    AMPH_WSTAMP(w_begin)
+#else
+#define AMPH_WSTAMP(v_)
 #endif
     constexpr int n_fft = 2 * kNc;
     const int span_len = (FT - 1) * p.hop + n_fft;
@@ -463,6 +474,7 @@ __global__ __launch_bounds__(64 * NW) void k_stft_mel(StftParams p, int n_tiles)
     const bool pre_fits = nd <= kThreads * U;
 
     for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        AMPH_WSTAMP(w_t0)
         const TileSrc d = describe(t);
         const int row = t / p.tiles_per_row;
         const int f_base = (t - row * p.tiles_per_row) * FT;
@@ -510,6 +522,7 @@ __global__ __launch_bounds__(64 * NW) void k_stft_mel(StftParams p, int n_tiles)
             }
         }
         __syncthreads();
+        AMPH_WSTAMP(w_t1)
         // ---- prefetch the next tile's samples; they land while this tile's frames are transformed
         have_pre = false;
         if (t + (int)gridDim.x < n_tiles && pre_fits) {
@@ -525,6 +538,9 @@ __global__ __launch_bounds__(64 * NW) void k_stft_mel(StftParams p, int n_tiles)
     const int k1b = lane_f / T_LO, t_lo = lane_f % T_LO;
     // stage C leaves k2b bit-reversed across the quad (radix-4); the radix-2 form is in order
     const int k2b = T_LO == 4 ? (((t_lo & 1) << 1) | (t_lo >> 1)) : t_lo;
+    const float sgn_a = t_lo < 2 ? 1.0f : -1.0f;          // first butterfly (lanes 2 apart): x + p or p - x
+    const float sgn_b = (t_lo & 1) == 0 ? 1.0f : -1.0f;   // second butterfly (adjacent lanes)
+    const bool rot3 = T_LO == 4 && t_lo == 3;
     for (int fl0 = wave * SLOTS; fl0 < FT; fl0 += NW * SLOTS) {
         if (f_base + fl0 >= p.n_frames) break;        // wave-uniform: the wave's first frame slot is past the end
         const int fl = fl0 + slot;
@@ -579,23 +595,17 @@ __global__ __launch_bounds__(64 * NW) void k_stft_mel(StftParams p, int n_tiles)
                 const float2 w = tw_b[k2a * T_LO + t_lo];
                 AMPH_CMUL(r, i, w.x, w.y);
             }
-            // ---- stage C: radix-T_LO over adjacent lanes (DPP xor butterflies)
+            // ---- stage C: radix-T_LO over adjacent lanes (DPP xor butterflies).  The lane-dependent add / subtract
+            //      is one fma with a per-lane sign (x * (+-1) + partner rounds exactly as x + partner / partner - x),
+            //      the -i of lane 3 two selects
             if (T_LO == 4) {
-                const float pr = dpp_xor2(r), pi = dpp_xor2(i);
-                float nr, ni;
-                if (t_lo < 2) { nr = r + pr; ni = i + pi; }
-                else {
-                    const float dr = pr - r, di = pi - i;          // v[t_lo-2] - v[t_lo]
-                    if (t_lo == 3) { nr = di; ni = -dr; }          // * (-i)
-                    else { nr = dr; ni = di; }
-                }
-                const float qr = dpp_xor1(nr), qi = dpp_xor1(ni);
-                if ((t_lo & 1) == 0) { r = nr + qr; i = ni + qi; }
-                else { r = qr - nr; i = qi - ni; }
+                const float nr = fmaf(r, sgn_a, dpp_xor2(r)), ni = fmaf(i, sgn_a, dpp_xor2(i));
+                const float tr = rot3 ? ni : nr, ti = rot3 ? -nr : ni;          // lane 3: * (-i)
+                r = fmaf(tr, sgn_b, dpp_xor1(tr));
+                i = fmaf(ti, sgn_b, dpp_xor1(ti));
             } else {
-                const float pr = dpp_xor1(r), pi = dpp_xor1(i);
-                if (t_lo == 0) { r = r + pr; i = i + pi; }
-                else { r = pr - r; i = pi - i; }
+                r = fmaf(r, sgn_b, dpp_xor1(r));
+                i = fmaf(i, sgn_b, dpp_xor1(i));
             }
             // lane holds X[k1b + 16 k2a + 256 k2b]
             Z[k1b + 16 * k2a + (256 + kZPad) * k2b] = make_float2(r, i);
@@ -674,8 +684,25 @@ __global__ __launch_bounds__(64 * NW) void k_stft_mel(StftParams p, int n_tiles)
         wave_lds_sync();                              // the scratch is rewritten by the next frame
         AMPH_STAMP(9)
     }
+        AMPH_WSTAMP(w_t2)
         __syncthreads();                              // every wave is done with `span` before it is restaged
+        AMPH_WSTAMP(w_t3)
+#ifdef AMPH_STAMPS
+        w_stage += w_t1 - w_t0; w_frames += w_t2 - w_t1; w_endbar += w_t3 - w_t2;
+#endif
     }
+#ifdef AMPH_STAMPS
+    if (tid == 0) {       // per-workgroup timeline (wave 0): where the tiles' time goes, and the in-kernel clock
+        unsigned long long w_end;
+        AMPH_WSTAMP(w_end)
+        p.stamps[(size_t)blockIdx.x * 16 + 10] = w_stage;
+        p.stamps[(size_t)blockIdx.x * 16 + 11] = w_frames;
+        p.stamps[(size_t)blockIdx.x * 16 + 12] = w_endbar;
+        p.stamps[(size_t)blockIdx.x * 16 + 13] = w_end - w_begin;
+        p.stamps[(size_t)blockIdx.x * 16 + 14] = __builtin_amdgcn_s_memrealtime() - w_rt0;
+        p.stamps[(size_t)blockIdx.x * 16 + 15] = w_t0 - w_begin;
+    }
+#endif
 }
 
 static int table_bytes_for(int n_fft) { return n_fft == 2048 ? FftGeo<4>::TABLE_BYTES : FftGeo<2>::TABLE_BYTES; }

@@ -13,12 +13,18 @@ for name in N.EXPORTED_SYMBOLS:
     fn, ref = getattr(lib, name), getattr(N.lib, name)
     fn.restype, fn.argtypes = ref.restype, ref.argtypes
 N.lib = lib
-from amphibian_vae_latent_detector_amd.encoder import AmphSession
+from amphibian_vae_latent_detector_amd import SPECS
+from amphibian_vae_latent_detector_amd.encoder import HipEncoder, random_init_state
 from amphibian_vae_latent_detector_amd.synth import synth_batch_pcm16
 cfg = PRESETS["bench-1s"]
-s = AmphSession(cfg, None, None, "cuda:0", max_batch=256)
-y = torch.from_numpy(synth_batch_pcm16(list(range(256)), cfg.n_samples, cfg.sr).astype(np.float32) / 32768).to("cuda:0")
+spec = SPECS["thesis-shape"](cfg.target_frames, cfg.n_mels)
+s = HipEncoder(spec, random_init_state(spec, 0), "cuda:0", max_batch=256).session(cfg)
+s.configure("lanes", 1)
+pcm = torch.from_numpy(synth_batch_pcm16(list(range(256)), cfg.n_samples, cfg.sr)).to("cuda:0")
+for key in [a for a in sys.argv[2:] if "=" in a]:      # e.g. stft_s16=0
+    k, v = key.split("=")
+    s.configure(k, int(v))
 for _ in range(3):
-    s.mel_power(y)
+    s.encode(pcm, apply_rms=True)                       # the PCM16 + RMS path of the benchmark
 torch.cuda.synchronize()
-s.configure("dump_stamps", 512)
+s.configure("dump_stamps", int(sys.argv[1]) if len(sys.argv) > 1 else 256)   # workgroups of the launch (12-wave kernel: 256)
