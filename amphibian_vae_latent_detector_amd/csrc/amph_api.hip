@@ -84,6 +84,9 @@ struct amph_ctx {
     float *d_map_means = nullptr, *d_map_prec = nullptr;   // Gaussian-MAP parameters (amph_decide_map)
     double *d_map_logdet = nullptr, *d_map_lprior = nullptr;
     size_t map_prec_cap = 0;
+    double *d_rs_win = nullptr, *d_rs_delta = nullptr;     // resampler tables (amph_resample_f32)
+    size_t rs_cap = 0;
+    std::vector<double> rs_host;
     float* d_zeros = nullptr;              // 256 bytes of zeros: the source of padded taps (k_conv_gemm_p3)
     int head_splits = 1;
     int flat = 0, latent = 0;
@@ -797,6 +800,7 @@ void amph_destroy(amph_ctx* c) {
     for (auto& w : c->lanes) free_lane(w);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     fr(c->d_centroids); fr(c->d_thr); fr(c->d_rank);
+    fr(c->d_rs_win); fr(c->d_rs_delta);
     fr(c->d_map_means); fr(c->d_map_prec); fr(c->d_map_logdet); fr(c->d_map_lprior);
     for (int i = 0; i < 2; ++i) {
         if (c->pin_in[i]) (void)hipHostFree(c->pin_in[i]);
@@ -1129,6 +1133,51 @@ int amph_decide_map(amph_ctx* c, const float* d_z, int64_t n_rows, int dim, cons
     p.pred = d_pred; p.best_score = d_best_score; p.scores = d_scores;
     if (n_rows > 0) launch_score_map(p, n_rows, s);
     return check_launch(c, "decide_map");
+}
+
+int amph_resample_length(int n_in, int orig_sr, int target_sr) {
+    if (n_in < 0 || orig_sr <= 0 || target_sr <= 0) return -1;
+    return (int)std::ceil((double)n_in * ((double)target_sr / (double)orig_sr));
+}
+
+int amph_resample_f32(amph_ctx* c, const float* d_in, int n_rows, int n_in, int orig_sr, int target_sr,
+                      const double* h_half_window, int n_window, int num_table, float* d_out, int out_stride, void* stream) {
+    if (!c) return AMPH_ERR_INVALID_ARG;
+    if (n_rows < 0 || n_in <= 0 || orig_sr <= 0 || target_sr <= 0 || !h_half_window || n_window < 2 || num_table < 1 ||
+        (n_rows > 0 && (!d_in || !d_out)))
+        return fail(c, AMPH_ERR_INVALID_ARG, "bad resample arguments");
+    const double ratio = (double)target_sr / (double)orig_sr;
+    const int n_out = (int)((double)n_in * ratio), n_fix = (int)std::ceil((double)n_in * ratio);
+    if (n_out < 1) return fail(c, AMPH_ERR_INVALID_ARG, "input signal length is too small to resample");
+    if (out_stride < n_fix) return fail(c, AMPH_ERR_INVALID_ARG, "out_stride %d < resampled length %d", out_stride, n_fix);
+    const double scale = std::min(1.0, ratio);
+    const int index_step = (int)(scale * (double)num_table);
+    if (index_step < 1) return fail(c, AMPH_ERR_UNSUPPORTED, "ratio %.6g too small for a table of %d entries per zero crossing", ratio, num_table);
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(c, hipStreamSynchronize(s));                      // the previous call's table upload / kernel are done
+    if ((size_t)n_window > c->rs_cap) {
+        if (c->d_rs_win) (void)hipFree(c->d_rs_win);
+        if (c->d_rs_delta) (void)hipFree(c->d_rs_delta);
+        c->d_rs_win = c->d_rs_delta = nullptr; c->rs_cap = 0;
+        HIP_TRY(c, hipMalloc((void**)&c->d_rs_win, (size_t)n_window * sizeof(double)));
+        HIP_TRY(c, hipMalloc((void**)&c->d_rs_delta, (size_t)n_window * sizeof(double)));
+        c->rs_cap = n_window;
+    }
+    // resampy.core.resample: interp_win *= ratio when downsampling; interp_delta[:-1] = diff(interp_win)
+    c->rs_host.assign((size_t)2 * n_window, 0.0);
+    double* win = c->rs_host.data();
+    double* delta = win + n_window;
+    for (int i = 0; i < n_window; ++i) win[i] = ratio < 1.0 ? ratio * h_half_window[i] : h_half_window[i];
+    for (int i = 0; i + 1 < n_window; ++i) delta[i] = win[i + 1] - win[i];
+    HIP_TRY(c, hipMemcpyAsync(c->d_rs_win, win, (size_t)n_window * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->d_rs_delta, delta, (size_t)n_window * sizeof(double), hipMemcpyHostToDevice, s));
+    ResampleParams p;
+    p.x = d_in; p.in_stride = n_in; p.n_in = n_in; p.y = d_out; p.out_stride = out_stride; p.n_out = n_out; p.n_fix = n_fix;
+    p.win = c->d_rs_win; p.delta = c->d_rs_delta; p.nwin = n_window; p.num_table = num_table; p.index_step = index_step;
+    p.scale = scale; p.time_inc = 1.0 / ratio;
+    launch_resample(p, n_rows, s);
+    return check_launch(c, "resample");
 }
 
 // ---------------------------------------------------------------------------- WAV ingest

@@ -66,6 +66,21 @@ int stft_mel_scratch_floats(int n_fft);   // floats of per-frame scratch the pow
 hipError_t stft_mel_configure(int lds_bytes);   // raises the dynamic-LDS limit of the STFT kernels
 void launch_dbnorm(const DbNormParams& p, int n_rows, hipStream_t s);
 
+struct ResampleParams {      // resampy's resample_f for rows of equal length
+    const float* x;          // [rows][in_stride]
+    long long in_stride;
+    int n_in;
+    float* y;                // [rows][out_stride]
+    long long out_stride;
+    int n_out;               // int(n_in * ratio): samples resampy computes
+    int n_fix;               // ceil(n_in * ratio): length after librosa's fix_length (zero padded)
+    const double* win;       // device [nwin] half window (already scaled by the ratio when downsampling)
+    const double* delta;     // device [nwin] diff(win), last element 0
+    int nwin, num_table, index_step;
+    double scale, time_inc;  // min(1, ratio), 1 / ratio
+};
+void launch_resample(const ResampleParams& p, int n_rows, hipStream_t s);
+
 // ----------------------------------------------------------------------------
 // Encoder
 // ----------------------------------------------------------------------------

@@ -871,4 +871,51 @@ void launch_rms_apply_pcm16(const int16_t* in, int n_rows, int n, const float* s
     hipLaunchKernelGGL(k_rms_apply_pcm16, dim3(bx, n_rows), dim3(256), 0, s, in, n, scale, ok, out);
 }
 
+// ----------------------------------------------------------------------------
+// K8: sample-rate conversion of librosa.load (map_detector_core.py:210) = resampy 0.4.3's resample_f with
+// the kaiser_best windowed-sinc table (restated in oracle/resample.py; parity unpinned, see there).
+// One thread per output sample: left wing then right wing of the table with linear interpolation between
+// entries; products in float64, the running sum rounded to float32 after every tap exactly as resampy's
+// `y[t] += weight * x[n - i]` on a float32 output array.  Not on the benchmark path (synthetic chunks are
+// written at the preset rate); ~280 taps per output sample at 48 kHz -> 22.05 kHz.
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_resample(ResampleParams p) {
+#pragma clang fp contract(off)
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int row = blockIdx.y;
+    if (t >= p.n_fix) return;
+    float* y = p.y + (long long)row * p.out_stride;
+    if (t >= p.n_out) { y[t] = 0.0f; return; }             // librosa.util.fix_length pads with zeros
+    const float* x = p.x + (long long)row * p.in_stride;
+    const double tr = (double)t * p.time_inc;
+    const int n = (int)tr;
+    double frac = p.scale * (tr - (double)n);
+    double index_frac = frac * (double)p.num_table;
+    int offset = (int)index_frac;
+    double eta = index_frac - (double)offset;
+    float acc = 0.0f;
+    const int i_max = min(n + 1, (p.nwin - offset) / p.index_step);
+    for (int i = 0; i < i_max; ++i) {
+        const int idx = offset + i * p.index_step;
+        const double w = p.win[idx] + eta * p.delta[idx];
+        acc = (float)((double)acc + w * (double)x[n - i]);
+    }
+    frac = p.scale - frac;
+    index_frac = frac * (double)p.num_table;
+    offset = (int)index_frac;
+    eta = index_frac - (double)offset;
+    const int k_max = min(p.n_in - n - 1, (p.nwin - offset) / p.index_step);
+    for (int k = 0; k < k_max; ++k) {
+        const int idx = offset + k * p.index_step;
+        const double w = p.win[idx] + eta * p.delta[idx];
+        acc = (float)((double)acc + w * (double)x[n + k + 1]);
+    }
+    y[t] = acc;
+}
+
+void launch_resample(const ResampleParams& p, int n_rows, hipStream_t s) {
+    if (n_rows <= 0 || p.n_fix <= 0) return;
+    hipLaunchKernelGGL(k_resample, dim3((unsigned)((p.n_fix + 255) / 256), (unsigned)n_rows), dim3(256), 0, s, p);
+}
+
 }  // namespace amph

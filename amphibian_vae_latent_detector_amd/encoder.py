@@ -262,6 +262,25 @@ class AmphSession:
             torch.cuda.current_stream(self.device).synchronize()   # host arrays above must outlive the async copies
         return pred, best
 
+    def resample(self, y, orig_sr: int, target_sr: int) -> torch.Tensor:
+        """librosa.load's rate conversion (resampy kaiser_best + fix_length) for rows of float32 samples, on the GPU
+        (K8, amph_resample_f32).  y: [n] or [B, n] -> device tensor [B, ceil(n * target_sr / orig_sr)]."""
+        from .resample import kaiser_best_window
+        y = self._dev(y, torch.float32)
+        if y.ndim == 1:
+            y = y[None]
+        B, n_in = y.shape
+        n_out = N.lib.amph_resample_length(int(n_in), int(orig_sr), int(target_sr))
+        if n_out < 1:
+            raise RuntimeError("Input signal length is too small to resample")
+        win, num_table = kaiser_best_window()
+        out = torch.empty((B, n_out), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            self._chk(N.lib.amph_resample_f32(self._ctx, _ptr(y), B, n_in, int(orig_sr), int(target_sr),
+                                              win.ctypes.data_as(C.c_void_p), win.shape[0], num_table, _ptr(out), n_out,
+                                              self._stream()))
+        return out
+
     def decide_map(self, z: torch.Tensor, means: np.ndarray, precisions: np.ndarray, logdets: np.ndarray,
                    log_priors: np.ndarray, tau: Optional[float] = None, want_scores: bool = False):
         """Gaussian-MAP scoring + decision (K7, include/amph.h amph_decide_map).

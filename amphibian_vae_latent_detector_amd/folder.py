@@ -22,6 +22,8 @@ import torch
 import torch.distributed as dist
 
 from . import wavio
+from ._native import AMPH_ERR_IO as N_IO
+from ._native import AMPH_ERR_UNSUPPORTED as N_UNSUPPORTED
 from .config import FrontendConfig
 
 
@@ -79,6 +81,16 @@ def encode_paths(encoder, paths: Sequence[Path], cfg: FrontendConfig, *, apply_r
         finally:
             del pcm
             wavio.free_pinned(pin)
+        # files the native reader declined (stereo, another subtype, another sample rate): the general loader
+        # (channel mean, libsndfile scaling, GPU resampler) one file at a time, as librosa.load would
+        for i in np.nonzero(st == N_UNSUPPORTED)[0]:
+            try:
+                y = wavio.load_float_mono(part[i], cfg.sr, session=sess)[:max_samples]
+                mu, _, _ = sess.encode(y[None], lengths=np.array([y.shape[0]], dtype=np.int32), apply_rms=apply_rms)
+                Z[off + i] = mu[0]
+                status[off + i] = 0
+            except Exception:  # noqa: BLE001  (the reference counts the file as failed and continues, 08:504-506)
+                status[off + i] = N_IO
     return Z, status
 
 

@@ -166,7 +166,7 @@ def _frontend_session(cfg: FrontendConfig, device) -> AmphSession:
     return s
 
 
-def _load_wave(wav_path: Path, cfg: FrontendConfig):
+def _load_wave(wav_path: Path, cfg: FrontendConfig, device=None):
     """-> (array [n], n_valid): int16 through the native reader for mono PCM16,
     float32 otherwise.  Only the first n_samples are needed (fix_length truncates)."""
     wav_path = Path(wav_path)
@@ -174,8 +174,8 @@ def _load_wave(wav_path: Path, cfg: FrontendConfig):
         raise FileNotFoundError(f"No existe WAV: {wav_path}")
     try:
         return wavio.read_pcm16_mono(wav_path, cfg.sr, cfg.n_samples)
-    except NotImplementedError:
-        y = wavio.load_float_mono(wav_path, cfg.sr)[:cfg.n_samples]
+    except NotImplementedError:                          # stereo, another subtype or another rate: general path
+        y = wavio.load_float_mono(wav_path, cfg.sr, session=_frontend_session(cfg, device))[:cfg.n_samples]
         return y, y.shape[0]
 
 
@@ -184,7 +184,7 @@ def wav_to_mel(wav_path: Path, *, sr: int, duration: float, n_mels: int, fmin: f
     """float32 [n_mels, target_frames] on the host, computed by the HIP front end."""
     cfg = _config(sr, duration, n_mels, fmin, fmax, hop_length, n_fft, target_frames)
     sess = _frontend_session(cfg, device)
-    y, n_valid = _load_wave(Path(wav_path), cfg)
+    y, n_valid = _load_wave(Path(wav_path), cfg, device)
     if y.dtype == np.int16:
         y = y.astype(np.float32) / np.float32(32768.0)
     mel = sess.mel(y[None], lengths=np.array([n_valid], dtype=np.int32), layout=0)
@@ -222,7 +222,7 @@ def _adapt_output(out) -> np.ndarray:
 def encode_wav_to_latent(encoder, wav_path: Path, device: torch.device, *, sr: int, duration: float, n_mels: int,
                          fmin: float, fmax: float, hop_length: int, n_fft: int, target_frames: int) -> np.ndarray:
     cfg = _config(sr, duration, n_mels, fmin, fmax, hop_length, n_fft, target_frames)
-    y, n_valid = _load_wave(Path(wav_path), cfg)
+    y, n_valid = _load_wave(Path(wav_path), cfg, device)
     if isinstance(encoder, HipEncoder):
         sess = encoder.session(cfg)
         mu, _, _ = sess.encode(y[None], lengths=np.array([n_valid], dtype=np.int32), apply_rms=False)

@@ -1,14 +1,18 @@
-"""WAV ingest for the hot path: the libsndfile decode that `librosa.load(path,
-sr=sr, mono=True)` performs at latent_space_exploration/map_detector_core.py:210,
-for PCM16 files already at the requested rate (resampling = SURVEY §8(f) rank 4,
-not built).  Mono files go through libamph's native reader; anything else
-through the stdlib parser + a channel mean, as float32."""
+"""WAV ingest for the hot path: what `librosa.load(path, sr=sr, mono=True)` does at
+latent_space_exploration/map_detector_core.py:210 - libsndfile decode to float32, channel
+mean, and (only when the file's rate differs from `sr`) resampy "kaiser_best" resampling.
+
+  fast path   mono PCM16 at the requested rate: libamph's native reader (+ host thread pool)
+  general     RIFF/WAVE with PCM 8/16/24/32-bit, IEEE float 32/64, WAVE_FORMAT_EXTENSIBLE, any channel
+              count: parsed here with numpy (`load_audio`), converted with libsndfile's float scaling,
+              averaged over channels; a rate mismatch goes through the HIP resampler (K8,
+              amph_resample_f32 - SURVEY 8(f) rank 4; parity unpinned)."""
 from __future__ import annotations
 
 import ctypes as C
-import wave
+import struct
 from pathlib import Path
-from typing import Sequence, Tuple
+from typing import Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -28,17 +32,64 @@ def read_pcm16_mono(path: Path, sr: int, max_samples: int) -> Tuple[np.ndarray, 
     return out, int(n.value)
 
 
-def load_float_mono(path: Path, sr: int) -> np.ndarray:
-    """float32 mono signal as librosa.load returns it (int16 / 32768, channel mean)."""
-    with wave.open(str(path), "rb") as w:
-        if w.getsampwidth() != 2 or w.getcomptype() != "NONE":
-            raise RuntimeError(f"{path}: only PCM16 WAV is supported")
-        if w.getframerate() != sr:
-            raise RuntimeError(f"{path}: sample rate {w.getframerate()} != {sr} (resampling is not implemented)")
-        ch = w.getnchannels()
-        q = np.frombuffer(w.readframes(w.getnframes()), dtype="<i2").reshape(-1, ch)
-    y = q.astype(np.float32) / np.float32(32768.0)
-    return np.ascontiguousarray(y.mean(axis=1, dtype=np.float32) if ch > 1 else y[:, 0])
+def load_audio(path: Path) -> Tuple[np.ndarray, int]:
+    """(float32 mono signal, native sample rate): soundfile.read(dtype="float32") + librosa.to_mono.
+    Integer PCM is scaled as libsndfile does (int16 / 2^15, int24 / 2^23, int32 / 2^31, uint8 -> (x - 128) / 128)."""
+    data = Path(path).read_bytes()
+    if len(data) < 12 or data[:4] != b"RIFF" or data[8:12] != b"WAVE":
+        raise RuntimeError(f"{path}: not a RIFF/WAVE file")
+    pos, fmt, body = 12, None, None
+    while pos + 8 <= len(data):
+        cid, size = data[pos:pos + 4], struct.unpack_from("<I", data, pos + 4)[0]
+        start = pos + 8
+        if cid == b"fmt ":
+            if size < 16:
+                raise RuntimeError(f"{path}: short fmt chunk")
+            tag, ch, rate, _, _, bits = struct.unpack_from("<HHIIHH", data, start)
+            if tag == 0xFFFE and size >= 26:                       # WAVE_FORMAT_EXTENSIBLE: sub-format GUID's first word
+                tag = struct.unpack_from("<H", data, start + 24)[0]
+            fmt = (tag, ch, rate, bits)
+        elif cid == b"data":
+            body = data[start:min(start + size, len(data))]
+            break
+        pos = start + size + (size & 1)
+    if fmt is None or body is None:
+        raise RuntimeError(f"{path}: missing fmt or data chunk")
+    tag, ch, rate, bits = fmt
+    if ch < 1 or rate < 1:
+        raise RuntimeError(f"{path}: bad channel count / sample rate")
+    nbytes = bits // 8
+    n = len(body) // (nbytes * ch) * ch
+    if tag == 1 and bits == 16:
+        y = np.frombuffer(body, dtype="<i2", count=n).astype(np.float32) / np.float32(32768.0)
+    elif tag == 1 and bits == 8:
+        y = (np.frombuffer(body, dtype=np.uint8, count=n).astype(np.float32) - np.float32(128.0)) / np.float32(128.0)
+    elif tag == 1 and bits == 24:
+        b = np.frombuffer(body, dtype=np.uint8, count=n * 3).reshape(-1, 3).astype(np.int32)
+        v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
+        v = np.where(v & 0x800000, v - 0x1000000, v)
+        y = v.astype(np.float32) / np.float32(8388608.0)
+    elif tag == 1 and bits == 32:
+        y = (np.frombuffer(body, dtype="<i4", count=n).astype(np.float64) / 2147483648.0).astype(np.float32)
+    elif tag == 3 and bits == 32:
+        y = np.frombuffer(body, dtype="<f4", count=n).astype(np.float32)
+    elif tag == 3 and bits == 64:
+        y = np.frombuffer(body, dtype="<f8", count=n).astype(np.float32)
+    else:
+        raise RuntimeError(f"{path}: unsupported WAV encoding (format tag {tag}, {bits} bits)")
+    y = y.reshape(-1, ch)
+    return np.ascontiguousarray(y.mean(axis=1, dtype=np.float32) if ch > 1 else y[:, 0]), int(rate)
+
+
+def load_float_mono(path: Path, sr: int, session=None) -> np.ndarray:
+    """float32 mono signal at `sr` as librosa.load returns it.  A file at another rate is resampled on the GPU by
+    `session` (an AmphSession); without one it raises."""
+    y, rate = load_audio(path)
+    if rate != sr:
+        if session is None:
+            raise RuntimeError(f"{path}: sample rate {rate} != {sr} and no GPU session was given to resample with")
+        y = session.resample(y, rate, sr).cpu().numpy()[0]
+    return y
 
 
 def read_many_pcm16(paths: Sequence[Path], sr: int, max_samples: int, n_threads: int = 8, pinned: bool = False):

@@ -199,6 +199,23 @@ int amph_decide_map(amph_ctx* ctx, const float* d_z, int64_t n_rows, int dim,
                     int32_t* d_pred, double* d_best_score, double* d_scores, void* stream);
 
 /* -------------------------------------------------------------------------
+ * Sample-rate conversion - the resample step of librosa.load(path, sr=sr)
+ * (map_detector_core.py:210; 00_normalize_dataset_rms.py:51) for files whose rate
+ * differs from `sr`: resampy's windowed-sinc interpolation (librosa 0.9.2 default
+ * res_type "kaiser_best") followed by librosa's fix_length to ceil(n_in * ratio).
+ * Rows of n_in float32 samples (row stride n_in) -> rows of amph_resample_length()
+ * samples at row stride out_stride.  h_half_window is the UNSCALED half window of the
+ * filter (resampy.filters.sinc_window output, float64 [n_window]), num_table its
+ * samples per zero crossing; the library applies resampy's ratio scaling and builds the
+ * interpolation deltas.  Parity unpinned (resampy and its table are absent from the
+ * build image; oracle/resample.py restates the published algorithm).
+ * ------------------------------------------------------------------------- */
+int amph_resample_length(int n_in, int orig_sr, int target_sr);
+int amph_resample_f32(amph_ctx* ctx, const float* d_in, int n_rows, int n_in, int orig_sr, int target_sr,
+                      const double* h_half_window, int n_window, int num_table,
+                      float* d_out, int out_stride, void* stream);
+
+/* -------------------------------------------------------------------------
  * WAV ingest — the libsndfile decode inside librosa.load
  * (map_detector_core.py:210) for mono PCM16 RIFF files already at `sr`.
  * Reads up to max_samples int16 samples into h_out (zero-filled beyond the

@@ -531,9 +531,9 @@ def test_map_detector_core_surface(env, tmp_path):
     # error behaviour: ordinary per-file exceptions
     with pytest.raises(FileNotFoundError):
         core.encode_wav_to_latent(encoder, tmp_path / "nope.wav", torch.device("cuda"), **kw)
-    synth.write_wav_pcm16(tmp_path / "sr.wav", q, 48000)
-    with pytest.raises(RuntimeError, match="sample rate"):
-        core.encode_wav_to_latent(encoder, tmp_path / "sr.wav", torch.device("cuda"), **kw)
+    synth.write_wav_pcm16(tmp_path / "sr.wav", q, 48000)             # another rate: resampled as librosa.load would (K8)
+    z48 = core.encode_wav_to_latent(encoder, tmp_path / "sr.wav", torch.device("cuda"), **kw)
+    assert z48.shape == (8,) and np.isfinite(z48).all() and not np.allclose(z48, z)
     (tmp_path / "junk.wav").write_bytes(b"junk")
     with pytest.raises(Exception):
         core.wav_to_mel(tmp_path / "junk.wav", **kw)
@@ -708,3 +708,55 @@ def test_cli_07_single_wav_jsonl(env, tmp_path, capsys):
     assert "✅ Latent dim: 8" in out
     with pytest.raises(SystemExit):
         cli.main(["--wav", str(wav), "--encoder", str(tmp_path / "missing.pt")])
+
+# ----------------------------------------------------------------------------- K8: ingest generality
+def test_resampler_against_the_restatement_and_file_ingest(env, fe, tmp_path):
+    """K8 against the CPU restatement of resampy's loop (same taps, float64 products, float32 running sum: equal to
+    float32 rounding noise), then a 48 kHz stereo 24-bit file through the reference-shaped API: decode, channel mean,
+    GPU resample to the preset rate, mel + encode, equal to the oracle pipeline on the oracle-resampled signal."""
+    from amphibian_vae_latent_detector_amd import map_detector_core as core
+    from amphibian_vae_latent_detector_amd.encoder import save_checkpoint
+    from oracle import resample as ors
+    import sys
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    from test_host_logic import _write_wav
+    rng = np.random.default_rng(12)
+    for (sr0, sr1, n) in ((48000, 22050, 3000), (22050, 48000, 1500), (44100, 22050, 2001), (16000, 22050, 900)):
+        y = (0.3 * rng.standard_normal((2, n))).astype(np.float32)
+        z = fe.resample(y, sr0, sr1).cpu().numpy()
+        for r in range(2):
+            want = ors.resample(y[r], sr0, sr1)
+            assert z.shape[1] == want.shape[0]
+            assert np.abs(z[r] - want).max() <= 2e-6, (sr0, sr1, float(np.abs(z[r] - want).max()))
+    with pytest.raises(RuntimeError):
+        fe.resample(np.zeros((1, 1), np.float32), 48000, 8000)
+    # file level: 1.2 s of 48 kHz stereo, 24-bit
+    cfg = env.cfg
+    sr0 = 48000
+    t = np.arange(int(1.2 * sr0)) / sr0
+    sig = 0.2 * np.sin(2 * np.pi * 1500 * t) * np.hanning(t.size) + 0.1 * np.sin(2 * np.pi * 4200 * t) + 0.01 * rng.standard_normal(t.size)
+    st = np.stack([sig, 0.5 * sig + 0.02 * rng.standard_normal(t.size)], axis=1)
+    i24 = np.round(st * 8388607).astype(np.int32)
+    wav = tmp_path / "field_48k_stereo24.wav"
+    _write_wav(wav, i24, sr0, 1, 24)
+    mono = (i24.astype(np.float32) / np.float32(8388608.0)).mean(axis=1, dtype=np.float32)
+    y_ref = ors.resample(mono, sr0, cfg.sr)
+    kw = cfg.mel_kwargs()
+    mel = core.wav_to_mel(wav, **kw)
+    y_fix = np.zeros(cfg.n_samples, np.float32)
+    y_fix[:min(cfg.n_samples, y_ref.shape[0])] = y_ref[:cfg.n_samples]
+    want_mel = env.ofe.wave_to_mel(y_fix, **kw)
+    assert np.abs(mel.numpy() - want_mel).max() <= 1e-4
+    spec = env.SPECS["tiny"](cfg.target_frames, cfg.n_mels)
+    state = env.random_init_state(spec, seed=0)
+    pt, ym = tmp_path / "model.pt", tmp_path / "enc.yaml"
+    save_checkpoint(pt, ym, spec, state)
+    encoder = core.load_encoder(pt, ym, tmp_path, torch.device("cuda"))
+    z = core.encode_wav_to_latent(encoder, wav, torch.device("cuda"), **kw)
+    tenc = env.oenc.build_torch_encoder(spec.to_dict(), state)
+    _assert_latents(z[None], env.oenc.encode_mel_to_latent(tenc, want_mel)[None])
+    # folder ingest: the native reader declines the file (status 5), the general path encodes it
+    from amphibian_vae_latent_detector_amd import folder as pfolder
+    Z, status = pfolder.encode_paths(encoder, [wav, tmp_path / "missing.wav"], cfg)
+    assert status.tolist()[0] == 0 and status.tolist()[1] != 0
+    _assert_latents(Z[:1].cpu().numpy(), z[None])

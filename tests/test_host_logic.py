@@ -37,7 +37,8 @@ def test_no_cpu_device_and_no_fallback():
     with pytest.raises(RuntimeError, match="no CPU path"):
         penc._device_index("cpu")
     src = "".join((ROOT / "amphibian_vae_latent_detector_amd" / f).read_text()
-                  for f in ("map_detector_core.py", "encoder.py", "folder.py", "radial.py", "wavio.py", "_native.py"))
+                  for f in ("map_detector_core.py", "encoder.py", "folder.py", "radial.py", "wavio.py", "_native.py",
+                            "map_detector.py", "resample.py", "pipeline.py", "encode_wav_to_latent.py", "config.py", "synth.py"))
     assert "oracle" not in src                       # the product never touches the checker
 
 
@@ -239,6 +240,77 @@ def test_cli_flags_are_the_reference_07_flags():
     assert a.device == "cuda"
     with pytest.raises(SystemExit):
         parse_args([])                                             # --wav is required
+
+
+def _write_wav(path, data, rate, tag, bits, extensible=False):
+    """Minimal RIFF writer for the loader tests (data: [n, ch] array already in the sample dtype)."""
+    import struct
+    ch = data.shape[1]
+    if bits == 24:
+        v = data.astype(np.int32) & 0xFFFFFF
+        body = np.stack([v & 0xFF, (v >> 8) & 0xFF, (v >> 16) & 0xFF], axis=-1).astype(np.uint8).tobytes()
+    else:
+        body = data.tobytes()
+    block = ch * bits // 8
+    if extensible:
+        guid = struct.pack("<H", tag) + bytes.fromhex("000000001000800000aa00389b71")
+        fmt = struct.pack("<HHIIHHHHI", 0xFFFE, ch, rate, rate * block, block, bits, 22, bits, 0) + guid
+    else:
+        fmt = struct.pack("<HHIIHH", tag, ch, rate, rate * block, block, bits)
+    chunks = b"fmt " + struct.pack("<I", len(fmt)) + fmt + b"LIST" + struct.pack("<I", 4) + b"abcd" + \
+        b"data" + struct.pack("<I", len(body)) + body
+    path.write_bytes(b"RIFF" + struct.pack("<I", 4 + len(chunks)) + b"WAVE" + chunks)
+
+
+def test_general_wav_loader_subtypes_and_channel_mean(tmp_path):
+    """librosa.load's decode for everything the native PCM16-mono reader declines: libsndfile's float scaling per
+    subtype, channel mean, native sample rate reported (resampling itself needs the GPU)."""
+    rng = np.random.default_rng(3)
+    x = rng.uniform(-0.9, 0.9, size=(500, 2))
+    i16 = np.round(x * 32767).astype("<i2")
+    _write_wav(tmp_path / "s16.wav", i16, 22050, 1, 16)
+    y, rate = wavio.load_audio(tmp_path / "s16.wav")
+    assert rate == 22050 and y.dtype == np.float32 and y.shape == (500,)
+    want = (i16.astype(np.float32) / np.float32(32768.0)).mean(axis=1, dtype=np.float32)
+    assert np.array_equal(y, want)
+    i24 = np.round(x * 8388607).astype(np.int32)
+    _write_wav(tmp_path / "s24.wav", i24, 48000, 1, 24)
+    y, rate = wavio.load_audio(tmp_path / "s24.wav")
+    assert rate == 48000 and np.allclose(y, (i24 / 8388608.0).mean(axis=1), atol=1e-7)
+    i32 = np.round(x[:, :1] * 2147483647).astype("<i4")
+    _write_wav(tmp_path / "s32.wav", i32, 44100, 1, 32, extensible=True)
+    y, rate = wavio.load_audio(tmp_path / "s32.wav")
+    assert rate == 44100 and np.allclose(y, i32[:, 0] / 2147483648.0, atol=1e-7)
+    u8 = np.round(x[:, :1] * 127 + 128).astype(np.uint8)
+    _write_wav(tmp_path / "u8.wav", u8, 8000, 1, 8)
+    y, _ = wavio.load_audio(tmp_path / "u8.wav")
+    assert np.array_equal(y, (u8[:, 0].astype(np.float32) - 128) / 128)
+    f32 = x.astype("<f4")
+    _write_wav(tmp_path / "f32.wav", f32, 22050, 3, 32)
+    y, _ = wavio.load_audio(tmp_path / "f32.wav")
+    assert np.array_equal(y, f32.mean(axis=1, dtype=np.float32))
+    _write_wav(tmp_path / "f64.wav", x.astype("<f8"), 22050, 3, 64)
+    y, _ = wavio.load_audio(tmp_path / "f64.wav")
+    assert np.allclose(y, x.astype(np.float32).mean(axis=1), atol=1e-7)
+    # same rate: no session needed; another rate without a session: a Python exception, not an abort
+    assert np.array_equal(wavio.load_float_mono(tmp_path / "s16.wav", 22050), want)
+    with pytest.raises(RuntimeError, match="sample rate"):
+        wavio.load_float_mono(tmp_path / "s24.wav", 22050)
+    (tmp_path / "bad.wav").write_bytes(b"RIFFxxxxWAVEjunk")
+    with pytest.raises(RuntimeError):
+        wavio.load_audio(tmp_path / "bad.wav")
+    _write_wav(tmp_path / "adpcm.wav", i16, 22050, 2, 16)
+    with pytest.raises(RuntimeError, match="unsupported"):
+        wavio.load_audio(tmp_path / "adpcm.wav")
+
+
+def test_kaiser_best_table_is_the_published_construction():
+    from amphibian_vae_latent_detector_amd.resample import KAISER_BEST, kaiser_best_window
+    win, num_table = kaiser_best_window()
+    assert (KAISER_BEST["num_zeros"], KAISER_BEST["precision"]) == (64, 9) and num_table == 512
+    assert win.dtype == np.float64 and win.shape == (32769,) and win[0] == KAISER_BEST["rolloff"]
+    assert N.lib.amph_resample_length(22050, 48000, 22050) == int(np.ceil(22050 * 22050 / 48000))
+    assert N.lib.amph_resample_length(1000, 22050, 48000) == int(np.ceil(1000 * 48000 / 22050))
 
 # ------------------------------------------------------------------ synthetic data + WAV ingest
 def test_synth_is_deterministic_and_shaped():

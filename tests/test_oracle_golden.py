@@ -223,3 +223,36 @@ def test_map_decision_matches_reference(golden):
         det, sp, best = omap.decide(z, species, means, precs, logdets, pri2, None)
         assert det and sp == str(g2["pred"][r])
         np.testing.assert_allclose(best, g2["best_score"][r], rtol=1e-6, atol=1e-6)
+
+
+# ----------------------------------------------------------------------------- resampler restatement (parity unpinned)
+def test_resample_restatement_anchors():
+    """No resampy / librosa here and no resampled fixture in the reference: the restatement is anchored on
+    signal-level known answers only: a band-limited tone keeps its waveform, lengths follow
+    librosa's ceil rule, scipy's polyphase resampler agrees to filter-design tolerance."""
+    from scipy.signal import resample_poly
+    from oracle import resample as ors
+    win, num_table = ors.sinc_window(**ors.KAISER_BEST)
+    assert win.shape == (64 * 512 + 1,) and num_table == 512 and abs(win[0] - ors.KAISER_BEST["rolloff"]) < 1e-15
+    assert abs(win[-1]) < 1e-7 and np.all(np.abs(win[512::512][:20]) < 0.06)           # near-zeros of the sinc, tapered end
+    sr0, sr1, n = 48000, 22050, 4800
+    t = np.arange(n) / sr0
+    y = (0.5 * np.sin(2 * np.pi * 3000.0 * t) + 0.2 * np.sin(2 * np.pi * 7000.0 * t + 0.3)).astype(np.float32)
+    z = ors.resample(y, sr0, sr1)
+    assert z.dtype == np.float32 and z.shape == (int(np.ceil(n * sr1 / sr0)),)
+    t1 = np.arange(z.shape[0]) / sr1
+    want = 0.5 * np.sin(2 * np.pi * 3000.0 * t1) + 0.2 * np.sin(2 * np.pi * 7000.0 * t1 + 0.3)
+    mid = slice(200, -200)
+    assert np.abs(z[mid] - want[mid]).max() < 1e-3          # integer index_step stretches the filter by 0.1 %: gain 1.00085
+    assert np.abs(z[mid] - resample_poly(y.astype(np.float64), 147, 320)[:z.shape[0]][mid]).max() < 2e-3
+    # a tone above the new Nyquist is removed
+    alias = (0.5 * np.sin(2 * np.pi * 15000.0 * t)).astype(np.float32)
+    assert np.abs(ors.resample(alias, sr0, sr1)[mid]).max() < 1e-4
+    # upsampling keeps the table unscaled: exact to float32 noise
+    y2 = (0.5 * np.sin(2 * np.pi * 3000.0 * np.arange(1000) / sr1)).astype(np.float32)
+    z2 = ors.resample(y2, sr1, sr0)
+    t2 = np.arange(z2.shape[0]) / sr0
+    assert z2.shape == (int(np.ceil(1000 * sr0 / sr1)),)
+    assert np.abs(z2[300:-300] - 0.5 * np.sin(2 * np.pi * 3000.0 * t2)[300:-300]).max() < 2e-6
+    with pytest.raises(ValueError):
+        ors.resample(np.zeros(1, np.float32), 48000, 8000)
