@@ -184,7 +184,8 @@ def main():
             ach = prof["bytes_per_chunk"] * chunks_per_launch / (ms * 1e-3) / 1e9
             roof = {"kernel": prof["stage"], "bound": "hbm", "achieved": round(ach, 2), "peak": PEAK_HBM_GBS,
                     "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 5), "traffic": None,
-                    "valu_tflops": round(prof["flops_per_chunk"] * chunks_per_launch / (ms * 1e-3) / 1e12, 3)}
+                    "valu_tflops": round(prof["flops_per_chunk"] * chunks_per_launch / (ms * 1e-3) / 1e12, 3),
+                    "valu_frac_of_fp32_peak": round(prof["flops_per_chunk"] * chunks_per_launch / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
         iso_ms = stages[dom]["total_ms"] / max(1, stages[dom]["launches"])
         iso_cpl = args.chunks / max(1, stages[dom]["launches"])
         iso = (prof["flops_per_chunk"] * iso_cpl / (iso_ms * 1e-3) / 1e12 if is_mfma
