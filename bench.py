@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--spec", default="thesis-shape")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="0 disables the CPU baseline leg")
     ap.add_argument("--pcie", action="store_true", help="also time the host-buffer (PCIe-inclusive) entry point")
+    ap.add_argument("--files", type=int, default=0, help="also time the end-to-end folder ingest on this many WAV files "
+                                                         "(written to a temp dir first; parse + H2D + encode; never the headline value)")
     ap.add_argument("--lanes", type=int, default=0, help="HIP streams the batches are spread over (0 = library default)")
     args = ap.parse_args()
 
@@ -239,6 +241,28 @@ def main():
             line["pcie_inclusive"] = {"value": round(3 * args.chunks / (time.perf_counter() - t1), 1), "unit": "chunks/s",
                                       "note": "amph_encode_pcm16_host: pageable host rows -> pinned double buffer -> HBM, "
                                               "encode, latents copied back; never the headline value"}
+        if world == 1 and args.files > 0:
+            # end to end from FILES (SURVEY 8(d) "feed bounds"): PCM16 WAVs on local disk -> native RIFF reader on the host
+            # thread pool -> pinned rows -> H2D -> encode -> latents on the device.  Page cache is warm (just written).
+            import tempfile
+            from amphibian_vae_latent_detector_amd import folder as _folder
+            from amphibian_vae_latent_detector_amd.synth import write_wav_pcm16
+            with tempfile.TemporaryDirectory(prefix="amph_bench_") as td:
+                paths = []
+                for i in range(args.files):
+                    pth = Path(td) / f"chunk_{i:06d}.wav"
+                    write_wav_pcm16(pth, pcm_host[i % pcm_host.shape[0]], cfg.sr)
+                    paths.append(pth)
+                threads = min(16, os.cpu_count() or 8)
+                _folder.encode_paths(enc, paths[:min(512, len(paths))], cfg, apply_rms=True, loader_threads=threads)   # warm-up
+                t1 = time.perf_counter()
+                _, st_f = _folder.encode_paths(enc, paths, cfg, apply_rms=True, loader_threads=threads)
+                torch.cuda.synchronize(dev)
+                dt = time.perf_counter() - t1
+            line["from_files"] = {"value": round(args.files / dt, 1), "unit": "files/s", "files": args.files,
+                                  "loader_threads": threads, "failed": int((st_f != 0).sum()),
+                                  "note": "folder.encode_paths: amph_wav_read_many (4x chunk length read for the file-level RMS) -> "
+                                          "pinned -> HBM -> encode; page cache warm; never the headline value"}
         if world == 1 and args.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(cfg, spec, state, pcm_host[:4000], args.cpu_seconds)
         print(json.dumps(line), flush=True)
