@@ -214,7 +214,7 @@ def main():
             "metric": "1 s audio chunks encoded to latent/sec", "value": round(value, 1), "unit": "chunks/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE.json configs[1]: {args.chunks} synthetic 1 s / {cfg.sr} Hz PCM16 chunks per GPU "
+            "config": {"workload": f"BASELINE.json configs[1]: {args.chunks} synthetic {cfg.duration:g} s / {cfg.sr} Hz PCM16 chunks per GPU "
                                    f"resident in HBM, preset {args.preset}, {args.spec} VAE encoder (latent_dim {D}), "
                                    f"batch {args.batch}, RMS normalise + mel + encoder, fp32",
                        "chunks_per_gpu": args.chunks, "batch": args.batch, "lanes": n_lanes,
