@@ -490,19 +490,34 @@ __global__ __launch_bounds__(256) void k_conv_gemm_p3(ConvGemmParams p) {
     // register stages (plain named variables: a struct passed to a lambda ends up in scratch memory)
     float4 sa0x, sa0y, sa1x, sa1y, sa2x, sa2y;           // A rows r0 and r0 + 32 of the three stages
     float4 sb0a, sb0b, sb1a, sb1b, sb2a, sb2b;
-#define AMPH_P3_LOAD(q)                                                                    \
+// the load of one slice in pieces small enough for one 64-cycle MFMA shadow each (one wave per SIMD has no partner to
+// cover a long gap: with everything behind the first MFMA the second waited ~190 cycles for the issue stream)
+#define AMPH_P3_LOADB(q)                                                                   \
+    {                                                                                      \
+        sb##q##a = *reinterpret_cast<const float4*>(wp0);                                  \
+        sb##q##b = *reinterpret_cast<const float4*>(wp1);                                  \
+    }
+#define AMPH_P3_LOADA0(q)                                                                  \
     {                                                                                      \
         const int koff_ = (l_kh * p.W + l_kw) * p.C_in + l_ci0;                            \
         sa##q##x = *reinterpret_cast<const float4*>(((vmask0 >> l_kpos) & 1u) ? pa0 + koff_ : p.zeros); \
+    }
+#define AMPH_P3_LOADA1(q)                                                                  \
+    {                                                                                      \
+        const int koff_ = (l_kh * p.W + l_kw) * p.C_in + l_ci0;                            \
         sa##q##y = *reinterpret_cast<const float4*>(((vmask1 >> l_kpos) & 1u) ? pa1 + koff_ : p.zeros); \
-        sb##q##a = *reinterpret_cast<const float4*>(wp0);                                  \
-        sb##q##b = *reinterpret_cast<const float4*>(wp1);                                  \
-        /* advance with selects only: the loop body stays one basic block */               \
+    }
+    /* advance with selects only: the loop body stays one basic block */
+#define AMPH_P3_ADV1()                                                                     \
+    {                                                                                      \
         const int adv_ = l_left > 1 ? 1 : 0;                                               \
         l_left -= adv_;                                                                    \
         wp0 += kBK * adv_;                                                                 \
         wp1 += kBK * adv_;                                                                 \
         l_ci0 += kBK * adv_;                                                               \
+    }
+#define AMPH_P3_ADV2()                                                                     \
+    {                                                                                      \
         const int wrap_ = l_ci0 >= p.C_in ? 1 : 0;                                         \
         l_ci0 -= wrap_ * p.C_in;                                                           \
         l_kpos += wrap_;                                                                   \
@@ -511,6 +526,7 @@ __global__ __launch_bounds__(256) void k_conv_gemm_p3(ConvGemmParams p) {
         l_kw -= wrap2_ * p.k;                                                              \
         l_kh += wrap2_;                                                                    \
     }
+#define AMPH_P3_LOAD(q) { AMPH_P3_LOADB(q) AMPH_P3_LOADA0(q) AMPH_P3_LOADA1(q) AMPH_P3_ADV1() AMPH_P3_ADV2() }
     const int st_off = r0 * kLdsRow + 4 * c4;
 #define AMPH_P3_STORE(q, buf_)                                                             \
     {                                                                                      \
@@ -549,7 +565,7 @@ __global__ __launch_bounds__(256) void k_conv_gemm_p3(ConvGemmParams p) {
 #define AMPH_P3_ACC()
 #endif
     // one slice from LDS buffer R; stage R receives slice s+3, stage (R+2)%3 goes to buffer (R+2)%3
-#define AMPH_P3_STEP(R, QL, QS)                                                 \
+#define AMPH_P3_STEP(R, QL, QS)                                                            \
     {                                                                                      \
         float4 f1a, f1b, f2a, f2b, f3a, f3b, n0a, n0b;                                     \
         AMPH_P3_T(ts0)                                                                     \
@@ -557,20 +573,32 @@ __global__ __launch_bounds__(256) void k_conv_gemm_p3(ConvGemmParams p) {
         AMPH_SB();                                                                         \
         AMPH_P3_MFMA(f0a.x, f0b.x)                                                         \
         AMPH_SB();                                                                         \
-        AMPH_P3_LOAD(QL)                                                                   \
+        AMPH_P3_LOADB(QL)                                                                  \
         AMPH_SB();                                                                         \
         AMPH_P3_MFMA(f0a.y, f0b.y)                                                         \
         AMPH_SB();                                                                         \
         AMPH_P3_READ(f2a, f2b, R, 2)                                                       \
         AMPH_SB();                                                                         \
         AMPH_P3_MFMA(f0a.z, f0b.z)                                                         \
+        AMPH_SB();                                                                         \
+        AMPH_P3_LOADA0(QL)                                                                 \
+        AMPH_SB();                                                                         \
         AMPH_P3_MFMA(f0a.w, f0b.w)                                                         \
+        AMPH_SB();                                                                         \
+        AMPH_P3_LOADA1(QL)                                                                 \
+        AMPH_SB();                                                                         \
         AMPH_P3_MFMA(f1a.x, f1b.x)                                                         \
         AMPH_SB();                                                                         \
         AMPH_P3_READ(f3a, f3b, R, 3)                                                       \
         AMPH_SB();                                                                         \
         AMPH_P3_MFMA(f1a.y, f1b.y)                                                         \
+        AMPH_SB();                                                                         \
+        AMPH_P3_ADV1()                                                                     \
+        AMPH_SB();                                                                         \
         AMPH_P3_MFMA(f1a.z, f1b.z)                                                         \
+        AMPH_SB();                                                                         \
+        AMPH_P3_ADV2()                                                                     \
+        AMPH_SB();                                                                         \
         AMPH_P3_MFMA(f1a.w, f1b.w)                                                         \
         AMPH_P3_MFMA(f2a.x, f2b.x)                                                         \
         AMPH_SB();                                                                         \
