@@ -53,22 +53,31 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_down(v, o));
     return v;
 }
-// Block-wide reductions for 256-thread blocks; result valid in every thread.
+// Block-wide reductions for blocks of NW waves (4 or 16); result valid in every thread.
+template <int NW = 4>
 __device__ __forceinline__ double block_sum(double v, double* sh) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     v = wave_sum(v);
     __syncthreads();
     if (lane == 0) sh[w] = v;
     __syncthreads();
-    return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    if (NW == 4) return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    double q[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) q[g] = (sh[4 * g] + sh[4 * g + 1]) + (sh[4 * g + 2] + sh[4 * g + 3]);
+    return (q[0] + q[1]) + (q[2] + q[3]);
 }
+template <int NW = 4>
 __device__ __forceinline__ float block_max(float v, float* sh) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     v = wave_max(v);
     __syncthreads();
     if (lane == 0) sh[w] = v;
     __syncthreads();
-    return fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+    float m = sh[0];
+#pragma unroll
+    for (int g = 1; g < NW; ++g) m = fmaxf(m, sh[g]);
+    return m;
 }
 
 // ----------------------------------------------------------------------------
@@ -772,10 +781,13 @@ __device__ __forceinline__ float to_db(float s, float ref_db) {
 
 // kCache > 0: every thread keeps its kCache dB values in registers (one log10f per element);
 // kCache == 0: values are recomputed per pass (any size).
-template <int kCache>
-__global__ __launch_bounds__(256) void k_dbnorm(DbNormParams p) {
-    __shared__ double shd[4];
-    __shared__ float shf[4];
+// NT threads per block: 256, or 1024 so that a 5 s chunk's 626 x 64 values (40 per thread) stay in registers too
+// (recomputed per pass they cost three log10 sweeps of an L2-resident 160 KB array: 149 -> 40 us per 256 chunks).
+template <int kCache, int NT>
+__global__ __launch_bounds__(NT) void k_dbnorm(DbNormParams p) {
+    constexpr int NW = NT / 64;
+    __shared__ double shd[16];
+    __shared__ float shf[16];
     const int row = blockIdx.x, tid = threadIdx.x;
     const int n = p.n_frames * p.n_mels;
     const float* S = p.melpow + (long long)row * n;
@@ -784,28 +796,28 @@ __global__ __launch_bounds__(256) void k_dbnorm(DbNormParams p) {
     float mx = -INFINITY;
     if (kCache > 0) {
 #pragma unroll
-        for (int j = 0; j < C; ++j) { const int i = tid + 256 * j; v[j] = i < n ? S[i] : -INFINITY; mx = fmaxf(mx, v[j]); }
+        for (int j = 0; j < C; ++j) { const int i = tid + NT * j; v[j] = i < n ? S[i] : -INFINITY; mx = fmaxf(mx, v[j]); }
     } else {
-        for (int i = tid; i < n; i += 256) mx = fmaxf(mx, S[i]);
+        for (int i = tid; i < n; i += NT) mx = fmaxf(mx, S[i]);
     }
-    mx = block_max(mx, shf);
+    mx = block_max<NW>(mx, shf);
     const float ref_db = 10.0f * log10f(fmaxf(1e-10f, mx));             // same two operations as to_db (no FMA)
     double acc = 0.0;
     if (kCache > 0) {
 #pragma unroll
-        for (int j = 0; j < C; ++j) if (tid + 256 * j < n) { v[j] = to_db(v[j], ref_db); acc += (double)v[j]; }
+        for (int j = 0; j < C; ++j) if (tid + NT * j < n) { v[j] = to_db(v[j], ref_db); acc += (double)v[j]; }
     } else {
-        for (int i = tid; i < n; i += 256) acc += (double)to_db(S[i], ref_db);
+        for (int i = tid; i < n; i += NT) acc += (double)to_db(S[i], ref_db);
     }
-    const float mean = (float)(block_sum(acc, shd) / (double)n);
+    const float mean = (float)(block_sum<NW>(acc, shd) / (double)n);
     acc = 0.0;
     if (kCache > 0) {
 #pragma unroll
-        for (int j = 0; j < C; ++j) if (tid + 256 * j < n) { const float d = v[j] - mean; acc += (double)(d * d); }
+        for (int j = 0; j < C; ++j) if (tid + NT * j < n) { const float d = v[j] - mean; acc += (double)(d * d); }
     } else {
-        for (int i = tid; i < n; i += 256) { const float d = to_db(S[i], ref_db) - mean; acc += (double)(d * d); }
+        for (int i = tid; i < n; i += NT) { const float d = to_db(S[i], ref_db) - mean; acc += (double)(d * d); }
     }
-    const float sd = sqrtf((float)(block_sum(acc, shd) / (double)n));
+    const float sd = sqrtf((float)(block_sum<NW>(acc, shd) / (double)n));
     const float den = sd + 1e-8f;
     // crop_or_pad_time (map_detector_core.py:185-195): destination frame = source frame - shift
     const int T = p.n_frames, TT = p.target_frames, M = p.n_mels;
@@ -814,7 +826,7 @@ __global__ __launch_bounds__(256) void k_dbnorm(DbNormParams p) {
     if (kCache > 0) {
 #pragma unroll
         for (int j = 0; j < C; ++j) {
-            const int i = tid + 256 * j;
+            const int i = tid + NT * j;
             if (i < n) {
                 const int fr = i / M, m = i - fr * M, tt = fr - shift;
                 if (tt >= 0 && tt < TT) {
@@ -826,7 +838,7 @@ __global__ __launch_bounds__(256) void k_dbnorm(DbNormParams p) {
         }
         if (T < TT) {                                   // literal zero padding, left then right
             const int left = -shift, right0 = left + T;
-            for (int i = tid; i < (TT - T) * M; i += 256) {
+            for (int i = tid; i < (TT - T) * M; i += NT) {
                 const int fr = i / M, m = i - fr * M;
                 const int tt = fr < left ? fr : right0 + (fr - left);
                 if (p.layout == 1) out[tt * M + m] = 0.0f;
@@ -834,7 +846,7 @@ __global__ __launch_bounds__(256) void k_dbnorm(DbNormParams p) {
             }
         }
     } else {
-        for (int i = tid; i < TT * M; i += 256) {
+        for (int i = tid; i < TT * M; i += NT) {
             const int tt = i / M, m = i - tt * M;
             const int src = tt + shift;
             float z = 0.0f;
@@ -847,9 +859,11 @@ __global__ __launch_bounds__(256) void k_dbnorm(DbNormParams p) {
 
 void launch_dbnorm(const DbNormParams& p, int n_rows, hipStream_t s) {
     const int n = p.n_frames * p.n_mels;
-    if (n <= 256 * 16) hipLaunchKernelGGL(k_dbnorm<16>, dim3(n_rows), dim3(256), 0, s, p);          // 1 s chunks, 64 mels
-    else if (n <= 256 * 48) hipLaunchKernelGGL(k_dbnorm<48>, dim3(n_rows), dim3(256), 0, s, p);     // e.g. 87 frames x 128 mels
-    else hipLaunchKernelGGL(k_dbnorm<0>, dim3(n_rows), dim3(256), 0, s, p);                          // 5 s chunks: recompute per pass
+    if (n <= 256 * 16) hipLaunchKernelGGL((k_dbnorm<16, 256>), dim3(n_rows), dim3(256), 0, s, p);          // 1 s chunks, 64 mels
+    else if (n <= 256 * 48) hipLaunchKernelGGL((k_dbnorm<48, 256>), dim3(n_rows), dim3(256), 0, s, p);     // e.g. 87 frames x 128 mels
+    else if (n <= 1024 * 24) hipLaunchKernelGGL((k_dbnorm<24, 1024>), dim3(n_rows), dim3(1024), 0, s, p);  // 3 s chunks (376 x 64)
+    else if (n <= 1024 * 40) hipLaunchKernelGGL((k_dbnorm<40, 1024>), dim3(n_rows), dim3(1024), 0, s, p);  // 5 s chunks (626 x 64)
+    else hipLaunchKernelGGL((k_dbnorm<0, 256>), dim3(n_rows), dim3(256), 0, s, p);                          // anything longer: recompute per pass
 }
 
 void launch_rms_scale_pcm16(const int16_t* in, long long row_stride, const int32_t* lengths, int n_in, int n_rows,
