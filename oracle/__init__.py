@@ -11,6 +11,14 @@ Pinning status (see DESIGN.md "Oracle"):
   fit and the radial decision are PINNED against the reference's own functions
   (imported in the build container by `tests/golden/make_golden.py`; the
   captured vectors are committed under `tests/golden/`).
+* the Gaussian-MAP detector (`oracle.map_score`: estimate_cov, inv_and_logdet,
+  gaussian_logpdf_from_precision, the 08b fit block, priors, the 10b decision) is
+  PINNED the same way (`tests/golden/make_golden_map.py` -> `map_fit.npz`,
+  `map_decide*.npz`).
+* the resampler (`oracle.resample`: resampy 0.4.3 kaiser_best + librosa's
+  fix_length, used by librosa.load only when a file's rate differs from `sr`) is
+  **parity unpinned**: neither package nor its filter table is available and the
+  reference holds no resampled fixture; anchored on signal-level known answers.
 * the mel front end (librosa==0.9.2 arithmetic) and the encoder architecture
   (un-vendored `soundscape_vae`) are **parity unpinned**: librosa is not
   installable here and the reference holds no fixtures for it, so
