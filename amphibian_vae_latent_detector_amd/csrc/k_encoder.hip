@@ -766,6 +766,28 @@ __global__ __launch_bounds__(256) void k_conv_gemm_f3(ConvGemmParams p) {
             if (iwB >= 0 && iwB < p.W) hm1 |= 1u << (kh * p.k + kw);
         }
     }
+    // B (weight) slices do not depend on the tile: the load pointer runs CYCLICALLY over the K slices, so the last three
+    // steps of a tile already fetch slices 0, 1, 2 for the next one (n_slices % 3 == 0: the stage rotation lines up) and
+    // only the first tile's prologue loads them.  BN constants of the epilogue: tile-independent too, loaded once.
+    const int n_slices = p.K_pad / kBK;                  // == k * k taps (C_in == 32), splits == 1
+    const float* wp0 = p.w + (long long)(n_blk + r0) * p.K_pad + 4 * c4;
+    const float* wp1 = wp0 + 32ll * p.K_pad;
+    int l_left = n_slices;                               // slices until the pointer wraps
+    float4 sb0a, sb0b, sb1a, sb1b, sb2a, sb2b;           // B register stages
+    bool b_primed = false;
+    float4 e_sc0, e_sc1, e_sc2, e_sc3, e_sh0, e_sh1, e_sh2, e_sh3;
+    {
+        const int nb = n_blk + (wave & 1) * 32 + 4 * (lane >> 5);
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        e_sc0 = nb + 0 < p.N ? *reinterpret_cast<const float4*>(p.scale + nb + 0) : z4;
+        e_sc1 = nb + 8 < p.N ? *reinterpret_cast<const float4*>(p.scale + nb + 8) : z4;
+        e_sc2 = nb + 16 < p.N ? *reinterpret_cast<const float4*>(p.scale + nb + 16) : z4;
+        e_sc3 = nb + 24 < p.N ? *reinterpret_cast<const float4*>(p.scale + nb + 24) : z4;
+        e_sh0 = nb + 0 < p.N ? *reinterpret_cast<const float4*>(p.shift + nb + 0) : z4;
+        e_sh1 = nb + 8 < p.N ? *reinterpret_cast<const float4*>(p.shift + nb + 8) : z4;
+        e_sh2 = nb + 16 < p.N ? *reinterpret_cast<const float4*>(p.shift + nb + 16) : z4;
+        e_sh3 = nb + 24 < p.N ? *reinterpret_cast<const float4*>(p.shift + nb + 24) : z4;
+    }
     if ((int)blockIdx.x < n_tiles) AMPH_F3_FETCH_PATCH(blockIdx.x)
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int m_blk = tile * BM;
@@ -791,13 +813,7 @@ __global__ __launch_bounds__(256) void k_conv_gemm_f3(ConvGemmParams p) {
             if (m_blk + r0 + 32 < p.M && ihB + kh >= 0 && ihB + kh < p.H) vmask1 |= hm1 & rowbits;
         }
     }
-    const int n_slices = p.K_pad / kBK;                  // == k * k taps (C_in == 32), splits == 1
-    const float* wp0 = p.w + (long long)(n_blk + r0) * p.K_pad + 4 * c4;
-    const float* wp1 = wp0 + 32ll * p.K_pad;
-    int l_left = n_slices;                               // B slices not yet loaded
     int c_kpos = 0, c_kh = 0, c_kw = 0;                  // tap of the next slice to COMPUTE (wave-uniform)
-
-    float4 sb0a, sb0b, sb1a, sb1b, sb2a, sb2b;           // B register stages
     float4 a0, a1;                                       // the A stage being computed (rows r0, r0 + 32)
     float pv0_0, pv0_1, pv0_2, pv0_3, pv0_4, pv0_5, pv0_6, pv0_7, pv0_8;
     float pv1_0, pv1_1, pv1_2, pv1_3, pv1_4, pv1_5, pv1_6, pv1_7, pv1_8;
@@ -806,10 +822,11 @@ __global__ __launch_bounds__(256) void k_conv_gemm_f3(ConvGemmParams p) {
     {                                                                                      \
         sb##q##a = *reinterpret_cast<const float4*>(wp0);                                  \
         sb##q##b = *reinterpret_cast<const float4*>(wp1);                                  \
-        const int adv_ = l_left > 1 ? 1 : 0;                                               \
-        l_left -= adv_;                                                                    \
-        wp0 += kBK * adv_;                                                                 \
-        wp1 += kBK * adv_;                                                                 \
+        --l_left;                                                                          \
+        const int step_ = l_left == 0 ? -(n_slices - 1) * kBK : kBK;   /* wrap to slice 0 */ \
+        l_left = l_left == 0 ? n_slices : l_left;                                          \
+        wp0 += step_;                                                                      \
+        wp1 += step_;                                                                      \
     }
     // window of row i for the tap being computed (taps past the end have no mask bit: all zero)
 #define AMPH_F3_WINDOW(i)                                                                  \
@@ -939,9 +956,12 @@ __global__ __launch_bounds__(256) void k_conv_gemm_f3(ConvGemmParams p) {
     }
 
     // prologue: B of slices 0, 1, 2 into the register stages; A of slices 0 and 1 computed; 0 and 1 on to LDS
-    AMPH_F3_LOADB(0)
-    AMPH_F3_LOADB(1)
-    AMPH_F3_LOADB(2)
+    if (!b_primed) {
+        AMPH_F3_LOADB(0)
+        AMPH_F3_LOADB(1)
+        AMPH_F3_LOADB(2)
+        b_primed = true;
+    }
     __syncthreads();                                     // the patch is staged
     if (tile + (int)gridDim.x < n_tiles) AMPH_F3_FETCH_PATCH(tile + gridDim.x)
     AMPH_F3_COMPUTE_ALL()
@@ -973,18 +993,20 @@ __global__ __launch_bounds__(256) void k_conv_gemm_f3(ConvGemmParams p) {
     {
         const int m = m_blk + row_tile * 32 + (lane & 31);
         if (m < p.M) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n0 = n_blk + col_tile * 32 + 8 * g + 4 * (lane >> 5);
-                if (n0 < p.N) {
-                    const float4 sc = *reinterpret_cast<const float4*>(p.scale + n0);
-                    const float4 sh = *reinterpret_cast<const float4*>(p.shift + n0);
-                    float4 v;
-                    v.x = fmaxf(fmaf(acc[4 * g], sc.x, sh.x), 0.0f); v.y = fmaxf(fmaf(acc[4 * g + 1], sc.y, sh.y), 0.0f);
-                    v.z = fmaxf(fmaf(acc[4 * g + 2], sc.z, sh.z), 0.0f); v.w = fmaxf(fmaf(acc[4 * g + 3], sc.w, sh.w), 0.0f);
-                    *reinterpret_cast<float4*>(p.y + (long long)m * p.N + n0) = v;
-                }
+#define AMPH_F3_OUT(g)                                                                     \
+            {                                                                              \
+                const int n0 = n_blk + col_tile * 32 + 8 * g + 4 * (lane >> 5);            \
+                if (n0 < p.N) {                                                            \
+                    float4 v;                                                              \
+                    v.x = fmaxf(fmaf(acc[4 * g], e_sc##g.x, e_sh##g.x), 0.0f);             \
+                    v.y = fmaxf(fmaf(acc[4 * g + 1], e_sc##g.y, e_sh##g.y), 0.0f);         \
+                    v.z = fmaxf(fmaf(acc[4 * g + 2], e_sc##g.z, e_sh##g.z), 0.0f);         \
+                    v.w = fmaxf(fmaf(acc[4 * g + 3], e_sc##g.w, e_sh##g.w), 0.0f);         \
+                    *reinterpret_cast<float4*>(p.y + (long long)m * p.N + n0) = v;         \
+                }                                                                          \
             }
+            AMPH_F3_OUT(0) AMPH_F3_OUT(1) AMPH_F3_OUT(2) AMPH_F3_OUT(3)
+#undef AMPH_F3_OUT
         }
     }
     }   // tile loop (the last step's barrier has retired every LDS read of this tile)
@@ -1009,7 +1031,7 @@ static size_t conv_gemm_f3_lds(const ConvGemmParams& p, int bm) {
 bool conv_gemm_f3_ok(const ConvGemmParams& p, int bm) {
     const int ohw = p.OH * p.OW;
     return bm == 64 && p.img != nullptr && p.k1 == 3 && p.C_in == kBK && p.K == p.K_pad && p.k * p.k <= 32 && p.splits == 1 && (p.N % 4) == 0 &&
-           p.epilogue == 0 && ohw % bm == 0 && bm % p.OW == 0 && conv_gemm_f3_lds(p, bm) <= 80 * 1024 &&
+           p.epilogue == 0 && ohw % bm == 0 && bm % p.OW == 0 && conv_gemm_f3_lds(p, bm) <= 80 * 1024 && (p.K_pad / kBK) % 3 == 0 &&
            (((bm / p.OW - 1) * p.stride + p.k - 1) * p.s1 + 3) * (p.W0 + 2 * p.p1) <= 256 * 8;
 }
 
