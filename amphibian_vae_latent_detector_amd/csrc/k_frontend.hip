@@ -475,10 +475,15 @@ __global__ __launch_bounds__(64 * NW) void k_stft_mel(StftParams p, int n_tiles)
         return d;
     };
     constexpr int U = NW == 4 ? 10 : 5;                // dwords per thread per batch (one batch for FT = 8 / 12)
-    uint32_t pre[U];                                   // next tile's samples, prefetched (fast tiles only)
+    constexpr int US = 2 * U;                          // samples per thread per tile on the per-sample path
+    // next tile's samples, prefetched while this tile's frames are transformed.  pre_kind 1: dwords (two PCM16
+    // samples) of an interior PCM16 tile; 2: one decoded, not yet normalised sample per register - the edge tiles of
+    // a row (reflect / zero padding: two of the five tiles of a 1 s row) and every tile of a float32 row, whose
+    // synchronous loads were ~2.5 k exposed cycles per tile in front of the first barrier
+    uint32_t pre[US];
 #pragma unroll
-    for (int u = 0; u < U; ++u) pre[u] = 0;
-    bool have_pre = false;
+    for (int u = 0; u < US; ++u) pre[u] = 0;
+    int pre_kind = 0;
     const int nd = span_len >> 1;
     const bool pre_fits = nd <= kThreads * U;
 
@@ -492,7 +497,7 @@ __global__ __launch_bounds__(64 * NW) void k_stft_mel(StftParams p, int n_tiles)
             const uint32_t* src32 = reinterpret_cast<const uint32_t*>(d.rowp + 2 * (size_t)d.s0);
             for (int base = 0; base < nd; base += kThreads * U) {
                 uint32_t v[U];
-                if (have_pre) {
+                if (pre_kind == 1) {
 #pragma unroll
                     for (int u = 0; u < U; ++u) v[u] = pre[u];
                 } else {
@@ -509,6 +514,12 @@ __global__ __launch_bounds__(64 * NW) void k_stft_mel(StftParams p, int n_tiles)
                             make_float2(normalise_sample(p.src, lo, d.sc), normalise_sample(p.src, hi, d.sc));
                     }
                 }
+            }
+        } else if (pre_kind == 2) {
+#pragma unroll
+            for (int u = 0; u < US; ++u) {
+                const int i = tid + kThreads * u;
+                if (i < span_len) span[i] = normalise_sample(p.src, __uint_as_float(pre[u]), d.sc);
             }
         } else {
             const int N = p.n_samples;
@@ -533,14 +544,26 @@ __global__ __launch_bounds__(64 * NW) void k_stft_mel(StftParams p, int n_tiles)
         __syncthreads();
         AMPH_WSTAMP(w_t1)
         // ---- prefetch the next tile's samples; they land while this tile's frames are transformed
-        have_pre = false;
+        pre_kind = 0;
         if (t + (int)gridDim.x < n_tiles && pre_fits) {
             const TileSrc dn = describe(t + gridDim.x);
             if (dn.fast) {
                 const uint32_t* src32 = reinterpret_cast<const uint32_t*>(dn.rowp + 2 * (size_t)dn.s0);
 #pragma unroll
                 for (int u = 0; u < U; ++u) pre[u] = src32[min(tid + kThreads * u, nd - 1)];
-                have_pre = true;
+                pre_kind = 1;
+            } else {
+                const int N = p.n_samples;
+#pragma unroll
+                for (int u = 0; u < US; ++u) {
+                    int sidx = dn.s0 + tid + kThreads * u;
+                    if (p.pad_mode == 0) {                // reflect (np.pad mode="reflect")
+                        if (sidx < 0) sidx = -sidx;
+                        if (sidx >= N) sidx = 2 * (N - 1) - sidx;
+                    } else if (sidx >= N) sidx = -1;      // constant (zero) padding
+                    pre[u] = __float_as_uint(load_sample<PCM16>(dn.rowp, sidx, dn.len));
+                }
+                pre_kind = 2;
             }
         }
 
