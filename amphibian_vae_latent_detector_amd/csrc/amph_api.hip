@@ -864,8 +864,8 @@ int amph_configure(amph_ctx* c, const char* key, int value) {
         for (int k = 1; k < 10; ++k) fprintf(stderr, "  stamp %-16s %9.0f cycles (mean over %d workgroups, first frame of wave 0)\n", nm[k], sum[k] / value, value);
         double w[6] = {0};
         for (int b = 0; b < value; ++b) for (int k = 0; k < 6; ++k) w[k] += (double)h[(size_t)b * 16 + 10 + k];
-        fprintf(stderr, "  workgroup (wave 0) sums over its tiles: stage+sync %.0f  frames %.0f  end barrier %.0f | kernel %.0f cycles = %.0f ticks of 10 ns (clock %.2f GHz)\n",
-                w[0] / value, w[1] / value, w[2] / value, w[3] / value, w[4] / value, w[4] > 0 ? w[3] / w[4] / 10.0 : 0.0);
+        fprintf(stderr, "  workgroup (wave 0) sums over its tiles: stage+sync %.0f (own staging work %.0f)  frames %.0f  end barrier %.0f | kernel %.0f cycles = %.0f ticks of 10 ns (clock %.2f GHz)\n",
+                w[0] / value, w[5] / value, w[1] / value, w[2] / value, w[3] / value, w[4] / value, w[4] > 0 ? w[3] / w[4] / 10.0 : 0.0);
         return AMPH_OK;
     }
 #endif

@@ -420,7 +420,7 @@ __global__ __launch_bounds__(64 * NW) void k_stft_mel(StftParams p, int n_tiles)
     const int FT = p.frames_per_block;
 #ifdef AMPH_STAMPS
     { const int fl = 0; AMPH_STAMP(0) }
-    unsigned long long w_t0 = 0, w_t1 = 0, w_t2 = 0, w_t3 = 0, w_stage = 0, w_frames = 0, w_endbar = 0, w_begin = 0;
+    unsigned long long w_t0 = 0, w_ta = 0, w_t1 = 0, w_t2 = 0, w_t3 = 0, w_stage = 0, w_stagework = 0, w_frames = 0, w_endbar = 0, w_begin = 0;
     const unsigned long long w_rt0 = __builtin_amdgcn_s_memrealtime();
 #define AMPH_WSTAMP(v_)                                                                     \
     {                                                                                       \
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(64 * NW) void k_stft_mel(StftParams p, int n_tiles)
     }
 
     // per-tile source description
-    struct TileSrc { const char* rowp; int len, s0; float sc; bool fast; };
+    struct TileSrc { const char* rowp; int len, s0, row, f_base; float sc; bool fast; };
     auto describe = [&](int t) {
         TileSrc d;
         const int r = t / p.tiles_per_row, tl = t - r * p.tiles_per_row;
@@ -469,6 +469,8 @@ __global__ __launch_bounds__(64 * NW) void k_stft_mel(StftParams p, int n_tiles)
         d.len = min(len, p.n_samples);               // truncation of fix_length (:217)
         d.sc = p.src.scale ? p.src.scale[r] : 1.0f;
         d.s0 = tl * FT * p.hop - (n_fft >> 1);
+        d.row = r;
+        d.f_base = tl * FT;
         // interior tile of a PCM16 row: one contiguous, 4-byte aligned run -> dword loads
         d.fast = PCM16 && d.s0 >= 0 && d.s0 + span_len <= d.len && (span_len & 1) == 0 &&
                  ((reinterpret_cast<uintptr_t>(d.rowp) + 2 * (size_t)d.s0) & 3u) == 0;
@@ -487,11 +489,10 @@ __global__ __launch_bounds__(64 * NW) void k_stft_mel(StftParams p, int n_tiles)
     const int nd = span_len >> 1;
     const bool pre_fits = nd <= kThreads * U;
 
+    TileSrc d = describe(min((int)blockIdx.x, n_tiles - 1)), dn = d;      // the next tile's description is computed once
     for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         AMPH_WSTAMP(w_t0)
-        const TileSrc d = describe(t);
-        const int row = t / p.tiles_per_row;
-        const int f_base = (t - row * p.tiles_per_row) * FT;
+        const int row = d.row, f_base = d.f_base;
         // ---- stage this tile's sample span (decode / normalise on the way into LDS)
         if (d.fast) {
             const uint32_t* src32 = reinterpret_cast<const uint32_t*>(d.rowp + 2 * (size_t)d.s0);
@@ -541,12 +542,13 @@ __global__ __launch_bounds__(64 * NW) void k_stft_mel(StftParams p, int n_tiles)
                 }
             }
         }
+        AMPH_WSTAMP(w_ta)
         __syncthreads();
         AMPH_WSTAMP(w_t1)
         // ---- prefetch the next tile's samples; they land while this tile's frames are transformed
         pre_kind = 0;
+        if (t + (int)gridDim.x < n_tiles) dn = describe(t + gridDim.x);
         if (t + (int)gridDim.x < n_tiles && pre_fits) {
-            const TileSrc dn = describe(t + gridDim.x);
             if (dn.fast) {
                 const uint32_t* src32 = reinterpret_cast<const uint32_t*>(dn.rowp + 2 * (size_t)dn.s0);
 #pragma unroll
@@ -720,8 +722,9 @@ __global__ __launch_bounds__(64 * NW) void k_stft_mel(StftParams p, int n_tiles)
         __syncthreads();                              // every wave is done with `span` before it is restaged
         AMPH_WSTAMP(w_t3)
 #ifdef AMPH_STAMPS
-        w_stage += w_t1 - w_t0; w_frames += w_t2 - w_t1; w_endbar += w_t3 - w_t2;
+        w_stage += w_t1 - w_t0; w_stagework += w_ta - w_t0; w_frames += w_t2 - w_t1; w_endbar += w_t3 - w_t2;
 #endif
+        d = dn;
     }
 #ifdef AMPH_STAMPS
     if (tid == 0) {       // per-workgroup timeline (wave 0): where the tiles' time goes, and the in-kernel clock
@@ -732,7 +735,7 @@ __global__ __launch_bounds__(64 * NW) void k_stft_mel(StftParams p, int n_tiles)
         p.stamps[(size_t)blockIdx.x * 16 + 12] = w_endbar;
         p.stamps[(size_t)blockIdx.x * 16 + 13] = w_end - w_begin;
         p.stamps[(size_t)blockIdx.x * 16 + 14] = __builtin_amdgcn_s_memrealtime() - w_rt0;
-        p.stamps[(size_t)blockIdx.x * 16 + 15] = w_t0 - w_begin;
+        p.stamps[(size_t)blockIdx.x * 16 + 15] = w_stagework;      // staging before its barrier (wave 0)
     }
 #endif
 }
