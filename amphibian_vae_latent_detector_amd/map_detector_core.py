@@ -271,67 +271,70 @@ def gaussian_logpdf_from_precision(z: np.ndarray, mu: np.ndarray, prec: np.ndarr
     return -0.5 * (quad + float(logdet_cov) + d * float(np.log(2.0 * np.pi)))
 
 
-def get_priors_from_map_meta(cfg: Dict[str, Any], species) -> Dict[str, float]:
-    """cfg["map_detector"]["meta_fit"]["per_species"][sp]["prior"], normalised; fallback uniform."""
-    priors: Dict[str, float] = {}
+def _map_block(cfg: Dict[str, Any]) -> Dict[str, Any]:
     md = cfg.get("map_detector", {})
-    meta = md.get("meta_fit", {}) if isinstance(md, dict) else {}
-    per = meta.get("per_species", {}) if isinstance(meta, dict) else {}
-    ok = True
+    return md if isinstance(md, dict) else {}
+
+
+def _meta_fit(cfg: Dict[str, Any]) -> Dict[str, Any]:
+    meta = _map_block(cfg).get("meta_fit", {})
+    return meta if isinstance(meta, dict) else {}
+
+
+def get_priors_from_map_meta(cfg: Dict[str, Any], species) -> Dict[str, float]:
+    """Priors stored by the fit (`map_detector.meta_fit.per_species[sp].prior`), clipped at 0 and renormalised when
+    every species has one; otherwise uniform (ref :326-356)."""
+    per = _meta_fit(cfg).get("per_species", {})
+    found: Dict[str, float] = {}
     for sp in species:
         try:
-            priors[sp] = float(per.get(sp, {}).get("prior"))
-        except Exception:  # noqa: BLE001
-            ok = False
+            found[sp] = float(per.get(sp, {}).get("prior"))
+        except Exception:  # noqa: BLE001  (missing / None / non-numeric: fall back for ALL species)
+            found = {}
             break
-    if ok and priors:
-        s = sum(max(0.0, v) for v in priors.values())
-        if s > 0:
-            priors = {k: max(0.0, v) / s for k, v in priors.items()}
-        return priors
-    K = len(species)
-    if K == 0:
-        return {}
-    return {sp: 1.0 / K for sp in species}
+    total = sum(max(0.0, v) for v in found.values())
+    if found and total > 0:
+        return {sp: max(0.0, v) / total for sp, v in found.items()}
+    if found:
+        return found
+    return {sp: 1.0 / len(species) for sp in species} if len(species) else {}
 
 
 def get_chunk_seconds_for_map(cfg: Dict[str, Any]) -> float:
-    md = cfg.get("map_detector", {})
-    if isinstance(md, dict):
-        meta = md.get("meta_fit", {})
-        if isinstance(meta, dict) and "chunk_seconds" in meta:
+    """meta_fit.chunk_seconds of the MAP fit if present, else config.json:chunk_seconds, else 5.0 (ref :359-371)."""
+    for source in (_meta_fit(cfg), cfg):
+        if "chunk_seconds" in source:
             try:
-                return float(meta["chunk_seconds"])
+                return float(source["chunk_seconds"])
             except Exception:  # noqa: BLE001
-                pass
-    try:
-        return float(cfg.get("chunk_seconds", 5.0))
-    except Exception:  # noqa: BLE001
-        return 5.0
+                if source is cfg:
+                    return 5.0
+    return 5.0
 
 
 def read_map_detector_params(cfg: Dict[str, Any]):
-    """-> (means {sp: f32[D]}, precisions {sp: f32[D,D]}, logdets {sp: float}, tau float|None) as 08b stores them."""
+    """-> (means {sp: f32[D]}, precisions {sp: f32[D,D]}, logdets {sp: float}, tau float|None) as 08b stores them
+    (ref :374-420; same checks and messages)."""
     md = cfg.get("map_detector", None)
     if not isinstance(md, dict):
         raise ValueError("config.json no contiene map_detector (dict). Ejecuta antes 08b_fit_map_detector.py")
     if md.get("model", "") != "gaussian_map":
         raise ValueError(f"map_detector.model inesperado: {md.get('model')}")
-    means_raw, prec_raw, logdet_raw = md.get("means", None), md.get("precision", None), md.get("logdet_cov", None)
-    if not isinstance(means_raw, dict) or not isinstance(prec_raw, dict) or not isinstance(logdet_raw, dict):
+    raw = [md.get(key, None) for key in ("means", "precision", "logdet_cov")]
+    if not all(isinstance(r, dict) for r in raw):
         raise ValueError("map_detector debe contener 'means', 'precision' y 'logdet_cov' como dicts.")
-    means = {sp: np.array(v, dtype=np.float32) for sp, v in means_raw.items()
-             if isinstance(sp, str) and isinstance(v, list) and len(v) > 0}
+    usable = lambda sp, v: isinstance(sp, str) and isinstance(v, list) and len(v) > 0   # noqa: E731
+    means = {sp: np.asarray(v, dtype=np.float32) for sp, v in raw[0].items() if usable(sp, v)}
     precisions: Dict[str, np.ndarray] = {}
-    for sp, mat in prec_raw.items():
-        if isinstance(sp, str) and isinstance(mat, list) and len(mat) > 0:
-            P = np.array(mat, dtype=np.float32)
-            if P.ndim != 2 or P.shape[0] != P.shape[1]:
-                raise ValueError(f"precision[{sp}] debe ser matriz cuadrada, obtuve shape={P.shape}")
-            precisions[sp] = P
-    logdets = {sp: float(v) for sp, v in logdet_raw.items() if isinstance(sp, str)}
-    tau = md.get("tau", None)
-    tau_f = float(tau) if tau is not None else None
-    if not means or not precisions or not logdets:
+    for sp, mat in raw[1].items():
+        if not usable(sp, mat):
+            continue
+        P = np.asarray(mat, dtype=np.float32)
+        if P.ndim != 2 or P.shape[0] != P.shape[1]:
+            raise ValueError(f"precision[{sp}] debe ser matriz cuadrada, obtuve shape={P.shape}")
+        precisions[sp] = P
+    logdets = {sp: float(v) for sp, v in raw[2].items() if isinstance(sp, str)}
+    if not (means and precisions and logdets):
         raise ValueError("means/precision/logdet_cov vacíos o mal formateados en config.json.")
-    return means, precisions, logdets, tau_f
+    tau = md.get("tau", None)
+    return means, precisions, logdets, (None if tau is None else float(tau))
