@@ -484,3 +484,47 @@ def test_list_audio_files_is_recursive_and_sorted(tmp_path):
         (tmp_path / rel).parent.mkdir(parents=True, exist_ok=True)
         (tmp_path / rel).write_bytes(b"")
     assert [p.name for p in ppipe.list_audio_files(tmp_path / "sp")] == ["a.wav", "b.wav", "a.WAV"]
+
+# ------------------------------------------------------------------ properties (hypothesis)
+def test_properties_shards_loader_and_crop():
+    from hypothesis import given, settings
+    from hypothesis import strategies as st
+    from amphibian_vae_latent_detector_amd import map_detector_core as core
+
+    @settings(max_examples=200, deadline=None)
+    @given(st.integers(0, 100000), st.integers(1, 16))
+    def shards(n, world):
+        plan, per = pfolder.plan_shards(n, world)
+        assert len(plan) == world and per == max(1, (n + world - 1) // world)
+        covered = [i for a, b in plan for i in range(a, b)] if n <= 2000 else None
+        assert all(0 <= a <= b <= n and b - a <= per for a, b in plan)
+        assert sum(b - a for a, b in plan) == n and (covered is None or covered == list(range(n)))
+    shards()
+
+    @settings(max_examples=100, deadline=None)
+    @given(st.integers(1, 300), st.integers(1, 300), st.integers(1, 5))
+    def crop(T, target, M):
+        mel = np.arange(M * T, dtype=np.float32).reshape(M, T)
+        out = core.crop_or_pad_time(mel, target)
+        assert out.shape == (M, target) and out.dtype == np.float32
+        if T >= target:
+            s0 = (T - target) // 2
+            assert np.array_equal(out, mel[:, s0:s0 + target])
+        else:
+            left = (target - T) // 2
+            assert np.array_equal(out[:, left:left + T], mel) and out[:, :left].sum() == 0 and out[:, left + T:].sum() == 0
+    crop()
+
+    @settings(max_examples=60, deadline=None)
+    @given(st.integers(1, 400), st.integers(1, 3), st.sampled_from([8000, 22050, 48000]), st.integers(0, 2 ** 31 - 1))
+    def pcm16_roundtrip(n, ch, rate, seed):
+        import tempfile
+        q = np.random.default_rng(seed).integers(-32768, 32768, size=(n, ch)).astype("<i2")
+        with tempfile.TemporaryDirectory() as td:
+            pth = Path(td) / "x.wav"
+            _write_wav(pth, q, rate, 1, 16)
+            y, r = wavio.load_audio(pth)
+        assert r == rate and y.shape == (n,) and y.dtype == np.float32
+        want = (q.astype(np.float32) / np.float32(32768.0))
+        assert np.array_equal(y, want.mean(axis=1, dtype=np.float32) if ch > 1 else want[:, 0])
+    pcm16_roundtrip()
