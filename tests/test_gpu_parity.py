@@ -325,6 +325,20 @@ def test_reference_default_preset_crop_path(env):
     _assert_latents(mu.cpu().numpy(), _oracle_latents(env, tenc, pcm, cfg))
 
 
+def test_reference_07cli_preset_and_long_chunk_dbnorm_paths(env):
+    """07's CLI default (48 kHz, 3 s, 376 frames: the 24-values-per-thread dB kernel) and a 9 s chunk (1126 frames:
+    beyond every register-cached form, the recompute-per-pass kernel)."""
+    from dataclasses import replace
+    for cfg, frames in ((env.PRESETS["ref-07cli"], 376), (replace(env.PRESETS["ref-default"], duration=9.0), 1126)):
+        sess = env.AmphSession(cfg, None, None, DEV, max_batch=2)
+        assert sess.raw_frames == frames
+        y = env.ofe.pcm16_to_float(env.synth([3, 49], cfg.n_samples, cfg.sr))       # chunk 49 is digital silence
+        mel = sess.mel(y, layout=0).cpu().numpy()
+        want = np.stack([env.ofe.wave_to_mel(v, **cfg.mel_kwargs()) for v in y])
+        assert mel.shape == (2, 64, 192) and np.abs(mel - want).max() <= 1e-4
+        assert np.all(mel[1] == 0.0)
+
+
 def test_n_fft_1024_preset_128_mels(env):
     """BASELINE.json configs[3] front end: n_fft = 1024, hop 256, 128 mel bins (preset bench-1s-128):
     half-wave FFT geometry (two frames per wave), 87 raw frames zero-padded 4 left / 5 right to 96."""
