@@ -70,6 +70,16 @@ def encode_paths(encoder, paths: Sequence[Path], cfg: FrontendConfig, *, apply_r
     # with RMS normalisation the whole file contributes to the RMS (00 normalises the file,
     # 07 truncates afterwards): read up to 4x the chunk length, enough for any chunked dataset
     max_samples = cfg.n_samples * (4 if apply_rms else 1)
+    if apply_rms and n:
+        # ... but no more than the longest file holds: a folder of chunk-length files then moves 1x, not 4x, the bytes
+        # through memset / parse / PCIe (file size bounds the sample count of a PCM16 file from above)
+        longest = 0
+        for pth in paths:
+            try:
+                longest = max(longest, Path(pth).stat().st_size // 2)
+            except OSError:
+                pass
+        max_samples = max(cfg.n_samples, min(max_samples, (longest + 7) // 8 * 8))      # rows stay 16-byte aligned
     for off in range(0, n, file_batch):
         part = paths[off:off + file_batch]
         pcm, lengths, st, pin = wavio.read_many_pcm16(part, cfg.sr, max_samples, n_threads=loader_threads, pinned=True)

@@ -253,7 +253,7 @@ def main():
                     pth = Path(td) / f"chunk_{i:06d}.wav"
                     write_wav_pcm16(pth, pcm_host[i % pcm_host.shape[0]], cfg.sr)
                     paths.append(pth)
-                threads = min(16, os.cpu_count() or 8)
+                threads = min(32, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 8))
                 _folder.encode_paths(enc, paths[:min(512, len(paths))], cfg, apply_rms=True, loader_threads=threads)   # warm-up
                 t1 = time.perf_counter()
                 _, st_f = _folder.encode_paths(enc, paths, cfg, apply_rms=True, loader_threads=threads)
@@ -261,8 +261,8 @@ def main():
                 dt = time.perf_counter() - t1
             line["from_files"] = {"value": round(args.files / dt, 1), "unit": "files/s", "files": args.files,
                                   "loader_threads": threads, "failed": int((st_f != 0).sum()),
-                                  "note": "folder.encode_paths: amph_wav_read_many (4x chunk length read for the file-level RMS) -> "
-                                          "pinned -> HBM -> encode; page cache warm; never the headline value"}
+                                  "note": "folder.encode_paths: amph_wav_read_many on the host thread pool -> pinned -> HBM -> encode "
+                                          "(file-level RMS); page cache warm; never the headline value"}
         if world == 1 and args.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(cfg, spec, state, pcm_host[:4000], args.cpu_seconds)
         print(json.dumps(line), flush=True)
