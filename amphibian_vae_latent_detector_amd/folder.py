@@ -60,7 +60,7 @@ def _dist_info(group=None) -> Tuple[int, int]:
 
 
 def encode_paths(encoder, paths: Sequence[Path], cfg: FrontendConfig, *, apply_rms: bool = False,
-                 loader_threads: int = 8, file_batch: int = 4096) -> Tuple[torch.Tensor, np.ndarray]:
+                 loader_threads: int = 8, file_batch: int = 2048) -> Tuple[torch.Tensor, np.ndarray]:
     """Decode + encode a list of WAVs on this rank's GPU.
     Returns (Z [n, D] float32 device tensor, status [n] int32; 0 = ok)."""
     sess = encoder.session(cfg)
@@ -80,17 +80,40 @@ def encode_paths(encoder, paths: Sequence[Path], cfg: FrontendConfig, *, apply_r
             except OSError:
                 pass
         max_samples = max(cfg.n_samples, min(max_samples, (longest + 7) // 8 * 8))      # rows stay 16-byte aligned
-    for off in range(0, n, file_batch):
-        part = paths[off:off + file_batch]
-        pcm, lengths, st, pin = wavio.read_many_pcm16(part, cfg.sr, max_samples, n_threads=loader_threads, pinned=True)
+    # two reusable pinned slots: a host thread parses batch b + 1 (the C call releases the GIL) while batch b is
+    # copied to the device and encoded
+    import threading
+    offs = list(range(0, n, file_batch))
+    results = {}
+
+    with torch.cuda.device(sess.device):                  # pinned slots are allocated by THIS thread, on this rank's device
+        slots = [wavio.PINNED.rows(k, min(file_batch, n), max_samples) for k in range(min(2, len(offs)))]
+
+    def read(bi):
+        part_ = paths[offs[bi]:offs[bi] + file_batch]
+        rows = slots[bi & 1][:len(part_)]
         try:
-            status[off:off + len(part)] = st
-            dev_pcm = torch.from_numpy(pcm).to(sess.device, non_blocking=True)
-            sess.encode(dev_pcm, lengths=lengths, apply_rms=apply_rms, out_mu=Z[off:off + len(part)])
-            torch.cuda.current_stream(sess.device).synchronize()
-        finally:
-            del pcm
-            wavio.free_pinned(pin)
+            results[bi] = (rows,) + wavio.read_many_into(rows, part_, cfg.sr, n_threads=loader_threads)
+        except Exception as e:  # noqa: BLE001
+            results[bi] = e
+
+    reader = threading.Thread(target=read, args=(0,)) if offs else None
+    if reader:
+        reader.start()
+    for bi, off in enumerate(offs):
+        part = paths[off:off + file_batch]
+        reader.join()
+        got = results.pop(bi)
+        if isinstance(got, Exception):
+            raise got
+        pcm, lengths, st = got
+        if bi + 1 < len(offs):
+            reader = threading.Thread(target=read, args=(bi + 1,))
+            reader.start()
+        status[off:off + len(part)] = st
+        dev_pcm = torch.from_numpy(pcm).to(sess.device, non_blocking=True)
+        sess.encode(dev_pcm, lengths=lengths, apply_rms=apply_rms, out_mu=Z[off:off + len(part)])
+        torch.cuda.current_stream(sess.device).synchronize()      # the slot is reused two batches later
         # files the native reader declined (stereo, another subtype, another sample rate): the general loader
         # (channel mean, libsndfile scaling, GPU resampler) one file at a time, as librosa.load would
         for i in np.nonzero(st == N_UNSUPPORTED)[0]:
