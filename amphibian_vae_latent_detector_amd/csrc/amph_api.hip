@@ -1172,6 +1172,7 @@ int amph_resample_f32(amph_ctx* c, const float* d_in, int n_rows, int n_in, int 
     for (int i = 0; i + 1 < n_window; ++i) delta[i] = win[i + 1] - win[i];
     HIP_TRY(c, hipMemcpyAsync(c->d_rs_win, win, (size_t)n_window * sizeof(double), hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(c->d_rs_delta, delta, (size_t)n_window * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipStreamSynchronize(s));                      // rs_host may be rewritten by the next call (any stream)
     ResampleParams p;
     p.x = d_in; p.in_stride = n_in; p.n_in = n_in; p.y = d_out; p.out_stride = out_stride; p.n_out = n_out; p.n_fix = n_fix;
     p.win = c->d_rs_win; p.delta = c->d_rs_delta; p.nwin = n_window; p.num_table = num_table; p.index_step = index_step;

@@ -207,7 +207,8 @@ int amph_decide_map(amph_ctx* ctx, const float* d_z, int64_t n_rows, int dim,
  * samples at row stride out_stride.  h_half_window is the UNSCALED half window of the
  * filter (resampy.filters.sinc_window output, float64 [n_window]), num_table its
  * samples per zero crossing; the library applies resampy's ratio scaling and builds the
- * interpolation deltas.  Parity unpinned (resampy and its table are absent from the
+ * interpolation deltas (uploaded per call: the call synchronises `stream` twice and is meant
+ * for ingest, not for a hot loop).  Parity unpinned (resampy and its table are absent from the
  * build image; oracle/resample.py restates the published algorithm).
  * ------------------------------------------------------------------------- */
 int amph_resample_length(int n_in, int orig_sr, int target_sr);
