@@ -89,7 +89,7 @@ const char* amph_last_error(const amph_ctx* ctx);   /* ctx may be NULL: create-t
 
 /* Tuning knobs (all have working defaults):
  *   "lanes"            1..8  HIP streams + workspaces the encode entry points spread their
- *                            batches over (default 2; lane 0 is the caller's stream, the
+ *                            batches over (default 4; lane 0 is the caller's stream, the
  *                            others are forked from / joined to it with events)
  *   "stft_waves"       4/12  waves per STFT workgroup: 12 = one 768-thread workgroup per CU (three waves
  *                            per SIMD; the default when its LDS image fits 160 KB), 4 = two 256-thread ones
