@@ -774,7 +774,6 @@ __global__ __launch_bounds__(256) void k_conv_gemm_f3(ConvGemmParams p) {
     const float* wp1 = wp0 + 32ll * p.K_pad;
     int l_left = n_slices;                               // slices until the pointer wraps
     float4 sb0a, sb0b, sb1a, sb1b, sb2a, sb2b;           // B register stages
-    bool b_primed = false;
     float4 e_sc0, e_sc1, e_sc2, e_sc3, e_sh0, e_sh1, e_sh2, e_sh3;
     {
         const int nb = n_blk + (wave & 1) * 32 + 4 * (lane >> 5);
@@ -789,29 +788,31 @@ __global__ __launch_bounds__(256) void k_conv_gemm_f3(ConvGemmParams p) {
         e_sh3 = nb + 24 < p.N ? *reinterpret_cast<const float4*>(p.shift + nb + 24) : z4;
     }
     if ((int)blockIdx.x < n_tiles) AMPH_F3_FETCH_PATCH(blockIdx.x)
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const int m_blk = tile * BM;
-#ifdef AMPH_STAMPS
-    AMPH_GSTAMP(q_tile)
-#endif
-
-    // ---- image patch of this tile (whole output rows of one chunk): fetched one tile ahead (all loads of a fetch are
-    //      issued together and land under the previous tile's main loop; staged per element with a load -> LDS write
-    //      per trip it was ~4 us of serialised round trips per tile)
-    const int b = m_blk / ohw, oh_first = (m_blk - b * ohw) / p.OW;
-#pragma unroll
-    for (int u = 0; u < PU; ++u)
-        if (tid + 256 * u < n_patch) patch[tid + 256 * u] = pf[u];
-    // ---- valid-tap masks of the two A rows: horizontal validity is tile-independent (hm*), the vertical one depends on
-    //      the tile's first output row only
-    unsigned vmask0 = 0, vmask1 = 0;
-    {
-        const int ihA = (oh_first + ohl0) * p.stride - p.pad, ihB = (oh_first + ohl1) * p.stride - p.pad;
-        for (int kh = 0; kh < p.k; ++kh) {
-            const unsigned rowbits = ((1u << p.k) - 1u) << (kh * p.k);
-            if (m_blk + r0 < p.M && ihA + kh >= 0 && ihA + kh < p.H) vmask0 |= hm0 & rowbits;
-            if (m_blk + r0 + 32 < p.M && ihB + kh >= 0 && ihB + kh < p.H) vmask1 |= hm1 & rowbits;
-        }
+    // ---- compute-side state (the slice whose A stage is being recomputed): its tile's valid-tap masks and patch buffer.
+    //      The slice stream is CONTINUOUS across this workgroup's tiles: slices 9 and 10 of a tile are slices 0 and 1 of
+    //      its next tile (the B pointer is cyclic, the LDS ring and the stage rotation line up because 9 % 3 == 0), so
+    //      steps 7 and 8 - which used to recompute all-zero stages - prepare the next tile from the SECOND patch buffer
+    //      and only the first tile pays a prologue.
+    float* patch_a = patch;
+    float* patch_b = patch + ((n_patch + 3) & ~3);
+    float* patch_c = patch_a;                            // patch of the tile being COMPUTED
+    unsigned vmc0 = 0, vmc1 = 0;
+#define AMPH_F3_MASKS(t_)                                                                  \
+    {                                                                                      \
+        const int mb_ = (t_) * BM;                                                         \
+        const int b_ = mb_ / ohw, ohf_ = (mb_ - b_ * ohw) / p.OW;                          \
+        const int ihA = (ohf_ + ohl0) * p.stride - p.pad, ihB = (ohf_ + ohl1) * p.stride - p.pad; \
+        vmc0 = 0; vmc1 = 0;                                                                \
+        for (int kh = 0; kh < p.k; ++kh) {                                                 \
+            const unsigned rowbits = ((1u << p.k) - 1u) << (kh * p.k);                     \
+            if (mb_ + r0 < p.M && ihA + kh >= 0 && ihA + kh < p.H) vmc0 |= hm0 & rowbits;  \
+            if (mb_ + r0 + 32 < p.M && ihB + kh >= 0 && ihB + kh < p.H) vmc1 |= hm1 & rowbits; \
+        }                                                                                  \
+    }
+#define AMPH_F3_WRITE_PATCH(dst_)                                                          \
+    {                                                                                      \
+        _Pragma("unroll") for (int u = 0; u < PU; ++u)                                     \
+            if (tid + 256 * u < n_patch) (dst_)[tid + 256 * u] = pf[u];                    \
     }
     int c_kpos = 0, c_kh = 0, c_kw = 0;                  // tap of the next slice to COMPUTE (wave-uniform)
     float4 a0, a1;                                       // the A stage being computed (rows r0, r0 + 32)
@@ -831,8 +832,8 @@ __global__ __launch_bounds__(256) void k_conv_gemm_f3(ConvGemmParams p) {
     // window of row i for the tap being computed (taps past the end have no mask bit: all zero)
 #define AMPH_F3_WINDOW(i)                                                                  \
     {                                                                                      \
-        ok##i = (vmask##i >> c_kpos) & 1u;                                                 \
-        const float* pp_ = patch + (ok##i ? rowbase##i + (c_kh * p.s1 * PW + c_kw * p.s1) : 0); \
+        ok##i = (vmc##i >> c_kpos) & 1u;                                                   \
+        const float* pp_ = patch_c + (ok##i ? rowbase##i + (c_kh * p.s1 * PW + c_kw * p.s1) : 0); \
         pv##i##_0 = pp_[0]; pv##i##_1 = pp_[1]; pv##i##_2 = pp_[2];                        \
         pv##i##_3 = pp_[PW]; pv##i##_4 = pp_[PW + 1]; pv##i##_5 = pp_[PW + 2];             \
         pv##i##_6 = pp_[2 * PW]; pv##i##_7 = pp_[2 * PW + 1]; pv##i##_8 = pp_[2 * PW + 2]; \
@@ -955,15 +956,17 @@ __global__ __launch_bounds__(256) void k_conv_gemm_f3(ConvGemmParams p) {
         f0a = n0a; f0b = n0b;                                                              \
     }
 
-    // prologue: B of slices 0, 1, 2 into the register stages; A of slices 0 and 1 computed; 0 and 1 on to LDS
-    if (!b_primed) {
-        AMPH_F3_LOADB(0)
-        AMPH_F3_LOADB(1)
-        AMPH_F3_LOADB(2)
-        b_primed = true;
+
+    // ---- first tile: patch, masks, B slices 0..2, A of slices 0 and 1, on to LDS buffers 0 and 1
+    if ((int)blockIdx.x < n_tiles) {
+        AMPH_F3_WRITE_PATCH(patch_a)
+        AMPH_F3_MASKS(blockIdx.x)
     }
+    AMPH_F3_LOADB(0)
+    AMPH_F3_LOADB(1)
+    AMPH_F3_LOADB(2)
     __syncthreads();                                     // the patch is staged
-    if (tile + (int)gridDim.x < n_tiles) AMPH_F3_FETCH_PATCH(tile + gridDim.x)
+    if ((int)(blockIdx.x + gridDim.x) < n_tiles) AMPH_F3_FETCH_PATCH(blockIdx.x + gridDim.x)
     AMPH_F3_COMPUTE_ALL()
     AMPH_F3_STORE(0, 0)
     AMPH_F3_COMPUTE_ALL()
@@ -971,53 +974,60 @@ __global__ __launch_bounds__(256) void k_conv_gemm_f3(ConvGemmParams p) {
     __syncthreads();
     float4 f0a, f0b;
     AMPH_P3_READ(f0a, f0b, 0, 0)
-#ifdef AMPH_STAMPS
-    AMPH_GSTAMP(q_loop)
-    q_pro += q_loop - q_tile;
-#endif
-    int ks = 0;
-    for (; ks + 3 <= n_slices; ks += 3) {
+
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int m_blk = tile * BM;
+        const int nt = tile + (int)gridDim.x;
+        const bool has_next = nt < n_tiles;
+        float* patch_n = patch_c == patch_a ? patch_b : patch_a;
+        AMPH_F3_STEP(0, 0, 2)                            // slices 0..2 multiplied, 2..4 recomputed
+        AMPH_F3_STEP(1, 1, 0)
+        AMPH_F3_STEP(2, 2, 1)
+        // the next tile's patch goes to the spare buffer (last read at step 6 of the previous tile; first read at
+        // step 7 of this one, several barriers from here), the patch after it into the registers
+        if (has_next) AMPH_F3_WRITE_PATCH(patch_n)
+        if (nt + (int)gridDim.x < n_tiles) AMPH_F3_FETCH_PATCH(nt + gridDim.x)
         AMPH_F3_STEP(0, 0, 2)
         AMPH_F3_STEP(1, 1, 0)
         AMPH_F3_STEP(2, 2, 1)
-    }
-    if (ks < n_slices) {
-        AMPH_F3_STEP(0, 0, 2)
-        if (ks + 1 < n_slices) AMPH_F3_STEP(1, 1, 0)
-    }
-
-#ifdef AMPH_STAMPS
-    { unsigned long long q_e; AMPH_GSTAMP(q_e) q_main += q_e - q_loop; }
-#endif
-    // epilogue on the transposed accumulator: lane = row m, register group g = channels n0 .. n0 + 3
-    {
-        const int m = m_blk + row_tile * 32 + (lane & 31);
-        if (m < p.M) {
+        AMPH_F3_STEP(0, 0, 2)                            // slice 6 multiplied, 8 recomputed
+        // the compute side moves on to the next tile (no tile: empty masks -> all-zero stages, never multiplied)
+        c_kpos = 0; c_kh = 0; c_kw = 0;
+        if (has_next) { AMPH_F3_MASKS(nt) patch_c = patch_n; }
+        else { vmc0 = 0; vmc1 = 0; }
+        AMPH_F3_STEP(1, 1, 0)                            // slices 7, 8 multiplied; the NEXT tile's 0, 1 recomputed
+        AMPH_F3_STEP(2, 2, 1)
+        // epilogue on the transposed accumulator: lane = row m, register group g = channels n0 .. n0 + 3
+        {
+            const int m = m_blk + row_tile * 32 + (lane & 31);
+            if (m < p.M) {
 #define AMPH_F3_OUT(g)                                                                     \
-            {                                                                              \
-                const int n0 = n_blk + col_tile * 32 + 8 * g + 4 * (lane >> 5);            \
-                if (n0 < p.N) {                                                            \
-                    float4 v;                                                              \
-                    v.x = fmaxf(fmaf(acc[4 * g], e_sc##g.x, e_sh##g.x), 0.0f);             \
-                    v.y = fmaxf(fmaf(acc[4 * g + 1], e_sc##g.y, e_sh##g.y), 0.0f);         \
-                    v.z = fmaxf(fmaf(acc[4 * g + 2], e_sc##g.z, e_sh##g.z), 0.0f);         \
-                    v.w = fmaxf(fmaf(acc[4 * g + 3], e_sc##g.w, e_sh##g.w), 0.0f);         \
-                    *reinterpret_cast<float4*>(p.y + (long long)m * p.N + n0) = v;         \
-                }                                                                          \
-            }
-            AMPH_F3_OUT(0) AMPH_F3_OUT(1) AMPH_F3_OUT(2) AMPH_F3_OUT(3)
+                {                                                                          \
+                    const int n0 = n_blk + col_tile * 32 + 8 * g + 4 * (lane >> 5);        \
+                    if (n0 < p.N) {                                                        \
+                        float4 v;                                                          \
+                        v.x = fmaxf(fmaf(acc[4 * g], e_sc##g.x, e_sh##g.x), 0.0f);         \
+                        v.y = fmaxf(fmaf(acc[4 * g + 1], e_sc##g.y, e_sh##g.y), 0.0f);     \
+                        v.z = fmaxf(fmaf(acc[4 * g + 2], e_sc##g.z, e_sh##g.z), 0.0f);     \
+                        v.w = fmaxf(fmaf(acc[4 * g + 3], e_sc##g.w, e_sh##g.w), 0.0f);     \
+                        *reinterpret_cast<float4*>(p.y + (long long)m * p.N + n0) = v;     \
+                    }                                                                      \
+                }
+                AMPH_F3_OUT(0) AMPH_F3_OUT(1) AMPH_F3_OUT(2) AMPH_F3_OUT(3)
 #undef AMPH_F3_OUT
+            }
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
     }
-    }   // tile loop (the last step's barrier has retired every LDS read of this tile)
 #ifdef AMPH_STAMPS
     if (tid == 0 && p.stamps) {
         unsigned long long q_end;
         AMPH_GSTAMP(q_end)
         unsigned long long* o = p.stamps + (size_t)blockIdx.x * 8;
-        o[0] = q_p1; o[1] = q_pro; o[2] = q_p2; o[3] = q_bar; o[4] = q_end - q_begin;   // sums over this workgroup's tiles
+        o[0] = q_p1; o[1] = 0; o[2] = q_p2; o[3] = q_bar; o[4] = q_end - q_begin;   // sums over this workgroup's tiles
         o[5] = __builtin_amdgcn_s_memrealtime() - q_rt0;
-        o[6] = q_main;                                 // main-loop cycles (all tiles)
+        o[6] = 0;
         o[7] = q_rt0 & 0xffffffffull;
     }
 #endif
@@ -1026,11 +1036,12 @@ __global__ __launch_bounds__(256) void k_conv_gemm_f3(ConvGemmParams p) {
 static size_t conv_gemm_f3_lds(const ConvGemmParams& p, int bm) {
     const int n_oh = bm / p.OW;
     const int rows = ((n_oh - 1) * p.stride + p.k - 1) * p.s1 + p.k1;
-    return ((size_t)3 * (bm + kBN) * kLdsRow + (size_t)rows * (p.W0 + 2 * p.p1)) * sizeof(float);
+    const size_t patch = ((size_t)rows * (p.W0 + 2 * p.p1) + 3) & ~(size_t)3;          // two buffers (current / next tile)
+    return ((size_t)3 * (bm + kBN) * kLdsRow + 2 * patch) * sizeof(float);
 }
 bool conv_gemm_f3_ok(const ConvGemmParams& p, int bm) {
     const int ohw = p.OH * p.OW;
-    return bm == 64 && p.img != nullptr && p.k1 == 3 && p.C_in == kBK && p.K == p.K_pad && p.k * p.k <= 32 && p.splits == 1 && (p.N % 4) == 0 &&
+    return bm == 64 && p.img != nullptr && p.k1 == 3 && p.C_in == kBK && p.K == p.K_pad && p.k == 3 && p.splits == 1 && (p.N % 4) == 0 &&
            p.epilogue == 0 && ohw % bm == 0 && bm % p.OW == 0 && conv_gemm_f3_lds(p, bm) <= 80 * 1024 && (p.K_pad / kBK) % 3 == 0 &&
            (((bm / p.OW - 1) * p.stride + p.k - 1) * p.s1 + 3) * (p.W0 + 2 * p.p1) <= 256 * 8;
 }
