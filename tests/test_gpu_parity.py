@@ -254,10 +254,10 @@ def test_config1_100_chunks_tiny_vae_end_to_end(env):
     assert np.array_equal(z[49], z[99])                                  # silence -> identical latents
 
 
-def test_config2_thesis_shape_subset_and_full_size_properties(env):
+def test_config2_thesis_shape_all_10000_chunks_and_full_size_properties(env):
     """BASELINE.json configs[1]: 10k chunks, thesis-shape encoder (latent_dim 32), batch 256, fp32.
-    Oracle diff on a 320-chunk subset; on all 10 000: determinism, batch-composition
-    invariance, permutation equivariance, finiteness."""
+    Oracle diff on ALL 10 000 chunks (the CPU restatement single-threaded: ~15 s), plus determinism,
+    batch-composition invariance, permutation equivariance, finiteness."""
     cfg = env.cfg
     enc, tenc, spec = _encoders(env, "thesis-shape", max_batch=256)
     sess = enc.session(cfg)
@@ -267,8 +267,15 @@ def test_config2_thesis_shape_subset_and_full_size_properties(env):
     mu, _, ok = sess.encode(dev_pcm, apply_rms=True)
     z = mu.cpu().numpy()
     assert z.shape == (n, 32) and np.isfinite(z).all() and int(ok.sum()) == n - n // 50
-    sub = np.r_[0:256, 4990:5022, 9968:10000]
-    _assert_latents(z[sub], _oracle_latents(env, tenc, pcm[sub], cfg))
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)                                             # a batch-1 loop fanned out over all cores crawls
+    try:
+        z_cpu = _oracle_latents(env, tenc, pcm, cfg)
+    finally:
+        torch.set_num_threads(threads)
+    _assert_latents(z, z_cpu)
+    rel = np.linalg.norm(z - z_cpu, axis=1) / np.maximum(np.linalg.norm(z_cpu, axis=1), 1e-30)
+    print(f"\n[config 2, all {n} chunks] max rel L2 vs CPU oracle: {rel.max():.3e}, median {np.median(rel):.3e}")
     mu2, _, _ = sess.encode(dev_pcm, apply_rms=True)
     assert torch.equal(mu, mu2)                                          # deterministic
     perm = torch.from_numpy(np.random.default_rng(0).permutation(n)).to(DEV)
