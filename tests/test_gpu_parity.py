@@ -420,6 +420,17 @@ def test_unsupported_and_invalid_configurations_raise(env):
     enc, _, _ = _encoders(env, "tiny")
     with pytest.raises(RuntimeError, match="front end produces"):
         enc.session(replace(env.cfg, target_frames=96))
+    # tuning knobs: bad values are rejected, and every workgroup shape of the STFT kernel gives the same bits
+    sess = env.AmphSession(env.cfg, None, None, DEV, max_batch=8)
+    for key, bad in (("stft_waves", 5), ("frames_per_block", 6), ("lanes", 0), ("no_such_knob", 1)):
+        with pytest.raises(env.N.AmphError):
+            sess.configure(key, bad)
+    y = env.ofe.pcm16_to_float(env.synth([0, 1, 2, 49, 4], env.cfg.n_samples, env.cfg.sr))
+    ref = sess.mel_power(y)                                   # default: 12 waves x 12 frames
+    for waves, ft in ((4, 8), (4, 16), (12, 8), (12, 12)):
+        sess.configure("frames_per_block", ft)
+        sess.configure("stft_waves", waves)
+        assert torch.equal(sess.mel_power(y), ref), (waves, ft)
 
 
 # ----------------------------------------------------------------------------- K6: radial decision
