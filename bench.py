@@ -92,6 +92,9 @@ def main():
     ap.add_argument("--files", type=int, default=0, help="also time the end-to-end folder ingest on this many WAV files "
                                                          "(written to a temp dir first; parse + H2D + encode; never the headline value)")
     ap.add_argument("--lanes", type=int, default=0, help="HIP streams the batches are spread over (0 = library default)")
+    ap.add_argument("--bf16", action="store_true", help="BASELINE.json configs[3]: encoder in bf16 (weights, activations, "
+                                                        "bf16 MFMA, fp32 accumulate); relaxes the parity bar to ~5e-3, "
+                                                        "so it is never the default / headline configuration")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -122,6 +125,8 @@ def main():
     state = random_init_state(spec, seed=0)
     enc = HipEncoder(spec, state, dev, max_batch=args.batch)
     sess = enc.session(cfg)
+    if args.bf16:
+        sess.configure("bf16_encoder", 1)
     D = spec.latent_dim
 
     # synthetic chunks of this rank's shard (distinct per rank), resident in HBM before timing
@@ -175,6 +180,7 @@ def main():
     sess.profile_enable(False)
 
     if rank == 0:
+        peak_mfma = 2500.0 if args.bf16 else PEAK_F32_MFMA_TFLOPS      # dense bf16 MFMA peak / f32-input MFMA peak
         total_chunks = world * args.chunks * args.steps
         value = total_chunks / elapsed
         launches = max(1, prof["launches"])
@@ -183,8 +189,8 @@ def main():
         is_mfma = prof["stage"].startswith("conv") and prof["stage"] != "conv1" or prof["stage"] == "head_gemm"
         if is_mfma:
             ach = prof["flops_per_chunk"] * chunks_per_launch / (ms * 1e-3) / 1e12
-            roof = {"kernel": prof["stage"], "bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None}
+            roof = {"kernel": prof["stage"], "bound": "mfma", "achieved": round(ach, 3), "peak": peak_mfma,
+                    "unit": "TFLOP/s", "frac": round(ach / peak_mfma, 4), "traffic": None}
         else:
             ach = prof["bytes_per_chunk"] * chunks_per_launch / (ms * 1e-3) / 1e9
             roof = {"kernel": prof["stage"], "bound": "hbm", "achieved": round(ach, 2), "peak": PEAK_HBM_GBS,
@@ -199,7 +205,7 @@ def main():
         # (bench.py cannot run rocprofv3 on itself); null when the profile has no entry for the kernel
         try:
             tr = json.load(open(ROOT / "profiles" / "r01_traffic_v4.json"))["kernels"].get(prof["stage"])
-            if tr and args.batch == 256 and args.preset == "bench-1s" and args.spec == "thesis-shape":
+            if tr and args.batch == 256 and args.preset == "bench-1s" and args.spec == "thesis-shape" and not args.bf16:
                 roof["traffic"] = tr["traffic_bytes"]
                 roof["traffic_source"] = "profiles/r01_traffic_v4.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
                 roof["algorithmic_bytes_per_launch"] = int(prof["bytes_per_chunk"] * args.batch)
@@ -216,10 +222,11 @@ def main():
         line = {
             "metric": "1 s audio chunks encoded to latent/sec", "value": round(value, 1), "unit": "chunks/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16 encoder (fp32 front end, fp32 accumulate)" if args.bf16 else "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE.json configs[1]: {args.chunks} synthetic {cfg.duration:g} s / {cfg.sr} Hz PCM16 chunks per GPU "
                                    f"resident in HBM, preset {args.preset}, {args.spec} VAE encoder (latent_dim {D}), "
-                                   f"batch {args.batch}, RMS normalise + mel + encoder, fp32",
+                                   f"batch {args.batch}, RMS normalise + mel + encoder, " + ("bf16 encoder" if args.bf16 else "fp32"),
                        "chunks_per_gpu": args.chunks, "batch": args.batch, "lanes": n_lanes,
                        "parallelism": f"dp{world} (chunk shards, 1 all-gather)"},
             "roofline": roof,
@@ -228,7 +235,7 @@ def main():
             "kernels_isolated": [
                 {"kernel": s["stage"], "ms_per_launch": round(s["total_ms"] / s["launches"], 5),
                  **({"bound": "mfma", "achieved_TFLOPs": round(s["flops_per_chunk"] * args.chunks / s["total_ms"] / 1e9, 2),
-                     "frac": round(s["flops_per_chunk"] * args.chunks / s["total_ms"] / 1e9 / PEAK_F32_MFMA_TFLOPS, 4)}
+                     "frac": round(s["flops_per_chunk"] * args.chunks / s["total_ms"] / 1e9 / peak_mfma, 4)}
                     if (s["stage"].startswith("conv") and s["stage"] != "conv1") or s["stage"] == "head_gemm" else
                     {"bound": "hbm", "achieved_GBps": round(s["bytes_per_chunk"] * args.chunks / s["total_ms"] / 1e6, 1),
                      "frac": round(s["bytes_per_chunk"] * args.chunks / s["total_ms"] / 1e6 / PEAK_HBM_GBS, 5)})}
