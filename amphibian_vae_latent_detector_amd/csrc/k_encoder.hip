@@ -440,7 +440,7 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvGemmParams p) {
 // ----------------------------------------------------------------------------
 #define AMPH_SB() __builtin_amdgcn_sched_barrier(0)
 
-template <int BM>
+template <int BM, bool ACC2>
 __global__ __launch_bounds__(256) void k_conv_gemm_p3(ConvGemmParams p) {
     static_assert(BM == 64, "one 32x32 tile per wave");
     constexpr int A_ROWS = BM / 32;
@@ -538,9 +538,9 @@ __global__ __launch_bounds__(256) void k_conv_gemm_p3(ConvGemmParams p) {
         *reinterpret_cast<float4*>(b_ + 32 * kLdsRow) = sb##q##b;                          \
     }
 
-    f32x16 acc;
+    f32x16 acc, acc2;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    for (int r = 0; r < 16; ++r) acc[r] = acc2[r] = 0.0f;
     const int row_tile = wave >> 1, col_tile = wave & 1;
     const float* a_rd = As + (row_tile * 32 + (lane & 31)) * kLdsRow + 4 * (lane >> 5);
     const float* b_rd = Bs + (col_tile * 32 + (lane & 31)) * kLdsRow + 4 * (lane >> 5);
@@ -552,6 +552,10 @@ __global__ __launch_bounds__(256) void k_conv_gemm_p3(ConvGemmParams p) {
 // row m, registers 4g..4g+3 = four consecutive channels n), so the epilogue is 4 x 16-byte stores per lane instead of
 // 16 dword stores (store issue was ~7k cycles per tile).  Products commute: the sums are bit-identical.
 #define AMPH_P3_MFMA(x_, y_) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(y_, x_, acc, 0, 0, 0);
+// ACC2: the odd k-steps go to a second accumulator, so that no MFMA waits on the one in flight
+#define AMPH_P3_MFMB(x_, y_)                                                               \
+    if constexpr (ACC2) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(y_, x_, acc2, 0, 0, 0); \
+    else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(y_, x_, acc, 0, 0, 0);
 #ifdef AMPH_STAMPS
 #define AMPH_P3_T(v_) AMPH_GSTAMP(v_)
 #define AMPH_P3_WAITLOADS() asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -575,7 +579,7 @@ __global__ __launch_bounds__(256) void k_conv_gemm_p3(ConvGemmParams p) {
         AMPH_SB();                                                                         \
         AMPH_P3_LOADB(QL)                                                                  \
         AMPH_SB();                                                                         \
-        AMPH_P3_MFMA(f0a.y, f0b.y)                                                         \
+        AMPH_P3_MFMB(f0a.y, f0b.y)                                                         \
         AMPH_SB();                                                                         \
         AMPH_P3_READ(f2a, f2b, R, 2)                                                       \
         AMPH_SB();                                                                         \
@@ -583,7 +587,7 @@ __global__ __launch_bounds__(256) void k_conv_gemm_p3(ConvGemmParams p) {
         AMPH_SB();                                                                         \
         AMPH_P3_LOADA0(QL)                                                                 \
         AMPH_SB();                                                                         \
-        AMPH_P3_MFMA(f0a.w, f0b.w)                                                         \
+        AMPH_P3_MFMB(f0a.w, f0b.w)                                                         \
         AMPH_SB();                                                                         \
         AMPH_P3_LOADA1(QL)                                                                 \
         AMPH_SB();                                                                         \
@@ -591,7 +595,7 @@ __global__ __launch_bounds__(256) void k_conv_gemm_p3(ConvGemmParams p) {
         AMPH_SB();                                                                         \
         AMPH_P3_READ(f3a, f3b, R, 3)                                                       \
         AMPH_SB();                                                                         \
-        AMPH_P3_MFMA(f1a.y, f1b.y)                                                         \
+        AMPH_P3_MFMB(f1a.y, f1b.y)                                                         \
         AMPH_SB();                                                                         \
         AMPH_P3_ADV1()                                                                     \
         AMPH_SB();                                                                         \
@@ -599,7 +603,7 @@ __global__ __launch_bounds__(256) void k_conv_gemm_p3(ConvGemmParams p) {
         AMPH_SB();                                                                         \
         AMPH_P3_ADV2()                                                                     \
         AMPH_SB();                                                                         \
-        AMPH_P3_MFMA(f1a.w, f1b.w)                                                         \
+        AMPH_P3_MFMB(f1a.w, f1b.w)                                                         \
         AMPH_P3_MFMA(f2a.x, f2b.x)                                                         \
         AMPH_SB();                                                                         \
         AMPH_P3_T(ts1)                                                                     \
@@ -607,16 +611,16 @@ __global__ __launch_bounds__(256) void k_conv_gemm_p3(ConvGemmParams p) {
         AMPH_P3_T(ts2)                                                                     \
         AMPH_P3_STORE(QS, (R + 2) % 3)                                                     \
         AMPH_SB();                                                                         \
-        AMPH_P3_MFMA(f2a.y, f2b.y)                                                         \
+        AMPH_P3_MFMB(f2a.y, f2b.y)                                                         \
         AMPH_P3_MFMA(f2a.z, f2b.z)                                                         \
-        AMPH_P3_MFMA(f2a.w, f2b.w)                                                         \
+        AMPH_P3_MFMB(f2a.w, f2b.w)                                                         \
         AMPH_P3_MFMA(f3a.x, f3b.x)                                                         \
         AMPH_SB();                                                                         \
         AMPH_P3_READ(n0a, n0b, (R + 1) % 3, 0)                                             \
         AMPH_SB();                                                                         \
-        AMPH_P3_MFMA(f3a.y, f3b.y)                                                         \
+        AMPH_P3_MFMB(f3a.y, f3b.y)                                                         \
         AMPH_P3_MFMA(f3a.z, f3b.z)                                                         \
-        AMPH_P3_MFMA(f3a.w, f3b.w)                                                         \
+        AMPH_P3_MFMB(f3a.w, f3b.w)                                                         \
         AMPH_SB();                                                                         \
         AMPH_P3_T(ts3)                                                                     \
         __syncthreads();                                                                   \
@@ -658,6 +662,10 @@ __global__ __launch_bounds__(256) void k_conv_gemm_p3(ConvGemmParams p) {
         o[6] = o[7] = 0;
     }
 #endif
+    if constexpr (ACC2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
+    }
     // epilogue on the transposed accumulator: lane = row m, register group g = channels n0 .. n0 + 3
     {
         const int m = m_blk + row_tile * 32 + (lane & 31);
@@ -667,6 +675,212 @@ __global__ __launch_bounds__(256) void k_conv_gemm_p3(ConvGemmParams p) {
             for (int g = 0; g < 4; ++g) {
                 const int n0 = n_blk + col_tile * 32 + 8 * g + 4 * (lane >> 5);
                 if (n0 < p.N) {                                                      // N % 4 == 0 (host check)
+                    float4 v = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+                    if (p.epilogue == 0) {
+                        const float4 sc = *reinterpret_cast<const float4*>(p.scale + n0);
+                        const float4 sh = *reinterpret_cast<const float4*>(p.shift + n0);
+                        v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.0f); v.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.0f);
+                        v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.0f); v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.0f);
+                    }
+                    *reinterpret_cast<float4*>(ybase + (long long)m * p.N + n0) = v;
+                }
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------
+// Wave-specialised form of k_conv_gemm_p3 ("w3") for grids that leave one MFMA wave per SIMD (conv4: 256
+// workgroups, the head: 128..256): 8 waves, waves 0-3 only read fragments and issue MFMAs, waves 4-7 only load
+// global memory and store the LDS slice buffers.  A SIMD then holds one wave of each kind: the MFMA wave's issue
+// stream carries no VMEM / address / ds_write instruction, and the producer has a whole slice time per slice.
+// Same buffers, same barrier per slice, same MFMA order as p3 => bit-identical results.
+// ----------------------------------------------------------------------------
+template <int BM>
+__global__ __launch_bounds__(512) void k_conv_gemm_w3(ConvGemmParams p) {
+    static_assert(BM == 64, "one 32x32 tile per MFMA wave");
+    constexpr int A_ROWS = BM / 32;
+    constexpr int kABuf = BM * kLdsRow, kBBuf = kBN * kLdsRow;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* As = reinterpret_cast<float*>(smem);                         // [3][BM][36]
+    float* Bs = As + 3 * kABuf;                                         // [3][64][36]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m_blk = blockIdx.x * BM, n_blk = blockIdx.y * kBN;
+    const int n_slices = p.K_pad / kBK;
+    const int sps = n_slices / p.splits;
+    const int ks_begin = blockIdx.z * sps, ks_end = ks_begin + sps;
+
+    if (wave >= 4) {
+        // ------------------------------------------------------------ producer waves
+        const int ptid = tid - 256;
+        const int c4 = ptid & 7, r0 = ptid >> 3;
+        const float* pa[A_ROWS];
+        unsigned vmask[A_ROWS];
+        const int ohw = p.OH * p.OW;
+#pragma unroll
+        for (int i = 0; i < A_ROWS; ++i) {
+            const int m = m_blk + r0 + 32 * i;
+            const bool mv = m < p.M;
+            const int mm = mv ? m : 0;
+            const int b = mm / ohw, rem = mm - b * ohw;
+            const int oh = rem / p.OW, ow = rem - oh * p.OW;
+            const int ih0 = oh * p.stride - p.pad, iw0 = ow * p.stride - p.pad;
+            pa[i] = p.x + (long long)b * p.H * p.W * p.C_in + ((long long)ih0 * p.W + iw0) * p.C_in + 4 * c4;
+            unsigned vm = 0;
+            for (int kh = 0; kh < p.k; ++kh)
+                for (int kw = 0; kw < p.k; ++kw)
+                    if (mv && ih0 + kh >= 0 && ih0 + kh < p.H && iw0 + kw >= 0 && iw0 + kw < p.W) vm |= 1u << (kh * p.k + kw);
+            vmask[i] = vm;
+        }
+        const float *pa0 = pa[0], *pa1 = pa[1];
+        const unsigned vmask0 = vmask[0], vmask1 = vmask[1];
+        const float* wp0 = p.w + (long long)(n_blk + r0) * p.K_pad + 4 * c4 + ks_begin * kBK;
+        const float* wp1 = wp0 + 32ll * p.K_pad;
+        int l_kpos = (ks_begin * kBK) / p.C_in;
+        int l_ci0 = ks_begin * kBK - l_kpos * p.C_in;
+        int l_kh = l_kpos / p.k, l_kw = l_kpos - l_kh * p.k;
+        int l_left = sps;
+        float4 sa0x, sa0y, sa1x, sa1y, sa2x, sa2y;
+        float4 sb0a, sb0b, sb1a, sb1b, sb2a, sb2b;
+        const int st_off = r0 * kLdsRow + 4 * c4;
+        // slice s is consumed from buffer s % 3 while slice s+2 (stage QS) goes to buffer (s+2) % 3 and slice s+3 is loaded
+#ifdef AMPH_STAMPS
+        unsigned long long pt0 = 0, pt1 = 0, pt2 = 0, pt3 = 0, pq_issue = 0, pq_wait = 0, pq_bar = 0;
+#define AMPH_W3_PT(v_) AMPH_GSTAMP(v_)
+#define AMPH_W3_PWAIT() asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+#define AMPH_W3_PACC() { pq_issue += pt1 - pt0; pq_wait += pt2 - pt1; pq_bar += pt3 - pt2; }
+#else
+#define AMPH_W3_PT(v_)
+#define AMPH_W3_PWAIT()
+#define AMPH_W3_PACC()
+#endif
+#define AMPH_W3_PSTEP(R, QL, QS)                                                           \
+    {                                                                                      \
+        AMPH_W3_PT(pt0)                                                                    \
+        AMPH_P3_LOAD(QL)                                                                   \
+        AMPH_SB();                                                                         \
+        AMPH_W3_PT(pt1)                                                                    \
+        AMPH_W3_PWAIT()                                                                    \
+        AMPH_W3_PT(pt2)                                                                    \
+        AMPH_P3_STORE(QS, (R + 2) % 3)                                                     \
+        AMPH_SB();                                                                         \
+        __syncthreads();                                                                   \
+        AMPH_W3_PT(pt3)                                                                    \
+        AMPH_W3_PACC()                                                                     \
+    }
+        AMPH_P3_LOAD(0)
+        AMPH_P3_LOAD(1)
+        AMPH_P3_LOAD(2)
+        AMPH_P3_STORE(0, 0)
+        AMPH_P3_STORE(1, 1)
+        __syncthreads();
+        int ks = ks_begin;
+        for (; ks + 3 <= ks_end; ks += 3) {
+            AMPH_W3_PSTEP(0, 0, 2)
+            AMPH_W3_PSTEP(1, 1, 0)
+            AMPH_W3_PSTEP(2, 2, 1)
+        }
+        if (ks < ks_end) {
+            AMPH_W3_PSTEP(0, 0, 2)
+            if (ks + 1 < ks_end) AMPH_W3_PSTEP(1, 1, 0)
+        }
+#ifdef AMPH_STAMPS
+        if (tid == 256 && p.stamps) {
+            unsigned long long* o = p.stamps + (size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8;
+            o[1] = pq_wait; o[2] = pq_bar; o[6] = pq_issue;
+        }
+#endif
+        return;
+    }
+
+    // ---------------------------------------------------------------- MFMA waves
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    const int row_tile = wave >> 1, col_tile = wave & 1;
+    const float* a_rd = As + (row_tile * 32 + (lane & 31)) * kLdsRow + 4 * (lane >> 5);
+    const float* b_rd = Bs + (col_tile * 32 + (lane & 31)) * kLdsRow + 4 * (lane >> 5);
+#ifdef AMPH_STAMPS
+    unsigned long long ct0 = 0, ct1 = 0, ct2 = 0, cq_mfma = 0, cq_bar = 0, cq_begin = 0;
+    AMPH_GSTAMP(cq_begin)
+    const unsigned long long cq_rt0 = __builtin_amdgcn_s_memrealtime();
+#define AMPH_W3_CT(v_) AMPH_GSTAMP(v_)
+#define AMPH_W3_CACC() { cq_mfma += ct1 - ct0; cq_bar += ct2 - ct1; }
+#else
+#define AMPH_W3_CT(v_)
+#define AMPH_W3_CACC()
+#endif
+#define AMPH_W3_CSTEP(R)                                                                   \
+    {                                                                                      \
+        float4 f1a, f1b, f2a, f2b, f3a, f3b, n0a, n0b;                                     \
+        AMPH_W3_CT(ct0)                                                                    \
+        AMPH_P3_READ(f1a, f1b, R, 1)                                                       \
+        AMPH_P3_READ(f2a, f2b, R, 2)                                                       \
+        AMPH_SB();                                                                         \
+        AMPH_P3_MFMA(f0a.x, f0b.x)                                                         \
+        AMPH_P3_MFMA(f0a.y, f0b.y)                                                         \
+        AMPH_P3_MFMA(f0a.z, f0b.z)                                                         \
+        AMPH_P3_MFMA(f0a.w, f0b.w)                                                         \
+        AMPH_SB();                                                                         \
+        AMPH_P3_READ(f3a, f3b, R, 3)                                                       \
+        AMPH_SB();                                                                         \
+        AMPH_P3_MFMA(f1a.x, f1b.x)                                                         \
+        AMPH_P3_MFMA(f1a.y, f1b.y)                                                         \
+        AMPH_P3_MFMA(f1a.z, f1b.z)                                                         \
+        AMPH_P3_MFMA(f1a.w, f1b.w)                                                         \
+        AMPH_SB();                                                                         \
+        AMPH_P3_READ(n0a, n0b, (R + 1) % 3, 0)                                             \
+        AMPH_SB();                                                                         \
+        AMPH_P3_MFMA(f2a.x, f2b.x)                                                         \
+        AMPH_P3_MFMA(f2a.y, f2b.y)                                                         \
+        AMPH_P3_MFMA(f2a.z, f2b.z)                                                         \
+        AMPH_P3_MFMA(f2a.w, f2b.w)                                                         \
+        AMPH_P3_MFMA(f3a.x, f3b.x)                                                         \
+        AMPH_P3_MFMA(f3a.y, f3b.y)                                                         \
+        AMPH_P3_MFMA(f3a.z, f3b.z)                                                         \
+        AMPH_P3_MFMA(f3a.w, f3b.w)                                                         \
+        AMPH_SB();                                                                         \
+        AMPH_W3_CT(ct1)                                                                    \
+        __syncthreads();                                                                   \
+        AMPH_W3_CT(ct2)                                                                    \
+        AMPH_W3_CACC()                                                                     \
+        f0a = n0a; f0b = n0b;                                                              \
+    }
+    if (p.flags & 1) __builtin_amdgcn_s_setprio(2);
+    __syncthreads();
+    float4 f0a, f0b;
+    AMPH_P3_READ(f0a, f0b, 0, 0)
+    {
+        int ks = ks_begin;
+        for (; ks + 3 <= ks_end; ks += 3) {
+            AMPH_W3_CSTEP(0)
+            AMPH_W3_CSTEP(1)
+            AMPH_W3_CSTEP(2)
+        }
+        if (ks < ks_end) {
+            AMPH_W3_CSTEP(0)
+            if (ks + 1 < ks_end) AMPH_W3_CSTEP(1)
+        }
+    }
+#ifdef AMPH_STAMPS
+    if (tid == 0 && p.stamps) {
+        unsigned long long q_end;
+        AMPH_GSTAMP(q_end)
+        unsigned long long* o = p.stamps + (size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8;
+        o[0] = cq_mfma; o[3] = cq_bar; o[4] = q_end - cq_begin;
+        o[5] = __builtin_amdgcn_s_memrealtime() - cq_rt0;
+        o[7] = 0;
+    }
+#endif
+    {
+        const int m = m_blk + row_tile * 32 + (lane & 31);
+        float* ybase = p.y + (p.epilogue == 1 ? (long long)blockIdx.z * p.M * p.N : 0ll);
+        if (m < p.M) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n0 = n_blk + col_tile * 32 + 8 * g + 4 * (lane >> 5);
+                if (n0 < p.N) {
                     float4 v = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
                     if (p.epilogue == 0) {
                         const float4 sc = *reinterpret_cast<const float4*>(p.scale + n0);
@@ -1082,7 +1296,13 @@ void launch_conv_gemm(const ConvGemmParams& p_in, int bm, bool fuse, hipStream_t
     const size_t lds = std::max(conv_gemm_lds(p, bm, fuse), (size_t)g_gemm_min_lds);
     if (!fuse && (g_gemm_flags & 2) == 0 && conv_gemm_p3_ok(p, bm)) {
         const size_t lds3 = std::max((size_t)3 * (bm + kBN) * kLdsRow * sizeof(float), (size_t)g_gemm_min_lds);
-        hipLaunchKernelGGL((k_conv_gemm_p3<64>), grid, dim3(256), lds3, s, p);
+        // gemm_flags bit 3: wave-specialised variant for every p3 launch; bit 4: only for grids of at most one workgroup per CU
+        const unsigned n_wg = grid.x * grid.y * grid.z;
+        if ((g_gemm_flags & 8) || ((g_gemm_flags & 16) && n_wg <= (unsigned)g_num_cus))
+            hipLaunchKernelGGL((k_conv_gemm_w3<64>), grid, dim3(512), lds3, s, p);
+        else
+            if (g_gemm_flags & 32) hipLaunchKernelGGL((k_conv_gemm_p3<64, true>), grid, dim3(256), lds3, s, p);
+            else hipLaunchKernelGGL((k_conv_gemm_p3<64, false>), grid, dim3(256), lds3, s, p);
         return;
     }
     if (fuse && (g_gemm_flags & 4) == 0 && conv_gemm_f3_ok(p, bm)) {

@@ -18,6 +18,8 @@ cfg = PRESETS["bench-1s"]
 spec = SPECS["thesis-shape"](64, 64)
 s = HipEncoder(spec, random_init_state(spec, 0), "cuda:0", max_batch=256).session(cfg)
 s.configure("lanes", 1)
+if len(sys.argv) > 1:
+    s.configure("gemm_flags", int(sys.argv[1]))
 x = torch.randn(256, 1, 64, 64, device="cuda:0")
 for _ in range(3):
     s.encoder_forward(x)
