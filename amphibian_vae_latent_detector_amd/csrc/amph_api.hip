@@ -830,6 +830,22 @@ int amph_configure(amph_ctx* c, const char* key, int value) {
             (void)hipMemcpy(h.data(), c->d_gstamps + (size_t)gi * 8192 * 8, h.size() * 8, hipMemcpyDeviceToHost);
             double s8[8] = {0};
             for (int w = 0; w < nwg; ++w) for (int k = 0; k < 8; ++k) s8[k] += (double)h[(size_t)w * 8 + k];
+            if (gi == 0) {                                  // fused kernel: o[6] packs three 20-bit sums (mid-tile patch work, masks, epilogue)
+                double m3[3] = {0, 0, 0};
+                for (int w = 0; w < nwg; ++w) {
+                    const unsigned long long v = h[(size_t)w * 8 + 6];
+                    m3[0] += (double)(v >> 40); m3[1] += (double)((v >> 20) & 0xfffff); m3[2] += (double)(v & 0xfffff);
+                }
+                double pr[4] = {0, 0, 0, 0};
+                for (int w = 0; w < nwg; ++w) {
+                    const unsigned long long v = h[(size_t)w * 8 + 1];
+                    for (int k = 0; k < 4; ++k) pr[k] += 2.0 * (double)((v >> (48 - 16 * k)) & 0xffff);
+                }
+                fprintf(stderr, "  gemm 0 prologue cycles per workgroup: setup %.0f, patch fetch + write + masks %.0f, B loads + barrier %.0f, two stages + barrier %.0f\n",
+                        pr[0] / nwg, pr[1] / nwg, pr[2] / nwg, pr[3] / nwg);
+                fprintf(stderr, "  gemm 0 out-of-step cycles per workgroup: patch write+fetch %.0f, masks %.0f, epilogue %.0f\n",
+                        m3[0] / nwg, m3[1] / nwg, m3[2] / nwg);
+            }
             fprintf(stderr, "  gemm %d (%d workgroups) mean cycles per workgroup:", gi, nwg);
             for (int k = 0; k < 8; ++k) fprintf(stderr, " %8.0f", s8[k] / nwg);
             unsigned long long t0 = ~0ull, t1 = 0, l0 = ~0ull, l1 = 0;

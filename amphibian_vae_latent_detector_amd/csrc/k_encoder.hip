@@ -19,6 +19,7 @@
 namespace amph {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // ----------------------------------------------------------------------------
 // First layer (C_in == 1): direct convolution.  One thread = one output pixel x
@@ -906,6 +907,16 @@ __global__ __launch_bounds__(512) void k_conv_gemm_w3(ConvGemmParams p) {
 // LDS 3 x 36.9 KB + patch = 62 KB: two workgroups per CU, so the 1024 workgroups of a 256-chunk batch
 // run as two full rounds (the first-generation fused kernel: 43 KB, three per CU, 768 + 256).
 // ----------------------------------------------------------------------------
+// floor(n / d) for 0 <= n < 2^22, d >= 1, rcp = 1.0f / d: float estimate (off by at most one) + correction.  The
+// compiler's 32-bit integer division is ~40 VALU instructions; the fused kernel's per-thread setup had a dozen of them.
+__device__ __forceinline__ int div_small(int n, int d, float rcp) {
+    int q = (int)((float)n * rcp);
+    int r = n - q * d;
+    if (r < 0) { --q; r += d; }
+    if (r >= d) ++q;
+    return q;
+}
+
 template <int BM>
 __global__ __launch_bounds__(256) void k_conv_gemm_f3(ConvGemmParams p) {
     static_assert(BM == 64, "one 32x32 tile per wave");
@@ -920,6 +931,7 @@ __global__ __launch_bounds__(256) void k_conv_gemm_f3(ConvGemmParams p) {
     const int n_blk = blockIdx.y * kBN;
     const int ohw = p.OH * p.OW;
     const int PW = p.W0 + 2 * p.p1;
+    const float rcp_pw = 1.0f / (float)PW, rcp_ow = 1.0f / (float)p.OW, rcp_ohw = 1.0f / (float)ohw;
     const int n_tiles = (p.M + BM - 1) / BM;
 #ifdef AMPH_STAMPS
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, q_p1 = 0, q_ld = 0, q_p2 = 0, q_bar = 0, q_begin = 0, q_loop = 0,
@@ -939,19 +951,26 @@ __global__ __launch_bounds__(256) void k_conv_gemm_f3(ConvGemmParams p) {
         sc1 = *reinterpret_cast<const float4*>(p.scale1 + 4 * c4);
         sh1 = *reinterpret_cast<const float4*>(p.shift1 + 4 * c4);
     }
+    // the same constants as channel PAIRS: layer 1 is evaluated with v_pk_fma_f32 (two IEEE fmas per instruction, so the
+    // per-element FMA order - and every bit of the result - is k_conv_first's).  f32 MFMAs and VALU instructions time-share
+    // a SIMD (tools/probe/mfma_valu_samewave.hip: every VALU instruction adds its 4 cycles to the MFMA time, and every
+    // MFMA -> VALU -> MFMA switch 12 more), so the recompute is paid in full: halve its instruction count, keep it in few gaps.
+#define AMPH_F3_PAIR(t) const f32x2 wl_##t = {w1_##t.x, w1_##t.y}, wh_##t = {w1_##t.z, w1_##t.w};
+    AMPH_F3_PAIR(0) AMPH_F3_PAIR(1) AMPH_F3_PAIR(2) AMPH_F3_PAIR(3) AMPH_F3_PAIR(4) AMPH_F3_PAIR(5) AMPH_F3_PAIR(6) AMPH_F3_PAIR(7) AMPH_F3_PAIR(8)
+    const f32x2 sc1l = {sc1.x, sc1.y}, sc1h = {sc1.z, sc1.w}, sh1l = {sh1.x, sh1.y}, sh1h = {sh1.z, sh1.w};
     // PERSISTENT over the M tiles (grid.x = two workgroups per CU): a second dispatch round of this kernel started
     // 5-8 us after the workgroups it replaced had ended (start / end histograms of the stamps build); one resident
     // round that walks its tiles has no such gap
     // patch slots of this thread (the same for every tile): element i = tid + 256 u of the [rows][PW] patch
     constexpr int PU = 8;
-    const int n_oh = BM / p.OW;
+    const int n_oh = div_small(BM, p.OW, rcp_ow);
     const int r1_cnt = (n_oh - 1) * p.stride + p.k;
     const int n_patch = ((r1_cnt - 1) * p.s1 + 3) * PW;            // <= 256 * PU (host check)
     int p_r[PU], p_ic[PU];
 #pragma unroll
     for (int u = 0; u < PU; ++u) {
         const int i = tid + 256 * u;
-        const int r = i / PW, ic = i - r * PW - p.p1;
+        const int r = div_small(i, PW, rcp_pw), ic = i - r * PW - p.p1;
         p_r[u] = i < n_patch ? r : -(1 << 20);                       // out-of-patch slots never pass the row test
         p_ic[u] = (ic >= 0 && ic < p.W0) ? ic : -1;
     }
@@ -959,26 +978,28 @@ __global__ __launch_bounds__(256) void k_conv_gemm_f3(ConvGemmParams p) {
 #define AMPH_F3_FETCH_PATCH(tile_)                                                         \
     {                                                                                      \
         const int mb_ = (tile_) * BM;                                                      \
-        const int b_ = mb_ / ohw, ohf_ = (mb_ - b_ * ohw) / p.OW;                          \
+        const int b_ = div_small(mb_, ohw, rcp_ohw), ohf_ = div_small(mb_ - b_ * ohw, p.OW, rcp_ow); \
         const int plo_ = (ohf_ * p.stride - p.pad) * p.s1 - p.p1;                          \
         const float* img_ = p.img + (long long)b_ * p.H0 * p.W0;                           \
         _Pragma("unroll") for (int u = 0; u < PU; ++u) {                                   \
             const int ir_ = plo_ + p_r[u];                                                 \
-            pf[u] = (ir_ >= 0 && ir_ < p.H0 && p_ic[u] >= 0) ? img_[ir_ * p.W0 + p_ic[u]] : 0.0f; \
+            pf[u] = *((ir_ >= 0 && ir_ < p.H0 && p_ic[u] >= 0) ? img_ + ir_ * p.W0 + p_ic[u] : p.zeros); \
         }                                                                                  \
     }
+    // every load of the prologue is in flight before anything waits: the first tile's patch here, the B slices below
+    if ((int)blockIdx.x < n_tiles) AMPH_F3_FETCH_PATCH(blockIdx.x)
     // per-thread A rows r0 and r0 + 32 inside a tile (whole output rows of one chunk, so tile-independent): local output
     // row / column, window origin in the patch for tap (0, 0) and the horizontally valid taps
-    const int ohl0 = r0 / p.OW, owl0 = r0 - ohl0 * p.OW, ohl1 = (r0 + 32) / p.OW, owl1 = (r0 + 32) - ohl1 * p.OW;
+    const int ohl0 = div_small(r0, p.OW, rcp_ow), owl0 = r0 - ohl0 * p.OW, ohl1 = div_small(r0 + 32, p.OW, rcp_ow), owl1 = (r0 + 32) - ohl1 * p.OW;
     const int rowbase0 = (ohl0 * p.stride * p.s1) * PW + (owl0 * p.stride - p.pad) * p.s1;
     const int rowbase1 = (ohl1 * p.stride * p.s1) * PW + (owl1 * p.stride - p.pad) * p.s1;
-    unsigned hm0 = 0, hm1 = 0;
-    for (int kw = 0; kw < p.k; ++kw) {
-        const int iwA = owl0 * p.stride - p.pad + kw, iwB = owl1 * p.stride - p.pad + kw;
-        for (int kh = 0; kh < p.k; ++kh) {
-            if (iwA >= 0 && iwA < p.W) hm0 |= 1u << (kh * p.k + kw);
-            if (iwB >= 0 && iwB < p.W) hm1 |= 1u << (kh * p.k + kw);
-        }
+    unsigned hm0, hm1;                                   // k == 3 (host check): bit kh * 3 + kw
+    {
+        const int iwA = owl0 * p.stride - p.pad, iwB = owl1 * p.stride - p.pad;
+        hm0 = ((unsigned)iwA < (unsigned)p.W ? 0x049u : 0u) | ((unsigned)(iwA + 1) < (unsigned)p.W ? 0x092u : 0u) |
+              ((unsigned)(iwA + 2) < (unsigned)p.W ? 0x124u : 0u);
+        hm1 = ((unsigned)iwB < (unsigned)p.W ? 0x049u : 0u) | ((unsigned)(iwB + 1) < (unsigned)p.W ? 0x092u : 0u) |
+              ((unsigned)(iwB + 2) < (unsigned)p.W ? 0x124u : 0u);
     }
     // B (weight) slices do not depend on the tile: the load pointer runs CYCLICALLY over the K slices, so the last three
     // steps of a tile already fetch slices 0, 1, 2 for the next one (n_slices % 3 == 0: the stage rotation lines up) and
@@ -990,18 +1011,22 @@ __global__ __launch_bounds__(256) void k_conv_gemm_f3(ConvGemmParams p) {
     float4 sb0a, sb0b, sb1a, sb1b, sb2a, sb2b;           // B register stages
     float4 e_sc0, e_sc1, e_sc2, e_sc3, e_sh0, e_sh1, e_sh2, e_sh3;
     {
+        // the select is on the ADDRESS (columns past N read the zero line): a select on the loaded value makes the
+        // prologue wait for these loads - a full cold global round trip - before the patch fetch is even issued
         const int nb = n_blk + (wave & 1) * 32 + 4 * (lane >> 5);
-        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        e_sc0 = nb + 0 < p.N ? *reinterpret_cast<const float4*>(p.scale + nb + 0) : z4;
-        e_sc1 = nb + 8 < p.N ? *reinterpret_cast<const float4*>(p.scale + nb + 8) : z4;
-        e_sc2 = nb + 16 < p.N ? *reinterpret_cast<const float4*>(p.scale + nb + 16) : z4;
-        e_sc3 = nb + 24 < p.N ? *reinterpret_cast<const float4*>(p.scale + nb + 24) : z4;
-        e_sh0 = nb + 0 < p.N ? *reinterpret_cast<const float4*>(p.shift + nb + 0) : z4;
-        e_sh1 = nb + 8 < p.N ? *reinterpret_cast<const float4*>(p.shift + nb + 8) : z4;
-        e_sh2 = nb + 16 < p.N ? *reinterpret_cast<const float4*>(p.shift + nb + 16) : z4;
-        e_sh3 = nb + 24 < p.N ? *reinterpret_cast<const float4*>(p.shift + nb + 24) : z4;
+        e_sc0 = *reinterpret_cast<const float4*>(nb + 0 < p.N ? p.scale + nb + 0 : p.zeros);
+        e_sc1 = *reinterpret_cast<const float4*>(nb + 8 < p.N ? p.scale + nb + 8 : p.zeros);
+        e_sc2 = *reinterpret_cast<const float4*>(nb + 16 < p.N ? p.scale + nb + 16 : p.zeros);
+        e_sc3 = *reinterpret_cast<const float4*>(nb + 24 < p.N ? p.scale + nb + 24 : p.zeros);
+        e_sh0 = *reinterpret_cast<const float4*>(nb + 0 < p.N ? p.shift + nb + 0 : p.zeros);
+        e_sh1 = *reinterpret_cast<const float4*>(nb + 8 < p.N ? p.shift + nb + 8 : p.zeros);
+        e_sh2 = *reinterpret_cast<const float4*>(nb + 16 < p.N ? p.shift + nb + 16 : p.zeros);
+        e_sh3 = *reinterpret_cast<const float4*>(nb + 24 < p.N ? p.shift + nb + 24 : p.zeros);
     }
-    if ((int)blockIdx.x < n_tiles) AMPH_F3_FETCH_PATCH(blockIdx.x)
+#ifdef AMPH_STAMPS
+    unsigned long long pq0 = 0, pq1 = 0, pq2 = 0, pq3 = 0;
+    AMPH_GSTAMP(pq0)
+#endif
     // ---- compute-side state (the slice whose A stage is being recomputed): its tile's valid-tap masks and patch buffer.
     //      The slice stream is CONTINUOUS across this workgroup's tiles: slices 9 and 10 of a tile are slices 0 and 1 of
     //      its next tile (the B pointer is cyclic, the LDS ring and the stage rotation line up because 9 % 3 == 0), so
@@ -1014,14 +1039,14 @@ __global__ __launch_bounds__(256) void k_conv_gemm_f3(ConvGemmParams p) {
 #define AMPH_F3_MASKS(t_)                                                                  \
     {                                                                                      \
         const int mb_ = (t_) * BM;                                                         \
-        const int b_ = mb_ / ohw, ohf_ = (mb_ - b_ * ohw) / p.OW;                          \
+        const int b_ = div_small(mb_, ohw, rcp_ohw), ohf_ = div_small(mb_ - b_ * ohw, p.OW, rcp_ow); \
         const int ihA = (ohf_ + ohl0) * p.stride - p.pad, ihB = (ohf_ + ohl1) * p.stride - p.pad; \
-        vmc0 = 0; vmc1 = 0;                                                                \
-        for (int kh = 0; kh < p.k; ++kh) {                                                 \
-            const unsigned rowbits = ((1u << p.k) - 1u) << (kh * p.k);                     \
-            if (mb_ + r0 < p.M && ihA + kh >= 0 && ihA + kh < p.H) vmc0 |= hm0 & rowbits;  \
-            if (mb_ + r0 + 32 < p.M && ihB + kh >= 0 && ihB + kh < p.H) vmc1 |= hm1 & rowbits; \
-        }                                                                                  \
+        const unsigned rbA = ((unsigned)(ihA) < (unsigned)p.H ? 0x007u : 0u) | ((unsigned)(ihA + 1) < (unsigned)p.H ? 0x038u : 0u) | \
+                             ((unsigned)(ihA + 2) < (unsigned)p.H ? 0x1c0u : 0u);         /* k == 3 (host check) */ \
+        const unsigned rbB = ((unsigned)(ihB) < (unsigned)p.H ? 0x007u : 0u) | ((unsigned)(ihB + 1) < (unsigned)p.H ? 0x038u : 0u) | \
+                             ((unsigned)(ihB + 2) < (unsigned)p.H ? 0x1c0u : 0u);          \
+        vmc0 = mb_ + r0 < p.M ? hm0 & rbA : 0u;                                            \
+        vmc1 = mb_ + r0 + 32 < p.M ? hm1 & rbB : 0u;                                       \
     }
 #define AMPH_F3_WRITE_PATCH(dst_)                                                          \
     {                                                                                      \
@@ -1029,10 +1054,10 @@ __global__ __launch_bounds__(256) void k_conv_gemm_f3(ConvGemmParams p) {
             if (tid + 256 * u < n_patch) (dst_)[tid + 256 * u] = pf[u];                    \
     }
     int c_kpos = 0, c_kh = 0, c_kw = 0;                  // tap of the next slice to COMPUTE (wave-uniform)
-    float4 a0, a1;                                       // the A stage being computed (rows r0, r0 + 32)
+    f32x2 a0l, a0h, a1l, a1h;                            // the A stage being computed (rows r0, r0 + 32; channel pairs)
     float pv0_0, pv0_1, pv0_2, pv0_3, pv0_4, pv0_5, pv0_6, pv0_7, pv0_8;
     float pv1_0, pv1_1, pv1_2, pv1_3, pv1_4, pv1_5, pv1_6, pv1_7, pv1_8;
-    bool ok0 = false, ok1 = false;
+    float cap0 = 0.0f, cap1 = 0.0f;                      // +inf for a tap inside the image, 0 for a padded one
 #define AMPH_F3_LOADB(q)                                                                   \
     {                                                                                      \
         sb##q##a = *reinterpret_cast<const float4*>(wp0);                                  \
@@ -1046,21 +1071,23 @@ __global__ __launch_bounds__(256) void k_conv_gemm_f3(ConvGemmParams p) {
     // window of row i for the tap being computed (taps past the end have no mask bit: all zero)
 #define AMPH_F3_WINDOW(i)                                                                  \
     {                                                                                      \
-        ok##i = (vmc##i >> c_kpos) & 1u;                                                   \
-        const float* pp_ = patch_c + (ok##i ? rowbase##i + (c_kh * p.s1 * PW + c_kw * p.s1) : 0); \
+        const bool ok_ = (vmc##i >> c_kpos) & 1u;                                          \
+        cap##i = ok_ ? __builtin_inff() : 0.0f;                                            \
+        const float* pp_ = patch_c + (ok_ ? rowbase##i + (c_kh * p.s1 * PW + c_kw * p.s1) : 0); \
         pv##i##_0 = pp_[0]; pv##i##_1 = pp_[1]; pv##i##_2 = pp_[2];                        \
         pv##i##_3 = pp_[PW]; pv##i##_4 = pp_[PW + 1]; pv##i##_5 = pp_[PW + 2];             \
         pv##i##_6 = pp_[2 * PW]; pv##i##_7 = pp_[2 * PW + 1]; pv##i##_8 = pp_[2 * PW + 2]; \
     }
 #define AMPH_F3_TAP(i, t)                                                                  \
-    a##i.x = fmaf(pv##i##_##t, w1_##t.x, a##i.x); a##i.y = fmaf(pv##i##_##t, w1_##t.y, a##i.y); \
-    a##i.z = fmaf(pv##i##_##t, w1_##t.z, a##i.z); a##i.w = fmaf(pv##i##_##t, w1_##t.w, a##i.w);
-#define AMPH_F3_ZERO(i) a##i = make_float4(0.f, 0.f, 0.f, 0.f);
+    a##i##l = __builtin_elementwise_fma(f32x2{pv##i##_##t, pv##i##_##t}, wl_##t, a##i##l); \
+    a##i##h = __builtin_elementwise_fma(f32x2{pv##i##_##t, pv##i##_##t}, wh_##t, a##i##h);
+#define AMPH_F3_ZERO(i) a##i##l = f32x2{0.f, 0.f}; a##i##h = f32x2{0.f, 0.f};
+    // BN, then ReLU and the padding mask in one v_med3_f32: med3(x, 0, +inf) = max(x, 0), med3(x, 0, 0) = 0
 #define AMPH_F3_FIN(i)                                                                     \
-    a##i.x = ok##i ? fmaxf(fmaf(a##i.x, sc1.x, sh1.x), 0.0f) : 0.0f;                       \
-    a##i.y = ok##i ? fmaxf(fmaf(a##i.y, sc1.y, sh1.y), 0.0f) : 0.0f;                       \
-    a##i.z = ok##i ? fmaxf(fmaf(a##i.z, sc1.z, sh1.z), 0.0f) : 0.0f;                       \
-    a##i.w = ok##i ? fmaxf(fmaf(a##i.w, sc1.w, sh1.w), 0.0f) : 0.0f;
+    a##i##l = __builtin_elementwise_fma(a##i##l, sc1l, sh1l);                              \
+    a##i##h = __builtin_elementwise_fma(a##i##h, sc1h, sh1h);                              \
+    a##i##l.x = __builtin_amdgcn_fmed3f(a##i##l.x, 0.0f, cap##i); a##i##l.y = __builtin_amdgcn_fmed3f(a##i##l.y, 0.0f, cap##i); \
+    a##i##h.x = __builtin_amdgcn_fmed3f(a##i##h.x, 0.0f, cap##i); a##i##h.y = __builtin_amdgcn_fmed3f(a##i##h.y, 0.0f, cap##i);
 #define AMPH_F3_NEXT_TAP()                                                                 \
     {                                                                                      \
         ++c_kpos; ++c_kw;                                                                  \
@@ -1073,8 +1100,8 @@ __global__ __launch_bounds__(256) void k_conv_gemm_f3(ConvGemmParams p) {
     {                                                                                      \
         float* a_ = As + (buf_) * kABuf + st_off;                                          \
         float* b_ = Bs + (buf_) * kBBuf + st_off;                                          \
-        *reinterpret_cast<float4*>(a_) = a0;                                               \
-        *reinterpret_cast<float4*>(a_ + 32 * kLdsRow) = a1;                                \
+        *reinterpret_cast<float4*>(a_) = make_float4(a0l.x, a0l.y, a0h.x, a0h.y);          \
+        *reinterpret_cast<float4*>(a_ + 32 * kLdsRow) = make_float4(a1l.x, a1l.y, a1h.x, a1h.y); \
         *reinterpret_cast<float4*>(b_) = sb##q##a;                                         \
         *reinterpret_cast<float4*>(b_ + 32 * kLdsRow) = sb##q##b;                          \
     }
@@ -1108,52 +1135,35 @@ __global__ __launch_bounds__(256) void k_conv_gemm_f3(ConvGemmParams p) {
         AMPH_SB();                                                                         \
         AMPH_F3_LOADB(QL)                                                                  \
         AMPH_F3_WINDOW(0)                                                                  \
+        AMPH_F3_WINDOW(1)                                                                  \
         AMPH_SB();                                                                         \
         AMPH_P3_MFMA(f0a.y, f0b.y)                                                         \
         AMPH_SB();                                                                         \
         AMPH_P3_READ(f2a, f2b, R, 2)                                                       \
-        AMPH_F3_WINDOW(1)                                                                  \
         AMPH_SB();                                                                         \
         AMPH_P3_MFMA(f0a.z, f0b.z)                                                         \
-        AMPH_SB();                                                                         \
-        AMPH_F3_ZERO(0) AMPH_F3_TAP(0, 0) AMPH_F3_TAP(0, 1) AMPH_F3_TAP(0, 2)              \
-        AMPH_SB();                                                                         \
         AMPH_P3_MFMA(f0a.w, f0b.w)                                                         \
-        AMPH_SB();                                                                         \
-        AMPH_F3_TAP(0, 3) AMPH_F3_TAP(0, 4) AMPH_F3_TAP(0, 5)                              \
-        AMPH_SB();                                                                         \
         AMPH_P3_MFMA(f1a.x, f1b.x)                                                         \
         AMPH_SB();                                                                         \
         AMPH_P3_READ(f3a, f3b, R, 3)                                                       \
-        AMPH_F3_TAP(0, 6) AMPH_F3_TAP(0, 7) AMPH_F3_TAP(0, 8)                              \
-        AMPH_SB();                                                                         \
-        AMPH_P3_MFMA(f1a.y, f1b.y)                                                         \
-        AMPH_SB();                                                                         \
-        AMPH_F3_FIN(0)                                                                     \
-        AMPH_SB();                                                                         \
-        AMPH_P3_MFMA(f1a.z, f1b.z)                                                         \
-        AMPH_SB();                                                                         \
-        AMPH_F3_ZERO(1) AMPH_F3_TAP(1, 0) AMPH_F3_TAP(1, 1) AMPH_F3_TAP(1, 2)              \
-        AMPH_SB();                                                                         \
-        AMPH_P3_MFMA(f1a.w, f1b.w)                                                         \
-        AMPH_SB();                                                                         \
-        AMPH_F3_TAP(1, 3) AMPH_F3_TAP(1, 4) AMPH_F3_TAP(1, 5)                              \
-        AMPH_SB();                                                                         \
-        AMPH_P3_MFMA(f2a.x, f2b.x)                                                         \
-        AMPH_SB();                                                                         \
-        AMPH_F3_TAP(1, 6) AMPH_F3_TAP(1, 7) AMPH_F3_TAP(1, 8)                              \
-        AMPH_SB();                                                                         \
-        AMPH_P3_MFMA(f2a.y, f2b.y)                                                         \
-        AMPH_SB();                                                                         \
-        AMPH_F3_FIN(1)                                                                     \
+        AMPH_F3_ZERO(0) AMPH_F3_ZERO(1)                                                    \
+        AMPH_F3_TAP(0, 0) AMPH_F3_TAP(1, 0) AMPH_F3_TAP(0, 1) AMPH_F3_TAP(1, 1) AMPH_F3_TAP(0, 2) AMPH_F3_TAP(1, 2) \
+        AMPH_F3_TAP(0, 3) AMPH_F3_TAP(1, 3) AMPH_F3_TAP(0, 4) AMPH_F3_TAP(1, 4) AMPH_F3_TAP(0, 5) AMPH_F3_TAP(1, 5) \
+        AMPH_F3_TAP(0, 6) AMPH_F3_TAP(1, 6) AMPH_F3_TAP(0, 7) AMPH_F3_TAP(1, 7) AMPH_F3_TAP(0, 8) AMPH_F3_TAP(1, 8) \
+        AMPH_F3_FIN(0) AMPH_F3_FIN(1)                                                      \
         AMPH_F3_NEXT_TAP()                                                                 \
         AMPH_SB();                                                                         \
-        AMPH_P3_MFMA(f2a.z, f2b.z)                                                         \
+        AMPH_P3_MFMA(f1a.y, f1b.y)                                                         \
         AMPH_SB();                                                                         \
         AMPH_P3_T(ts1)                                                                     \
         AMPH_P3_T(ts2)                                                                     \
         AMPH_F3_STORE(QS, (R + 2) % 3)                                                     \
         AMPH_SB();                                                                         \
+        AMPH_P3_MFMA(f1a.z, f1b.z)                                                         \
+        AMPH_P3_MFMA(f1a.w, f1b.w)                                                         \
+        AMPH_P3_MFMA(f2a.x, f2b.x)                                                         \
+        AMPH_P3_MFMA(f2a.y, f2b.y)                                                         \
+        AMPH_P3_MFMA(f2a.z, f2b.z)                                                         \
         AMPH_P3_MFMA(f2a.w, f2b.w)                                                         \
         AMPH_P3_MFMA(f3a.x, f3b.x)                                                         \
         AMPH_SB();                                                                         \
@@ -1172,14 +1182,16 @@ __global__ __launch_bounds__(256) void k_conv_gemm_f3(ConvGemmParams p) {
 
 
     // ---- first tile: patch, masks, B slices 0..2, A of slices 0 and 1, on to LDS buffers 0 and 1
+    AMPH_F3_LOADB(0)                                     // issued before the patch is waited for
+    AMPH_F3_LOADB(1)
+    AMPH_F3_LOADB(2)
     if ((int)blockIdx.x < n_tiles) {
         AMPH_F3_WRITE_PATCH(patch_a)
         AMPH_F3_MASKS(blockIdx.x)
     }
-    AMPH_F3_LOADB(0)
-    AMPH_F3_LOADB(1)
-    AMPH_F3_LOADB(2)
+    AMPH_GSTAMP(pq1)
     __syncthreads();                                     // the patch is staged
+    AMPH_GSTAMP(pq2)
     if ((int)(blockIdx.x + gridDim.x) < n_tiles) AMPH_F3_FETCH_PATCH(blockIdx.x + gridDim.x)
     AMPH_F3_COMPUTE_ALL()
     AMPH_F3_STORE(0, 0)
@@ -1188,6 +1200,13 @@ __global__ __launch_bounds__(256) void k_conv_gemm_f3(ConvGemmParams p) {
     __syncthreads();
     float4 f0a, f0b;
     AMPH_P3_READ(f0a, f0b, 0, 0)
+#ifdef AMPH_STAMPS
+    unsigned long long tq0 = 0, tq1 = 0, q_mid = 0, q_msk = 0, q_epi = 0;
+    AMPH_GSTAMP(tq0)
+    q_pro = tq0 - q_begin;
+    pq3 = tq0;
+    q_pro = (((pq0 - q_begin) >> 1) << 48) | (((pq1 - pq0) >> 1) << 32) | (((pq2 - pq1) >> 1) << 16) | ((pq3 - pq2) >> 1);
+#endif
 
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int m_blk = tile * BM;
@@ -1199,19 +1218,33 @@ __global__ __launch_bounds__(256) void k_conv_gemm_f3(ConvGemmParams p) {
         AMPH_F3_STEP(2, 2, 1)
         // the next tile's patch goes to the spare buffer (last read at step 6 of the previous tile; first read at
         // step 7 of this one, several barriers from here), the patch after it into the registers
+        AMPH_GSTAMP(tq0)
         if (has_next) AMPH_F3_WRITE_PATCH(patch_n)
         if (nt + (int)gridDim.x < n_tiles) AMPH_F3_FETCH_PATCH(nt + gridDim.x)
+        AMPH_GSTAMP(tq1)
+#ifdef AMPH_STAMPS
+        q_mid += tq1 - tq0;
+#endif
         AMPH_F3_STEP(0, 0, 2)
         AMPH_F3_STEP(1, 1, 0)
         AMPH_F3_STEP(2, 2, 1)
         AMPH_F3_STEP(0, 0, 2)                            // slice 6 multiplied, 8 recomputed
         // the compute side moves on to the next tile (no tile: empty masks -> all-zero stages, never multiplied)
+        AMPH_GSTAMP(tq0)
         c_kpos = 0; c_kh = 0; c_kw = 0;
         if (has_next) { AMPH_F3_MASKS(nt) patch_c = patch_n; }
         else { vmc0 = 0; vmc1 = 0; }
+        AMPH_GSTAMP(tq1)
+#ifdef AMPH_STAMPS
+        q_msk += tq1 - tq0;
+#endif
         AMPH_F3_STEP(1, 1, 0)                            // slices 7, 8 multiplied; the NEXT tile's 0, 1 recomputed
         AMPH_F3_STEP(2, 2, 1)
-        // epilogue on the transposed accumulator: lane = row m, register group g = channels n0 .. n0 + 3
+        // epilogue on the transposed accumulator: lane = row m, register group g = channels n0 .. n0 + 3.  (A version that
+        // transposed each wave's tile through LDS so that every store instruction wrote 8 whole 128-byte lines instead of 32
+        // lines x 32 bytes was SLOWER, 2.65 k -> 4.1 k cycles per tile: the cost is the burst itself - all 512 workgroups
+        // store their 16 KB at about the same time - not the shape of the store instructions.)
+        AMPH_GSTAMP(tq0)
         {
             const int m = m_blk + row_tile * 32 + (lane & 31);
             if (m < p.M) {
@@ -1233,15 +1266,19 @@ __global__ __launch_bounds__(256) void k_conv_gemm_f3(ConvGemmParams p) {
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        AMPH_GSTAMP(tq1)
+#ifdef AMPH_STAMPS
+        q_epi += tq1 - tq0;
+#endif
     }
 #ifdef AMPH_STAMPS
     if (tid == 0 && p.stamps) {
         unsigned long long q_end;
         AMPH_GSTAMP(q_end)
         unsigned long long* o = p.stamps + (size_t)blockIdx.x * 8;
-        o[0] = q_p1; o[1] = 0; o[2] = q_p2; o[3] = q_bar; o[4] = q_end - q_begin;   // sums over this workgroup's tiles
+        o[0] = q_p1; o[1] = q_pro; o[2] = q_p2; o[3] = q_bar; o[4] = q_end - q_begin;   // sums over this workgroup's tiles
         o[5] = __builtin_amdgcn_s_memrealtime() - q_rt0;
-        o[6] = 0;
+        o[6] = (q_mid << 40) | (q_msk << 20) | q_epi;                                  // three 20-bit fields
         o[7] = q_rt0 & 0xffffffffull;
     }
 #endif
@@ -1256,6 +1293,7 @@ static size_t conv_gemm_f3_lds(const ConvGemmParams& p, int bm) {
 bool conv_gemm_f3_ok(const ConvGemmParams& p, int bm) {
     const int ohw = p.OH * p.OW;
     return bm == 64 && p.img != nullptr && p.k1 == 3 && p.C_in == kBK && p.K == p.K_pad && p.k == 3 && p.splits == 1 && (p.N % 4) == 0 &&
+           p.M < (1 << 22) && p.zeros != nullptr &&
            p.epilogue == 0 && ohw % bm == 0 && bm % p.OW == 0 && conv_gemm_f3_lds(p, bm) <= 80 * 1024 && (p.K_pad / kBK) % 3 == 0 &&
            (((bm / p.OW - 1) * p.stride + p.k - 1) * p.s1 + 3) * (p.W0 + 2 * p.p1) <= 256 * 8;
 }
