@@ -41,7 +41,9 @@ struct Workspace {
     int32_t* ok = nullptr;
     float* melpow = nullptr;
     float* image = nullptr;
-    std::vector<float*> act;               // one per conv layer
+    std::vector<float*> act;               // one per conv layer; each has act_guard[i] zero bytes in front (same allocation)
+    std::vector<void*> act_raw;            // the allocations
+    std::vector<int> act_guard;
     float* partial = nullptr;
 };
 
@@ -466,9 +468,16 @@ int alloc_lane(amph_ctx* c, Workspace& w, bool own_stream) {
             const amph_conv_layer& l = c->spec.conv[i];
             H = (H + 2 * l.pad - l.kernel) / l.stride + 1;
             W = (W + 2 * l.pad - l.kernel) / l.stride + 1;
-            float* p = nullptr;
-            HIP_TRY(c, hipMalloc((void**)&p, (size_t)MB * H * W * l.c_out * sizeof(float)));
-            w.act.push_back(p);
+            // the layer that READS this buffer (conv i+1, or the head as a H x W "convolution") takes its padded taps
+            // from a zero guard in front of it (k_conv_gemm_p3)
+            const size_t guard = i + 1 < c->spec.n_conv ? amph::conv_gemm_x_guard(c->spec.conv[i + 1].kernel, W, l.c_out)
+                                                        : amph::conv_gemm_x_guard(1, 1, H * W * l.c_out);     // the head: 1 x 1 over the flattened map
+            char* raw = nullptr;
+            HIP_TRY(c, hipMalloc((void**)&raw, guard + (size_t)MB * H * W * l.c_out * sizeof(float)));
+            HIP_TRY(c, hipMemset(raw, 0, guard));
+            w.act_raw.push_back(raw);
+            w.act_guard.push_back((int)guard);
+            w.act.push_back(reinterpret_cast<float*>(raw + guard));
         }
         HIP_TRY(c, hipMalloc((void**)&w.partial, (size_t)c->head_splits * MB * 2 * c->latent * sizeof(float)));
     }
@@ -478,7 +487,7 @@ int alloc_lane(amph_ctx* c, Workspace& w, bool own_stream) {
 void free_lane(Workspace& w) {
     auto fr = [](void* p) { if (p) (void)hipFree(p); };
     fr(w.scale); fr(w.ok); fr(w.melpow); fr(w.image);
-    for (auto p : w.act) fr(p);
+    for (auto p : w.act_raw) fr(p);
     fr(w.partial);
     if (w.done) (void)hipEventDestroy(w.done);
     if (w.stream) (void)hipStreamDestroy(w.stream);
@@ -583,6 +592,7 @@ int run_encoder(amph_ctx* c, Workspace& w, const float* d_x, int nb, float* d_mu
         ConvGemmParams& p = prm[gi];
         p = c->gemm[gi].prm;
         p.x = w.act[gi];
+        p.x_guard = w.act_guard[gi];
         p.M = nb * p.OH * p.OW;
         p.img = nullptr;
         p.zeros = c->d_zeros;

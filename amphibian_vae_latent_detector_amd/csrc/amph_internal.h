@@ -110,7 +110,8 @@ struct ConvGemmParams {      // implicit GEMM: M = B*OH*OW, N = C_out, K = k*k*C
     const float* scale1;     // [C_in]
     const float* shift1;     // [C_in]
     int H0, W0, k1, s1, p1;
-    const float* zeros;      // >= 16 bytes of zeros (16-byte aligned): source of padded taps in k_conv_gemm_p3
+    const float* zeros;      // >= 16 bytes of zeros (16-byte aligned): source of masked loads in the fused kernel
+    int x_guard;             // bytes of ZEROS in front of x (same allocation): padded taps of k_conv_gemm_p3 read there
     int flags;               // bit 1: use the first-generation kernel; bit 0: static issue priority from the wave's slot on its SIMD (see k_conv_gemm)
 #ifdef AMPH_STAMPS
     unsigned long long* stamps;   // diagnostic build: [workgroup][role][4]
@@ -131,6 +132,7 @@ extern int g_gemm_flags;
 extern int g_num_cus;
 extern int g_stft_grid;
 bool conv_gemm_can_fuse(const ConvGemmParams& p, int bm);
+size_t conv_gemm_x_guard(int k, int W, int C_in);          // zero guard k_conv_gemm_p3 needs in front of its input
 bool conv_gemm_f3_ok(const ConvGemmParams& p, int bm);   // second-generation fused kernel (64-row tiles, 32 first-layer channels)
 void launch_conv_gemm(const ConvGemmParams& p, int bm, bool fuse_first, hipStream_t s);
 void launch_head_reduce(const HeadReduceParams& p, int n_rows, hipStream_t s);

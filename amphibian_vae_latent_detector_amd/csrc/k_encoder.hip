@@ -441,10 +441,19 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvGemmParams p) {
 // ----------------------------------------------------------------------------
 #define AMPH_SB() __builtin_amdgcn_sched_barrier(0)
 
+// floor(n / d) for 0 <= n < 2^22, d >= 1, rcp = 1.0f / d: float estimate (off by at most one) + correction.  The
+// compiler's 32-bit integer division is ~40 VALU instructions; the fused kernel's per-thread setup had a dozen of them.
+__device__ __forceinline__ int div_small(int n, int d, float rcp) {
+    int q = (int)((float)n * rcp);
+    int r = n - q * d;
+    if (r < 0) { --q; r += d; }
+    if (r >= d) ++q;
+    return q;
+}
+
 template <int BM, bool ACC2>
 __global__ __launch_bounds__(256) void k_conv_gemm_p3(ConvGemmParams p) {
     static_assert(BM == 64, "one 32x32 tile per wave");
-    constexpr int A_ROWS = BM / 32;
     constexpr int kABuf = BM * kLdsRow, kBBuf = kBN * kLdsRow;          // floats per slice buffer
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* As = reinterpret_cast<float*>(smem);                         // [3][BM][36]
@@ -453,81 +462,119 @@ __global__ __launch_bounds__(256) void k_conv_gemm_p3(ConvGemmParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c4 = tid & 7, r0 = tid >> 3;
     const int m_blk = blockIdx.x * BM, n_blk = blockIdx.y * kBN;
-
-    // per-thread A rows: pointer to (window origin, channel 4*c4) of the NHWC input (never dereferenced
-    // for padded taps) and the bitmask of the taps that are in range
-    const float* pa[A_ROWS];
-    unsigned vmask[A_ROWS];
-    const int ohw = p.OH * p.OW;
-#pragma unroll
-    for (int i = 0; i < A_ROWS; ++i) {
-        const int m = m_blk + r0 + 32 * i;
-        const bool mv = m < p.M;
-        const int mm = mv ? m : 0;
-        const int b = mm / ohw, rem = mm - b * ohw;
-        const int oh = rem / p.OW, ow = rem - oh * p.OW;
-        const int ih0 = oh * p.stride - p.pad, iw0 = ow * p.stride - p.pad;
-        pa[i] = p.x + (long long)b * p.H * p.W * p.C_in + ((long long)ih0 * p.W + iw0) * p.C_in + 4 * c4;
-        unsigned vm = 0;
-        for (int kh = 0; kh < p.k; ++kh)
-            for (int kw = 0; kw < p.k; ++kw)
-                if (mv && ih0 + kh >= 0 && ih0 + kh < p.H && iw0 + kw >= 0 && iw0 + kw < p.W) vm |= 1u << (kh * p.k + kw);
-        vmask[i] = vm;
-    }
-    const float *pa0 = pa[0], *pa1 = pa[1];
-    const unsigned vmask0 = vmask[0], vmask1 = vmask[1];
     const int n_slices = p.K_pad / kBK;
     const int sps = n_slices / p.splits;
     const int ks_begin = blockIdx.z * sps, ks_end = ks_begin + sps;
-    const float* wp0 = p.w + (long long)(n_blk + r0) * p.K_pad + 4 * c4 + ks_begin * kBK;
-    const float* wp1 = wp0 + 32ll * p.K_pad;
 
-    // wave-uniform position of the next slice to LOAD: tap (kh, kw) = kpos, first channel ci0
-    int l_kpos = (ks_begin * kBK) / p.C_in;
-    int l_ci0 = ks_begin * kBK - l_kpos * p.C_in;
-    int l_kh = l_kpos / p.k, l_kw = l_kpos - l_kh * p.k;
-    int l_left = sps;                                   // slices not yet loaded (stays on the last one at the end)
-
+    // Addressing: buffer loads - a resource (SGPRs) + a 32-bit per-lane byte offset that never changes + a wave-uniform
+    // offset in an SGPR that scalar instructions advance (`buffer_load_dwordx4 v, v_off, s[rsrc], s_off offen`).  f32 MFMAs
+    // and VALU instructions time-share the SIMD (tools/probe/mfma_valu_samewave.hip), so every per-slice VALU instruction
+    // is MFMA time lost, and a load with one 32-bit address VGPR costs 11 cycles of issue in an MFMA gap against 26 for the
+    // 64-bit-VGPR-address form.  (Written as global loads from `uniform pointer + lane offset`, the compiler strength-
+    // reduces the sum back into a per-lane 64-bit pointer.)
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(p.x) - p.x_guard), 0, -1, 0x00020000);
+#define AMPH_P3_BUFLOAD(rs_, voff_, soff_) __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_, voff_, soff_, 0))
     // register stages (plain named variables: a struct passed to a lambda ends up in scratch memory)
     float4 sa0x, sa0y, sa1x, sa1y, sa2x, sa2y;           // A rows r0 and r0 + 32 of the three stages
     float4 sb0a, sb0b, sb1a, sb1b, sb2a, sb2b;
+    // B (weights [N][K_pad]): the three prologue slices are requested before any setup arithmetic
+    int w_soff = ks_begin * kBK * 4;                     // byte offset of the next B slice (wave-uniform)
+    const unsigned woff0 = ((unsigned)(n_blk + r0) * (unsigned)p.K_pad + 4u * c4) * 4u, woff1 = woff0 + 32u * (unsigned)p.K_pad * 4u;
+    {
+        const int o1 = sps > 1 ? kBK * 4 : 0, o2 = sps > 2 ? 2 * kBK * 4 : o1;          // slice min(s, sps - 1), as AMPH_P3_ADV1 clamps
+        sb0a = AMPH_P3_BUFLOAD(rs_w, woff0, w_soff);      sb0b = AMPH_P3_BUFLOAD(rs_w, woff1, w_soff);
+        sb1a = AMPH_P3_BUFLOAD(rs_w, woff0, w_soff + o1); sb1b = AMPH_P3_BUFLOAD(rs_w, woff1, w_soff + o1);
+        sb2a = AMPH_P3_BUFLOAD(rs_w, woff0, w_soff + o2); sb2b = AMPH_P3_BUFLOAD(rs_w, woff1, w_soff + o2);
+    }
+    // A (NHWC input): base = x - guard; lane offset = guard + (window origin, channel 4 c4) for a tap inside the image,
+    // 0 for a padded one - the address then falls into the zero guard the host keeps in front of x (conv_gemm_x_guard)
+    const int ohw = p.OH * p.OW;
+    const float rcp_ohw = 1.0f / (float)ohw, rcp_ow = 1.0f / (float)p.OW;
+    unsigned aoff0, aoff1, vmask0, vmask1;
+#define AMPH_P3_ROW(i)                                                                     \
+    {                                                                                      \
+        const int m = m_blk + r0 + 32 * i;                                                 \
+        const bool mv = m < p.M;                                                           \
+        const int mm = mv ? m : 0;                                                         \
+        const int b = div_small(mm, ohw, rcp_ohw), rem = mm - b * ohw;                     \
+        const int oh = div_small(rem, p.OW, rcp_ow), ow = rem - oh * p.OW;                 \
+        const int ih0 = oh * p.stride - p.pad, iw0 = ow * p.stride - p.pad;                \
+        aoff##i = (unsigned)p.x_guard + 4u * (unsigned)(((b * p.H + ih0) * p.W + iw0) * p.C_in + 4 * c4); \
+        unsigned vm = 0;                                                                   \
+        if (p.k == 3) {                                                                    \
+            const unsigned hb = ((unsigned)iw0 < (unsigned)p.W ? 0x049u : 0u) | ((unsigned)(iw0 + 1) < (unsigned)p.W ? 0x092u : 0u) | \
+                                ((unsigned)(iw0 + 2) < (unsigned)p.W ? 0x124u : 0u);       \
+            const unsigned rb = ((unsigned)ih0 < (unsigned)p.H ? 0x007u : 0u) | ((unsigned)(ih0 + 1) < (unsigned)p.H ? 0x038u : 0u) | \
+                                ((unsigned)(ih0 + 2) < (unsigned)p.H ? 0x1c0u : 0u);       \
+            vm = hb & rb;                                                                  \
+        } else {                                                                           \
+            for (int kh = 0; kh < p.k; ++kh)                                               \
+                for (int kw = 0; kw < p.k; ++kw)                                           \
+                    if ((unsigned)(ih0 + kh) < (unsigned)p.H && (unsigned)(iw0 + kw) < (unsigned)p.W) vm |= 1u << (kh * p.k + kw); \
+        }                                                                                  \
+        vmask##i = mv ? vm : 0u;                                                           \
+    }
+    AMPH_P3_ROW(0)
+    AMPH_P3_ROW(1)
+#undef AMPH_P3_ROW
+
+    // wave-uniform position of the next slice to LOAD: tap (kh, kw) = kpos, first channel ci0 - kept as the two things the
+    // loads use: the byte offset of (tap, ci0) inside a window, 4 ((kh W + kw) C_in + ci0), and the tap's mask bit.  In NHWC
+    // the next channel slice and the next tap of a row are both +128 bytes; only a new tap row adds 4 (W - k) C_in.
+    // (readfirstlane pins them to SGPRs: left alone, the compiler carries the tap index in a VGPR for the mask test and
+    // then wraps every buffer load whose scalar offset derives from it in a waterfall loop.)
+    int l_left = sps;                                   // slices not yet loaded (stays on the last one at the end)
+    int l_ci0, l_kw, x_soff;
+    unsigned l_bit;
+    {
+        const int kpos = (ks_begin * kBK) / p.C_in;
+        l_ci0 = ks_begin * kBK - kpos * p.C_in;
+        const int kh = kpos / p.k;
+        l_kw = kpos - kh * p.k;
+        x_soff = 4 * ((kh * p.W + l_kw) * p.C_in + l_ci0);
+        l_bit = 1u << kpos;
+    }
+    const int row_skip = 4 * (p.W - p.k) * p.C_in;
+
 // the load of one slice in pieces small enough for one 64-cycle MFMA shadow each (one wave per SIMD has no partner to
 // cover a long gap: with everything behind the first MFMA the second waited ~190 cycles for the issue stream)
 #define AMPH_P3_LOADB(q)                                                                   \
     {                                                                                      \
-        sb##q##a = *reinterpret_cast<const float4*>(wp0);                                  \
-        sb##q##b = *reinterpret_cast<const float4*>(wp1);                                  \
+        sb##q##a = AMPH_P3_BUFLOAD(rs_w, woff0, w_soff);                                   \
+        sb##q##b = AMPH_P3_BUFLOAD(rs_w, woff1, w_soff);                                   \
     }
 #define AMPH_P3_LOADA0(q)                                                                  \
     {                                                                                      \
-        const int koff_ = (l_kh * p.W + l_kw) * p.C_in + l_ci0;                            \
-        sa##q##x = *reinterpret_cast<const float4*>(((vmask0 >> l_kpos) & 1u) ? pa0 + koff_ : p.zeros); \
+        sa##q##x = AMPH_P3_BUFLOAD(rs_x, (vmask0 & l_bit) ? aoff0 : 0u, x_soff);           \
     }
 #define AMPH_P3_LOADA1(q)                                                                  \
     {                                                                                      \
-        const int koff_ = (l_kh * p.W + l_kw) * p.C_in + l_ci0;                            \
-        sa##q##y = *reinterpret_cast<const float4*>(((vmask1 >> l_kpos) & 1u) ? pa1 + koff_ : p.zeros); \
+        sa##q##y = AMPH_P3_BUFLOAD(rs_x, (vmask1 & l_bit) ? aoff1 : 0u, x_soff);           \
     }
     /* advance with selects only: the loop body stays one basic block */
 #define AMPH_P3_ADV1()                                                                     \
     {                                                                                      \
         const int adv_ = l_left > 1 ? 1 : 0;                                               \
         l_left -= adv_;                                                                    \
-        wp0 += kBK * adv_;                                                                 \
-        wp1 += kBK * adv_;                                                                 \
+        w_soff += kBK * 4 * adv_;                                                          \
+        x_soff += kBK * 4 * adv_;                                                          \
         l_ci0 += kBK * adv_;                                                               \
     }
 #define AMPH_P3_ADV2()                                                                     \
     {                                                                                      \
         const int wrap_ = l_ci0 >= p.C_in ? 1 : 0;                                         \
         l_ci0 -= wrap_ * p.C_in;                                                           \
-        l_kpos += wrap_;                                                                   \
+        l_bit = __builtin_amdgcn_readfirstlane(l_bit << wrap_);                            \
         l_kw += wrap_;                                                                     \
         const int wrap2_ = l_kw >= p.k ? 1 : 0;                                            \
         l_kw -= wrap2_ * p.k;                                                              \
-        l_kh += wrap2_;                                                                    \
+        x_soff = __builtin_amdgcn_readfirstlane(x_soff + wrap2_ * row_skip);               \
+        w_soff = __builtin_amdgcn_readfirstlane(w_soff);                                   \
     }
 #define AMPH_P3_LOAD(q) { AMPH_P3_LOADB(q) AMPH_P3_LOADA0(q) AMPH_P3_LOADA1(q) AMPH_P3_ADV1() AMPH_P3_ADV2() }
+#define AMPH_P3_LOADA(q) { AMPH_P3_LOADA0(q) AMPH_P3_LOADA1(q) AMPH_P3_ADV1() AMPH_P3_ADV2() }
     const int st_off = r0 * kLdsRow + 4 * c4;
 #define AMPH_P3_STORE(q, buf_)                                                             \
     {                                                                                      \
@@ -631,9 +678,9 @@ __global__ __launch_bounds__(256) void k_conv_gemm_p3(ConvGemmParams p) {
     }
 
     // prologue: slices 0, 1, 2 into the register stages, 0 and 1 on to LDS
-    AMPH_P3_LOAD(0)
-    AMPH_P3_LOAD(1)
-    AMPH_P3_LOAD(2)
+    AMPH_P3_LOADA(0)                                     // (their B halves were requested at the top)
+    AMPH_P3_LOADA(1)
+    AMPH_P3_LOADA(2)
     AMPH_P3_STORE(0, 0)
     AMPH_P3_STORE(1, 1)
     __syncthreads();
@@ -691,212 +738,6 @@ __global__ __launch_bounds__(256) void k_conv_gemm_p3(ConvGemmParams p) {
 }
 
 // ----------------------------------------------------------------------------
-// Wave-specialised form of k_conv_gemm_p3 ("w3") for grids that leave one MFMA wave per SIMD (conv4: 256
-// workgroups, the head: 128..256): 8 waves, waves 0-3 only read fragments and issue MFMAs, waves 4-7 only load
-// global memory and store the LDS slice buffers.  A SIMD then holds one wave of each kind: the MFMA wave's issue
-// stream carries no VMEM / address / ds_write instruction, and the producer has a whole slice time per slice.
-// Same buffers, same barrier per slice, same MFMA order as p3 => bit-identical results.
-// ----------------------------------------------------------------------------
-template <int BM>
-__global__ __launch_bounds__(512) void k_conv_gemm_w3(ConvGemmParams p) {
-    static_assert(BM == 64, "one 32x32 tile per MFMA wave");
-    constexpr int A_ROWS = BM / 32;
-    constexpr int kABuf = BM * kLdsRow, kBBuf = kBN * kLdsRow;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* As = reinterpret_cast<float*>(smem);                         // [3][BM][36]
-    float* Bs = As + 3 * kABuf;                                         // [3][64][36]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m_blk = blockIdx.x * BM, n_blk = blockIdx.y * kBN;
-    const int n_slices = p.K_pad / kBK;
-    const int sps = n_slices / p.splits;
-    const int ks_begin = blockIdx.z * sps, ks_end = ks_begin + sps;
-
-    if (wave >= 4) {
-        // ------------------------------------------------------------ producer waves
-        const int ptid = tid - 256;
-        const int c4 = ptid & 7, r0 = ptid >> 3;
-        const float* pa[A_ROWS];
-        unsigned vmask[A_ROWS];
-        const int ohw = p.OH * p.OW;
-#pragma unroll
-        for (int i = 0; i < A_ROWS; ++i) {
-            const int m = m_blk + r0 + 32 * i;
-            const bool mv = m < p.M;
-            const int mm = mv ? m : 0;
-            const int b = mm / ohw, rem = mm - b * ohw;
-            const int oh = rem / p.OW, ow = rem - oh * p.OW;
-            const int ih0 = oh * p.stride - p.pad, iw0 = ow * p.stride - p.pad;
-            pa[i] = p.x + (long long)b * p.H * p.W * p.C_in + ((long long)ih0 * p.W + iw0) * p.C_in + 4 * c4;
-            unsigned vm = 0;
-            for (int kh = 0; kh < p.k; ++kh)
-                for (int kw = 0; kw < p.k; ++kw)
-                    if (mv && ih0 + kh >= 0 && ih0 + kh < p.H && iw0 + kw >= 0 && iw0 + kw < p.W) vm |= 1u << (kh * p.k + kw);
-            vmask[i] = vm;
-        }
-        const float *pa0 = pa[0], *pa1 = pa[1];
-        const unsigned vmask0 = vmask[0], vmask1 = vmask[1];
-        const float* wp0 = p.w + (long long)(n_blk + r0) * p.K_pad + 4 * c4 + ks_begin * kBK;
-        const float* wp1 = wp0 + 32ll * p.K_pad;
-        int l_kpos = (ks_begin * kBK) / p.C_in;
-        int l_ci0 = ks_begin * kBK - l_kpos * p.C_in;
-        int l_kh = l_kpos / p.k, l_kw = l_kpos - l_kh * p.k;
-        int l_left = sps;
-        float4 sa0x, sa0y, sa1x, sa1y, sa2x, sa2y;
-        float4 sb0a, sb0b, sb1a, sb1b, sb2a, sb2b;
-        const int st_off = r0 * kLdsRow + 4 * c4;
-        // slice s is consumed from buffer s % 3 while slice s+2 (stage QS) goes to buffer (s+2) % 3 and slice s+3 is loaded
-#ifdef AMPH_STAMPS
-        unsigned long long pt0 = 0, pt1 = 0, pt2 = 0, pt3 = 0, pq_issue = 0, pq_wait = 0, pq_bar = 0;
-#define AMPH_W3_PT(v_) AMPH_GSTAMP(v_)
-#define AMPH_W3_PWAIT() asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-#define AMPH_W3_PACC() { pq_issue += pt1 - pt0; pq_wait += pt2 - pt1; pq_bar += pt3 - pt2; }
-#else
-#define AMPH_W3_PT(v_)
-#define AMPH_W3_PWAIT()
-#define AMPH_W3_PACC()
-#endif
-#define AMPH_W3_PSTEP(R, QL, QS)                                                           \
-    {                                                                                      \
-        AMPH_W3_PT(pt0)                                                                    \
-        AMPH_P3_LOAD(QL)                                                                   \
-        AMPH_SB();                                                                         \
-        AMPH_W3_PT(pt1)                                                                    \
-        AMPH_W3_PWAIT()                                                                    \
-        AMPH_W3_PT(pt2)                                                                    \
-        AMPH_P3_STORE(QS, (R + 2) % 3)                                                     \
-        AMPH_SB();                                                                         \
-        __syncthreads();                                                                   \
-        AMPH_W3_PT(pt3)                                                                    \
-        AMPH_W3_PACC()                                                                     \
-    }
-        AMPH_P3_LOAD(0)
-        AMPH_P3_LOAD(1)
-        AMPH_P3_LOAD(2)
-        AMPH_P3_STORE(0, 0)
-        AMPH_P3_STORE(1, 1)
-        __syncthreads();
-        int ks = ks_begin;
-        for (; ks + 3 <= ks_end; ks += 3) {
-            AMPH_W3_PSTEP(0, 0, 2)
-            AMPH_W3_PSTEP(1, 1, 0)
-            AMPH_W3_PSTEP(2, 2, 1)
-        }
-        if (ks < ks_end) {
-            AMPH_W3_PSTEP(0, 0, 2)
-            if (ks + 1 < ks_end) AMPH_W3_PSTEP(1, 1, 0)
-        }
-#ifdef AMPH_STAMPS
-        if (tid == 256 && p.stamps) {
-            unsigned long long* o = p.stamps + (size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8;
-            o[1] = pq_wait; o[2] = pq_bar; o[6] = pq_issue;
-        }
-#endif
-        return;
-    }
-
-    // ---------------------------------------------------------------- MFMA waves
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    const int row_tile = wave >> 1, col_tile = wave & 1;
-    const float* a_rd = As + (row_tile * 32 + (lane & 31)) * kLdsRow + 4 * (lane >> 5);
-    const float* b_rd = Bs + (col_tile * 32 + (lane & 31)) * kLdsRow + 4 * (lane >> 5);
-#ifdef AMPH_STAMPS
-    unsigned long long ct0 = 0, ct1 = 0, ct2 = 0, cq_mfma = 0, cq_bar = 0, cq_begin = 0;
-    AMPH_GSTAMP(cq_begin)
-    const unsigned long long cq_rt0 = __builtin_amdgcn_s_memrealtime();
-#define AMPH_W3_CT(v_) AMPH_GSTAMP(v_)
-#define AMPH_W3_CACC() { cq_mfma += ct1 - ct0; cq_bar += ct2 - ct1; }
-#else
-#define AMPH_W3_CT(v_)
-#define AMPH_W3_CACC()
-#endif
-#define AMPH_W3_CSTEP(R)                                                                   \
-    {                                                                                      \
-        float4 f1a, f1b, f2a, f2b, f3a, f3b, n0a, n0b;                                     \
-        AMPH_W3_CT(ct0)                                                                    \
-        AMPH_P3_READ(f1a, f1b, R, 1)                                                       \
-        AMPH_P3_READ(f2a, f2b, R, 2)                                                       \
-        AMPH_SB();                                                                         \
-        AMPH_P3_MFMA(f0a.x, f0b.x)                                                         \
-        AMPH_P3_MFMA(f0a.y, f0b.y)                                                         \
-        AMPH_P3_MFMA(f0a.z, f0b.z)                                                         \
-        AMPH_P3_MFMA(f0a.w, f0b.w)                                                         \
-        AMPH_SB();                                                                         \
-        AMPH_P3_READ(f3a, f3b, R, 3)                                                       \
-        AMPH_SB();                                                                         \
-        AMPH_P3_MFMA(f1a.x, f1b.x)                                                         \
-        AMPH_P3_MFMA(f1a.y, f1b.y)                                                         \
-        AMPH_P3_MFMA(f1a.z, f1b.z)                                                         \
-        AMPH_P3_MFMA(f1a.w, f1b.w)                                                         \
-        AMPH_SB();                                                                         \
-        AMPH_P3_READ(n0a, n0b, (R + 1) % 3, 0)                                             \
-        AMPH_SB();                                                                         \
-        AMPH_P3_MFMA(f2a.x, f2b.x)                                                         \
-        AMPH_P3_MFMA(f2a.y, f2b.y)                                                         \
-        AMPH_P3_MFMA(f2a.z, f2b.z)                                                         \
-        AMPH_P3_MFMA(f2a.w, f2b.w)                                                         \
-        AMPH_P3_MFMA(f3a.x, f3b.x)                                                         \
-        AMPH_P3_MFMA(f3a.y, f3b.y)                                                         \
-        AMPH_P3_MFMA(f3a.z, f3b.z)                                                         \
-        AMPH_P3_MFMA(f3a.w, f3b.w)                                                         \
-        AMPH_SB();                                                                         \
-        AMPH_W3_CT(ct1)                                                                    \
-        __syncthreads();                                                                   \
-        AMPH_W3_CT(ct2)                                                                    \
-        AMPH_W3_CACC()                                                                     \
-        f0a = n0a; f0b = n0b;                                                              \
-    }
-    if (p.flags & 1) __builtin_amdgcn_s_setprio(2);
-    __syncthreads();
-    float4 f0a, f0b;
-    AMPH_P3_READ(f0a, f0b, 0, 0)
-    {
-        int ks = ks_begin;
-        for (; ks + 3 <= ks_end; ks += 3) {
-            AMPH_W3_CSTEP(0)
-            AMPH_W3_CSTEP(1)
-            AMPH_W3_CSTEP(2)
-        }
-        if (ks < ks_end) {
-            AMPH_W3_CSTEP(0)
-            if (ks + 1 < ks_end) AMPH_W3_CSTEP(1)
-        }
-    }
-#ifdef AMPH_STAMPS
-    if (tid == 0 && p.stamps) {
-        unsigned long long q_end;
-        AMPH_GSTAMP(q_end)
-        unsigned long long* o = p.stamps + (size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8;
-        o[0] = cq_mfma; o[3] = cq_bar; o[4] = q_end - cq_begin;
-        o[5] = __builtin_amdgcn_s_memrealtime() - cq_rt0;
-        o[7] = 0;
-    }
-#endif
-    {
-        const int m = m_blk + row_tile * 32 + (lane & 31);
-        float* ybase = p.y + (p.epilogue == 1 ? (long long)blockIdx.z * p.M * p.N : 0ll);
-        if (m < p.M) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n0 = n_blk + col_tile * 32 + 8 * g + 4 * (lane >> 5);
-                if (n0 < p.N) {
-                    float4 v = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
-                    if (p.epilogue == 0) {
-                        const float4 sc = *reinterpret_cast<const float4*>(p.scale + n0);
-                        const float4 sh = *reinterpret_cast<const float4*>(p.shift + n0);
-                        v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.0f); v.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.0f);
-                        v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.0f); v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.0f);
-                    }
-                    *reinterpret_cast<float4*>(ybase + (long long)m * p.N + n0) = v;
-                }
-            }
-        }
-    }
-}
-
-// ----------------------------------------------------------------------------
 // Fused conv1 -> conv2 in the second-generation structure ("f3"): k_conv_gemm_p3 whose A stage is not
 // loaded but RECOMPUTED - layer 1 (C_in == 1 direct 3x3 conv + BN + ReLU, exactly k_conv_first's FMA
 // order, so fused == unfused bitwise) evaluated from an image patch in LDS for the 2 x 4 A-tile values
@@ -907,16 +748,6 @@ __global__ __launch_bounds__(512) void k_conv_gemm_w3(ConvGemmParams p) {
 // LDS 3 x 36.9 KB + patch = 62 KB: two workgroups per CU, so the 1024 workgroups of a 256-chunk batch
 // run as two full rounds (the first-generation fused kernel: 43 KB, three per CU, 768 + 256).
 // ----------------------------------------------------------------------------
-// floor(n / d) for 0 <= n < 2^22, d >= 1, rcp = 1.0f / d: float estimate (off by at most one) + correction.  The
-// compiler's 32-bit integer division is ~40 VALU instructions; the fused kernel's per-thread setup had a dozen of them.
-__device__ __forceinline__ int div_small(int n, int d, float rcp) {
-    int q = (int)((float)n * rcp);
-    int r = n - q * d;
-    if (r < 0) { --q; r += d; }
-    if (r >= d) ++q;
-    return q;
-}
-
 template <int BM>
 __global__ __launch_bounds__(256) void k_conv_gemm_f3(ConvGemmParams p) {
     static_assert(BM == 64, "one 32x32 tile per wave");
@@ -1298,8 +1129,17 @@ bool conv_gemm_f3_ok(const ConvGemmParams& p, int bm) {
            (((bm / p.OW - 1) * p.stride + p.k - 1) * p.s1 + 3) * (p.W0 + 2 * p.p1) <= 256 * 8;
 }
 
+// Zero bytes k_conv_gemm_p3 needs in front of its input: a padded tap's address is (x - guard) + tap offset, and a valid
+// tap's lane offset guard + window origin must not be negative (origin >= -(pad * W + pad) * C_in floats, pad < k).
+size_t conv_gemm_x_guard(int k, int W, int C_in) {
+    return ((size_t)k * (W + 1) * C_in * sizeof(float) + 64 + 255) & ~(size_t)255;
+}
+
 bool conv_gemm_p3_ok(const ConvGemmParams& p, int bm) {
-    return bm == 64 && (p.C_in % kBK) == 0 && p.K == p.K_pad && p.k * p.k <= 32 && p.zeros != nullptr && (p.N % 4) == 0;
+    const unsigned long long span = (unsigned long long)p.M / (p.OH * p.OW) * p.H * p.W * p.C_in * 4ull + p.x_guard;     // 32-bit lane offsets
+    return bm == 64 && (p.C_in % kBK) == 0 && p.K == p.K_pad && p.k * p.k <= 32 && (p.N % 4) == 0 && p.pad < p.k &&
+           (size_t)p.x_guard >= conv_gemm_x_guard(p.k, p.W, p.C_in) && span < (1ull << 32) &&
+           (unsigned long long)p.N * p.K_pad * 4ull < (1ull << 32) && p.M < (1 << 22);
 }
 
 // first-generation fused tile: the 64-row tile needs 43 KB (three workgroups per CU: 768 of a 256-chunk batch's 1024
@@ -1334,13 +1174,9 @@ void launch_conv_gemm(const ConvGemmParams& p_in, int bm, bool fuse, hipStream_t
     const size_t lds = std::max(conv_gemm_lds(p, bm, fuse), (size_t)g_gemm_min_lds);
     if (!fuse && (g_gemm_flags & 2) == 0 && conv_gemm_p3_ok(p, bm)) {
         const size_t lds3 = std::max((size_t)3 * (bm + kBN) * kLdsRow * sizeof(float), (size_t)g_gemm_min_lds);
-        // gemm_flags bit 3: wave-specialised variant for every p3 launch; bit 4: only for grids of at most one workgroup per CU
-        const unsigned n_wg = grid.x * grid.y * grid.z;
-        if ((g_gemm_flags & 8) || ((g_gemm_flags & 16) && n_wg <= (unsigned)g_num_cus))
-            hipLaunchKernelGGL((k_conv_gemm_w3<64>), grid, dim3(512), lds3, s, p);
-        else
-            if (g_gemm_flags & 32) hipLaunchKernelGGL((k_conv_gemm_p3<64, true>), grid, dim3(256), lds3, s, p);
-            else hipLaunchKernelGGL((k_conv_gemm_p3<64, false>), grid, dim3(256), lds3, s, p);
+        // gemm_flags bit 5: odd k-steps into a second accumulator (experiment: -0.7 us on conv3 / conv4, different rounding)
+        if (g_gemm_flags & 32) hipLaunchKernelGGL((k_conv_gemm_p3<64, true>), grid, dim3(256), lds3, s, p);
+        else hipLaunchKernelGGL((k_conv_gemm_p3<64, false>), grid, dim3(256), lds3, s, p);
         return;
     }
     if (fuse && (g_gemm_flags & 4) == 0 && conv_gemm_f3_ok(p, bm)) {
