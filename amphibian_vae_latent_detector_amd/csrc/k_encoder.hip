@@ -836,9 +836,10 @@ __global__ __launch_bounds__(256) void k_conv_gemm_f3(ConvGemmParams p) {
     // steps of a tile already fetch slices 0, 1, 2 for the next one (n_slices % 3 == 0: the stage rotation lines up) and
     // only the first tile's prologue loads them.  BN constants of the epilogue: tile-independent too, loaded once.
     const int n_slices = p.K_pad / kBK;                  // == k * k taps (C_in == 32), splits == 1
-    const float* wp0 = p.w + (long long)(n_blk + r0) * p.K_pad + 4 * c4;
-    const float* wp1 = wp0 + 32ll * p.K_pad;
-    int l_left = n_slices;                               // slices until the pointer wraps
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, -1, 0x00020000);
+    const unsigned woff0 = ((unsigned)(n_blk + r0) * (unsigned)p.K_pad + 4u * c4) * 4u, woff1 = woff0 + 32u * (unsigned)p.K_pad * 4u;
+    int w_soff = 0;                                      // byte offset of the next B slice (wave-uniform; buffer loads as in p3)
+    int l_left = n_slices;                               // slices until the offset wraps
     float4 sb0a, sb0b, sb1a, sb1b, sb2a, sb2b;           // B register stages
     float4 e_sc0, e_sc1, e_sc2, e_sc3, e_sh0, e_sh1, e_sh2, e_sh3;
     {
@@ -891,13 +892,11 @@ __global__ __launch_bounds__(256) void k_conv_gemm_f3(ConvGemmParams p) {
     float cap0 = 0.0f, cap1 = 0.0f;                      // +inf for a tap inside the image, 0 for a padded one
 #define AMPH_F3_LOADB(q)                                                                   \
     {                                                                                      \
-        sb##q##a = *reinterpret_cast<const float4*>(wp0);                                  \
-        sb##q##b = *reinterpret_cast<const float4*>(wp1);                                  \
+        sb##q##a = AMPH_P3_BUFLOAD(rs_w, woff0, w_soff);                                   \
+        sb##q##b = AMPH_P3_BUFLOAD(rs_w, woff1, w_soff);                                   \
         --l_left;                                                                          \
-        const int step_ = l_left == 0 ? -(n_slices - 1) * kBK : kBK;   /* wrap to slice 0 */ \
+        w_soff = __builtin_amdgcn_readfirstlane(l_left == 0 ? 0 : w_soff + kBK * 4);   /* wrap to slice 0 */ \
         l_left = l_left == 0 ? n_slices : l_left;                                          \
-        wp0 += step_;                                                                      \
-        wp1 += step_;                                                                      \
     }
     // window of row i for the tap being computed (taps past the end have no mask bit: all zero)
 #define AMPH_F3_WINDOW(i)                                                                  \
@@ -1124,7 +1123,7 @@ static size_t conv_gemm_f3_lds(const ConvGemmParams& p, int bm) {
 bool conv_gemm_f3_ok(const ConvGemmParams& p, int bm) {
     const int ohw = p.OH * p.OW;
     return bm == 64 && p.img != nullptr && p.k1 == 3 && p.C_in == kBK && p.K == p.K_pad && p.k == 3 && p.splits == 1 && (p.N % 4) == 0 &&
-           p.M < (1 << 22) && p.zeros != nullptr &&
+           p.M < (1 << 22) && p.zeros != nullptr && (unsigned long long)p.N * p.K_pad * 4ull < (1ull << 32) &&
            p.epilogue == 0 && ohw % bm == 0 && bm % p.OW == 0 && conv_gemm_f3_lds(p, bm) <= 80 * 1024 && (p.K_pad / kBK) % 3 == 0 &&
            (((bm / p.OW - 1) * p.stride + p.k - 1) * p.s1 + 3) * (p.W0 + 2 * p.p1) <= 256 * 8;
 }
