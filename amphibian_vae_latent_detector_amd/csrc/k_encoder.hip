@@ -590,6 +590,18 @@ __global__ __launch_bounds__(256) void k_conv_gemm_p3(ConvGemmParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = acc2[r] = 0.0f;
     const int row_tile = wave >> 1, col_tile = wave & 1;
+    // BN constants of the epilogue, requested now: loaded in the epilogue they cost every workgroup a global round trip
+    // with nothing left to hide it (columns past N read the vector's first element, the split-K form the weights': unused)
+    float4 e_sc0, e_sc1, e_sc2, e_sc3, e_sh0, e_sh1, e_sh2, e_sh3;
+    {
+        const int nb = n_blk + col_tile * 32 + 4 * (lane >> 5);
+        const bool bn = p.epilogue == 0;
+#define AMPH_P3_BN(g)                                                                      \
+        e_sc##g = *reinterpret_cast<const float4*>((bn ? p.scale : p.w) + ((bn && nb + 8 * g < p.N) ? nb + 8 * g : 0)); \
+        e_sh##g = *reinterpret_cast<const float4*>((bn ? p.shift : p.w) + ((bn && nb + 8 * g < p.N) ? nb + 8 * g : 0));
+        AMPH_P3_BN(0) AMPH_P3_BN(1) AMPH_P3_BN(2) AMPH_P3_BN(3)
+#undef AMPH_P3_BN
+    }
     const float* a_rd = As + (row_tile * 32 + (lane & 31)) * kLdsRow + 4 * (lane >> 5);
     const float* b_rd = Bs + (col_tile * 32 + (lane & 31)) * kLdsRow + 4 * (lane >> 5);
 
@@ -719,20 +731,20 @@ __global__ __launch_bounds__(256) void k_conv_gemm_p3(ConvGemmParams p) {
         const int m = m_blk + row_tile * 32 + (lane & 31);
         float* ybase = p.y + (p.epilogue == 1 ? (long long)blockIdx.z * p.M * p.N : 0ll);
         if (m < p.M) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n0 = n_blk + col_tile * 32 + 8 * g + 4 * (lane >> 5);
-                if (n0 < p.N) {                                                      // N % 4 == 0 (host check)
-                    float4 v = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
-                    if (p.epilogue == 0) {
-                        const float4 sc = *reinterpret_cast<const float4*>(p.scale + n0);
-                        const float4 sh = *reinterpret_cast<const float4*>(p.shift + n0);
-                        v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.0f); v.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.0f);
-                        v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.0f); v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.0f);
-                    }
-                    *reinterpret_cast<float4*>(ybase + (long long)m * p.N + n0) = v;
-                }
+#define AMPH_P3_OUT(g)                                                                     \
+            {                                                                              \
+                const int n0 = n_blk + col_tile * 32 + 8 * g + 4 * (lane >> 5);            \
+                if (n0 < p.N) {                                                      /* N % 4 == 0 (host check) */ \
+                    float4 v = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]); \
+                    if (p.epilogue == 0) {                                                 \
+                        v.x = fmaxf(fmaf(v.x, e_sc##g.x, e_sh##g.x), 0.0f); v.y = fmaxf(fmaf(v.y, e_sc##g.y, e_sh##g.y), 0.0f); \
+                        v.z = fmaxf(fmaf(v.z, e_sc##g.z, e_sh##g.z), 0.0f); v.w = fmaxf(fmaf(v.w, e_sc##g.w, e_sh##g.w), 0.0f); \
+                    }                                                                      \
+                    *reinterpret_cast<float4*>(ybase + (long long)m * p.N + n0) = v;       \
+                }                                                                          \
             }
+            AMPH_P3_OUT(0) AMPH_P3_OUT(1) AMPH_P3_OUT(2) AMPH_P3_OUT(3)
+#undef AMPH_P3_OUT
         }
     }
 }
