@@ -97,7 +97,8 @@ const char* amph_last_error(const amph_ctx* ctx);   /* ctx may be NULL: create-t
  *                            at n_fft = 2048, 24 at n_fft = 1024, 8 with 4 waves)
  *   "stft_grid"        0..   persistent STFT workgroups (0 = fill the chip); PROCESS-wide, like the diagnostic
  *                            knobs "gemm_flags" / "gemm_min_lds" (A/B switches of tools/sweep.py; "gemm_min_wg128" is per context:
- *                            bit 0 wave-slot priority, bit 1 first-generation plain GEMM, bit 2 first-generation fused GEMM)
+ *                            bit 0 wave-slot priority, bit 1 first-generation plain GEMM, bit 2 first-generation fused GEMM,
+ *                            bit 5 second accumulator for odd k-steps in the plain GEMM)
  *   "bf16_encoder"     0/1   encoder in bf16 (weights, activations, v_mfma_f32_32x32x16_bf16) with fp32
  *                            accumulation, BN/ReLU and latents (default 0 = fp32, the path the 1e-4 parity
  *                            bar applies to); the front end is always fp32
