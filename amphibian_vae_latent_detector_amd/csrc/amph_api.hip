@@ -910,6 +910,7 @@ int amph_configure(amph_ctx* c, const char* key, int value) {
         amph::g_stft_grid = value;
         return AMPH_OK;
     }
+    if (!std::strcmp(key, "stft_indep")) { amph::g_stft_indep = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "gemm_flags")) { amph::g_gemm_flags = value; return AMPH_OK; }
     if (!std::strcmp(key, "gemm_min_lds")) {
         if (value < 0 || value > 64 * 1024) return fail(c, AMPH_ERR_INVALID_ARG, "gemm_min_lds must be in 0..65536");

@@ -740,9 +740,317 @@ __global__ __launch_bounds__(64 * NW) void k_stft_mel(StftParams p, int n_tiles)
 #endif
 }
 
+// ----------------------------------------------------------------------------
+// The same transform with INDEPENDENT waves ("w"): no shared sample span, no workgroup barrier after the tables are
+// staged.  See the comment at the frame list below.  Same arithmetic on the same values as k_stft_mel: bit-identical.
+// ----------------------------------------------------------------------------
+template <bool PCM16, int T_LO, int NW>
+__global__ __launch_bounds__(64 * NW) void k_stft_mel_w(StftParams p, int n_tiles) {
+    constexpr int kThreads = 64 * NW;                  // NW waves per workgroup
+    using G = FftGeo<T_LO>;
+    constexpr int kNc = G::NC, L = G::L, SLOTS = G::SLOTS, EXS = G::EXS;
+    constexpr int kWinHalfBytes = G::WIN_BYTES, kTwBBytes = G::TWB_BYTES, kTableBytes = G::TABLE_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lane_f = lane & (L - 1), slot = lane / L;       // lane inside its frame, frame slot of the wave
+    const int FT = p.frames_per_block;
+#ifdef AMPH_STAMPS
+    { const int fl = 0; AMPH_STAMP(0) }
+    unsigned long long w_begin = 0;
+    const unsigned long long w_rt0 = __builtin_amdgcn_s_memrealtime();
+#define AMPH_WSTAMP(v_)                                                                     \
+    {                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v_)::"memory");          \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+    }
+    AMPH_WSTAMP(w_begin)
+#else
+#define AMPH_WSTAMP(v_)
+#endif
+    constexpr int n_fft = 2 * kNc;
+    float* win_h = reinterpret_cast<float*>(smem);
+    float2* tw_b = reinterpret_cast<float2*>(smem + kWinHalfBytes);
+    float2* tw_p = reinterpret_cast<float2*>(smem + kWinHalfBytes + kTwBBytes);
+    const float2* tw_a = p.tw_a;
+    const int meta_bytes = (p.n_mels * 12 + 15) & ~15;
+    const int melw_bytes = p.mel_w_floats * 4;                             // multiple of 64
+    int3* mel_meta = reinterpret_cast<int3*>(smem + kTableBytes);          // (start4, steps, wofs) per filter
+    float* mel_w = reinterpret_cast<float*>(smem + kTableBytes + meta_bytes);
+    char* wbase = smem + kTableBytes + meta_bytes + melw_bytes + wave * kWaveScratch;   // no shared sample span here
+    float2* ex = reinterpret_cast<float2*>(wbase + slot * G::SLOT_BYTES);   // this frame slot's scratch
+    float* P = reinterpret_cast<float*>(wbase + slot * G::SLOT_BYTES);
+
+    // ---- once per workgroup: tables (one packed global array = the LDS image) and the mel rows
+    {
+        const float4* src = reinterpret_cast<const float4*>(p.tables);
+        float4* dst = reinterpret_cast<float4*>(smem);
+        for (int i = tid; i < kTableBytes / 16; i += kThreads) dst[i] = src[i];
+        for (int m = tid; m < p.n_mels; m += kThreads) mel_meta[m] = make_int3(p.mel_start[m], p.mel_len[m], p.mel_wofs[m]);
+        const float4* wsrc = reinterpret_cast<const float4*>(p.mel_w);
+        float4* wdst = reinterpret_cast<float4*>(mel_w);
+        for (int i = tid; i < (p.mel_w_floats >> 2); i += kThreads) wdst[i] = wsrc[i];
+    }
+
+    __syncthreads();                                  // tables and mel rows staged: the ONLY workgroup barrier of the kernel
+
+    // ---- per-wave frame list: wave w of the workgroup takes frame slots w * SLOTS (+ NW * SLOTS ...) of the tiles
+    //      blockIdx.x, + gridDim.x, ... - the tile order keeps the overlapping frames of a row on one CU (L1 hits) - but
+    //      nothing is shared between the waves: every wave fetches its frame's n_fft samples itself (81 % overlap with
+    //      its neighbours: 5 x the global reads of a shared span, all from L1 / L2, and 5 x the normalise arithmetic,
+    //      on a VALU that has room) and no wave ever waits for another.  In the tile-synchronous kernel wave 0 spent 19 %
+    //      of its time staging + at the staging barrier and 24 % at the end-of-tile barrier.
+    struct Fr { const char* rowp; int len, s_begin, row, fr0; float sc; bool fast; };
+    int it_t = blockIdx.x, it_fl0 = wave * SLOTS;
+    auto seek = [&]() {                              // first valid (tile, slot) at or after the iterator; false at the end
+        while (it_t < n_tiles) {
+            const int r = it_t / p.tiles_per_row, tl = it_t - r * p.tiles_per_row;
+            if (it_fl0 < FT && tl * FT + it_fl0 < p.n_frames) return true;
+            it_t += gridDim.x;
+            it_fl0 = wave * SLOTS;
+        }
+        return false;
+    };
+    auto describe = [&]() {
+        Fr d;
+        const int r = it_t / p.tiles_per_row, tl = it_t - r * p.tiles_per_row;
+        d.row = r;
+        d.fr0 = tl * FT + it_fl0;
+        d.rowp = reinterpret_cast<const char*>(p.src.wave) + (long long)r * p.src.row_stride * (PCM16 ? 2 : 4);
+        const int len = p.src.lengths ? min(p.src.lengths[r], p.src.n_in) : p.src.n_in;
+        d.len = min(len, p.n_samples);               // truncation of fix_length (:217)
+        d.sc = p.src.scale ? p.src.scale[r] : 1.0f;
+        d.s_begin = d.fr0 * p.hop - (n_fft >> 1);
+        // every frame slot of the wave inside the row, even start, 4-byte aligned: one dword = the (even, odd) sample pair
+        const int s_last = d.s_begin + (SLOTS - 1) * p.hop;
+        d.fast = d.s_begin >= 0 && s_last + n_fft <= d.len && d.fr0 + SLOTS <= p.n_frames && ((p.hop | d.s_begin) & 1) == 0 &&
+                 ((reinterpret_cast<uintptr_t>(d.rowp) + (PCM16 ? 2 : 4) * (size_t)d.s_begin) & (PCM16 ? 3u : 7u)) == 0;
+        return d;
+    };
+    // the NEXT frame's raw dwords (PCM16 fast path): requested before the mel rows of the current frame, when the 16
+    // complex registers of the transform are dead
+    uint32_t nx[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) nx[j] = 0;
+    bool have_nx = false;
+    auto fetch_fast = [&](const Fr& d) {
+        const uint32_t* src32 = reinterpret_cast<const uint32_t*>(d.rowp + 2 * (size_t)(d.s_begin + slot * p.hop));
+#pragma unroll
+        for (int j = 0; j < 16; ++j) nx[j] = src32[lane_f + L * j];
+    };
+    bool more = seek();
+    Fr d = {};
+    if (more) {
+        d = describe();
+        if (PCM16 && d.fast) { fetch_fast(d); have_nx = true; }
+    }
+
+    const int k1b = lane_f / T_LO, t_lo = lane_f % T_LO;
+    // stage C leaves k2b bit-reversed across the quad (radix-4); the radix-2 form is in order
+    const int k2b = T_LO == 4 ? (((t_lo & 1) << 1) | (t_lo >> 1)) : t_lo;
+    const float sgn_a = t_lo < 2 ? 1.0f : -1.0f;          // first butterfly (lanes 2 apart): x + p or p - x
+    const float sgn_b = (t_lo & 1) == 0 ? 1.0f : -1.0f;   // second butterfly (adjacent lanes)
+    const bool rot3 = T_LO == 4 && t_lo == 3;
+    while (more) {
+        const int row = d.row;
+        const int fl = 0; (void)fl;                   // (stamps: every frame of wave 0)
+        const int frame = d.fr0 + slot;
+        const bool fvalid = frame < p.n_frames;       // the second half-wave may hold no frame
+        AMPH_STAMP(1)
+        float re[16], im[16];
+        // ---- this lane's 16 (even, odd) sample pairs, normalised, then window + even/odd packing:
+        //      z[n] = x[2n] w[2n] + i x[2n+1] w[2n+1], n = lane_f + L j
+        {
+            float x0[16], x1[16];
+            if (PCM16 && d.fast) {
+                if (!have_nx) fetch_fast(d);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    x0[j] = (float)(short)(nx[j] & 0xFFFFu) * (1.0f / 32768.0f);
+                    x1[j] = (float)((int)nx[j] >> 16) * (1.0f / 32768.0f);
+                }
+            } else if (!PCM16 && d.fast) {            // float32 rows: the pair is one 8-byte load (not prefetched: 32 registers)
+                const float2* src2 = reinterpret_cast<const float2*>(d.rowp + 4 * (size_t)(d.s_begin + slot * p.hop));
+#pragma unroll
+                for (int j = 0; j < 16; ++j) { const float2 v = src2[lane_f + L * j]; x0[j] = v.x; x1[j] = v.y; }
+            } else {
+                const int N = p.n_samples;
+                const int sb = d.s_begin + slot * p.hop;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        int sidx = sb + 2 * (lane_f + L * j) + h;
+                        if (p.pad_mode == 0) {                // reflect (np.pad mode="reflect")
+                            if (sidx < 0) sidx = -sidx;
+                            if (sidx >= N) sidx = 2 * (N - 1) - sidx;
+                        } else if (sidx >= N) sidx = -1;      // constant (zero) padding
+                        const float v = fvalid ? load_sample<PCM16>(d.rowp, sidx, d.len) : 0.0f;
+                        if (h == 0) x0[j] = v; else x1[j] = v;
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int n = lane_f + L * j;
+                float w0, w1;
+                if (j < 8) { const float2 w = reinterpret_cast<const float2*>(win_h)[n]; w0 = w.x; w1 = w.y; }
+                else { const int m = n_fft - 2 * n; w0 = win_h[m]; w1 = win_h[m - 1]; }   // w[2n] = w[N-2n], w[2n+1] = w[N-2n-1]
+                re[j] = normalise_sample(p.src, x0[j], d.sc) * w0;
+                im[j] = normalise_sample(p.src, x1[j], d.sc) * w1;
+            }
+        }
+        AMPH_STAMP(2)
+        // ---- stage A
+        dft16(re, im);
+#pragma unroll
+        for (int k1 = 0; k1 < 16; ++k1) {
+            float r = re[DFT16_POS(k1)], i = im[DFT16_POS(k1)];
+            if (k1 > 0) {
+                const float2 w = tw_a[(k1 - 1) * L + lane_f];
+                AMPH_CMUL(r, i, w.x, w.y);
+            }
+            ex[k1 * EXS + lane_f] = make_float2(r, i);
+        }
+        wave_lds_sync();
+        AMPH_STAMP(3)
+        // ---- stage B: lane (k1b, t_lo) gathers t = t_lo + T_LO m
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            const float2 v = ex[k1b * EXS + t_lo + T_LO * m];
+            re[m] = v.x;
+            im[m] = v.y;
+        }
+        AMPH_STAMP(4)
+        dft16(re, im);
+        AMPH_STAMP(5)
+        wave_lds_sync();                              // the Z image below overwrites `ex`
+        float2* Z = ex;
+#pragma unroll
+        for (int k2a = 0; k2a < 16; ++k2a) {
+            float r = re[DFT16_POS(k2a)], i = im[DFT16_POS(k2a)];
+            if (k2a > 0) {
+                const float2 w = tw_b[k2a * T_LO + t_lo];
+                AMPH_CMUL(r, i, w.x, w.y);
+            }
+            // ---- stage C: radix-T_LO over adjacent lanes (DPP xor butterflies).  The lane-dependent add / subtract
+            //      is one fma with a per-lane sign (x * (+-1) + partner rounds exactly as x + partner / partner - x),
+            //      the -i of lane 3 two selects
+            if (T_LO == 4) {
+                const float nr = fmaf(r, sgn_a, dpp_xor2(r)), ni = fmaf(i, sgn_a, dpp_xor2(i));
+                const float tr = rot3 ? ni : nr, ti = rot3 ? -nr : ni;          // lane 3: * (-i)
+                r = fmaf(tr, sgn_b, dpp_xor1(tr));
+                i = fmaf(ti, sgn_b, dpp_xor1(ti));
+            } else {
+                r = fmaf(r, sgn_b, dpp_xor1(r));
+                i = fmaf(i, sgn_b, dpp_xor1(i));
+            }
+            // lane holds X[k1b + 16 k2a + 256 k2b]
+            Z[k1b + 16 * k2a + (256 + kZPad) * k2b] = make_float2(r, i);
+        }
+        wave_lds_sync();
+        AMPH_STAMP(6)
+        // ---- real-FFT split: bins k and NC - k from Z[k], Z[NC - k]; the power spectrum
+        //      is written over the Z image, so every pair is read into registers first
+        {
+            float2 za[9], zb[9];
+#pragma unroll
+            for (int it = 0; it < 9; ++it) {
+                const int k = min(lane_f + L * it, kNc / 2);
+                const int k2 = (kNc - k) & (kNc - 1);
+                za[it] = Z[k + kZPad * (k >> 8)];
+                zb[it] = Z[k2 + kZPad * (k2 >> 8)];
+            }
+            wave_lds_sync();
+            AMPH_STAMP(7)
+#pragma unroll
+            for (int it = 0; it < 9; ++it) {
+                const int k = lane_f + L * it;
+                if (k <= kNc / 2) {
+                    const float2 a = za[it], b = zb[it];
+                    const float2 w = tw_p[k];
+                    const float xer = 0.5f * (a.x + b.x), xei = 0.5f * (a.y - b.y);      // (Z[k] + conj Z[N-k]) / 2
+                    const float xor_ = 0.5f * (a.y + b.y), xoi = -0.5f * (a.x - b.x);    // -i (Z[k] - conj Z[N-k]) / 2
+                    const float tr = xor_ * w.x - xoi * w.y, ti = xor_ * w.y + xoi * w.x;
+                    const float pr = xer + tr, pi = xei + ti, mr = xer - tr, mi = xei - ti;
+                    P[k] = pr * pr + pi * pi;
+                    if (k != kNc - k) P[kNc - k] = mr * mr + mi * mi;
+                }
+            }
+            for (int i = lane_f; i < p.p_tail; i += L) P[kNc + 1 + i] = 0.0f;   // zero the tail the padded mel rows touch
+        }
+        wave_lds_sync();
+        AMPH_STAMP(8)
+        // ---- the wave's next frame: its samples are requested now and land under the mel rows
+        const int cur_fr0 = d.fr0;
+        it_fl0 += NW * SLOTS;
+        more = seek();
+        have_nx = false;
+        if (more) {
+            d = describe();
+            if (PCM16 && d.fast) { fetch_fast(d); have_nx = true; }
+        }
+        // ---- mel rows: 4 lanes per filter, each lane 4 consecutive bins per step (aligned float4).
+        //      The host pads every filter of a 16-filter round to the round's longest row (zero
+        //      weights), so the step count is wave-uniform: no per-lane predication, no branches.
+        for (int sl = 0; sl < SLOTS; ++sl) {            // all 64 lanes work on one frame slot at a time
+            const int fr = cur_fr0 + sl;
+            if (fr >= p.n_frames) break;                      // wave-uniform
+            float* out = p.melpow + ((long long)row * p.n_frames + fr) * p.n_mels;
+            const float* Ps = reinterpret_cast<const float*>(wbase + sl * G::SLOT_BYTES);
+            const int q = lane & 3;
+            for (int m0 = 0; m0 < p.n_mels; m0 += 16) {
+                const int m = min(m0 + (lane >> 2), p.n_mels - 1);
+                const int3 meta = mel_meta[m];                                // (start4, steps of the round, wofs)
+                const int steps = __builtin_amdgcn_readfirstlane(meta.y);
+                const float4* w = reinterpret_cast<const float4*>(mel_w + meta.z) + q;    // (from global / L1 instead: +1 us)
+                const float4* pp = reinterpret_cast<const float4*>(Ps + meta.x) + q;
+                float acc0 = 0.0f, acc1 = 0.0f;
+                int i = 0;
+                for (; i + 1 < steps; i += 2) {
+                    const float4 a0 = w[4 * i], b0 = pp[4 * i], a1 = w[4 * i + 4], b1 = pp[4 * i + 4];
+                    acc0 = fmaf(a0.x, b0.x, acc0); acc1 = fmaf(a1.x, b1.x, acc1);
+                    acc0 = fmaf(a0.y, b0.y, acc0); acc1 = fmaf(a1.y, b1.y, acc1);
+                    acc0 = fmaf(a0.z, b0.z, acc0); acc1 = fmaf(a1.z, b1.z, acc1);
+                    acc0 = fmaf(a0.w, b0.w, acc0); acc1 = fmaf(a1.w, b1.w, acc1);
+                }
+                if (i < steps) {
+                    const float4 a0 = w[4 * i], b0 = pp[4 * i];
+                    acc0 = fmaf(a0.x, b0.x, acc0);
+                    acc0 = fmaf(a0.y, b0.y, acc0);
+                    acc0 = fmaf(a0.z, b0.z, acc0);
+                    acc0 = fmaf(a0.w, b0.w, acc0);
+                }
+                float acc = acc0 + acc1;
+                acc += dpp_xor1(acc);
+                acc += dpp_xor2(acc);
+                if (q == 0 && m0 + (lane >> 2) < p.n_mels) out[m] = acc;
+            }
+        }
+        (void)fvalid;
+        wave_lds_sync();                              // the scratch is rewritten by the next frame
+        AMPH_STAMP(9)
+    }
+#ifdef AMPH_STAMPS
+    if (tid == 0) {       // per-workgroup timeline (wave 0): where the tiles' time goes, and the in-kernel clock
+        unsigned long long w_end;
+        AMPH_WSTAMP(w_end)
+        p.stamps[(size_t)blockIdx.x * 16 + 10] = 0;
+        p.stamps[(size_t)blockIdx.x * 16 + 11] = w_end - w_begin;
+        p.stamps[(size_t)blockIdx.x * 16 + 12] = 0;
+        p.stamps[(size_t)blockIdx.x * 16 + 13] = w_end - w_begin;
+        p.stamps[(size_t)blockIdx.x * 16 + 14] = __builtin_amdgcn_s_memrealtime() - w_rt0;
+        p.stamps[(size_t)blockIdx.x * 16 + 15] = 0;
+    }
+#endif
+}
+
 static int table_bytes_for(int n_fft) { return n_fft == 2048 ? FftGeo<4>::TABLE_BYTES : FftGeo<2>::TABLE_BYTES; }
 
+int g_stft_indep = 1;    // 1: k_stft_mel_w (independent waves, no shared sample span); 0: the tile-synchronous kernel
+
 size_t stft_mel_lds_bytes(int n_fft, int hop, int frames_per_block, int n_mels, int mel_w_floats, int n_waves) {
+    // (sized for the tile-synchronous kernel, which also needs the span: either kernel may be launched)
     const size_t span = (((size_t)(frames_per_block - 1) * hop + n_fft) * 4 + 15) & ~(size_t)15;
     const size_t meta = ((size_t)n_mels * 12 + 15) & ~(size_t)15;
     return (size_t)table_bytes_for(n_fft) + meta + (size_t)mel_w_floats * 4 + span + (size_t)n_waves * kWaveScratch;
@@ -757,7 +1065,11 @@ hipError_t stft_mel_configure(int lds_bytes) {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rms_scale<int16_t>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)rms_scale_lds<int16_t>());
     if (e != hipSuccess) return e;
-    const void* fns[8] = {reinterpret_cast<const void*>(&k_stft_mel<true, 4, 4>), reinterpret_cast<const void*>(&k_stft_mel<false, 4, 4>),
+    const void* fns[16] = {reinterpret_cast<const void*>(&k_stft_mel_w<true, 4, 4>), reinterpret_cast<const void*>(&k_stft_mel_w<false, 4, 4>),
+                          reinterpret_cast<const void*>(&k_stft_mel_w<true, 2, 4>), reinterpret_cast<const void*>(&k_stft_mel_w<false, 2, 4>),
+                          reinterpret_cast<const void*>(&k_stft_mel_w<true, 4, 12>), reinterpret_cast<const void*>(&k_stft_mel_w<false, 4, 12>),
+                          reinterpret_cast<const void*>(&k_stft_mel_w<true, 2, 12>), reinterpret_cast<const void*>(&k_stft_mel_w<false, 2, 12>),
+                          reinterpret_cast<const void*>(&k_stft_mel<true, 4, 4>), reinterpret_cast<const void*>(&k_stft_mel<false, 4, 4>),
                           reinterpret_cast<const void*>(&k_stft_mel<true, 2, 4>), reinterpret_cast<const void*>(&k_stft_mel<false, 2, 4>),
                           reinterpret_cast<const void*>(&k_stft_mel<true, 4, 12>), reinterpret_cast<const void*>(&k_stft_mel<false, 4, 12>),
                           reinterpret_cast<const void*>(&k_stft_mel<true, 2, 12>), reinterpret_cast<const void*>(&k_stft_mel<false, 2, 12>)};
@@ -775,6 +1087,16 @@ static void launch_stft_mel_nw(const StftParams& p, int n_tiles, int sample_is_p
     const size_t lds = stft_mel_lds_bytes(p.n_fft, p.hop, p.frames_per_block, p.n_mels, p.mel_w_floats, NW);
     const int fill = NW == 4 ? 512 : 256;
     const dim3 grid((unsigned)std::min(n_tiles, g_stft_grid > 0 ? g_stft_grid : fill)), block(64 * NW);
+    if (g_stft_indep) {
+        if (p.n_fft == 2048) {
+            if (sample_is_pcm16) hipLaunchKernelGGL((k_stft_mel_w<true, 4, NW>), grid, block, lds, s, p, n_tiles);
+            else hipLaunchKernelGGL((k_stft_mel_w<false, 4, NW>), grid, block, lds, s, p, n_tiles);
+        } else {
+            if (sample_is_pcm16) hipLaunchKernelGGL((k_stft_mel_w<true, 2, NW>), grid, block, lds, s, p, n_tiles);
+            else hipLaunchKernelGGL((k_stft_mel_w<false, 2, NW>), grid, block, lds, s, p, n_tiles);
+        }
+        return;
+    }
     if (p.n_fft == 2048) {
         if (sample_is_pcm16) hipLaunchKernelGGL((k_stft_mel<true, 4, NW>), grid, block, lds, s, p, n_tiles);
         else hipLaunchKernelGGL((k_stft_mel<false, 4, NW>), grid, block, lds, s, p, n_tiles);

@@ -95,6 +95,9 @@ const char* amph_last_error(const amph_ctx* ctx);   /* ctx may be NULL: create-t
  *                            per SIMD; the default when its LDS image fits 160 KB), 4 = two 256-thread ones
  *   "frames_per_block" 4..32 STFT frames per workgroup tile (multiple of 4; default 12 with 12 waves
  *                            at n_fft = 2048, 24 at n_fft = 1024, 8 with 4 waves)
+ *   "stft_indep"       0/1   STFT kernel with independent waves (default 1: every wave fetches its own frame, no
+ *                            workgroup barrier per tile) or the tile-synchronous one with a shared sample span in LDS
+ *                            (0); PROCESS-wide; the two agree to the last bit or two (8e-8 relative)
  *   "stft_grid"        0..   persistent STFT workgroups (0 = fill the chip); PROCESS-wide, like the diagnostic
  *                            knobs "gemm_flags" / "gemm_min_lds" (A/B switches of tools/sweep.py; "gemm_min_wg128" is per context:
  *                            bit 0 wave-slot priority, bit 1 first-generation plain GEMM, bit 2 first-generation fused GEMM,
