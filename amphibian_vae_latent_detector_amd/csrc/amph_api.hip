@@ -604,6 +604,9 @@ int run_encoder(amph_ctx* c, Workspace& w, const float* d_x, int nb, float* d_mu
             // operand delivery) as long as they still give every CU a workgroup
             const long long wg128 = (long long)((p.M + 127) / 128) * ((p.N + 63) / 64);
             if (wg128 < c->gemm_min_wg128) bm = 64;
+            // (that rule was written for the first-generation kernel; the second-generation one only has 64-row tiles and
+            // beats the 128-row first-generation tile at every batch size)
+            if (conv_gemm_p3_ok(p, 64)) bm = 64;
         }
         bms[gi] = bm;
     }

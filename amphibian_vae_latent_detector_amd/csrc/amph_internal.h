@@ -136,6 +136,7 @@ bool conv_gemm_can_fuse(const ConvGemmParams& p, int bm);
 size_t conv_gemm_x_guard(int k, int W, int C_in);          // zero guard k_conv_gemm_p3 needs in front of its input
 bool conv_gemm_f3_ok(const ConvGemmParams& p, int bm);   // second-generation fused kernel (64-row tiles, 32 first-layer channels)
 void launch_conv_gemm(const ConvGemmParams& p, int bm, bool fuse_first, hipStream_t s);
+bool conv_gemm_p3_ok(const ConvGemmParams& p, int bm);
 void launch_head_reduce(const HeadReduceParams& p, int n_rows, hipStream_t s);
 // bf16 encoder path (k_encoder_bf16.hip): x / w are bf16, y bf16 (epilogue 0) or fp32 partials (epilogue 1);
 // K, K_pad and C_in count bf16 elements, K_pad % 64 == 0, C_in % 8 == 0
