@@ -32,13 +32,15 @@ __global__ __launch_bounds__(256) void k(const float* in, float* out, int iters,
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            if (KIND != 4) c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c0, 0, 0, 0);
+            if (KIND != 4 && KIND < 10) c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c0, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < PER; ++q) {
                 const int r = (j * PER + q) & 7;
                 if (KIND == 0 || KIND == 4) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(v[r]) : "v"(a));
-                else if (KIND == 1) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(pk[r]) : "v"(pk[(r + 1) & 7]));
+                else if (KIND == 1 || KIND == 10) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(pk[r]) : "v"(pk[(r + 1) & 7]));
+                else if (KIND == 11) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(pk[r]) : "v"(pk[(r + 1) & 7]));
+                else if (KIND == 12) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(pk[r]) : "v"(pk[(r + 1) & 7]));
                 else if (KIND == 2) asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(iv[r]) : "v"(tid));
                 else if (KIND == 3) asm volatile("s_add_u32 %0, %0, 3" : "+s"(sacc));
                 else if (KIND == 5) asm volatile("ds_read_b128 %0, %1" : "=v"(g[r]) : "v"(lds_off) : "memory");
@@ -85,12 +87,12 @@ int main() {
     float* d_in; float* d_out; unsigned long long* d_clk;
     (void)hipMalloc(&d_in, 1 << 20); (void)hipMalloc(&d_out, 1024 * 256 * 4); (void)hipMalloc(&d_clk, 8192 * 8);
     (void)hipMemset(d_in, 0, 1 << 20);
-    const char* names[10] = {"v_fma_f32", "v_pk_fma_f32", "v_lshl_add_u32", "s_add_u32", "v_fma_f32, no MFMA", "ds_read_b128", "ds_write_b128", "global_load_dwordx4", "global_load_dwordx4 saddr", "global_load_dword saddr"};
-    for (int wgs : {256}) {
+    const char* names[13] = {"v_fma_f32", "v_pk_fma_f32", "v_lshl_add_u32", "s_add_u32", "v_fma_f32, no MFMA", "ds_read_b128", "ds_write_b128", "global_load_dwordx4", "global_load_dwordx4 saddr", "global_load_dword saddr", "v_pk_fma_f32, no MFMA", "v_pk_add_f32, no MFMA", "v_pk_mul_f32, no MFMA"};
+    for (int wgs : {256, 512, 1024}) {
         printf("%d waves per SIMD: cycles per trip of 8 MFMAs (512 = MFMA bound) with 0 / 1 / 2 / 4 / 8 instructions after each MFMA\n", wgs / 256);
 #define ROW(K) printf("  %-20s %7.0f %7.0f %7.0f %7.0f %7.0f\n", names[K], run<0, K>(wgs, d_in, d_out, d_clk), run<1, K>(wgs, d_in, d_out, d_clk), \
                       run<2, K>(wgs, d_in, d_out, d_clk), run<4, K>(wgs, d_in, d_out, d_clk), run<8, K>(wgs, d_in, d_out, d_clk));
-        ROW(0) ROW(1) ROW(2) ROW(3) ROW(4) ROW(5) ROW(6) ROW(7) ROW(8) ROW(9)
+        ROW(4) ROW(10) ROW(11) ROW(12)
     }
     return 0;
 }
