@@ -431,6 +431,18 @@ def test_unsupported_and_invalid_configurations_raise(env):
         sess.configure("frames_per_block", ft)
         sess.configure("stft_waves", waves)
         assert torch.equal(sess.mel_power(y), ref), (waves, ft)
+    # the tile-synchronous kernel (shared sample span, two barriers per tile) against the default one with independent
+    # waves: the same arithmetic up to the compiler's FMA contractions (process-wide knob: restored)
+    try:
+        sess.configure("stft_indep", 0)
+        for waves, ft in ((12, 12), (4, 8)):
+            sess.configure("frames_per_block", ft)
+            sess.configure("stft_waves", waves)
+            got = sess.mel_power(y)
+            assert float((got - ref).abs().max()) <= 1e-6 * float(ref.max()), (waves, ft)
+            assert not got[3].any()                            # the silent row stays exactly zero
+    finally:
+        sess.configure("stft_indep", 1)
 
 
 # ----------------------------------------------------------------------------- K6: radial decision
