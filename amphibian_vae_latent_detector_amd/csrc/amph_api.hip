@@ -45,6 +45,8 @@ struct Workspace {
     std::vector<void*> act_raw;            // the allocations
     std::vector<int> act_guard;
     float* partial = nullptr;
+    int16_t* norm16 = nullptr;             // RMS-normalised PCM16 rows of the batch (what 00_normalize writes to disk), input of the STFT
+    size_t norm16_cap = 0;                 // samples
 };
 
 struct GemmLayer {
@@ -102,6 +104,7 @@ struct amph_ctx {
     int gemm_min_wg128 = 512;
     bool bf16_encoder = false;             // BASELINE config 4: bf16 weights/activations, bf16 MFMA, fp32 accumulate
     bool fuse_conv12 = true;               // recompute layer 1 inside layer 2's A staging when the tiling allows
+    bool stft_prenorm = true;              // PCM16 + RMS: write the normalised PCM16 rows once, STFT reads those
     // radial scratch
     float* d_centroids = nullptr;
     double* d_thr = nullptr;
@@ -489,6 +492,7 @@ void free_lane(Workspace& w) {
     fr(w.scale); fr(w.ok); fr(w.melpow); fr(w.image);
     for (auto p : w.act_raw) fr(p);
     fr(w.partial);
+    fr(w.norm16);
     if (w.done) (void)hipEventDestroy(w.done);
     if (w.stream) (void)hipStreamDestroy(w.stream);
     w = Workspace();
@@ -675,10 +679,26 @@ int run_frontend(amph_ctx* c, Workspace& w, const void* d_wave, bool pcm16, int 
     if (apply_rms) {
         StageTimer t(c, ST_RMS, s);
         int32_t* okp = d_rms_ok ? d_rms_ok : w.ok;
-        if (pcm16) launch_rms_scale_pcm16((const int16_t*)d_wave, n_in, d_len, n_in, nb, w.scale, okp, s);
+        int16_t* norm = nullptr;
+        // PCM16 rows: materialise the normalised, re-quantised samples once (the file 00_normalize_dataset_rms.py would have
+        // written), inside the K0 launch, instead of normalising inside the STFT kernel, whose independent waves would each
+        // redo it for the 81 % of a frame they share with their neighbours (6 VALU instructions per sample against 2 for a
+        // plain PCM16 decode)
+        if (pcm16 && c->stft_prenorm) {
+            const size_t need = (size_t)c->max_batch * (size_t)n_in;
+            if (w.norm16_cap < need) {
+                if (w.norm16) (void)hipFree(w.norm16);
+                w.norm16 = nullptr; w.norm16_cap = 0;
+                HIP_TRY(c, hipMalloc((void**)&w.norm16, need * sizeof(int16_t)));
+                w.norm16_cap = need;
+            }
+            norm = w.norm16;
+        }
+        if (pcm16) launch_rms_scale_pcm16((const int16_t*)d_wave, n_in, d_len, n_in, nb, w.scale, okp, norm, s);
         else launch_rms_scale_f32((const float*)d_wave, n_in, d_len, n_in, nb, w.scale, okp, s);
         src.scale = w.scale;
         src.requant = 1;
+        if (norm) { src.wave = norm; src.scale = nullptr; src.requant = 0; }
     } else if (d_rms_ok) {
         (void)hipMemsetAsync(d_rms_ok, 0, (size_t)nb * sizeof(int32_t), s);
     }
@@ -834,6 +854,7 @@ int amph_configure(amph_ctx* c, const char* key, int value) {
     HIP_TRY(c, hipSetDevice(c->device));
     if (!std::strcmp(key, "lanes")) return set_lanes(c, value);
     if (!std::strcmp(key, "fuse_conv12")) { c->fuse_conv12 = value != 0; return AMPH_OK; }
+    if (!std::strcmp(key, "stft_prenorm")) { c->stft_prenorm = value != 0; return AMPH_OK; }
 #ifdef AMPH_STAMPS
     if (!std::strcmp(key, "dump_gemm_stamps")) {
         (void)hipDeviceSynchronize();
@@ -973,7 +994,7 @@ int amph_rms_normalize_pcm16(amph_ctx* c, const int16_t* d_in, int n_rows, int n
         const int nb = std::min(c->max_batch, n_rows - off);
         Workspace& w = c->lanes[0];
         int32_t* okp = d_ok ? d_ok + off : w.ok;
-        launch_rms_scale_pcm16(d_in + (size_t)off * n, n, nullptr, n, nb, w.scale, okp, s);
+        launch_rms_scale_pcm16(d_in + (size_t)off * n, n, nullptr, n, nb, w.scale, okp, nullptr, s);
         launch_rms_apply_pcm16(d_in + (size_t)off * n, nb, n, w.scale, okp, d_out + (size_t)off * n, s);
     }
     return check_launch(c, "rms_normalize_pcm16");

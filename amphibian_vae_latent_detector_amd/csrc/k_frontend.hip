@@ -145,7 +145,7 @@ __device__ __forceinline__ float sq_of(float y) {
 template <typename T>
 __global__ __launch_bounds__(256) void k_rms_scale(const T* __restrict__ in, long long row_stride,
                                                    const int32_t* __restrict__ lengths, int n_in,
-                                                   float* __restrict__ scale, int32_t* __restrict__ ok) {
+                                                   float* __restrict__ scale, int32_t* __restrict__ ok, int16_t* __restrict__ norm_out) {
 #pragma clang fp contract(off)
     constexpr int kChunksPerPass = NpPass<T>::kChunks;
     constexpr int kPassElems = kChunksPerPass * kNpChunk;
@@ -267,6 +267,48 @@ __global__ __launch_bounds__(256) void k_rms_scale(const T* __restrict__ in, lon
         }
         scale[row] = sc;
         if (ok) ok[row] = good;
+        heap[0] = sc;
+        heap[1] = good ? 1.0f : 0.0f;
+    }
+    // PCM16 rows, optional: also write the normalised, re-quantised row - the samples 00_normalize_dataset_rms.py:51-57 puts on
+    // disk (decode q / 32768, scale, clip, rint(x * 32767)): k_rms_apply_pcm16's arithmetic, in this launch.  The STFT kernel
+    // then decodes plain PCM16 instead of normalising every sample of every (81 % overlapping) frame.
+    if constexpr (sizeof(T) == 2) {
+        if (norm_out) {
+            __syncthreads();
+            const float sc = heap[0];
+            const bool scaled = heap[1] != 0.0f;
+            int16_t* o = norm_out + (long long)row * row_stride;
+            auto conv = [&](int q) {
+                float v = (float)q * (1.0f / 32768.0f);
+                if (scaled) v = fminf(fmaxf(v * sc, -1.0f), 1.0f);
+                return (int)rintf(v * 32767.0f);
+            };
+            if (n_chunks <= kChunksPerPass && (reinterpret_cast<uintptr_t>(o) & 3u) == 0) {
+                // the whole valid row is still in the LDS image of its single pass (samples past the valid length are never
+                // read by the STFT kernel): no second global round trip
+                const int nd = n >> 1;
+                uint32_t* o2 = reinterpret_cast<uint32_t*>(o);
+                for (int i = tid; i < nd; i += 256) {
+                    const uint32_t v = *reinterpret_cast<const uint32_t*>(img + np_lds_off<T>(2 * i));
+                    const int lo = conv((int)(short)(v & 0xFFFFu)), hi = conv((int)v >> 16);
+                    o2[i] = ((uint32_t)lo & 0xFFFFu) | ((uint32_t)hi << 16);
+                }
+                if ((n & 1) && tid == 0) o[n - 1] = (int16_t)conv((int)*reinterpret_cast<const T*>(img + np_lds_off<T>(n - 1)));
+            } else if (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(o)) & 3u) == 0) {
+                const uint32_t* x2 = reinterpret_cast<const uint32_t*>(x);
+                uint32_t* o2 = reinterpret_cast<uint32_t*>(o);
+                const int nd = n_in >> 1;
+                for (int i = tid; i < nd; i += 256) {
+                    const uint32_t v = x2[i];
+                    const int lo = conv((int)(short)(v & 0xFFFFu)), hi = conv((int)v >> 16);
+                    o2[i] = ((uint32_t)lo & 0xFFFFu) | ((uint32_t)hi << 16);
+                }
+                if ((n_in & 1) && tid == 0) o[n_in - 1] = (int16_t)conv((int)x[n_in - 1]);
+            } else {
+                for (int i = tid; i < n_in; i += 256) o[i] = (int16_t)conv((int)x[i]);
+            }
+        }
     }
 }
 
@@ -1215,12 +1257,13 @@ void launch_dbnorm(const DbNormParams& p, int n_rows, hipStream_t s) {
 }
 
 void launch_rms_scale_pcm16(const int16_t* in, long long row_stride, const int32_t* lengths, int n_in, int n_rows,
-                            float* scale, int32_t* ok, hipStream_t s) {
-    hipLaunchKernelGGL(k_rms_scale<int16_t>, dim3(n_rows), dim3(256), rms_scale_lds<int16_t>(), s, in, row_stride, lengths, n_in, scale, ok);
+                            float* scale, int32_t* ok, int16_t* norm_out, hipStream_t s) {
+    hipLaunchKernelGGL(k_rms_scale<int16_t>, dim3(n_rows), dim3(256), rms_scale_lds<int16_t>(), s, in, row_stride, lengths, n_in, scale, ok, norm_out);
 }
 void launch_rms_scale_f32(const float* in, long long row_stride, const int32_t* lengths, int n_in, int n_rows,
                           float* scale, int32_t* ok, hipStream_t s) {
-    hipLaunchKernelGGL(k_rms_scale<float>, dim3(n_rows), dim3(256), rms_scale_lds<float>(), s, in, row_stride, lengths, n_in, scale, ok);
+    hipLaunchKernelGGL(k_rms_scale<float>, dim3(n_rows), dim3(256), rms_scale_lds<float>(), s, in, row_stride, lengths, n_in, scale, ok,
+                       static_cast<int16_t*>(nullptr));
 }
 void launch_rms_apply_f32(const float* in, int n_rows, int n, const float* scale, const int32_t* ok, float* out,
                           hipStream_t s) {

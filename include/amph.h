@@ -98,6 +98,9 @@ const char* amph_last_error(const amph_ctx* ctx);   /* ctx may be NULL: create-t
  *   "stft_indep"       0/1   STFT kernel with independent waves (default 1: every wave fetches its own frame, no
  *                            workgroup barrier per tile) or the tile-synchronous one with a shared sample span in LDS
  *                            (0); PROCESS-wide; the two agree to the last bit or two (8e-8 relative)
+ *   "stft_prenorm"     0/1   PCM16 input with apply_rms: the RMS kernel also writes the normalised, re-quantised PCM16
+ *                            rows (what 00_normalize_dataset_rms.py puts on disk) and the STFT kernel reads those
+ *                            (default 1) instead of normalising every sample of every frame itself (0); same bits
  *   "stft_grid"        0..   persistent STFT workgroups (0 = fill the chip); PROCESS-wide, like the diagnostic
  *                            knobs "gemm_flags" / "gemm_min_lds" (A/B switches of tools/sweep.py; "gemm_min_wg128" is per context:
  *                            bit 0 wave-slot priority, bit 1 first-generation plain GEMM, bit 2 first-generation fused GEMM,
