@@ -311,6 +311,18 @@ def test_encode_edge_cases(env):
     a, _, _ = sess.encode(pcm, apply_rms=True)
     b, _, _ = sess.encode(y, apply_rms=True)
     assert torch.equal(a, b)
+    # odd row stride (rows not 4-byte aligned: per-sample paths of K0's normalised-row write and of the STFT fetch), and the
+    # normalised rows written by K0 against the STFT kernel normalising on the fly: same bits
+    odd = np.ascontiguousarray(pcm[:, : cfg.n_samples + 2999])
+    lengths_odd = np.minimum(lengths, odd.shape[1]).astype(np.int32)
+    c, _, _ = sess.encode(odd, lengths=lengths_odd, apply_rms=True)
+    assert torch.equal(c, sess.encode(pcm, lengths=lengths_odd, apply_rms=True)[0])
+    try:
+        sess.configure("stft_prenorm", 0)
+        assert torch.equal(c, sess.encode(odd, lengths=lengths_odd, apply_rms=True)[0])
+        assert torch.equal(a, sess.encode(pcm, apply_rms=True)[0])
+    finally:
+        sess.configure("stft_prenorm", 1)
     # full-scale square wave: clipping + quantisation extremes
     sq = np.where(np.arange(cfg.n_samples) % 100 < 50, 32767, -32768).astype(np.int16)[None]
     mu, _, _ = sess.encode(sq, apply_rms=True)
