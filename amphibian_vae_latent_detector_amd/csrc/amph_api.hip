@@ -105,6 +105,7 @@ struct amph_ctx {
     bool bf16_encoder = false;             // BASELINE config 4: bf16 weights/activations, bf16 MFMA, fp32 accumulate
     bool fuse_conv12 = true;               // recompute layer 1 inside layer 2's A staging when the tiling allows
     bool stft_prenorm = true;              // PCM16 + RMS: write the normalised PCM16 rows once, STFT reads those
+    bool stft_prepad = true;               // ... fix_length'd and centre padded (independent-wave STFT kernel only)
     // radial scratch
     float* d_centroids = nullptr;
     double* d_thr = nullptr;
@@ -684,8 +685,15 @@ int run_frontend(amph_ctx* c, Workspace& w, const void* d_wave, bool pcm16, int 
         // written), inside the K0 launch, instead of normalising inside the STFT kernel, whose independent waves would each
         // redo it for the 81 % of a frame they share with their neighbours (6 VALU instructions per sample against 2 for a
         // plain PCM16 decode)
+        NormPad pad{};
         if (pcm16 && c->stft_prenorm) {
-            const size_t need = (size_t)c->max_batch * (size_t)n_in;
+            // with the independent-wave STFT kernel the rows are written as that kernel wants to read them: fix_length'd and
+            // centre padded, so that no frame needs index reflection
+            if (amph::g_stft_indep && c->stft_prepad) {
+                pad.lead = c->cfg.n_fft / 2; pad.n_fix = c->cfg.n_samples; pad.mode = c->cfg.pad_mode;
+                pad.out_stride = ((long long)pad.n_fix + 2 * pad.lead + 1) & ~1ll;
+            }
+            const size_t need = (size_t)c->max_batch * (pad.lead > 0 ? (size_t)pad.out_stride : (size_t)n_in);
             if (w.norm16_cap < need) {
                 if (w.norm16) (void)hipFree(w.norm16);
                 w.norm16 = nullptr; w.norm16_cap = 0;
@@ -694,11 +702,14 @@ int run_frontend(amph_ctx* c, Workspace& w, const void* d_wave, bool pcm16, int 
             }
             norm = w.norm16;
         }
-        if (pcm16) launch_rms_scale_pcm16((const int16_t*)d_wave, n_in, d_len, n_in, nb, w.scale, okp, norm, s);
+        if (pcm16) launch_rms_scale_pcm16((const int16_t*)d_wave, n_in, d_len, n_in, nb, w.scale, okp, norm, pad, s);
         else launch_rms_scale_f32((const float*)d_wave, n_in, d_len, n_in, nb, w.scale, okp, s);
         src.scale = w.scale;
         src.requant = 1;
-        if (norm) { src.wave = norm; src.scale = nullptr; src.requant = 0; }
+        if (norm) {
+            src.wave = norm; src.scale = nullptr; src.requant = 0;
+            if (pad.lead > 0) { src.lead = pad.lead; src.row_stride = pad.out_stride; src.lengths = nullptr; src.n_in = pad.n_fix + 2 * pad.lead; }
+        }
     } else if (d_rms_ok) {
         (void)hipMemsetAsync(d_rms_ok, 0, (size_t)nb * sizeof(int32_t), s);
     }
@@ -855,6 +866,7 @@ int amph_configure(amph_ctx* c, const char* key, int value) {
     if (!std::strcmp(key, "lanes")) return set_lanes(c, value);
     if (!std::strcmp(key, "fuse_conv12")) { c->fuse_conv12 = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "stft_prenorm")) { c->stft_prenorm = value != 0; return AMPH_OK; }
+    if (!std::strcmp(key, "stft_prepad")) { c->stft_prepad = value != 0; return AMPH_OK; }
 #ifdef AMPH_STAMPS
     if (!std::strcmp(key, "dump_gemm_stamps")) {
         (void)hipDeviceSynchronize();
@@ -994,7 +1006,7 @@ int amph_rms_normalize_pcm16(amph_ctx* c, const int16_t* d_in, int n_rows, int n
         const int nb = std::min(c->max_batch, n_rows - off);
         Workspace& w = c->lanes[0];
         int32_t* okp = d_ok ? d_ok + off : w.ok;
-        launch_rms_scale_pcm16(d_in + (size_t)off * n, n, nullptr, n, nb, w.scale, okp, nullptr, s);
+        launch_rms_scale_pcm16(d_in + (size_t)off * n, n, nullptr, n, nb, w.scale, okp, nullptr, NormPad{}, s);
         launch_rms_apply_pcm16(d_in + (size_t)off * n, nb, n, w.scale, okp, d_out + (size_t)off * n, s);
     }
     return check_launch(c, "rms_normalize_pcm16");

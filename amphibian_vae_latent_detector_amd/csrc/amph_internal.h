@@ -19,6 +19,15 @@ struct WaveSrc {
     int n_in;                // valid samples per row when lengths == nullptr
     const float* scale;      // nullable: per-row RMS scale (1.0 when gated)
     int requant;             // emulate the PCM16 write/read of 00_normalize (x*32767, rint, /32768)
+    int lead;                // > 0 (k_stft_mel_w only): rows already are fix_length'd and centre padded (`lead` samples in front and
+                             // behind, n_in = n_samples + 2 lead, lengths == nullptr): every frame is an interior frame
+};
+
+// K0's optional second output (PCM16 rows): lead == 0 -> the normalised row as it is (row_stride of the input);
+// lead > 0 -> truncated / zero padded to n_fix samples + `lead` samples of centre padding on both sides (mode 0 reflect, 1 zeros)
+struct NormPad {
+    int lead = 0, n_fix = 0, mode = 0;
+    long long out_stride = 0;
 };
 
 struct StftParams {
@@ -52,7 +61,7 @@ struct DbNormParams {
 
 // norm_out (nullable): also write the normalised, re-quantised PCM16 rows (same row stride)
 void launch_rms_scale_pcm16(const int16_t* in, long long row_stride, const int32_t* lengths, int n_in,
-                            int n_rows, float* scale, int32_t* ok, int16_t* norm_out, hipStream_t s);
+                            int n_rows, float* scale, int32_t* ok, int16_t* norm_out, const NormPad& pad, hipStream_t s);
 void launch_rms_scale_f32(const float* in, long long row_stride, const int32_t* lengths, int n_in,
                           int n_rows, float* scale, int32_t* ok, hipStream_t s);
 void launch_rms_apply_f32(const float* in, int n_rows, int n, const float* scale, const int32_t* ok, float* out,

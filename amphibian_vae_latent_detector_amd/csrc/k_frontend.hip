@@ -145,7 +145,8 @@ __device__ __forceinline__ float sq_of(float y) {
 template <typename T>
 __global__ __launch_bounds__(256) void k_rms_scale(const T* __restrict__ in, long long row_stride,
                                                    const int32_t* __restrict__ lengths, int n_in,
-                                                   float* __restrict__ scale, int32_t* __restrict__ ok, int16_t* __restrict__ norm_out) {
+                                                   float* __restrict__ scale, int32_t* __restrict__ ok, int16_t* __restrict__ norm_out,
+                                                   NormPad pad) {
 #pragma clang fp contract(off)
     constexpr int kChunksPerPass = NpPass<T>::kChunks;
     constexpr int kPassElems = kChunksPerPass * kNpChunk;
@@ -278,13 +279,48 @@ __global__ __launch_bounds__(256) void k_rms_scale(const T* __restrict__ in, lon
             __syncthreads();
             const float sc = heap[0];
             const bool scaled = heap[1] != 0.0f;
-            int16_t* o = norm_out + (long long)row * row_stride;
+            int16_t* o = norm_out + (long long)row * (pad.lead > 0 ? pad.out_stride : row_stride);
             auto conv = [&](int q) {
                 float v = (float)q * (1.0f / 32768.0f);
                 if (scaled) v = fminf(fmaxf(v * sc, -1.0f), 1.0f);
                 return (int)rintf(v * 32767.0f);
             };
-            if (n_chunks <= kChunksPerPass && (reinterpret_cast<uintptr_t>(o) & 3u) == 0) {
+            if (pad.lead > 0) {
+                // the row as the STFT sees it (map_detector_core.py:212-228): truncated / zero padded to n_fix samples, then
+                // pad.lead samples of librosa's centre padding on each side (reflect, or zeros) - every frame of the row then
+                // is an interior frame of this buffer: no index reflection, no per-sample path in the STFT kernel
+                const bool in_lds = n_chunks <= kChunksPerPass;
+                const int nv = min(n, pad.n_fix), total = pad.n_fix + 2 * pad.lead;
+                auto sample = [&](int idx) {
+                    int sidx = idx - pad.lead;
+                    if (pad.mode == 0) {                      // reflect (np.pad mode="reflect")
+                        if (sidx < 0) sidx = -sidx;
+                        if (sidx >= pad.n_fix) sidx = 2 * (pad.n_fix - 1) - sidx;
+                    }
+                    if (sidx < 0 || sidx >= nv) return 0;     // constant padding / the zeros of fix_length
+                    const int q = in_lds ? (int)*reinterpret_cast<const T*>(img + np_lds_off<T>(sidx)) : (int)x[sidx];
+                    return conv(q);
+                };
+                if ((reinterpret_cast<uintptr_t>(o) & 3u) == 0) {
+                    uint32_t* o2 = reinterpret_cast<uint32_t*>(o);
+                    // three loops without a branch inside: [0, i_lo) padding, [i_lo, i_hi) the row itself - an output dword there is
+                    // one dword of the LDS image -, [i_hi, total / 2) zeros of fix_length + padding
+                    const bool pairs = in_lds && (pad.lead & 1) == 0;
+                    const int i_lo = pairs ? pad.lead >> 1 : 0, i_hi = pairs ? i_lo + (nv >> 1) : 0;
+                    for (int i = tid; i < i_lo; i += 256)
+                        o2[i] = ((uint32_t)sample(2 * i) & 0xFFFFu) | ((uint32_t)sample(2 * i + 1) << 16);
+                    for (int i = i_lo + tid; i < i_hi; i += 256) {
+                        const uint32_t v = *reinterpret_cast<const uint32_t*>(img + np_lds_off<T>(2 * i - pad.lead));
+                        const int lo = conv((int)(short)(v & 0xFFFFu)), hi = conv((int)v >> 16);
+                        o2[i] = ((uint32_t)lo & 0xFFFFu) | ((uint32_t)hi << 16);
+                    }
+                    for (int i = i_hi + tid; i < (total >> 1); i += 256)
+                        o2[i] = ((uint32_t)sample(2 * i) & 0xFFFFu) | ((uint32_t)sample(2 * i + 1) << 16);
+                    if ((total & 1) && tid == 0) o[total - 1] = (int16_t)sample(total - 1);
+                } else {
+                    for (int i = tid; i < total; i += 256) o[i] = (int16_t)sample(i);
+                }
+            } else if (n_chunks <= kChunksPerPass && (reinterpret_cast<uintptr_t>(o) & 3u) == 0) {
                 // the whole valid row is still in the LDS image of its single pass (samples past the valid length are never
                 // read by the STFT kernel): no second global round trip
                 const int nd = n >> 1;
@@ -860,9 +896,9 @@ __global__ __launch_bounds__(64 * NW) void k_stft_mel_w(StftParams p, int n_tile
         d.fr0 = tl * FT + it_fl0;
         d.rowp = reinterpret_cast<const char*>(p.src.wave) + (long long)r * p.src.row_stride * (PCM16 ? 2 : 4);
         const int len = p.src.lengths ? min(p.src.lengths[r], p.src.n_in) : p.src.n_in;
-        d.len = min(len, p.n_samples);               // truncation of fix_length (:217)
+        d.len = p.src.lead > 0 ? p.src.n_in : min(len, p.n_samples);   // truncation of fix_length (:217); a padded row is complete
         d.sc = p.src.scale ? p.src.scale[r] : 1.0f;
-        d.s_begin = d.fr0 * p.hop - (n_fft >> 1);
+        d.s_begin = d.fr0 * p.hop - (n_fft >> 1) + p.src.lead;         // src.lead: centre padding already materialised (K0)
         // every frame slot of the wave inside the row, even start, 4-byte aligned: one dword = the (even, odd) sample pair
         const int s_last = d.s_begin + (SLOTS - 1) * p.hop;
         d.fast = d.s_begin >= 0 && s_last + n_fft <= d.len && d.fr0 + SLOTS <= p.n_frames && ((p.hop | d.s_begin) & 1) == 0 &&
@@ -923,7 +959,8 @@ __global__ __launch_bounds__(64 * NW) void k_stft_mel_w(StftParams p, int n_tile
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         int sidx = sb + 2 * (lane_f + L * j) + h;
-                        if (p.pad_mode == 0) {                // reflect (np.pad mode="reflect")
+                        if (p.src.lead > 0) {                 // padded rows: plain indexing (only reached for unaligned rows)
+                        } else if (p.pad_mode == 0) {         // reflect (np.pad mode="reflect")
                             if (sidx < 0) sidx = -sidx;
                             if (sidx >= N) sidx = 2 * (N - 1) - sidx;
                         } else if (sidx >= N) sidx = -1;      // constant (zero) padding
@@ -1257,13 +1294,14 @@ void launch_dbnorm(const DbNormParams& p, int n_rows, hipStream_t s) {
 }
 
 void launch_rms_scale_pcm16(const int16_t* in, long long row_stride, const int32_t* lengths, int n_in, int n_rows,
-                            float* scale, int32_t* ok, int16_t* norm_out, hipStream_t s) {
-    hipLaunchKernelGGL(k_rms_scale<int16_t>, dim3(n_rows), dim3(256), rms_scale_lds<int16_t>(), s, in, row_stride, lengths, n_in, scale, ok, norm_out);
+                            float* scale, int32_t* ok, int16_t* norm_out, const NormPad& pad, hipStream_t s) {
+    hipLaunchKernelGGL(k_rms_scale<int16_t>, dim3(n_rows), dim3(256), rms_scale_lds<int16_t>(), s, in, row_stride, lengths, n_in, scale, ok, norm_out,
+                       pad);
 }
 void launch_rms_scale_f32(const float* in, long long row_stride, const int32_t* lengths, int n_in, int n_rows,
                           float* scale, int32_t* ok, hipStream_t s) {
     hipLaunchKernelGGL(k_rms_scale<float>, dim3(n_rows), dim3(256), rms_scale_lds<float>(), s, in, row_stride, lengths, n_in, scale, ok,
-                       static_cast<int16_t*>(nullptr));
+                       static_cast<int16_t*>(nullptr), NormPad{});
 }
 void launch_rms_apply_f32(const float* in, int n_rows, int n, const float* scale, const int32_t* ok, float* out,
                           hipStream_t s) {

@@ -101,6 +101,9 @@ const char* amph_last_error(const amph_ctx* ctx);   /* ctx may be NULL: create-t
  *   "stft_prenorm"     0/1   PCM16 input with apply_rms: the RMS kernel also writes the normalised, re-quantised PCM16
  *                            rows (what 00_normalize_dataset_rms.py puts on disk) and the STFT kernel reads those
  *                            (default 1) instead of normalising every sample of every frame itself (0); same bits
+ *   "stft_prepad"      0/1   ... and writes them as the independent-wave STFT kernel reads them: truncated / zero padded to
+ *                            n_samples and centre padded (n_fft / 2 reflected samples, or zeros, on both sides), so that no
+ *                            frame needs index reflection (default 1; same bits)
  *   "stft_grid"        0..   persistent STFT workgroups (0 = fill the chip); PROCESS-wide, like the diagnostic
  *                            knobs "gemm_flags" / "gemm_min_lds" (A/B switches of tools/sweep.py; "gemm_min_wg128" is per context:
  *                            bit 0 wave-slot priority, bit 1 first-generation plain GEMM, bit 2 first-generation fused GEMM,

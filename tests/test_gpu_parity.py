@@ -318,11 +318,13 @@ def test_encode_edge_cases(env):
     c, _, _ = sess.encode(odd, lengths=lengths_odd, apply_rms=True)
     assert torch.equal(c, sess.encode(pcm, lengths=lengths_odd, apply_rms=True)[0])
     try:
-        sess.configure("stft_prenorm", 0)
-        assert torch.equal(c, sess.encode(odd, lengths=lengths_odd, apply_rms=True)[0])
-        assert torch.equal(a, sess.encode(pcm, apply_rms=True)[0])
+        for key in ("stft_prepad", "stft_prenorm"):           # K0 writes plain normalised rows / nothing: the STFT kernel pads
+            sess.configure(key, 0)                            # (and normalises) itself
+            assert torch.equal(c, sess.encode(odd, lengths=lengths_odd, apply_rms=True)[0]), key
+            assert torch.equal(a, sess.encode(pcm, apply_rms=True)[0]), key
     finally:
         sess.configure("stft_prenorm", 1)
+        sess.configure("stft_prepad", 1)
     # full-scale square wave: clipping + quantisation extremes
     sq = np.where(np.arange(cfg.n_samples) % 100 < 50, 32767, -32768).astype(np.int16)[None]
     mu, _, _ = sess.encode(sq, apply_rms=True)
