@@ -305,14 +305,33 @@ __global__ __launch_bounds__(256) void k_rms_scale(const T* __restrict__ in, lon
                     uint32_t* o2 = reinterpret_cast<uint32_t*>(o);
                     // three loops without a branch inside: [0, i_lo) padding, [i_lo, i_hi) the row itself - an output dword there is
                     // one dword of the LDS image -, [i_hi, total / 2) zeros of fix_length + padding
-                    const bool pairs = in_lds && (pad.lead & 1) == 0;
+                    const bool x_al = (reinterpret_cast<uintptr_t>(x) & 3u) == 0;
+                    const bool pairs = (in_lds || x_al) && (pad.lead & 1) == 0;
                     const int i_lo = pairs ? pad.lead >> 1 : 0, i_hi = pairs ? i_lo + (nv >> 1) : 0;
                     for (int i = tid; i < i_lo; i += 256)
                         o2[i] = ((uint32_t)sample(2 * i) & 0xFFFFu) | ((uint32_t)sample(2 * i + 1) << 16);
-                    for (int i = i_lo + tid; i < i_hi; i += 256) {
-                        const uint32_t v = *reinterpret_cast<const uint32_t*>(img + np_lds_off<T>(2 * i - pad.lead));
-                        const int lo = conv((int)(short)(v & 0xFFFFu)), hi = conv((int)v >> 16);
-                        o2[i] = ((uint32_t)lo & 0xFFFFu) | ((uint32_t)hi << 16);
+                    if (in_lds) {
+                        for (int i = i_lo + tid; i < i_hi; i += 256) {
+                            const uint32_t v = *reinterpret_cast<const uint32_t*>(img + np_lds_off<T>(2 * i - pad.lead));
+                            const int lo = conv((int)(short)(v & 0xFFFFu)), hi = conv((int)v >> 16);
+                            o2[i] = ((uint32_t)lo & 0xFFFFu) | ((uint32_t)hi << 16);
+                        }
+                    } else {                              // rows longer than one pass: from global memory again, 32 loads in flight
+                        const uint32_t* x2 = reinterpret_cast<const uint32_t*>(x);
+                        constexpr int UW = 32;
+                        for (int base = i_lo; base < i_hi; base += 256 * UW) {
+                            uint32_t v[UW];
+#pragma unroll
+                            for (int u = 0; u < UW; ++u) { const int i = base + tid + 256 * u; v[u] = i < i_hi ? x2[i - i_lo] : 0u; }
+#pragma unroll
+                            for (int u = 0; u < UW; ++u) {
+                                const int i = base + tid + 256 * u;
+                                if (i < i_hi) {
+                                    const int lo = conv((int)(short)(v[u] & 0xFFFFu)), hi = conv((int)v[u] >> 16);
+                                    o2[i] = ((uint32_t)lo & 0xFFFFu) | ((uint32_t)hi << 16);
+                                }
+                            }
+                        }
                     }
                     for (int i = i_hi + tid; i < (total >> 1); i += 256)
                         o2[i] = ((uint32_t)sample(2 * i) & 0xFFFFu) | ((uint32_t)sample(2 * i + 1) << 16);
