@@ -710,8 +710,24 @@ int run_frontend(amph_ctx* c, Workspace& w, const void* d_wave, bool pcm16, int 
             src.wave = norm; src.scale = nullptr; src.requant = 0;
             if (pad.lead > 0) { src.lead = pad.lead; src.row_stride = pad.out_stride; src.lengths = nullptr; src.n_in = pad.n_fix + 2 * pad.lead; }
         }
-    } else if (d_rms_ok) {
-        (void)hipMemsetAsync(d_rms_ok, 0, (size_t)nb * sizeof(int32_t), s);
+    } else {
+        if (d_rms_ok) (void)hipMemsetAsync(d_rms_ok, 0, (size_t)nb * sizeof(int32_t), s);
+        // PCM16 rows used as they are: the same fix_length'd, centre-padded copy, by a copy kernel (timed with the RMS stage)
+        if (pcm16 && c->stft_prenorm && c->stft_prepad && amph::g_stft_indep) {
+            StageTimer t(c, ST_RMS, s);
+            NormPad pad{};
+            pad.lead = c->cfg.n_fft / 2; pad.n_fix = c->cfg.n_samples; pad.mode = c->cfg.pad_mode;
+            pad.out_stride = ((long long)pad.n_fix + 2 * pad.lead + 1) & ~1ll;
+            const size_t need = (size_t)c->max_batch * (size_t)pad.out_stride;
+            if (w.norm16_cap < need) {
+                if (w.norm16) (void)hipFree(w.norm16);
+                w.norm16 = nullptr; w.norm16_cap = 0;
+                HIP_TRY(c, hipMalloc((void**)&w.norm16, need * sizeof(int16_t)));
+                w.norm16_cap = need;
+            }
+            launch_pad_rows_pcm16((const int16_t*)d_wave, n_in, d_len, n_in, nb, w.norm16, pad, s);
+            src.wave = w.norm16; src.lead = pad.lead; src.row_stride = pad.out_stride; src.lengths = nullptr; src.n_in = pad.n_fix + 2 * pad.lead;
+        }
     }
     {
         StageTimer t(c, ST_STFT, s);

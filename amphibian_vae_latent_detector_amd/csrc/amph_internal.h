@@ -62,6 +62,8 @@ struct DbNormParams {
 // norm_out (nullable): also write the normalised, re-quantised PCM16 rows (same row stride)
 void launch_rms_scale_pcm16(const int16_t* in, long long row_stride, const int32_t* lengths, int n_in,
                             int n_rows, float* scale, int32_t* ok, int16_t* norm_out, const NormPad& pad, hipStream_t s);
+void launch_pad_rows_pcm16(const int16_t* in, long long row_stride, const int32_t* lengths, int n_in, int n_rows, int16_t* out,
+                           const NormPad& pad, hipStream_t s);
 void launch_rms_scale_f32(const float* in, long long row_stride, const int32_t* lengths, int n_in,
                           int n_rows, float* scale, int32_t* ok, hipStream_t s);
 void launch_rms_apply_f32(const float* in, int n_rows, int n, const float* scale, const int32_t* ok, float* out,

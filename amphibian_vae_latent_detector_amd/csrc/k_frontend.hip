@@ -1317,6 +1317,50 @@ void launch_rms_scale_pcm16(const int16_t* in, long long row_stride, const int32
     hipLaunchKernelGGL(k_rms_scale<int16_t>, dim3(n_rows), dim3(256), rms_scale_lds<int16_t>(), s, in, row_stride, lengths, n_in, scale, ok, norm_out,
                        pad);
 }
+// Rows that are NOT RMS-normalised here (apply_rms == 0: files 00_normalize_dataset_rms.py already processed), PCM16: the
+// same fix_length'd, centre-padded copy K0 writes, so that the independent-wave STFT kernel has no edge frames in this mode
+// either.  A few workgroups per row; three branch-free loops (padding, the row as dwords, zeros + padding).
+__global__ __launch_bounds__(256) void k_pad_rows_pcm16(const int16_t* __restrict__ in, long long row_stride,
+                                                        const int32_t* __restrict__ lengths, int n_in, int16_t* __restrict__ out, NormPad pad) {
+    const int row = blockIdx.x, tid = blockIdx.y * 256 + threadIdx.x, nt = 256 * gridDim.y;   // gridDim.y workgroups share a row
+    const int16_t* x = in + (long long)row * row_stride;
+    int16_t* o = out + (long long)row * pad.out_stride;
+    const int n = lengths ? min(lengths[row], n_in) : n_in;
+    const int nv = min(n, pad.n_fix), total = pad.n_fix + 2 * pad.lead;
+    auto sample = [&](int idx) {
+        int sidx = idx - pad.lead;
+        if (pad.mode == 0) {
+            if (sidx < 0) sidx = -sidx;
+            if (sidx >= pad.n_fix) sidx = 2 * (pad.n_fix - 1) - sidx;
+        }
+        return (sidx < 0 || sidx >= nv) ? 0 : (int)x[sidx];
+    };
+    if (((reinterpret_cast<uintptr_t>(o) | reinterpret_cast<uintptr_t>(x)) & 3u) == 0 && (pad.lead & 1) == 0) {
+        uint32_t* o2 = reinterpret_cast<uint32_t*>(o);
+        const uint32_t* x2 = reinterpret_cast<const uint32_t*>(x);
+        const int i_lo = pad.lead >> 1, i_hi = i_lo + (nv >> 1);
+        for (int i = tid; i < i_lo; i += nt) o2[i] = ((uint32_t)sample(2 * i) & 0xFFFFu) | ((uint32_t)sample(2 * i + 1) << 16);
+        constexpr int UW = 8;
+        for (int base = i_lo; base < i_hi; base += nt * UW) {
+            uint32_t v[UW];
+#pragma unroll
+            for (int u = 0; u < UW; ++u) { const int i = base + tid + nt * u; v[u] = i < i_hi ? x2[i - i_lo] : 0u; }
+#pragma unroll
+            for (int u = 0; u < UW; ++u) { const int i = base + tid + nt * u; if (i < i_hi) o2[i] = v[u]; }
+        }
+        for (int i = i_hi + tid; i < (total >> 1); i += nt) o2[i] = ((uint32_t)sample(2 * i) & 0xFFFFu) | ((uint32_t)sample(2 * i + 1) << 16);
+        if ((total & 1) && tid == 0) o[total - 1] = (int16_t)sample(total - 1);
+    } else {
+        for (int i = tid; i < total; i += nt) o[i] = (int16_t)sample(i);
+    }
+}
+
+void launch_pad_rows_pcm16(const int16_t* in, long long row_stride, const int32_t* lengths, int n_in, int n_rows, int16_t* out,
+                           const NormPad& pad, hipStream_t s) {
+    const int total = pad.n_fix + 2 * pad.lead;
+    const int by = std::max(1, std::min(16, total / (2 * 256 * 8)));          // ~8 dwords per thread
+    hipLaunchKernelGGL(k_pad_rows_pcm16, dim3(n_rows, by), dim3(256), 0, s, in, row_stride, lengths, n_in, out, pad);
+}
 void launch_rms_scale_f32(const float* in, long long row_stride, const int32_t* lengths, int n_in, int n_rows,
                           float* scale, int32_t* ok, hipStream_t s) {
     hipLaunchKernelGGL(k_rms_scale<float>, dim3(n_rows), dim3(256), rms_scale_lds<float>(), s, in, row_stride, lengths, n_in, scale, ok,

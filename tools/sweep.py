@@ -24,6 +24,7 @@ def main():
     chunks = int(opts.get("chunks", 10000))
     rounds = int(opts.get("rounds", 3))
     steps = int(opts.get("steps", 3))
+    rms = bool(int(opts.get("rms", 1)))            # --rms=0: rows used as they are (already normalised files)
     cfg = PRESETS[opts.get("preset", "bench-1s")]
     spec = SPECS["thesis-shape"](cfg.target_frames, cfg.n_mels)
     enc = HipEncoder(spec, random_init_state(spec, 0), "cuda:0", max_batch=batch)
@@ -40,11 +41,11 @@ def main():
         for c in combos:
             for k, v in zip(keys, c):
                 sess.configure(k, v)
-            sess.encode(pcm, apply_rms=True, out_mu=mu)
+            sess.encode(pcm, apply_rms=rms, out_mu=mu)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(steps):
-                sess.encode(pcm, apply_rms=True, out_mu=mu)
+                sess.encode(pcm, apply_rms=rms, out_mu=mu)
             torch.cuda.synchronize()
             res[c].append(chunks * steps / (time.perf_counter() - t0))
             if ref is None:
@@ -57,7 +58,7 @@ def main():
                 sess.configure(k, v)
             sess.configure("lanes", 1)
             sess.profile_reset(); sess.profile_enable(True)
-            sess.encode(pcm, apply_rms=True, out_mu=mu)
+            sess.encode(pcm, apply_rms=rms, out_mu=mu)
             torch.cuda.synchronize()
             print("  isolated us/launch", dict(zip(keys, c)), {st["stage"]: round(1e3 * st["total_ms"] / st["launches"], 1) for st in sess.profile_read() if st["launches"]})
             sess.profile_enable(False); sess.profile_reset()
