@@ -1310,7 +1310,8 @@ __global__ __launch_bounds__(NT) void k_dbnorm(DbNormParams p) {
 
 void launch_dbnorm(const DbNormParams& p, int n_rows, hipStream_t s) {
     const int n = p.n_frames * p.n_mels;
-    if (n <= 256 * 16) hipLaunchKernelGGL((k_dbnorm<16, 256>), dim3(n_rows), dim3(256), 0, s, p);          // 1 s chunks, 64 mels
+    if (n <= 1024 * 4) hipLaunchKernelGGL((k_dbnorm<4, 1024>), dim3(n_rows), dim3(1024), 0, s, p);         // 1 s chunks, 64 mels
+    else if (n <= 256 * 16) hipLaunchKernelGGL((k_dbnorm<16, 256>), dim3(n_rows), dim3(256), 0, s, p);
     else if (n <= 1024 * 12) hipLaunchKernelGGL((k_dbnorm<12, 1024>), dim3(n_rows), dim3(1024), 0, s, p);  // e.g. 87 frames x 128 mels
     else if (n <= 1024 * 24) hipLaunchKernelGGL((k_dbnorm<24, 1024>), dim3(n_rows), dim3(1024), 0, s, p);  // 3 s chunks (376 x 64)
     else if (n <= 1024 * 40) hipLaunchKernelGGL((k_dbnorm<40, 1024>), dim3(n_rows), dim3(1024), 0, s, p);  // 5 s chunks (626 x 64)
