@@ -204,10 +204,10 @@ def main():
         # HBM-side bytes per launch of that kernel from the committed PMC profile of this same configuration
         # (bench.py cannot run rocprofv3 on itself); null when the profile has no entry for the kernel
         try:
-            tr = json.load(open(ROOT / "profiles" / "r01_traffic_v8.json"))["kernels"].get(prof["stage"])
+            tr = json.load(open(ROOT / "profiles" / "r01_traffic_v9.json"))["kernels"].get(prof["stage"])
             if tr and args.batch == 256 and args.preset == "bench-1s" and args.spec == "thesis-shape" and not args.bf16:
                 roof["traffic"] = tr["traffic_bytes"]
-                roof["traffic_source"] = "profiles/r01_traffic_v8.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+                roof["traffic_source"] = "profiles/r01_traffic_v9.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
                 roof["algorithmic_bytes_per_launch"] = int(prof["bytes_per_chunk"] * args.batch)
         except (OSError, ValueError, KeyError):
             pass
