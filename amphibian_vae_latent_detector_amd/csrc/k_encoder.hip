@@ -1227,8 +1227,17 @@ __global__ __launch_bounds__(256) void k_head_reduce(HeadReduceParams p, int n_r
     const int N = 2 * p.D;
     if (g >= n_rows * N) return;
     const int b = g / N, n = g - b * N;
+    // all partials requested at once, then added in split order (the loop form waited for one global round trip per split)
     float acc = 0.0f;
-    for (int s = 0; s < p.splits; ++s) acc += p.partial[((long long)s * n_rows + b) * N + n];
+    const float* src = p.partial + (long long)b * N + n;
+    const long long step = (long long)n_rows * N;
+    for (int s0 = 0; s0 < p.splits; s0 += 16) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = s0 + u < p.splits ? src[(long long)(s0 + u) * step] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) if (s0 + u < p.splits) acc += v[u];
+    }
     acc += p.bias[n];
     if (n < p.D) p.mu[(long long)b * p.D + n] = acc;
     else if (p.logvar) p.logvar[(long long)b * p.D + (n - p.D)] = acc;
