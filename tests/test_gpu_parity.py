@@ -169,6 +169,25 @@ def test_mel_image_against_oracle_both_pad_modes(env, pad_mode):
     assert np.array_equal(got_t, got.transpose(0, 2, 1))
     assert not got[:, :, :3].any() and not got[:, :, 61:].any()         # zero pad 3 left / 3 right (58 -> 64)
     sess.close()
+    # the PCM16 paths in the same pad mode: rows padded by K0 (apply_rms) / by the copy kernel, against the STFT kernel
+    # padding on the fly (stft_prepad 0), ragged lengths included - same bits; and against the CPU restatement
+    enc, tenc, spec = _encoders(env, "tiny", cfg=cfg, max_batch=4)
+    s2 = enc.session(cfg)
+    lengths = np.array([cfg.n_samples, 15001, 700, 0, cfg.n_samples, 1, 4097, cfg.n_samples, 9000], dtype=np.int32)
+    try:
+        for apply_rms in (True, False):
+            a = s2.encode(pcm, lengths=lengths, apply_rms=apply_rms)[0]
+            s2.configure("stft_prepad", 0)
+            assert torch.equal(a, s2.encode(pcm, lengths=lengths, apply_rms=apply_rms)[0]), apply_rms
+            s2.configure("stft_prepad", 1)
+        want_z = []
+        for r in range(9):
+            yr, _ = env.ofe.normalize_pcm16_chunk(pcm[r, :lengths[r]], True) if lengths[r] else (np.zeros(0, np.float32), False)
+            m = env.ofe.wave_to_mel(yr, pad_mode="reflect" if pad_mode == 0 else "constant", **cfg.mel_kwargs())
+            want_z.append(env.oenc.encode_mel_to_latent(tenc, m))
+        _assert_latents(s2.encode(pcm, lengths=lengths, apply_rms=True)[0].cpu().numpy(), np.stack(want_z))
+    finally:
+        s2.configure("stft_prepad", 1)
 
 
 def test_fix_length_padding_truncation_and_ragged_lengths(env, fe):
