@@ -34,6 +34,7 @@ from pathlib import Path
 # streams the lanes would share queues and serialise (measured: 7.3 instead of 6.1 ms/step).  Must be
 # set before the HIP runtime initialises.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver (already exported on the pool)
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
