@@ -766,9 +766,13 @@ int encode_common(amph_ctx* c, const void* d_wave, bool pcm16, int64_t n_rows, i
         HIP_TRY(c, hipEventRecord(c->ev_fork, s));
         for (int l = 1; l < L; ++l) HIP_TRY(c, hipStreamWaitEvent(c->lanes[l].stream, c->ev_fork, 0));
     }
+    // a partial batch goes FIRST (10 000 rows at max_batch 256: 16 + 39 x 256): as the last one it cost its lane a whole batch
+    // latency for a few rows while the other lanes had already drained; per-chunk results do not depend on the batch they are in
+    const int first = (int)(n_rows % c->max_batch);
     int64_t bi = 0;
-    for (int64_t off = 0; off < n_rows; off += c->max_batch, ++bi) {
-        const int nb = (int)std::min<int64_t>(c->max_batch, n_rows - off);
+    for (int64_t off = 0, nb_ = 0; off < n_rows; off += nb_, ++bi) {
+        const int nb = (bi == 0 && first > 0) ? first : (int)std::min<int64_t>(c->max_batch, n_rows - off);
+        nb_ = nb;
         Workspace& w = c->lanes[bi % L];
         hipStream_t ls = (bi % L == 0) ? s : w.stream;
         const char* wv = (const char*)d_wave + (size_t)off * n_in * esz;
