@@ -106,6 +106,7 @@ struct amph_ctx {
     bool fuse_conv12 = true;               // recompute layer 1 inside layer 2's A staging when the tiling allows
     bool stft_prenorm = true;              // PCM16 + RMS: write the normalised PCM16 rows once, STFT reads those
     bool stft_prepad = true;               // ... fix_length'd and centre padded (independent-wave STFT kernel only)
+    int rms_f64_scale = 1;                 // RMS gate + scale in the scalar arithmetic of numpy 1.26 (reference pin) instead of numpy 2.x's
     // radial scratch
     float* d_centroids = nullptr;
     double* d_thr = nullptr;
@@ -457,6 +458,20 @@ int build_encoder(amph_ctx* c, const float* hw, size_t n_floats) {
     return AMPH_OK;
 }
 
+// the normalised / padded PCM16 rows K0 (or the copy kernel) writes for the STFT kernel: sized at create for the padded
+// form (n_samples + n_fft per row); only a caller whose rows are longer than that AND who turned "stft_prepad" off grows it
+int ensure_norm16(amph_ctx* c, Workspace& w, size_t need, hipStream_t s) {
+    if (w.norm16_cap >= need) return AMPH_OK;
+    if (w.norm16) {
+        HIP_TRY(c, hipStreamSynchronize(s));               // an earlier batch of this lane may still read the old rows
+        (void)hipFree(w.norm16);
+    }
+    w.norm16 = nullptr; w.norm16_cap = 0;
+    HIP_TRY(c, hipMalloc((void**)&w.norm16, need * sizeof(int16_t)));
+    w.norm16_cap = need;
+    return AMPH_OK;
+}
+
 int alloc_lane(amph_ctx* c, Workspace& w, bool own_stream) {
     const int MB = c->max_batch;
     const amph_frontend_config& f = c->cfg;
@@ -466,6 +481,10 @@ int alloc_lane(amph_ctx* c, Workspace& w, bool own_stream) {
     HIP_TRY(c, hipMalloc((void**)&w.ok, (size_t)MB * sizeof(int32_t)));
     HIP_TRY(c, hipMalloc((void**)&w.melpow, (size_t)MB * c->n_frames * f.n_mels * sizeof(float)));
     HIP_TRY(c, hipMalloc((void**)&w.image, (size_t)MB * f.target_frames * f.n_mels * sizeof(float)));
+    {
+        const int rc = ensure_norm16(c, w, (size_t)MB * (size_t)(((long long)f.n_samples + f.n_fft + 1) & ~1ll), w.stream);
+        if (rc != AMPH_OK) return rc;
+    }
     if (c->has_encoder) {
         int H = c->spec.in_frames, W = c->spec.in_mels;
         for (int i = 0; i < c->spec.n_conv; ++i) {
@@ -693,17 +712,12 @@ int run_frontend(amph_ctx* c, Workspace& w, const void* d_wave, bool pcm16, int 
                 pad.lead = c->cfg.n_fft / 2; pad.n_fix = c->cfg.n_samples; pad.mode = c->cfg.pad_mode;
                 pad.out_stride = ((long long)pad.n_fix + 2 * pad.lead + 1) & ~1ll;
             }
-            const size_t need = (size_t)c->max_batch * (pad.lead > 0 ? (size_t)pad.out_stride : (size_t)n_in);
-            if (w.norm16_cap < need) {
-                if (w.norm16) (void)hipFree(w.norm16);
-                w.norm16 = nullptr; w.norm16_cap = 0;
-                HIP_TRY(c, hipMalloc((void**)&w.norm16, need * sizeof(int16_t)));
-                w.norm16_cap = need;
-            }
+            const int rc = ensure_norm16(c, w, (size_t)c->max_batch * (pad.lead > 0 ? (size_t)pad.out_stride : (size_t)n_in), s);
+            if (rc != AMPH_OK) return rc;
             norm = w.norm16;
         }
-        if (pcm16) launch_rms_scale_pcm16((const int16_t*)d_wave, n_in, d_len, n_in, nb, w.scale, okp, norm, pad, s);
-        else launch_rms_scale_f32((const float*)d_wave, n_in, d_len, n_in, nb, w.scale, okp, s);
+        if (pcm16) launch_rms_scale_pcm16((const int16_t*)d_wave, n_in, d_len, n_in, nb, w.scale, okp, c->rms_f64_scale, norm, pad, s);
+        else launch_rms_scale_f32((const float*)d_wave, n_in, d_len, n_in, nb, w.scale, okp, c->rms_f64_scale, s);
         src.scale = w.scale;
         src.requant = 1;
         if (norm) {
@@ -718,13 +732,8 @@ int run_frontend(amph_ctx* c, Workspace& w, const void* d_wave, bool pcm16, int 
             NormPad pad{};
             pad.lead = c->cfg.n_fft / 2; pad.n_fix = c->cfg.n_samples; pad.mode = c->cfg.pad_mode;
             pad.out_stride = ((long long)pad.n_fix + 2 * pad.lead + 1) & ~1ll;
-            const size_t need = (size_t)c->max_batch * (size_t)pad.out_stride;
-            if (w.norm16_cap < need) {
-                if (w.norm16) (void)hipFree(w.norm16);
-                w.norm16 = nullptr; w.norm16_cap = 0;
-                HIP_TRY(c, hipMalloc((void**)&w.norm16, need * sizeof(int16_t)));
-                w.norm16_cap = need;
-            }
+            const int rc = ensure_norm16(c, w, (size_t)c->max_batch * (size_t)pad.out_stride, s);
+            if (rc != AMPH_OK) return rc;
             launch_pad_rows_pcm16((const int16_t*)d_wave, n_in, d_len, n_in, nb, w.norm16, pad, s);
             src.wave = w.norm16; src.lead = pad.lead; src.row_stride = pad.out_stride; src.lengths = nullptr; src.n_in = pad.n_fix + 2 * pad.lead;
         }
@@ -770,22 +779,26 @@ int encode_common(amph_ctx* c, const void* d_wave, bool pcm16, int64_t n_rows, i
     // latency for a few rows while the other lanes had already drained; per-chunk results do not depend on the batch they are in
     const int first = (int)(n_rows % c->max_batch);
     int64_t bi = 0;
-    for (int64_t off = 0, nb_ = 0; off < n_rows; off += nb_, ++bi) {
+    int rc = AMPH_OK;
+    for (int64_t off = 0, nb_ = 0; off < n_rows && rc == AMPH_OK; off += nb_, ++bi) {
         const int nb = (bi == 0 && first > 0) ? first : (int)std::min<int64_t>(c->max_batch, n_rows - off);
         nb_ = nb;
         Workspace& w = c->lanes[bi % L];
         hipStream_t ls = (bi % L == 0) ? s : w.stream;
         const char* wv = (const char*)d_wave + (size_t)off * n_in * esz;
-        run_frontend(c, w, wv, pcm16, nb, n_in, d_len ? d_len + off : nullptr, apply_rms, d_rms_ok ? d_rms_ok + off : nullptr,
-                     w.melpow, ls);
-        run_dbnorm(c, w.melpow, nb, 1, w.image, ls);
-        run_encoder(c, w, w.image, nb, d_mu + off * D, d_logvar ? d_logvar + off * D : nullptr, ls);
+        // a stage that fails (an allocation, a launch) stops the call: the later stages of the batch would read stale buffers
+        rc = run_frontend(c, w, wv, pcm16, nb, n_in, d_len ? d_len + off : nullptr, apply_rms, d_rms_ok ? d_rms_ok + off : nullptr,
+                          w.melpow, ls);
+        if (rc == AMPH_OK) rc = run_dbnorm(c, w.melpow, nb, 1, w.image, ls);
+        if (rc == AMPH_OK) rc = run_encoder(c, w, w.image, nb, d_mu + off * D, d_logvar ? d_logvar + off * D : nullptr, ls);
+        if (rc == AMPH_OK) rc = check_launch(c, "encode");
     }
-    for (int l = 1; l < L; ++l) {           // join
-        HIP_TRY(c, hipEventRecord(c->lanes[l].done, c->lanes[l].stream));
-        HIP_TRY(c, hipStreamWaitEvent(s, c->lanes[l].done, 0));
+    for (int l = 1; l < L; ++l) {           // join (on failure too: the caller's stream must not run ahead of the lanes)
+        hipError_t e = hipEventRecord(c->lanes[l].done, c->lanes[l].stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(s, c->lanes[l].done, 0);
+        if (e != hipSuccess && rc == AMPH_OK) rc = fail(c, AMPH_ERR_HIP, "encode: joining lane %d: %s", l, hipGetErrorString(e));
     }
-    return check_launch(c, "encode");
+    return rc;
 }
 
 }  // namespace
@@ -887,6 +900,7 @@ int amph_configure(amph_ctx* c, const char* key, int value) {
     if (!std::strcmp(key, "fuse_conv12")) { c->fuse_conv12 = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "stft_prenorm")) { c->stft_prenorm = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "stft_prepad")) { c->stft_prepad = value != 0; return AMPH_OK; }
+    if (!std::strcmp(key, "rms_numpy2")) { c->rms_f64_scale = value ? 0 : 1; return AMPH_OK; }
 #ifdef AMPH_STAMPS
     if (!std::strcmp(key, "dump_gemm_stamps")) {
         (void)hipDeviceSynchronize();
@@ -1011,7 +1025,7 @@ int amph_rms_normalize_f32(amph_ctx* c, const float* d_in, int n_rows, int n, fl
         const int nb = std::min(c->max_batch, n_rows - off);
         Workspace& w = c->lanes[0];
         int32_t* okp = d_ok ? d_ok + off : w.ok;
-        launch_rms_scale_f32(d_in + (size_t)off * n, n, nullptr, n, nb, w.scale, okp, s);
+        launch_rms_scale_f32(d_in + (size_t)off * n, n, nullptr, n, nb, w.scale, okp, c->rms_f64_scale, s);
         launch_rms_apply_f32(d_in + (size_t)off * n, nb, n, w.scale, okp, d_out + (size_t)off * n, s);
     }
     return check_launch(c, "rms_normalize_f32");
@@ -1026,7 +1040,7 @@ int amph_rms_normalize_pcm16(amph_ctx* c, const int16_t* d_in, int n_rows, int n
         const int nb = std::min(c->max_batch, n_rows - off);
         Workspace& w = c->lanes[0];
         int32_t* okp = d_ok ? d_ok + off : w.ok;
-        launch_rms_scale_pcm16(d_in + (size_t)off * n, n, nullptr, n, nb, w.scale, okp, nullptr, NormPad{}, s);
+        launch_rms_scale_pcm16(d_in + (size_t)off * n, n, nullptr, n, nb, w.scale, okp, c->rms_f64_scale, nullptr, NormPad{}, s);
         launch_rms_apply_pcm16(d_in + (size_t)off * n, nb, n, w.scale, okp, d_out + (size_t)off * n, s);
     }
     return check_launch(c, "rms_normalize_pcm16");
@@ -1041,8 +1055,9 @@ int amph_mel_power_f32(amph_ctx* c, const float* d_wave, int n_rows, int n_in, c
     const size_t per = (size_t)c->n_frames * c->cfg.n_mels;
     for (int off = 0; off < n_rows; off += c->max_batch) {
         const int nb = std::min(c->max_batch, n_rows - off);
-        run_frontend(c, c->lanes[0], d_wave + (size_t)off * n_in, false, nb, n_in, d_lengths ? d_lengths + off : nullptr, 0,
-                     nullptr, d_melpow_out + (size_t)off * per, s);
+        const int rc = run_frontend(c, c->lanes[0], d_wave + (size_t)off * n_in, false, nb, n_in, d_lengths ? d_lengths + off : nullptr, 0,
+                                    nullptr, d_melpow_out + (size_t)off * per, s);
+        if (rc != AMPH_OK) return rc;
     }
     return check_launch(c, "mel_power_f32");
 }
@@ -1057,9 +1072,10 @@ int amph_mel_f32(amph_ctx* c, const float* d_wave, int n_rows, int n_in, const i
     const size_t per = (size_t)c->cfg.target_frames * c->cfg.n_mels;
     for (int off = 0; off < n_rows; off += c->max_batch) {
         const int nb = std::min(c->max_batch, n_rows - off);
-        run_frontend(c, c->lanes[0], d_wave + (size_t)off * n_in, false, nb, n_in, d_lengths ? d_lengths + off : nullptr, 0,
-                     nullptr, c->lanes[0].melpow, s);
-        run_dbnorm(c, c->lanes[0].melpow, nb, layout, d_mel_out + (size_t)off * per, s);
+        int rc = run_frontend(c, c->lanes[0], d_wave + (size_t)off * n_in, false, nb, n_in, d_lengths ? d_lengths + off : nullptr, 0,
+                              nullptr, c->lanes[0].melpow, s);
+        if (rc == AMPH_OK) rc = run_dbnorm(c, c->lanes[0].melpow, nb, layout, d_mel_out + (size_t)off * per, s);
+        if (rc != AMPH_OK) return rc;
     }
     return check_launch(c, "mel_f32");
 }
@@ -1074,7 +1090,8 @@ int amph_encoder_forward(amph_ctx* c, const float* d_x, int n_rows, float* d_mu,
     const int D = c->latent;
     for (int off = 0; off < n_rows; off += c->max_batch) {
         const int nb = std::min(c->max_batch, n_rows - off);
-        run_encoder(c, c->lanes[0], d_x + (size_t)off * per, nb, d_mu + (size_t)off * D, d_logvar ? d_logvar + (size_t)off * D : nullptr, s);
+        const int rc = run_encoder(c, c->lanes[0], d_x + (size_t)off * per, nb, d_mu + (size_t)off * D, d_logvar ? d_logvar + (size_t)off * D : nullptr, s);
+        if (rc != AMPH_OK) return rc;
     }
     return check_launch(c, "encoder_forward");
 }
@@ -1117,10 +1134,13 @@ int amph_encode_pcm16_host(amph_ctx* c, const int16_t* h_pcm, int64_t n_rows, in
     }
     float *d_mu = nullptr, *d_lv = nullptr;
     int32_t* d_ok = nullptr;
-    HIP_TRY(c, hipMalloc((void**)&d_mu, std::max<size_t>(1, (size_t)n_rows * D) * sizeof(float)));
-    if (h_logvar) HIP_TRY(c, hipMalloc((void**)&d_lv, std::max<size_t>(1, (size_t)n_rows * D) * sizeof(float)));
-    if (h_rms_ok) HIP_TRY(c, hipMalloc((void**)&d_ok, std::max<size_t>(1, (size_t)n_rows) * sizeof(int32_t)));
     int rc = AMPH_OK;
+    {
+        hipError_t e = hipMalloc((void**)&d_mu, std::max<size_t>(1, (size_t)n_rows * D) * sizeof(float));
+        if (e == hipSuccess && h_logvar) e = hipMalloc((void**)&d_lv, std::max<size_t>(1, (size_t)n_rows * D) * sizeof(float));
+        if (e == hipSuccess && h_rms_ok) e = hipMalloc((void**)&d_ok, std::max<size_t>(1, (size_t)n_rows) * sizeof(int32_t));
+        if (e != hipSuccess) rc = fail(c, AMPH_ERR_HIP, "encode_pcm16_host: result buffers: %s", hipGetErrorString(e));
+    }
     int slot = 0;
     bool used[2] = {false, false};
     for (int64_t off = 0; off < n_rows && rc == AMPH_OK; off += MB, slot ^= 1) {
@@ -1147,7 +1167,7 @@ int amph_encode_pcm16_host(amph_ctx* c, const int16_t* h_pcm, int64_t n_rows, in
     } else {
         (void)hipStreamSynchronize(c->compute_stream);
     }
-    (void)hipFree(d_mu);
+    if (d_mu) (void)hipFree(d_mu);
     if (d_lv) (void)hipFree(d_lv);
     if (d_ok) (void)hipFree(d_ok);
     return rc;

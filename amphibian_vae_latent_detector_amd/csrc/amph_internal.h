@@ -59,13 +59,14 @@ struct DbNormParams {
     float* out;
 };
 
+// scale_f64: 1 = the scalar arithmetic of numpy 1.26 (the reference's pin: float64 gate compare and scale, one cast), 0 = numpy 2.x (float32)
 // norm_out (nullable): also write the normalised, re-quantised PCM16 rows (same row stride)
 void launch_rms_scale_pcm16(const int16_t* in, long long row_stride, const int32_t* lengths, int n_in,
-                            int n_rows, float* scale, int32_t* ok, int16_t* norm_out, const NormPad& pad, hipStream_t s);
+                            int n_rows, float* scale, int32_t* ok, int scale_f64, int16_t* norm_out, const NormPad& pad, hipStream_t s);
 void launch_pad_rows_pcm16(const int16_t* in, long long row_stride, const int32_t* lengths, int n_in, int n_rows, int16_t* out,
                            const NormPad& pad, hipStream_t s);
 void launch_rms_scale_f32(const float* in, long long row_stride, const int32_t* lengths, int n_in,
-                          int n_rows, float* scale, int32_t* ok, hipStream_t s);
+                          int n_rows, float* scale, int32_t* ok, int scale_f64, hipStream_t s);
 void launch_rms_apply_f32(const float* in, int n_rows, int n, const float* scale, const int32_t* ok, float* out,
                           hipStream_t s);
 void launch_rms_apply_pcm16(const int16_t* in, int n_rows, int n, const float* scale, const int32_t* ok, int16_t* out,

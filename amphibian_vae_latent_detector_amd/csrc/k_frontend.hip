@@ -151,7 +151,7 @@ template <typename T>
 __global__ __launch_bounds__(kRmsThreads) void k_rms_scale(const T* __restrict__ in, long long row_stride,
                                                    const int32_t* __restrict__ lengths, int n_in,
                                                    float* __restrict__ scale, int32_t* __restrict__ ok, int16_t* __restrict__ norm_out,
-                                                   NormPad pad) {
+                                                   NormPad pad, int scale_f64) {
 #pragma clang fp contract(off)
     constexpr int kChunksPerPass = NpPass<T>::kChunks;
     constexpr int kPassElems = kChunksPerPass * kNpChunk;
@@ -269,7 +269,12 @@ __global__ __launch_bounds__(kRmsThreads) void k_rms_scale(const T* __restrict__
         int good = 0;
         if (n > 0) {
             const float rms = sqrtf(total / (float)n);           // np.mean = sum / n in float32; IEEE sqrt
-            if (!(rms < 1e-4f)) { sc = 0.05f / (rms + 1e-8f); good = 1; }
+            if (scale_f64) {
+                // numpy 1.26.4 (the reference's pin, requirements-thesis-baseline-macos-arm64.txt:46): np.float32 scalar <op> Python
+                // float promotes to float64, so the gate compares in float64 and `target_rms / (rms + eps)` is a float64 that the
+                // array multiply casts to float32 ONCE (00_normalize_dataset_rms.py:32-36)
+                if (!((double)rms < 1e-4)) { sc = (float)(0.05 / ((double)rms + 1e-8)); good = 1; }
+            } else if (!(rms < 1e-4f)) { sc = 0.05f / (rms + 1e-8f); good = 1; }   // numpy 2.x (NEP 50): float32 throughout
         }
         scale[row] = sc;
         if (ok) ok[row] = good;
@@ -1162,6 +1167,10 @@ int stft_mel_table_bytes(int n_fft) { return table_bytes_for(n_fft); }
 int stft_mel_scratch_floats(int n_fft) { return (n_fft == 2048 ? FftGeo<4>::SLOT_BYTES : FftGeo<2>::SLOT_BYTES) / 4; }
 
 hipError_t stft_mel_configure(int lds_bytes) {
+    // hipFuncAttributeMaxDynamicSharedMemorySize is a property of the kernel, i.e. PROCESS-wide, and a process routinely holds
+    // contexts with different LDS images (n_fft 2048 and 1024 presets side by side): only ever raise it
+    static int s_lds_max = 0;
+    if (lds_bytes <= s_lds_max) return hipSuccess;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rms_scale<float>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)rms_scale_lds<float>());
     if (e != hipSuccess) return e;
@@ -1180,6 +1189,7 @@ hipError_t stft_mel_configure(int lds_bytes) {
         e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
     }
+    s_lds_max = lds_bytes;
     return hipSuccess;
 }
 
@@ -1319,9 +1329,9 @@ void launch_dbnorm(const DbNormParams& p, int n_rows, hipStream_t s) {
 }
 
 void launch_rms_scale_pcm16(const int16_t* in, long long row_stride, const int32_t* lengths, int n_in, int n_rows,
-                            float* scale, int32_t* ok, int16_t* norm_out, const NormPad& pad, hipStream_t s) {
+                            float* scale, int32_t* ok, int scale_f64, int16_t* norm_out, const NormPad& pad, hipStream_t s) {
     hipLaunchKernelGGL(k_rms_scale<int16_t>, dim3(n_rows), dim3(kRmsThreads), rms_scale_lds<int16_t>(), s, in, row_stride, lengths, n_in, scale, ok, norm_out,
-                       pad);
+                       pad, scale_f64);
 }
 // Rows that are NOT RMS-normalised here (apply_rms == 0: files 00_normalize_dataset_rms.py already processed), PCM16: the
 // same fix_length'd, centre-padded copy K0 writes, so that the independent-wave STFT kernel has no edge frames in this mode
@@ -1368,9 +1378,9 @@ void launch_pad_rows_pcm16(const int16_t* in, long long row_stride, const int32_
     hipLaunchKernelGGL(k_pad_rows_pcm16, dim3(n_rows, by), dim3(256), 0, s, in, row_stride, lengths, n_in, out, pad);
 }
 void launch_rms_scale_f32(const float* in, long long row_stride, const int32_t* lengths, int n_in, int n_rows,
-                          float* scale, int32_t* ok, hipStream_t s) {
+                          float* scale, int32_t* ok, int scale_f64, hipStream_t s) {
     hipLaunchKernelGGL(k_rms_scale<float>, dim3(n_rows), dim3(kRmsThreads), rms_scale_lds<float>(), s, in, row_stride, lengths, n_in, scale, ok,
-                       static_cast<int16_t*>(nullptr), NormPad{});
+                       static_cast<int16_t*>(nullptr), NormPad{}, scale_f64);
 }
 void launch_rms_apply_f32(const float* in, int n_rows, int n, const float* scale, const int32_t* ok, float* out,
                           hipStream_t s) {

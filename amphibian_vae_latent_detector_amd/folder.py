@@ -13,6 +13,7 @@ sharded result is bit-identical to the single-GPU one.
 from __future__ import annotations
 
 import math
+import os
 import random
 from pathlib import Path
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
@@ -167,8 +168,12 @@ def encode_folder(encoder, chunks_dir: Path, species_list: Sequence[str], cfg: F
                   ) -> Tuple[Dict[str, np.ndarray], Dict[str, int]]:
     """08_fit_radial_detector.py:374,461-520 -> ({species: Z [N_sp, D]}, {species: n_failed}).
     With cache_dir, per-species `Z_<chunks_dir.name>_<sp>.npz` files (keys Z, failed, root)
-    are read when present and written (by rank 0) otherwise: the reference's cache format."""
-    rank, _ = _dist_info(group)
+    are read when present and written (by rank 0) otherwise: the reference's cache format.
+    Sharded runs: rank 0 alone decides which species are served from the cache and which files are encoded, and
+    broadcasts that plan - every rank then builds the same path list (the all-gather needs equal shapes) whatever its own
+    view of the cache directory is; cache files are written under a temporary name and renamed, and a barrier behind
+    the writes means a following call on any rank (08 then 08b share cache_npz) finds all of them complete."""
+    rank, world = _dist_info(group)
     chunks_dir = Path(chunks_dir).resolve()
     random.seed(seed)
     np.random.seed(seed)
@@ -176,18 +181,25 @@ def encode_folder(encoder, chunks_dir: Path, species_list: Sequence[str], cfg: F
 
     Z_by: Dict[str, np.ndarray] = {}
     failed_by: Dict[str, int] = {}
-    cached = []
+    cached: List[str] = []
+    wavs_by: Dict[str, List[Path]] = {}
     if cache_dir is not None:
         cache_dir = Path(cache_dir)
-        for sp in species_list:
-            cp = cache_dir / f"Z_{chunks_dir.name}_{sp}.npz"
-            if cp.exists() and (chunks_dir / sp).exists():
-                data = np.load(cp)
-                Z_by[sp] = data["Z"].astype(np.float32)
-                failed_by[sp] = int(data["failed"]) if "failed" in data else 0
-                cached.append(sp)
-                say(f"🧊 {sp}: cargado cache {cp.name} -> N={Z_by[sp].shape[0]}")
-    wavs_by = list_species_wavs(chunks_dir, species_list, max_per_class, skip=cached)
+    if rank == 0:
+        if cache_dir is not None:
+            cached = [sp for sp in species_list
+                      if (cache_dir / f"Z_{chunks_dir.name}_{sp}.npz").exists() and (chunks_dir / sp).exists()]
+        wavs_by = list_species_wavs(chunks_dir, species_list, max_per_class, skip=cached)
+    if world > 1:
+        plan = [cached, {sp: [str(p) for p in v] for sp, v in wavs_by.items()}]
+        dist.broadcast_object_list(plan, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        cached, wavs_by = plan[0], {sp: [Path(p) for p in v] for sp, v in plan[1].items()}
+    for sp in cached:
+        cp = cache_dir / f"Z_{chunks_dir.name}_{sp}.npz"
+        data = np.load(cp)
+        Z_by[sp] = data["Z"].astype(np.float32)
+        failed_by[sp] = int(data["failed"]) if "failed" in data else 0
+        say(f"🧊 {sp}: cargado cache {cp.name} -> N={Z_by[sp].shape[0]}")
     for sp in species_list:
         if sp not in cached and sp not in wavs_by:
             say(f"⚠️ {sp}: carpeta no existe o sin wavs en {chunks_dir / sp} (se omite).")
@@ -215,8 +227,13 @@ def encode_folder(encoder, chunks_dir: Path, species_list: Sequence[str], cfg: F
             say(f"🧪 {sp}: encoded N={Zm.shape[0]} (failed={failed_by[sp]})")
             if cache_dir is not None and rank == 0:
                 cache_dir.mkdir(parents=True, exist_ok=True)
-                np.savez_compressed(cache_dir / f"Z_{chunks_dir.name}_{sp}.npz", Z=Zm, failed=failed_by[sp],
-                                    root=str(chunks_dir))
+                final = cache_dir / f"Z_{chunks_dir.name}_{sp}.npz"
+                tmp = cache_dir / f".{final.name}.{os.getpid()}.tmp"
+                with open(tmp, "wb") as f:                            # a reader never sees a half-written npz
+                    np.savez_compressed(f, Z=Zm, failed=failed_by[sp], root=str(chunks_dir))
+                os.replace(tmp, final)
+    if world > 1 and cache_dir is not None:
+        dist.barrier(group=group)                                     # the cache is complete before ANY rank returns
     # keep config order
     Z_by = {sp: Z_by[sp] for sp in species_list if sp in Z_by}
     return Z_by, failed_by

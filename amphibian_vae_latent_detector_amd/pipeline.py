@@ -72,7 +72,7 @@ def _frontend_from(config: Dict[str, Any], fe: FrontendConfig) -> Tuple[Frontend
 
 
 def fit_radial_from_folder(encoder, chunks_dir: Path, config_path: Path, fe: FrontendConfig, *, q_in: float = 0.95,
-                           q_out: float = 0.10, max_per_class: int = 0, seed: int = 123,
+                           q_out: float = 0.01, max_per_class: int = 0, seed: int = 123,
                            cache_dir: Optional[Path] = None, apply_rms: bool = False, group=None,
                            latents: Optional[Tuple[Dict[str, np.ndarray], Dict[str, int]]] = None,
                            verbose: bool = True) -> Dict[str, Any]:

@@ -90,7 +90,16 @@ const char* amph_last_error(const amph_ctx* ctx);   /* ctx may be NULL: create-t
 /* Tuning knobs (all have working defaults):
  *   "lanes"            1..8  HIP streams + workspaces the encode entry points spread their
  *                            batches over (default 4; lane 0 is the caller's stream, the
- *                            others are forked from / joined to it with events)
+ *                            others are forked from / joined to it with events).  A process has 4
+ *                            hardware queues unless GPU_MAX_HW_QUEUES says otherwise (read by the ROCm
+ *                            runtime when HIP initialises): export GPU_MAX_HW_QUEUES=8 when other streams
+ *                            (RCCL, copies) run beside the lanes; the Python binding defaults it on import
+ *   "rms_numpy2"       0/1   scalar arithmetic of rms_normalize: 0 (default) = numpy 1.26.4, the reference's
+ *                            pin (requirements-thesis-baseline-macos-arm64.txt:46): np.float32 scalar <op>
+ *                            Python float in float64 - gate `rms < 1e-4` and scale `0.05 / (rms + 1e-8)`
+ *                            evaluated in double, the scale cast to float32 once; 1 = numpy 2.x (NEP 50):
+ *                            float32 throughout.  The scales differ by 1 ulp on about a third of all chunks,
+ *                            which the PCM16 re-quantisation behind it turns into whole LSBs
  *   "stft_waves"       4/12  waves per STFT workgroup: 12 = one 768-thread workgroup per CU (three waves
  *                            per SIMD; the default when its LDS image fits 160 KB), 4 = two 256-thread ones
  *   "frames_per_block" 4..32 STFT frames per workgroup tile (multiple of 4; default 12 with 12 waves

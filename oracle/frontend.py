@@ -15,9 +15,22 @@ restate its published algorithm; they follow the reference's call sites:
   standardise            latent_space_exploration/map_detector_core.py:232
   crop_or_pad_time       latent_space_exploration/map_detector_core.py:185-195
 
-numpy here is 2.x; the reference pins numpy 1.26.4.  The only place that
-matters is scalar promotion in `rms_normalize` (float64 scale under 1.26,
-float32 under 2.x; <= 1 ulp) and in power_to_db's reference value.
+numpy here is 2.x; the reference pins numpy 1.26.4
+(requirements-thesis-baseline-macos-arm64.txt:46).  The only place that matters
+is scalar promotion in `rms_normalize`: under 1.26 (value-based casting) an
+np.float32 SCALAR combined with a Python float is computed in float64, so the
+silence gate compares in float64 and the scale `target_rms / (rms + eps)` is a
+float64 that the array multiply casts to float32 once; under 2.x (NEP 50) both
+stay float32.  The scale then differs by 1 ulp on about a third of all chunks,
+and the PCM16 re-quantisation behind it (00 writes PCM16, 07 reads it back)
+turns that into whole LSBs.  `rms_normalize` therefore takes `promotion`:
+"numpy1" (default: the pinned environment, emulated with explicit float64
+scalars - no numpy 1.26 needed) or "numpy2" (what the reference's function
+computes when run on the numpy of this image).  Both are pinned by
+tests/golden/rms_normalize.npz (see tests/golden/make_golden.py for how the
+reference's own function was made to run either way).  power_to_db's reference
+value is an array op (np.maximum on a 0-d result of np.max) and is float32 in
+both.
 """
 from __future__ import annotations
 
@@ -31,13 +44,37 @@ import numpy as np
 # ----------------------------------------------------------------------------
 
 
-def rms_normalize(y, target_rms=0.05, rms_min=1e-4, eps=1e-8):
-    """00_normalize_dataset_rms.py:29-38 (same names, same order of operations)."""
+RMS_PROMOTION = "numpy1"   # default scalar arithmetic of rms_normalize: the reference's pinned numpy 1.26.4
+
+
+def rms_scale(y, target_rms=0.05, rms_min=1e-4, eps=1e-8, promotion=None):
+    """The scalar half of 00_normalize_dataset_rms.py:30-36: returns (scale as
+    np.float32, ok).  `promotion` "numpy1": np.float32 scalar <op> Python float
+    evaluated in float64 (numpy 1.26 value-based casting), the result cast to
+    float32 once by the array multiply; "numpy2": float32 throughout (NEP 50)."""
+    promotion = promotion or RMS_PROMOTION
     y = np.asarray(y)
-    rms = np.sqrt(np.mean(y ** 2))
+    rms = np.sqrt(np.mean(y ** 2))              # np.float32 for float32 input under either numpy
+    if promotion == "numpy1" and y.dtype == np.float32:
+        rms64 = np.float64(rms)
+        if rms64 < np.float64(rms_min):
+            return np.float32(1.0), False
+        return np.float32(np.float64(target_rms) / (rms64 + np.float64(eps))), True
+    if promotion not in ("numpy1", "numpy2"):
+        raise ValueError(promotion)
     if rms < rms_min:
+        return np.float32(1.0), False
+    return np.float32(target_rms / (rms + eps)), True
+
+
+def rms_normalize(y, target_rms=0.05, rms_min=1e-4, eps=1e-8, promotion=None):
+    """00_normalize_dataset_rms.py:29-38 (same names, same order of operations;
+    the scalar arithmetic per `promotion`, see rms_scale)."""
+    y = np.asarray(y)
+    scale, ok = rms_scale(y, target_rms, rms_min, eps, promotion)
+    if not ok:
         return y, False
-    y_norm = y * (target_rms / (rms + eps))
+    y_norm = y * scale                           # float32 array x float32 scalar
     y_norm = np.clip(y_norm, -1.0, 1.0)
     return y_norm, True
 
@@ -232,12 +269,12 @@ def wav_to_mel(wav_path, *, sr, duration, n_mels, fmin, fmax, hop_length, n_fft,
                        pad_mode=pad_mode)
 
 
-def normalize_pcm16_chunk(q, apply_rms=True):
+def normalize_pcm16_chunk(q, apply_rms=True, promotion=None):
     """The 00 -> disk -> 07 hand-off for one raw PCM16 chunk held in memory:
     decode (q/32768), rms_normalize, write PCM16 (x*32767, rint), decode again.
     With apply_rms=False the chunk is only decoded.  Returns (float32 y, ok)."""
     y = pcm16_to_float(q)
     if not apply_rms:
         return y, True
-    y_norm, ok = rms_normalize(y)
+    y_norm, ok = rms_normalize(y, promotion=promotion)
     return pcm16_to_float(float_to_pcm16(y_norm)), ok

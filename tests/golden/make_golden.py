@@ -68,13 +68,45 @@ def main():
     spiky[::500] = 0.9                       # rms small, peaks clip after scaling
     cases["clipping"] = spiky
     cases["short"] = (0.1 * rng.standard_normal(37)).astype(np.float32)
+    # rms == float32(1e-4) exactly: 9.99999975e-05 < 1e-4 in float64 (numpy 1.26: gated), not < float32(1e-4) (numpy 2: scaled)
+    # (its own generator, so the stream the later fixtures draw from does not move)
+    _b = np.random.default_rng(0).standard_normal(64).astype(np.float32)
+    cases["gate_boundary"] = (_b * np.float32(0.00010935918)).astype(np.float32)
+    assert np.sqrt(np.mean(cases["gate_boundary"] ** 2)) == np.float32(1e-4)
     out = {}
+    # The reference pins numpy 1.26.4 (requirements-thesis-baseline-macos-arm64.txt:46); this image has numpy 2.x, whose
+    # scalar promotion differs (NEP 50): `rms < rms_min` and `target_rms / (rms + eps)` with rms an np.float32 SCALAR are
+    # float64 operations under 1.26 and float32 ones under 2.x.  The reference's own function is run both ways:
+    #   out_np2_*  as it is, on this numpy (float32 scalars);
+    #   out_*      with ONE substitution in its module namespace: `np.sqrt` of a scalar returns the same value as a Python
+    #              float.  A Python float is what NEP 50 calls a weak scalar: `rms < rms_min`, `rms + eps` and the division are
+    #              then double arithmetic, and `y * scale` converts the double to float32 once and multiplies in float32 -
+    #              operation for operation what value-based casting did under numpy 1.26.  Every other line of the
+    #              reference function executes unchanged.
+    class _LegacyScalarNumpy:
+        def __getattr__(self, name):
+            return getattr(np, name)
+
+        @staticmethod
+        def sqrt(x):
+            r = np.sqrt(x)
+            return float(r) if np.ndim(r) == 0 else r
+
     for name, y in cases.items():
         y_norm, ok = m00.rms_normalize(y.copy())
         out[f"in_{name}"] = y
+        out[f"out_np2_{name}"] = np.asarray(y_norm)
+        out[f"ok_np2_{name}"] = np.array(bool(ok))
+        m00.np = _LegacyScalarNumpy()
+        try:
+            y_norm, ok = m00.rms_normalize(y.copy())
+        finally:
+            m00.np = np
+        assert np.asarray(y_norm).dtype == np.float32
         out[f"out_{name}"] = np.asarray(y_norm)
         out[f"ok_{name}"] = np.array(bool(ok))
     out["numpy_version"] = np.array(np.__version__)
+    out["promotion"] = np.array("out_* = numpy 1.26 scalar promotion (emulated, see make_golden.py); out_np2_* = numpy 2.x as run")
     np.savez_compressed(HERE / "rms_normalize.npz", **out)
 
     # ------------------------------------------------------- crop_or_pad_time

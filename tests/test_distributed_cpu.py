@@ -45,13 +45,17 @@ def _oracle_encode_fn():
     return fn
 
 
-def _worker(rank, world, port, root, out_dir):
+def _worker(rank, world, port, root, out_dir, tag=""):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        Z, failed = pfolder.encode_folder(None, Path(root), SPECIES, CFG, max_per_class=3, seed=123,
-                                          cache_dir=Path(out_dir) / "cache", encode_fn=_oracle_encode_fn(), verbose=False)
-        np.savez(Path(out_dir) / f"rank{rank}.npz", failed=np.array([failed[s] for s in Z]), **Z)
+        kw = dict(max_per_class=3, seed=123, cache_dir=Path(out_dir) / "cache", encode_fn=_oracle_encode_fn(), verbose=False)
+        Z, failed = pfolder.encode_folder(None, Path(root), SPECIES, CFG, **kw)
+        np.savez(Path(out_dir) / f"rank{rank}{tag}.npz", failed=np.array([failed[s] for s in Z]), **Z)
+        # straight away again on the same cache_dir (08 then 08b share cache_npz): every rank must find the complete
+        # cache rank 0 has just written - no rank may have returned from the first call before the files were in place
+        Z2, failed2 = pfolder.encode_folder(None, Path(root), SPECIES, CFG, **kw)
+        np.savez(Path(out_dir) / f"rank{rank}{tag}_again.npz", failed=np.array([failed2[s] for s in Z2]), **Z2)
     finally:
         dist.destroy_process_group()
 
@@ -80,6 +84,25 @@ def test_two_rank_sharded_folder_encode_equals_single_process(tmp_path):
     # rank 0 wrote the reference-format cache
     d = np.load(out / "cache" / f"Z_train_chunks_norm_{SPECIES[0]}.npz")
     assert np.array_equal(d["Z"], single[SPECIES[0]])
+    assert not [p for p in (out / "cache").iterdir() if p.name.endswith(".tmp")]        # written under a temporary name, renamed
+    # the second call of each worker was served from that cache on both ranks
+    for r in (0, 1):
+        again = np.load(out / f"rank{r}_again.npz")
+        for sp in SPECIES:
+            assert np.array_equal(again[sp], single[sp]), (r, sp)
+    # a partly filled cache: the plan (which species are cached, which files are drawn - the RNG skips cached species,
+    # 08_fit_radial_detector.py:468-484) is rank 0's, so both ranks build the same list; equal to one process on the same cache
+    import shutil
+    (out / "cache" / f"Z_train_chunks_norm_{SPECIES[2]}.npz").unlink()
+    shutil.copytree(out / "cache", tmp_path / "cache_copy")
+    mixed, failed_m = pfolder.encode_folder(None, root, SPECIES, CFG, max_per_class=3, seed=123, cache_dir=tmp_path / "cache_copy",
+                                            encode_fn=_oracle_encode_fn(), verbose=False)
+    mp.spawn(_worker, args=(2, _free_port(), str(root), str(out), "_mixed"), nprocs=2, join=True)
+    for r in (0, 1):
+        got = np.load(out / f"rank{r}_mixed.npz")
+        for sp in SPECIES:
+            assert np.array_equal(got[sp], mixed[sp]), (r, sp)
+        assert got["failed"].tolist() == [failed_m[s] for s in SPECIES]
 
 
 def test_gather_rows_pads_and_trims_single_process():

@@ -91,16 +91,29 @@ def test_mel_basis_equals_librosa_restatement(env, fe):
 
 
 # ----------------------------------------------------------------------------- K0: rms_normalize
-@pytest.mark.parametrize("case", ["noise_quiet", "noise_loud", "tone", "silent", "below_gate", "clipping", "short"])
-def test_rms_normalize_f32_against_reference_vectors(env, fe, golden, case):
+RMS_CASES = ["noise_quiet", "noise_loud", "tone", "silent", "below_gate", "clipping", "short", "gate_boundary"]
+
+
+@pytest.mark.parametrize("numpy2", [0, 1])
+@pytest.mark.parametrize("case", RMS_CASES)
+def test_rms_normalize_f32_against_reference_vectors(env, fe, golden, case, numpy2):
+    """Bit-exact against the reference function's own outputs, in both scalar-promotion environments
+    (tests/golden/make_golden.py): the default = numpy 1.26 (the reference's pin: float64 gate compare and
+    scale, cast once), and "rms_numpy2" = numpy 2.x (float32 scalars).  Gated rows are returned untouched,
+    scaled rows use numpy's float32 summation order.  `gate_boundary` has rms == float32(1e-4): gated under
+    1.26, scaled under 2.x."""
     g = golden("rms_normalize.npz")
-    out, ok = fe.rms_normalize(g[f"in_{case}"])
-    assert bool(ok.cpu().numpy()[0]) == bool(g[f"ok_{case}"])
-    want = g[f"out_{case}"]
-    # bit-exact against the reference function's own output (captured under numpy 2.x): gated rows
-    # are returned untouched, scaled rows use numpy's float32 summation order and float32 scale
-    assert np.array_equal(out.cpu().numpy()[0], want)
+    pre = "np2_" if numpy2 else ""
+    fe.configure("rms_numpy2", numpy2)
+    try:
+        out, ok = fe.rms_normalize(g[f"in_{case}"])
+    finally:
+        fe.configure("rms_numpy2", 0)
+    assert bool(ok.cpu().numpy()[0]) == bool(g[f"ok_{pre}{case}"])
+    assert np.array_equal(out.cpu().numpy()[0], g[f"out_{pre}{case}"])
     assert np.abs(out.cpu().numpy()).max() <= 1.0
+    if case == "gate_boundary":
+        assert bool(g["ok_np2_gate_boundary"]) and not bool(g["ok_gate_boundary"])
 
 
 def test_rms_normalize_pcm16_bit_exact(env, fe):
@@ -113,12 +126,17 @@ def test_rms_normalize_pcm16_bit_exact(env, fe):
     for n in (env.cfg.n_samples, 8192, 8193, 16385, 129, 100, 7, 48000):
         idx = list(range(20)) + [49] if n == env.cfg.n_samples else [int(v) for v in rng.integers(0, 5000, 5)]
         pcm = env.synth(idx, n, env.cfg.sr)
-        out, ok = fe.rms_normalize(pcm)
-        out, ok = out.cpu().numpy(), ok.cpu().numpy()
-        for r in range(pcm.shape[0]):
-            y, good = env.ofe.rms_normalize(env.ofe.pcm16_to_float(pcm[r]))
-            assert bool(ok[r]) == bool(good)
-            assert np.array_equal(out[r], env.ofe.float_to_pcm16(y)), (n, r)
+        for numpy2, promotion in ((0, "numpy1"), (1, "numpy2")):       # each mode against its oracle twin
+            fe.configure("rms_numpy2", numpy2)
+            try:
+                out, ok = fe.rms_normalize(pcm)
+            finally:
+                fe.configure("rms_numpy2", 0)
+            out, ok = out.cpu().numpy(), ok.cpu().numpy()
+            for r in range(pcm.shape[0]):
+                y, good = env.ofe.rms_normalize(env.ofe.pcm16_to_float(pcm[r]), promotion=promotion)
+                assert bool(ok[r]) == bool(good)
+                assert np.array_equal(out[r], env.ofe.float_to_pcm16(y)), (n, r, promotion)
     pcm = env.synth([49], env.cfg.n_samples, env.cfg.sr)
     out, ok = fe.rms_normalize(pcm)
     assert int(ok[0]) == 0 and not out.cpu().numpy().any()
@@ -305,6 +323,35 @@ def test_config2_thesis_shape_all_10000_chunks_and_full_size_properties(env):
     assert torch.equal(mu4, mu[:1000])
     mu_h, ok_h = sess.encode_host(pcm[:700], apply_rms=True)             # pinned host path
     assert np.array_equal(mu_h, z[:700]) and np.array_equal(ok_h, ok.cpu().numpy()[:700])
+    # What the scalar-promotion environment is worth: the default follows the reference's pinned
+    # numpy 1.26 (float64 scale, cast once); "rms_numpy2" is numpy 2.x.  Count the rows whose re-quantised PCM16
+    # samples differ between the two and the latent distance that costs.
+    fes = env.AmphSession(cfg, None, None, DEV, max_batch=256)
+    q1, ok1 = fes.rms_normalize(dev_pcm)
+    fes.configure("rms_numpy2", 1)
+    q2, ok2 = fes.rms_normalize(dev_pcm)
+    fes.close()
+    rows_changed = int((q1 != q2).any(dim=1).sum())
+    samples_changed = int((q1 != q2).sum())
+    assert torch.equal(ok1, ok2)
+    sess.configure("rms_numpy2", 1)
+    try:
+        z2 = sess.encode(dev_pcm, apply_rms=True)[0].cpu().numpy()
+    finally:
+        sess.configure("rms_numpy2", 0)
+    rel12 = np.linalg.norm(z2 - z, axis=1) / np.maximum(np.linalg.norm(z, axis=1), 1e-30)
+    print(f"[config 2] numpy-1.26 vs numpy-2 RMS scale: {rows_changed} of {n} rows change at least one PCM16 sample "
+          f"({samples_changed} samples, max |dq| {int((q1.int() - q2.int()).abs().max())}); latent rel L2 between the modes: "
+          f"max {rel12.max():.3e}, rows over 1e-4: {int((rel12 > 1e-4).sum())}")
+    assert (rel12 > 0).sum() == 0 or rows_changed > 0
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:                                                                 # the numpy-2 mode against ITS oracle twin (first 1000 rows)
+        z2_cpu = np.stack([env.oenc.encode_mel_to_latent(tenc, env.ofe.wave_to_mel(
+            env.ofe.normalize_pcm16_chunk(q, True, promotion="numpy2")[0], **cfg.mel_kwargs())) for q in pcm[:1000]])
+    finally:
+        torch.set_num_threads(threads)
+    _assert_latents(z2[:1000], z2_cpu)
 
 
 def test_encode_edge_cases(env):
