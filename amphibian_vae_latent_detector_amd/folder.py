@@ -128,16 +128,44 @@ def encode_paths(encoder, paths: Sequence[Path], cfg: FrontendConfig, *, apply_r
     return Z, status
 
 
+def _pad_block(local: torch.Tensor, per: int) -> torch.Tensor:
+    """A rank's rows padded with dummy (zero) rows to the common block height of the all-gather."""
+    if local.shape[0] == per:
+        return local.contiguous()
+    pad = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[:local.shape[0]] = local
+    return pad
+
+
 def gather_rows(local: torch.Tensor, per: int, n_total: int, group=None) -> torch.Tensor:
     """All-gather equal-size row blocks (padded to `per` rows) and drop the padding."""
     rank, world = _dist_info(group)
-    if world == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return local[:n_total]
-    pad = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    pad[:local.shape[0]] = local
+    # (a one-rank group still runs the collective: the exchange step is then exercised on a single-GPU box too)
     full = torch.empty((world * per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(full, pad, group=group)
+    dist.all_gather_into_tensor(full, _pad_block(local, per), group=group)
     return full[:n_total]
+
+
+def encode_resident_shards(sess, pcm: torch.Tensor, n_shards: int, *, apply_rms: bool = True,
+                           lengths: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """BASELINE configs[2] on ONE GPU: the HBM-resident chunk matrix `pcm` [n, n_in] (rows in the reference's list
+    order) is cut into `n_shards` contiguous slices exactly as `encode_file_list` cuts the path list (plan_shards:
+    ceil(n / shards) rows each, tail shards short or empty); every slice is encoded by its own call, as its rank would,
+    into a block padded to the common height; the blocks are laid out as all_gather_into_tensor lays them out and the
+    padding is dropped.  No collective runs: this is the data path of the 8-GPU job with the exchange step replaced by
+    the memory layout it produces.  -> Z [n, D] float32 on the device."""
+    n = int(pcm.shape[0])
+    shards, per = plan_shards(n, n_shards)
+    full = torch.empty((n_shards * per, sess.latent_dim), dtype=torch.float32, device=sess.device)
+    for r, (lo, hi) in enumerate(shards):
+        if hi > lo:
+            local, _, _ = sess.encode(pcm[lo:hi], lengths=lengths[lo:hi] if lengths is not None else None, apply_rms=apply_rms)
+        else:
+            local = torch.zeros((0, sess.latent_dim), dtype=torch.float32, device=sess.device)
+        full[r * per:(r + 1) * per] = _pad_block(local, per)
+    return full[:n]
 
 
 def encode_file_list(encoder, paths: Sequence[Path], cfg: FrontendConfig, *, apply_rms: bool = False, group=None,

@@ -45,7 +45,31 @@ def synth_chunk_pcm16(i: int, n_samples: int, sr: int) -> np.ndarray:
     return np.rint(y * 32767.0).astype(np.int16)
 
 
-def synth_batch_pcm16(indices: Sequence[int], n_samples: int, sr: int) -> np.ndarray:
+def synth_batch_pcm16(indices: Sequence[int], n_samples: int, sr: int, workers: int = 1) -> np.ndarray:
+    """Chunks `indices` as int16 [len(indices), n_samples].  `workers` > 1 (contiguous index ranges only, e.g. the
+    100 000 chunks of BASELINE configs[2]) fans the generation out over child processes that run THIS FILE as a script
+    (numpy only: they import neither torch nor the HIP library and never touch the GPU, so it is safe to call after the GPU
+    has been initialised)."""
+    idx = np.asarray(indices)
+    if workers > 1 and idx.size >= 64 * workers and np.array_equal(idx, np.arange(idx[0], idx[0] + idx.size)):
+        import subprocess
+        import sys
+        import tempfile
+        lo0, n = int(idx[0]), int(idx.size)
+        step = -(-n // workers)
+        out = np.empty((n, n_samples), dtype=np.int16)
+        with tempfile.TemporaryDirectory(prefix="amph_synth_") as td:
+            jobs = []
+            for w, a in enumerate(range(0, n, step)):
+                dst = Path(td) / f"part{w}.npy"
+                jobs.append((a, min(n, a + step), dst, subprocess.Popen(
+                    [sys.executable, str(Path(__file__).resolve()), str(lo0 + a), str(lo0 + min(n, a + step)), str(n_samples),
+                     str(sr), str(dst)])))
+            for a, b, dst, proc in jobs:
+                if proc.wait() != 0:
+                    raise RuntimeError(f"synth worker for chunks [{lo0 + a}, {lo0 + b}) failed")
+                out[a:b] = np.load(dst)
+        return out
     out = np.empty((len(indices), n_samples), dtype=np.int16)
     for r, i in enumerate(indices):
         out[r] = synth_chunk_pcm16(int(i), n_samples, sr)
@@ -76,3 +100,27 @@ def write_synth_folder(root: Path, n_chunks: int, n_samples: int, sr: int,
         write_wav_pcm16(p, synth_chunk_pcm16(i, n_samples, sr), sr)
         made.append((sp, p))
     return made
+
+
+def synth_folder_plan(n_chunks: int, max_per_class: int = 0, seed: int = 123, species: Sequence[str] = SPECIES):
+    """The ordered chunk list 08_fit_radial_detector.py:374,461-484 would build over write_synth_folder(root, n_chunks):
+    species in config order; inside a species the name-sorted files (chunk_<i:06d>.wav: numeric order); with
+    max_per_class > 0 a `random.sample` per species from ONE generator seeded once.  For chunk matrices that never
+    become files (bench.py --config3).  -> {species: [chunk index, ...]}"""
+    import random
+    random.seed(seed)
+    out = {}
+    for k, sp in enumerate(species):
+        idx = list(range(k, n_chunks, len(species)))
+        if not idx:
+            continue
+        if max_per_class and len(idx) > max_per_class:
+            idx = random.sample(idx, max_per_class)
+        out[sp] = idx
+    return out
+
+
+if __name__ == "__main__":      # worker of synth_batch_pcm16(workers > 1): lo hi n_samples sr out.npy
+    import sys
+    _lo, _hi, _n, _sr = (int(v) for v in sys.argv[1:5])
+    np.save(sys.argv[5], synth_batch_pcm16(range(_lo, _hi), _n, _sr))

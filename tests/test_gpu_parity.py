@@ -354,6 +354,126 @@ def test_config2_thesis_shape_all_10000_chunks_and_full_size_properties(env):
     _assert_latents(z2[:1000], z2_cpu)
 
 
+def test_config3_100k_chunks_as_8_virtual_shards_then_08_fit(env, capsys):
+    """BASELINE.json configs[2] at its size, on one GPU: 100 000 chunks (25 000 per species) in the reference's list order
+    (08_fit_radial_detector.py:461-484), encoded as 8 contiguous shards of 12 500 laid out as the all-gather lays them out
+    == one pass, bitwise; then 08's host fit (q_in 0.95, q_out 0.10) with max_per_class 0 and 400 (seed 123): thresholds
+    against those from CPU-oracle latents <= 1e-4 relative (on a 10 000-chunk subset for max_per_class 0, on all 1 600
+    sampled chunks for 400); the smallest relative decision margin |d - rk| / rk is printed."""
+    from amphibian_vae_latent_detector_amd import folder as pfolder
+    from amphibian_vae_latent_detector_amd import radial as prad
+    from amphibian_vae_latent_detector_amd import synth
+    cfg = env.cfg
+    n = 100000
+    enc, tenc, spec = _encoders(env, "thesis-shape", max_batch=256)
+    sess = enc.session(cfg)
+    plan = synth.synth_folder_plan(n, 0, 123)
+    assert list(plan) == list(synth.SPECIES) and all(len(v) == n // 4 for v in plan.values())
+    flat = np.concatenate([np.asarray(plan[sp]) for sp in synth.SPECIES])
+    pcm_all = env.synth(np.arange(n), cfg.n_samples, cfg.sr, workers=min(16, len(__import__("os").sched_getaffinity(0))))
+    dev_all = torch.from_numpy(pcm_all).to(DEV)
+    dev = dev_all[torch.from_numpy(flat).to(DEV)]                         # rows in list order: species-major, name-sorted
+    del dev_all
+    Z1 = sess.encode(dev, apply_rms=True)[0]
+    Z8 = pfolder.encode_resident_shards(sess, dev, 8, apply_rms=True)
+    assert torch.equal(Z8, Z1)
+    assert pfolder.plan_shards(n, 8)[1] == 12500
+    Z3 = pfolder.encode_resident_shards(sess, dev, 3, apply_rms=True)     # uneven: 33 334 + 33 334 + 33 332 rows, padded blocks
+    assert torch.equal(Z3, Z1)
+    Z = Z1.cpu().numpy()
+    assert np.isfinite(Z).all()
+    Zg = {sp: Z[k * (n // 4):(k + 1) * (n // 4)] for k, sp in enumerate(synth.SPECIES)}
+    full_fit = prad.fit_radial_detector(Zg, 0.95, 0.10, verbose=False)    # max_per_class 0: all 100 000 latents
+    assert all(np.isfinite(v) and v > 0 for v in full_fit["thresholds"].values())
+
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        def oracle(indices):
+            return _oracle_latents(env, tenc, pcm_all[np.asarray(indices)], cfg)
+        sub = {sp: plan[sp][:2500] for sp in synth.SPECIES}               # 10 000-chunk subset, list order
+        Zc_sub = {sp: oracle(sub[sp]) for sp in synth.SPECIES}
+        plan400 = synth.synth_folder_plan(n, 400, 123)
+        Zc_400 = {sp: oracle(plan400[sp]) for sp in synth.SPECIES}
+    finally:
+        torch.set_num_threads(threads)
+    Zg_sub = {sp: Zg[sp][:2500] for sp in synth.SPECIES}
+    pos = {int(c): i for i, c in enumerate(flat)}                         # chunk index -> row of the list
+    Zg_400 = {sp: Z[[pos[c] for c in plan400[sp]]] for sp in synth.SPECIES}
+    # the 1 600 sampled chunks encoded on their own (what 08 --max-per-class 400 would encode) == the same rows of the full job
+    rows400 = torch.from_numpy(np.array([pos[c] for sp in synth.SPECIES for c in plan400[sp]])).to(DEV)
+    assert torch.equal(sess.encode(dev[rows400], apply_rms=True)[0], Z1[rows400])
+    report = []
+    for tag, Zg_, Zc_ in (("max_per_class 0 (10 000-chunk subset)", Zg_sub, Zc_sub), ("max_per_class 400, seed 123", Zg_400, Zc_400)):
+        for sp in synth.SPECIES:
+            _assert_latents(Zg_[sp], Zc_[sp])
+        rg = prad.fit_radial_detector(Zg_, 0.95, 0.10, verbose=False)
+        rc = prad.fit_radial_detector(Zc_, 0.95, 0.10, verbose=False)
+        worst = 0.0
+        for sp in synth.SPECIES:
+            rel = abs(rg["thresholds"][sp] - rc["thresholds"][sp]) / rc["thresholds"][sp]
+            worst = max(worst, rel)
+            assert rel <= 1e-4, (tag, sp, rel)
+            assert np.abs(np.array(rg["centroids"][sp]) - np.array(rc["centroids"][sp])).max() <= 1e-4
+        # decisions with the CPU-side detector: GPU latents through K6 against the CPU rule on CPU latents
+        cents = {k: np.array(v, np.float32) for k, v in rc["centroids"].items()}
+        det = prad.RadialDetector(cents, rc["thresholds"], 32)
+        allg, allc = np.concatenate(list(Zg_.values())), np.concatenate(list(Zc_.values()))
+        pred, best = det.decide(sess, allg)
+        dmat = np.stack([np.sqrt(((allc - cents[s][None]) ** 2).sum(axis=1)) for s in det.names], axis=1)
+        thr = np.array([rc["thresholds"][s] for s in det.names])
+        margin = (np.abs(dmat - thr[None]) / thr[None]).min(axis=1)
+        differ = 0
+        for r in np.argsort(margin)[:200]:                                # the 200 closest calls, in full
+            d, sp_c, bd = env.orad.decide(allc[r], cents, rc["thresholds"])
+            got = det.names[pred[r]] if pred[r] >= 0 else None
+            if got != sp_c:
+                differ += 1
+                assert margin[r] <= 1e-4, (tag, r, margin[r])
+        report.append(f"[config 3, {tag}] thresholds GPU vs CPU-oracle latents: max rel {worst:.2e}; min |d-rk|/rk over "
+                      f"{allc.shape[0]} chunks: {margin.min():.3e}; decisions differing among the 200 closest calls: {differ}")
+    with capsys.disabled():
+        print()
+        for line in report:
+            print(line)
+        print("[config 3, all 100 000 latents] thresholds:", {k: round(v, 6) for k, v in full_fit["thresholds"].items()})
+
+
+def test_encode_file_list_with_the_hip_encode_under_an_rccl_group(env, tmp_path):
+    """The product's sharded folder encode with NOTHING injected: real WAV files -> native reader -> HIP encode ->
+    all_gather_into_tensor on a one-rank `nccl` (= RCCL) process group, against the same call without a group."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from amphibian_vae_latent_detector_amd import folder as pfolder
+    from amphibian_vae_latent_detector_amd import synth
+    cfg = env.cfg
+    enc, tenc, spec = _encoders(env, "tiny", max_batch=16)
+    root = tmp_path / "chunks"
+    made = synth.write_synth_folder(root, 45, cfg.n_samples, cfg.sr)
+    (root / synth.SPECIES[3] / "chunk_000003.wav").write_bytes(b"RIFFbroken")
+    paths = [p for sp in synth.SPECIES for p in sorted((root / sp).glob("*.wav"))]
+    Z0, st0 = pfolder.encode_file_list(enc, paths, cfg, apply_rms=True)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        Z1, st1 = pfolder.encode_file_list(enc, paths, cfg, apply_rms=True)
+        Zf, failed = pfolder.encode_folder(enc, root, list(synth.SPECIES), cfg, cache_dir=tmp_path / "cache", apply_rms=True, verbose=False)
+    finally:
+        dist.destroy_process_group()
+    assert np.array_equal(Z1, Z0) and np.array_equal(st1, st0) and int((st1 != 0).sum()) == 1
+    assert sum(failed.values()) == 1 and sum(z.shape[0] for z in Zf.values()) == 44
+    good = st0 == 0
+    assert np.array_equal(np.concatenate([Zf[sp] for sp in synth.SPECIES]), Z0[good])
+    ok_paths = [p for p, g in zip(paths, good) if g]
+    want = np.stack([env.oenc.encode_mel_to_latent(tenc, env.ofe.wave_to_mel(
+        env.ofe.normalize_pcm16_chunk(env.ofe.read_wav_pcm16(p)[0][:, 0], True)[0], **cfg.mel_kwargs())) for p in ok_paths])
+    _assert_latents(Z0[good], want)
+
+
 def test_encode_edge_cases(env):
     cfg = env.cfg
     enc, tenc, spec = _encoders(env, "tiny", max_batch=8)

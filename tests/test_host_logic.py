@@ -528,3 +528,40 @@ def test_properties_shards_loader_and_crop():
         want = (q.astype(np.float32) / np.float32(32768.0))
         assert np.array_equal(y, want.mean(axis=1, dtype=np.float32) if ch > 1 else want[:, 0])
     pcm16_roundtrip()
+
+
+def test_synth_folder_plan_equals_the_reference_listing_of_a_written_folder(tmp_path):
+    """bench.py --config3 / the config-3 GPU test order HBM-resident chunks with synth_folder_plan instead of writing
+    100 000 files: it must be the list 08_fit_radial_detector.py:374,461-484 builds over write_synth_folder's layout
+    (species order, name-sorted, ONE generator seeded once, random.sample per species)."""
+    import random
+    from amphibian_vae_latent_detector_amd import folder as pfolder
+    from amphibian_vae_latent_detector_amd import synth
+    synth.write_synth_folder(tmp_path / "r", 41, 64, 22050)
+    for mpc in (0, 7):
+        random.seed(123)
+        listed = pfolder.list_species_wavs(tmp_path / "r", list(synth.SPECIES), mpc)
+        plan = synth.synth_folder_plan(41, mpc, 123)
+        assert list(plan) == list(synth.SPECIES)
+        for sp in synth.SPECIES:
+            assert [int(p.stem.split("_")[1]) for p in listed[sp]] == plan[sp], (mpc, sp)
+    # the parallel generator gives the same chunks as the serial one
+    a = synth.synth_batch_pcm16(np.arange(100, 612), 2000, 22050, workers=4)
+    assert np.array_equal(a, synth.synth_batch_pcm16(np.arange(100, 612), 2000, 22050))
+
+
+def test_pad_block_layout_of_the_virtual_shards():
+    """encode_resident_shards lays its blocks out as all_gather_into_tensor does (rank-major, each padded to ceil(n / R) rows)."""
+    import torch
+    from amphibian_vae_latent_detector_amd import folder as pfolder
+
+    class FakeSession:
+        latent_dim = 3
+        device = torch.device("cpu")
+
+        def encode(self, pcm, lengths=None, apply_rms=True):
+            return pcm[:, :3].float() * 2.0, None, None
+    x = torch.arange(10 * 5).reshape(10, 5)
+    for shards in (1, 3, 4, 8, 16):
+        got = pfolder.encode_resident_shards(FakeSession(), x, shards)
+        assert torch.equal(got, x[:, :3].float() * 2.0), shards
