@@ -53,6 +53,7 @@ struct GemmLayer {
     ConvGemmParams prm{};   // x / y / M / splits filled per call
     int bm = 128;
     float* d_w = nullptr;
+    uint16_t* d_w_s3 = nullptr;     // three-term bf16 split [n_pad / 64][K_pad / 32][64][3][32] for k_conv_gemm_s3 (nullptr: shape not covered)
     uint16_t* d_w_bf16 = nullptr;   // bf16 copy [n_pad][K_pad_b] for the bf16 encoder path
     int K_pad_b = 0;                // K rounded up to 64 elements
     float* d_scale = nullptr;
@@ -106,6 +107,7 @@ struct amph_ctx {
     bool fuse_conv12 = true;               // recompute layer 1 inside layer 2's A staging when the tiling allows
     bool stft_prenorm = true;              // PCM16 + RMS: write the normalised PCM16 rows once, STFT reads those
     bool stft_prepad = true;               // ... fix_length'd and centre padded (independent-wave STFT kernel only)
+    bool split_gemm = true;                // GEMM layers on the bf16 matrix cores with three-term split operands (fp32-accurate)
     int rms_f64_scale = 1;                 // RMS gate + scale in the scalar arithmetic of numpy 1.26 (reference pin) instead of numpy 2.x's
     // radial scratch
     float* d_centroids = nullptr;
@@ -407,6 +409,11 @@ int build_encoder(amph_ctx* c, const float* hw, size_t n_floats) {
                     for (int t = 0; t < kk; ++t)
                         wg[(size_t)o * K_pad + (size_t)t * l.c_in + ci] = w[((size_t)o * l.c_in + ci) * kk + t];
             HIP_TRY(c, upload(&gl.d_w, wg));
+            if (l.c_in % 32 == 0) {
+                std::vector<uint16_t> w3((size_t)n_pad * K_pad * 3);
+                conv_gemm_s3_split_weights(wg.data(), n_pad, K_pad, w3.data());
+                HIP_TRY(c, upload(&gl.d_w_s3, w3));
+            }
             gl.K_pad_b = (K + 63) / 64 * 64;
             HIP_TRY(c, upload_bf16(&gl.d_w_bf16, wg, n_pad, K_pad, gl.K_pad_b));
             HIP_TRY(c, upload(&gl.d_scale, alpha));
@@ -441,6 +448,11 @@ int build_encoder(amph_ctx* c, const float* hw, size_t n_floats) {
         }
         GemmLayer gl;
         HIP_TRY(c, upload(&gl.d_w, wg));
+        if (flat % 32 == 0) {
+            std::vector<uint16_t> w3((size_t)n_pad * K_pad * 3);
+            conv_gemm_s3_split_weights(wg.data(), n_pad, K_pad, w3.data());
+            HIP_TRY(c, upload(&gl.d_w_s3, w3));
+        }
         gl.K_pad_b = (flat + 63) / 64 * 64;
         HIP_TRY(c, upload_bf16(&gl.d_w_bf16, wg, n_pad, K_pad, gl.K_pad_b));
         HIP_TRY(c, upload(&c->d_head_bias, bias));
@@ -662,7 +674,15 @@ int run_encoder(amph_ctx* c, Workspace& w, const float* d_x, int nb, float* d_mu
         if (fuse && gi == 0 && conv_gemm_f3_ok(prm[gi], bms[gi])) c->gstamp_wgs[gi] = std::min(c->gstamp_wgs[gi], 2 * amph::g_num_cus);
 #endif
         StageTimer t(c, head ? stage_head_gemm(c) : ST_CONV0 + 1 + gi, s);
-        launch_conv_gemm(prm[gi], bms[gi], fuse && gi == 0, s);
+        const bool fused_here = fuse && gi == 0;
+        // GEMM layers on the bf16 matrix cores with three-term split operands (fp32-accurate): k_encoder_split.hip
+        if (c->split_gemm && !fused_here && c->gemm[gi].d_w_s3 && conv_gemm_s3_ok(prm[gi])) {
+            ConvGemmParams ps = prm[gi];
+            ps.w = reinterpret_cast<const float*>(c->gemm[gi].d_w_s3);
+            launch_conv_gemm_s3(ps, s);
+            continue;
+        }
+        launch_conv_gemm(prm[gi], bms[gi], fused_here, s);
     }
     {
         StageTimer t(c, stage_head_reduce(c), s);
@@ -872,7 +892,7 @@ void amph_destroy(amph_ctx* c) {
     fr(c->d_tables); fr(c->d_tw_a);
     fr(c->d_mel_start); fr(c->d_mel_len); fr(c->d_mel_wofs); fr(c->d_mel_w);
     fr(c->d_first_w); fr(c->d_first_scale); fr(c->d_first_shift);
-    for (auto& g : c->gemm) { fr(g.d_w); fr(g.d_w_bf16); fr(g.d_scale); fr(g.d_shift); }
+    for (auto& g : c->gemm) { fr(g.d_w); fr(g.d_w_s3); fr(g.d_w_bf16); fr(g.d_scale); fr(g.d_shift); }
     fr(c->d_head_bias); fr(c->d_zeros);
     for (auto& w : c->lanes) free_lane(w);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -900,6 +920,7 @@ int amph_configure(amph_ctx* c, const char* key, int value) {
     if (!std::strcmp(key, "fuse_conv12")) { c->fuse_conv12 = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "stft_prenorm")) { c->stft_prenorm = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "stft_prepad")) { c->stft_prepad = value != 0; return AMPH_OK; }
+    if (!std::strcmp(key, "split_gemm")) { c->split_gemm = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "rms_numpy2")) { c->rms_f64_scale = value ? 0 : 1; return AMPH_OK; }
 #ifdef AMPH_STAMPS
     if (!std::strcmp(key, "dump_gemm_stamps")) {

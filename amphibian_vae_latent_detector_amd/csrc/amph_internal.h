@@ -151,10 +151,29 @@ bool conv_gemm_f3_ok(const ConvGemmParams& p, int bm);   // second-generation fu
 void launch_conv_gemm(const ConvGemmParams& p, int bm, bool fuse_first, hipStream_t s);
 bool conv_gemm_p3_ok(const ConvGemmParams& p, int bm);
 void launch_head_reduce(const HeadReduceParams& p, int n_rows, hipStream_t s);
+// fp32-accurate GEMM layers on the bf16 matrix cores (k_encoder_split.hip): p.w = split weights [n_pad / 64][K_pad / 32][64][3][32] bf16
+bool conv_gemm_s3_ok(const ConvGemmParams& p);
+void launch_conv_gemm_s3(const ConvGemmParams& p, hipStream_t s);
+void conv_gemm_s3_split_weights(const float* w, int n_pad, int K_pad, uint16_t* out);
 // bf16 encoder path (k_encoder_bf16.hip): x / w are bf16, y bf16 (epilogue 0) or fp32 partials (epilogue 1);
 // K, K_pad and C_in count bf16 elements, K_pad % 64 == 0, C_in % 8 == 0
 void launch_conv_first_bf16(const ConvFirstParams& p, int n_rows, hipStream_t s);
 void launch_conv_gemm_bf16(const ConvGemmParams& p, int bm, hipStream_t s);
+
+#ifdef __HIPCC__
+// x = h + m + l exactly, h = bf16(x), m = bf16(x - h), l = bf16(x - h - m) (RNE; every subtraction is exact): packed pairs
+typedef __bf16 amph_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void s3_split2(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
+    const amph_bf16x2 hp = {(__bf16)x0, (__bf16)x1};                  // v_cvt_pk_bf16_f32
+    h = __builtin_bit_cast(uint32_t, hp);
+    const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xFFFF0000u);
+    const amph_bf16x2 mp = {(__bf16)r0, (__bf16)r1};
+    m = __builtin_bit_cast(uint32_t, mp);
+    const float t0 = r0 - __uint_as_float(m << 16), t1 = r1 - __uint_as_float(m & 0xFFFF0000u);
+    const amph_bf16x2 lp = {(__bf16)t0, (__bf16)t1};
+    l = __builtin_bit_cast(uint32_t, lp);
+}
+#endif
 
 // ----------------------------------------------------------------------------
 // Radial decision

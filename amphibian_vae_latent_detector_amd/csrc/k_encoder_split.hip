@@ -1,0 +1,419 @@
+// fp32-accurate implicit-GEMM convolution on the bf16 matrix cores ("s3": three-term operand split).
+//
+// Replaces, like k_conv_gemm_p3, the conv2d + BatchNorm(eval) + ReLU layers 3.. and the dense head of
+// `encoder(x)` at latent_space_exploration/map_detector_core.py:270 (module built at :175-179).
+//
+// Why: v_mfma_f32_32x32x2_f32 runs at the fp32 VECTOR rate (64 cycles per 32x32x2 = 157 TF chip-wide) and time-shares
+// the SIMD with every VALU instruction beside it (tools/probe/mfma_valu_*.hip): the fp32 GEMM layers sit at 0.55-0.65
+// of a peak that is itself 1/16 of the bf16 one.  An fp32 value is EXACTLY the sum of three bf16 values
+//     x = h + m + l,   h = bf16(x), m = bf16(x - h), l = bf16(x - h - m)      (8 + 8 + 8 significand bits, RNE)
+// and a product of two bf16 values is exact in fp32, so
+//     x * w = hh + hm + mh + mm + hl + lh  (+ ml + lm + ll, each below 2^-23 |x w|: dropped)
+// is six v_mfma_f32_32x32x16_bf16 per K = 16 with fp32 accumulation: 192 cycles against 512 for the same K on the
+// f32 shape, and bf16 MFMAs leave the VALU / LDS / load issue of the SIMD usable beside them.  The result differs from
+// an fp32 fma chain by the dropped terms (<= 2.4e-7 relative per product, random sign) and by the accumulation order
+// inside a 16-deep MFMA: measured against the torch-CPU oracle it is at the level of fp32 rounding noise (tests).
+// Order is fixed (slice, k-step, term pair): results do not depend on batch size, lanes or tile placement.
+//
+// Data: weights are split ONCE on the host into [n tile][slice][64 n][term][32 k] bf16 (64 LDS row images, contiguous);
+// activations stay fp32 NHWC in HBM and the A tile is split on the way from the staging registers into LDS (44 VALU
+// instructions per thread and slice).  What bounds the kernel at a 256-chunk batch is data movement, not the matrix pipe
+// (in-kernel stamps, profiles/r02_s3_stamps.txt: ~1 400 cycles per slice for 768 cycles of MFMA time on a SIMD's two waves):
+// a 64 x 64 x 32 block needs 20 KB from L2 (64 B/clk/CU at the MFMA rate = the whole vector-cache path) and 24 KB of LDS
+// stores at ~79 B/clk/CU; larger tiles would halve both but a 256-chunk batch has only 512 / 256 tiles of 64 x 64 (conv3 /
+// conv4).  Tried and dropped: activations handed over pre-split (6 B per element, written by the producer's epilogue: A
+// staging a pure copy, no VALU) - 50 % more A bytes and 12 epilogue stores per lane instead of 4 cost more than the VALU
+// work they removed (conv2 33.2 -> 37.9, conv3 22.8 -> 24.6, conv4 25.0 -> 24.1 us); four register stages instead of three
+// (no change: the loop is not latency-bound).
+// LDS row = 3 x 64 B + 16 B pad = 208 B: ds_read_b128 of any 16 rows of a 32-row fragment covers all 64 banks.
+// Geometry, addressing (buffer loads, zero guard for padded taps, scalar tap state) and the transposed-accumulator
+// epilogue are k_conv_gemm_p3's.
+#include "amph_internal.h"
+
+#include <algorithm>
+#include <cstring>
+
+namespace amph {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kSBK = 32;                 // K elements per slice (one tap's 32-channel group)
+constexpr int kSRow = 208;               // LDS bytes per row: [h | m | l] x 32 bf16 + 16 B pad
+constexpr int kSBuf = 64 * kSRow;        // bytes per operand per slice buffer
+constexpr int kSWRow = 192;              // bytes per (n, slice) in the split weight matrix
+
+__device__ __forceinline__ int s3_div_small(int n, int d, float rcp) {
+    int q = (int)((float)n * rcp);
+    int r = n - q * d;
+    if (r < 0) { --q; r += d; }
+    if (r >= d) ++q;
+    return q;
+}
+
+#define AMPH_S3_SB() __builtin_amdgcn_sched_barrier(0)
+
+#ifdef AMPH_STAMPS
+#define AMPH_S3_T(v_)                                                                      \
+    {                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v_)::"memory");         \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+    }
+#else
+#define AMPH_S3_T(v_)
+#endif
+
+__global__ __launch_bounds__(256, 2) void k_conv_gemm_s3(ConvGemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef AMPH_STAMPS
+    unsigned long long q_t0 = 0, q_t1 = 0, q_t2 = 0, q_t3 = 0, q_ta = 0, q_tb = 0;
+    const unsigned long long q_rt0 = __builtin_amdgcn_s_memrealtime();
+    AMPH_S3_T(q_t0)
+#endif
+    char* As = smem;                                   // [3][64][208]
+    char* Bs = smem + 3 * kSBuf;                       // [3][64][208]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c4 = tid & 7, r0 = tid >> 3;             // A staging: rows r0, r0 + 32; k = 4 c4 .. 4 c4 + 3 of the slice
+    // B staging: the (n tile, slice) block of the split weight matrix is 64 rows x 192 B CONTIGUOUS in global memory; load i of
+    // thread t takes its 16 bytes at (256 i + t) * 16: every wave instruction reads 1 KB of whole cache lines.  (Per-row
+    // addressing - 4 threads x 3 loads per 192-byte row - made every instruction touch 16 rows x 2-3 lines for a third of
+    // their bytes: the layers were bound by line processing in the vector cache, 22.8 us for 6.6 us of MFMA time.)
+    const int m_blk = blockIdx.x * 64, n_blk = blockIdx.y * 64;
+    const int n_slices = p.K_pad / kSBK;
+    const int sps = n_slices / p.splits;
+    const int ks_begin = blockIdx.z * sps, ks_end = ks_begin + sps;
+
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(p.x) - p.x_guard), 0, -1, 0x00020000);
+#define AMPH_S3_BUFLOAD(rs_, voff_, soff_) __builtin_amdgcn_raw_buffer_load_b128(rs_, voff_, soff_, 0)
+    // register stages (plain named variables, see k_conv_gemm_p3)
+    // FOUR stages: the loads of slice s + 4 are issued in iteration s and consumed in iteration s + 2.  The layers are bound by
+    // operand delivery from L2 (20 KB per workgroup and slice against 384 cycles of MFMA time per wave), i.e. by the bytes a
+    // CU keeps in flight: with three stages (one slice in flight per workgroup) conv3 took 22.8 us against 6.6 us of MFMA time
+    float4 sa0x, sa0y, sa1x, sa1y, sa2x, sa2y, sa3x, sa3y;             // rows r0, r0 + 32
+    uint4 sb0a, sb0b, sb0c, sb1a, sb1b, sb1c, sb2a, sb2b, sb2c, sb3a, sb3b, sb3c;
+    int w_soff = (blockIdx.y * n_slices + ks_begin) * (64 * kSWRow);
+    const unsigned woff = 16u * (unsigned)tid;
+#define AMPH_S3_LOADB(q)                                                                   \
+    {                                                                                      \
+        sb##q##a = __builtin_bit_cast(uint4, AMPH_S3_BUFLOAD(rs_w, woff, w_soff));          \
+        sb##q##b = __builtin_bit_cast(uint4, AMPH_S3_BUFLOAD(rs_w, woff + 4096u, w_soff));  \
+        sb##q##c = __builtin_bit_cast(uint4, AMPH_S3_BUFLOAD(rs_w, woff + 8192u, w_soff));  \
+    }
+
+    // the B halves of the four prologue slices are requested before any setup arithmetic (slice min(s, sps - 1), as ADV clamps)
+    {
+        const int blk = 64 * kSWRow;
+        const int o1 = sps > 1 ? blk : 0, o2 = sps > 2 ? 2 * blk : o1, o3 = sps > 3 ? 3 * blk : o2;
+        AMPH_S3_LOADB(0)
+        w_soff += o1; AMPH_S3_LOADB(1)
+        w_soff += o2 - o1; AMPH_S3_LOADB(2)
+        w_soff += o3 - o2; AMPH_S3_LOADB(3)
+        w_soff -= o3;
+    }
+    const int ohw = p.OH * p.OW;
+    const float rcp_ohw = 1.0f / (float)ohw, rcp_ow = 1.0f / (float)p.OW;
+    constexpr int kEl = 4;                              // bytes per activation element in HBM
+    unsigned aoff0, aoff1, vmask0, vmask1;
+#define AMPH_S3_ROW(i)                                                                     \
+    {                                                                                      \
+        const int m = m_blk + r0 + 32 * i;                                                 \
+        const bool mv = m < p.M;                                                           \
+        const int mm = mv ? m : 0;                                                         \
+        const int b = s3_div_small(mm, ohw, rcp_ohw), rem = mm - b * ohw;                  \
+        const int oh = s3_div_small(rem, p.OW, rcp_ow), ow = rem - oh * p.OW;              \
+        const int ih0 = oh * p.stride - p.pad, iw0 = ow * p.stride - p.pad;                \
+        aoff##i = (unsigned)p.x_guard + (unsigned)kEl * (unsigned)(((b * p.H + ih0) * p.W + iw0) * p.C_in) + 16u * (unsigned)c4; \
+        unsigned vm = 0;                                                                   \
+        if (p.k == 3) {                                                                    \
+            const unsigned hb = ((unsigned)iw0 < (unsigned)p.W ? 0x049u : 0u) | ((unsigned)(iw0 + 1) < (unsigned)p.W ? 0x092u : 0u) | \
+                                ((unsigned)(iw0 + 2) < (unsigned)p.W ? 0x124u : 0u);       \
+            const unsigned rb_ = ((unsigned)ih0 < (unsigned)p.H ? 0x007u : 0u) | ((unsigned)(ih0 + 1) < (unsigned)p.H ? 0x038u : 0u) | \
+                                 ((unsigned)(ih0 + 2) < (unsigned)p.H ? 0x1c0u : 0u);      \
+            vm = hb & rb_;                                                                 \
+        } else {                                                                           \
+            for (int kh = 0; kh < p.k; ++kh)                                               \
+                for (int kw = 0; kw < p.k; ++kw)                                           \
+                    if ((unsigned)(ih0 + kh) < (unsigned)p.H && (unsigned)(iw0 + kw) < (unsigned)p.W) vm |= 1u << (kh * p.k + kw); \
+        }                                                                                  \
+        vmask##i = mv ? vm : 0u;                                                           \
+    }
+    AMPH_S3_ROW(0)
+    AMPH_S3_ROW(1)
+#undef AMPH_S3_ROW
+
+    int l_left = sps;
+    int l_ci0, l_kw, x_soff;
+    unsigned l_bit;
+    {
+        const int kpos = (ks_begin * kSBK) / p.C_in;
+        l_ci0 = ks_begin * kSBK - kpos * p.C_in;
+        const int kh = kpos / p.k;
+        l_kw = kpos - kh * p.k;
+        x_soff = kEl * ((kh * p.W + l_kw) * p.C_in + l_ci0);
+        l_bit = 1u << kpos;
+    }
+    const int row_skip = kEl * (p.W - p.k) * p.C_in;
+#define AMPH_S3_LOADA(q)                                                                   \
+    {                                                                                      \
+        sa##q##x = __builtin_bit_cast(float4, AMPH_S3_BUFLOAD(rs_x, (vmask0 & l_bit) ? aoff0 : 0u, x_soff)); \
+        sa##q##y = __builtin_bit_cast(float4, AMPH_S3_BUFLOAD(rs_x, (vmask1 & l_bit) ? aoff1 : 0u, x_soff)); \
+    }
+#define AMPH_S3_ADV()                                                                      \
+    {                                                                                      \
+        const int adv_ = l_left > 1 ? 1 : 0;                                               \
+        l_left -= adv_;                                                                    \
+        w_soff = __builtin_amdgcn_readfirstlane(w_soff + 64 * kSWRow * adv_);              \
+        x_soff += kSBK * kEl * adv_;                                                       \
+        l_ci0 += kSBK * adv_;                                                              \
+        const int wrap_ = l_ci0 >= p.C_in ? 1 : 0;                                         \
+        l_ci0 -= wrap_ * p.C_in;                                                           \
+        l_bit = __builtin_amdgcn_readfirstlane(l_bit << wrap_);                            \
+        l_kw += wrap_;                                                                     \
+        const int wrap2_ = l_kw >= p.k ? 1 : 0;                                            \
+        l_kw -= wrap2_ * p.k;                                                              \
+        x_soff = __builtin_amdgcn_readfirstlane(x_soff + wrap2_ * row_skip);               \
+    }
+#define AMPH_S3_LOAD(q) { AMPH_S3_LOADB(q) AMPH_S3_LOADA(q) AMPH_S3_ADV() }
+#define AMPH_S3_LOADA_ADV(q) { AMPH_S3_LOADA(q) AMPH_S3_ADV() }
+
+    // stage q -> LDS buffer buf_: B rows are the LDS image already; A rows are split here
+    const int st_a = r0 * kSRow + 8 * c4;
+    int st_b0, st_b1, st_b2;                           // byte o of the block -> LDS row o / 192, column o % 192
+    {
+        const int o0 = 16 * tid, o1 = o0 + 4096, o2 = o0 + 8192;
+        st_b0 = (o0 / kSWRow) * kSRow + o0 % kSWRow;
+        st_b1 = (o1 / kSWRow) * kSRow + o1 % kSWRow;
+        st_b2 = (o2 / kSWRow) * kSRow + o2 % kSWRow;
+    }
+#define AMPH_S3_SPLIT_ROW(v_, dst_)                                                        \
+    {                                                                                      \
+        uint32_t h0, m0, l0, h1, m1, l1;                                                   \
+        s3_split2(v_.x, v_.y, h0, m0, l0);                                                 \
+        s3_split2(v_.z, v_.w, h1, m1, l1);                                                 \
+        *reinterpret_cast<uint2*>(dst_) = make_uint2(h0, h1);                              \
+        *reinterpret_cast<uint2*>(dst_ + 64) = make_uint2(m0, m1);                         \
+        *reinterpret_cast<uint2*>(dst_ + 128) = make_uint2(l0, l1);                        \
+    }
+#define AMPH_S3_STORE(q, buf_)                                                             \
+    {                                                                                      \
+        char* a_ = As + (buf_) * kSBuf + st_a;                                             \
+        char* b_ = Bs + (buf_) * kSBuf;                                                    \
+        *reinterpret_cast<uint4*>(b_ + st_b0) = sb##q##a;                                  \
+        *reinterpret_cast<uint4*>(b_ + st_b1) = sb##q##b;                                  \
+        *reinterpret_cast<uint4*>(b_ + st_b2) = sb##q##c;                                  \
+        AMPH_S3_SPLIT_ROW(sa##q##x, a_)                                                    \
+        AMPH_S3_SPLIT_ROW(sa##q##y, (a_ + 32 * kSRow))                                     \
+    }
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    const int row_tile = wave >> 1, col_tile = wave & 1;
+    float4 e_sc0, e_sc1, e_sc2, e_sc3, e_sh0, e_sh1, e_sh2, e_sh3;
+    {
+        const int nb = n_blk + col_tile * 32 + 4 * (lane >> 5);
+        const bool bn = p.epilogue == 0;
+        const float* zsrc = p.zeros;                    // (split-K form: the constants are unused; any readable address)
+#define AMPH_S3_BN(g)                                                                      \
+        e_sc##g = *reinterpret_cast<const float4*>((bn ? p.scale : zsrc) + ((bn && nb + 8 * g < p.N) ? nb + 8 * g : 0)); \
+        e_sh##g = *reinterpret_cast<const float4*>((bn ? p.shift : zsrc) + ((bn && nb + 8 * g < p.N) ? nb + 8 * g : 0));
+        AMPH_S3_BN(0) AMPH_S3_BN(1) AMPH_S3_BN(2) AMPH_S3_BN(3)
+#undef AMPH_S3_BN
+    }
+    // fragment addresses: lane l holds row (l & 31), k = 16 kstep + 8 (l >> 5) + j of each term
+    const char* a_rd = As + (row_tile * 32 + (lane & 31)) * kSRow + 16 * (lane >> 5);
+    const char* b_rd = Bs + (col_tile * 32 + (lane & 31)) * kSRow + 16 * (lane >> 5);
+#define AMPH_S3_FRAG(base_, buf_, ks_, t_) __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>((base_) + (buf_) * kSBuf + 64 * (t_) + 32 * (ks_)))
+    // weights as the FIRST operand: transposed accumulator (lane = output row m, registers 4g .. 4g + 3 = channels), see p3
+#define AMPH_S3_MFMA(w_, x_) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_, x_, acc, 0, 0, 0);
+#define AMPH_S3_READ6(pre_, buf_, ks_)                                                     \
+    pre_##xh = AMPH_S3_FRAG(a_rd, buf_, ks_, 0); pre_##xm = AMPH_S3_FRAG(a_rd, buf_, ks_, 1); pre_##xl = AMPH_S3_FRAG(a_rd, buf_, ks_, 2); \
+    pre_##wh = AMPH_S3_FRAG(b_rd, buf_, ks_, 0); pre_##wm = AMPH_S3_FRAG(b_rd, buf_, ks_, 1); pre_##wl = AMPH_S3_FRAG(b_rd, buf_, ks_, 2);
+    // pieces of the staging work of one slice (stage q -> LDS buffer buf_), one per MFMA gap
+#define AMPH_S3_ST_B(q, buf_)                                                              \
+    {                                                                                      \
+        char* b_ = Bs + (buf_) * kSBuf;                                                    \
+        *reinterpret_cast<uint4*>(b_ + st_b0) = sb##q##a;                                  \
+        *reinterpret_cast<uint4*>(b_ + st_b1) = sb##q##b;                                  \
+        *reinterpret_cast<uint4*>(b_ + st_b2) = sb##q##c;                                  \
+    }
+#define AMPH_S3_ST_AX(q, buf_) { char* a_ = As + (buf_) * kSBuf + st_a; AMPH_S3_SPLIT_ROW(sa##q##x, a_) }
+#define AMPH_S3_ST_AY(q, buf_) { char* a_ = As + (buf_) * kSBuf + st_a + 32 * kSRow; AMPH_S3_SPLIT_ROW(sa##q##y, a_) }
+#if defined(AMPH_S3_ABL_NOLOAD)            /* timing-only ablations (make ablations_s3; never shipped) */
+#define AMPH_S3_LOOPLOAD(QL) AMPH_S3_ADV()
+#else
+#define AMPH_S3_LOOPLOAD(QL) AMPH_S3_LOAD(QL)
+#endif
+#if defined(AMPH_S3_ABL_NOMFMA)
+#define AMPH_S3_M(w_, x_) acc[0] += (float)w_[0] + (float)x_[1];
+#else
+#define AMPH_S3_M(w_, x_) AMPH_S3_MFMA(w_, x_)
+#endif
+#if defined(AMPH_S3_ABL_NOSTORE)
+#define AMPH_S3_SB_(q, buf_) acc[1] += __uint_as_float(sb##q##a.x ^ sb##q##b.y ^ sb##q##c.z);
+#define AMPH_S3_SX_(q, buf_) acc[2] += sa##q##x.x;
+#define AMPH_S3_SY_(q, buf_) acc[3] += sa##q##y.y;
+#else
+#define AMPH_S3_SB_(q, buf_) AMPH_S3_ST_B(q, buf_)
+#define AMPH_S3_SX_(q, buf_) AMPH_S3_ST_AX(q, buf_)
+#define AMPH_S3_SY_(q, buf_) AMPH_S3_ST_AY(q, buf_)
+#endif
+    // One slice from LDS buffer R.  On entry f0* holds its k-step-0 fragments (read before the previous barrier).  Stage QL
+    // receives slice s + 4, stage QS (slice s + 2) goes to buffer (R + 2) % 3 in the gaps of the first six MFMAs; the k-step-1
+    // fragments are read under those, the next slice's k-step-0 fragments (buffer (R + 1) % 3, published by the previous
+    // barrier) under the last six: no MFMA waits for an LDS round trip it could not overlap.
+#define AMPH_S3_STEP(R, QL, QS)                                                            \
+    {                                                                                      \
+        bf16x8 f1xh, f1xm, f1xl, f1wh, f1wm, f1wl, n0xh, n0xm, n0xl, n0wh, n0wm, n0wl;     \
+        AMPH_S3_LOOPLOAD(QL)                                                               \
+        AMPH_S3_READ6(f1, R, 1)                                                            \
+        AMPH_S3_SB();                                                                      \
+        AMPH_S3_M(f0wl, f0xh)                                                              \
+        AMPH_S3_SB();                                                                      \
+        AMPH_S3_SB_(QS, (R + 2) % 3)                                                       \
+        AMPH_S3_SB();                                                                      \
+        AMPH_S3_M(f0wh, f0xl)                                                              \
+        AMPH_S3_M(f0wm, f0xm)                                                              \
+        AMPH_S3_SB();                                                                      \
+        AMPH_S3_SX_(QS, (R + 2) % 3)                                                       \
+        AMPH_S3_SB();                                                                      \
+        AMPH_S3_M(f0wm, f0xh)                                                              \
+        AMPH_S3_M(f0wh, f0xm)                                                              \
+        AMPH_S3_SB();                                                                      \
+        AMPH_S3_SY_(QS, (R + 2) % 3)                                                       \
+        AMPH_S3_SB();                                                                      \
+        AMPH_S3_M(f0wh, f0xh)                                                              \
+        AMPH_S3_SB();                                                                      \
+        AMPH_S3_READ6(n0, (R + 1) % 3, 0)                                                  \
+        AMPH_S3_SB();                                                                      \
+        AMPH_S3_M(f1wl, f1xh)                                                              \
+        AMPH_S3_M(f1wh, f1xl)                                                              \
+        AMPH_S3_M(f1wm, f1xm)                                                              \
+        AMPH_S3_M(f1wm, f1xh)                                                              \
+        AMPH_S3_M(f1wh, f1xm)                                                              \
+        AMPH_S3_M(f1wh, f1xh)                                                              \
+        AMPH_S3_SB();                                                                      \
+        __syncthreads();                                                                   \
+        f0xh = n0xh; f0xm = n0xm; f0xl = n0xl; f0wh = n0wh; f0wm = n0wm; f0wl = n0wl;      \
+    }
+
+    // prologue: slices 0 .. 3 into the register stages, 0 and 1 on to LDS
+    AMPH_S3_LOADA_ADV(0)
+    AMPH_S3_LOADA_ADV(1)
+    AMPH_S3_LOADA_ADV(2)
+    AMPH_S3_LOADA_ADV(3)
+    AMPH_S3_T(q_ta)
+    AMPH_S3_STORE(0, 0)
+    AMPH_S3_T(q_tb)
+    AMPH_S3_STORE(1, 1)
+    __syncthreads();
+    bf16x8 f0xh, f0xm, f0xl, f0wh, f0wm, f0wl;
+    AMPH_S3_READ6(f0, 0, 0)
+    AMPH_S3_T(q_t1)
+    // step s uses LDS buffer s % 3 and register stages s % 4 (load) / (s + 2) % 4 (store): twelve steps per trip keep every
+    // index a compile-time constant
+#define AMPH_S3_STEPS_0_11(X)                                                              \
+    X(0, 0, 0, 2) X(1, 1, 1, 3) X(2, 2, 2, 0) X(3, 0, 3, 1) X(4, 1, 0, 2) X(5, 2, 1, 3)   \
+    X(6, 0, 2, 0) X(7, 1, 3, 1) X(8, 2, 0, 2) X(9, 0, 1, 3) X(10, 1, 2, 0) X(11, 2, 3, 1)
+    int ks = ks_begin;
+    for (; ks + 12 <= ks_end; ks += 12) {
+#define AMPH_S3_X(i, R, QL, QS) AMPH_S3_STEP(R, QL, QS)
+        AMPH_S3_STEPS_0_11(AMPH_S3_X)
+#undef AMPH_S3_X
+    }
+    {
+        const int rem = ks_end - ks;
+#define AMPH_S3_X(i, R, QL, QS) if (rem > i) AMPH_S3_STEP(R, QL, QS)
+        AMPH_S3_STEPS_0_11(AMPH_S3_X)
+#undef AMPH_S3_X
+    }
+
+    AMPH_S3_T(q_t2)
+    {
+        const int m = m_blk + row_tile * 32 + (lane & 31);
+        float* ybase = p.y + (p.epilogue == 1 ? (long long)blockIdx.z * p.M * p.N : 0ll);
+        if (m < p.M) {
+#define AMPH_S3_OUT(g)                                                                     \
+            {                                                                              \
+                const int n0 = n_blk + col_tile * 32 + 8 * g + 4 * (lane >> 5);            \
+                if (n0 < p.N) {                                                            \
+                    float4 v = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]); \
+                    if (p.epilogue == 0) {                                                 \
+                        v.x = fmaxf(fmaf(v.x, e_sc##g.x, e_sh##g.x), 0.0f); v.y = fmaxf(fmaf(v.y, e_sc##g.y, e_sh##g.y), 0.0f); \
+                        v.z = fmaxf(fmaf(v.z, e_sc##g.z, e_sh##g.z), 0.0f); v.w = fmaxf(fmaf(v.w, e_sc##g.w, e_sh##g.w), 0.0f); \
+                    }                                                                      \
+                    *reinterpret_cast<float4*>(ybase + (long long)m * p.N + n0) = v;       \
+                }                                                                          \
+            }
+            AMPH_S3_OUT(0) AMPH_S3_OUT(1) AMPH_S3_OUT(2) AMPH_S3_OUT(3)
+#undef AMPH_S3_OUT
+        }
+    }
+#ifdef AMPH_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    AMPH_S3_T(q_t3)
+    if (tid == 0 && p.stamps) {       // setup + issue of the prologue loads | wait for slice 0 (first global round trip) + split | rest of prologue | loop | epilogue
+        unsigned long long* o = p.stamps + (size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8;
+        o[0] = q_ta - q_t0; o[1] = q_tb - q_ta; o[2] = q_t1 - q_tb; o[3] = q_t2 - q_t1; o[4] = q_t3 - q_t0;
+        o[5] = __builtin_amdgcn_s_memrealtime() - q_rt0;
+        o[6] = q_t3 - q_t2; o[7] = q_rt0;
+    }
+#endif
+}
+
+constexpr size_t kS3Lds = (size_t)6 * kSBuf;           // 79 872 B: two workgroups per CU
+
+bool conv_gemm_s3_ok(const ConvGemmParams& p) {
+    const unsigned long long span = (unsigned long long)p.M / (p.OH * p.OW) * p.H * p.W * p.C_in * 4ull + p.x_guard;     // 32-bit lane offsets
+    return (p.C_in % kSBK) == 0 && p.K == p.K_pad && p.k * p.k <= 32 && (p.N % 4) == 0 && p.pad < p.k && p.zeros != nullptr &&
+           (size_t)p.x_guard >= conv_gemm_x_guard(p.k, p.W, p.C_in) && span < (1ull << 32) &&
+           (unsigned long long)((p.N + 63) / 64 * 64) * (p.K_pad / kSBK) * kSWRow < (1ull << 31) && p.M < (1 << 22);
+}
+
+// p.w = the split weight matrix [n_pad / 64][K_pad / 32][64][3][32] bf16 (conv_gemm_s3_split_weights)
+void launch_conv_gemm_s3(const ConvGemmParams& p, hipStream_t s) {
+    static bool raised[64] = {false};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !raised[dev]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_gemm_s3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kS3Lds);
+        raised[dev] = true;
+    }
+    const dim3 grid((unsigned)((p.M + 63) / 64), (unsigned)((p.N + 63) / 64), (unsigned)p.splits);
+    hipLaunchKernelGGL(k_conv_gemm_s3, grid, dim3(256), kS3Lds, s, p);
+}
+
+// host: x -> (h, m, l) exactly as s3_split2 does on the device (RNE; every subtraction exact)
+static uint16_t s3_bf16_rne(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static float s3_bf16_f32(uint16_t h) {
+    const uint32_t u = (uint32_t)h << 16;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+void conv_gemm_s3_split_weights(const float* w, int n_pad, int K_pad, uint16_t* out) {
+    const int n_slices = K_pad / kSBK;
+    for (int n = 0; n < n_pad; ++n)
+        for (int sl = 0; sl < n_slices; ++sl)
+            for (int k = 0; k < kSBK; ++k) {
+                const float x = w[(size_t)n * K_pad + (size_t)sl * kSBK + k];
+                const uint16_t h = s3_bf16_rne(x);
+                const float r = x - s3_bf16_f32(h);
+                const uint16_t m = s3_bf16_rne(r);
+                const uint16_t l = s3_bf16_rne(r - s3_bf16_f32(m));
+                uint16_t* o = out + (((size_t)(n / 64) * n_slices + sl) * 64 + (size_t)(n % 64)) * 3 * kSBK;
+                o[k] = h; o[kSBK + k] = m; o[2 * kSBK + k] = l;
+            }
+}
+
+}  // namespace amph

@@ -249,14 +249,55 @@ def test_fused_first_two_layers_equal_unfused_bitwise(env, name):
     enc, tenc, spec = _encoders(env, name, max_batch=16)
     sess = enc.session(env.cfg)
     x = torch.from_numpy(np.random.default_rng(7).standard_normal((37, 1, 64, 64)).astype(np.float32))
-    sess.configure("fuse_conv12", 1)
-    mu1, lv1 = sess.encoder_forward(x)
-    sess.configure("fuse_conv12", 0)
-    mu0, lv0 = sess.encoder_forward(x)
-    sess.configure("fuse_conv12", 1)
+    # (the f32-MFMA forms of both: with "split_gemm" the unfused layer 2 runs on the bf16 matrix cores, the fused one does not)
+    sess.configure("split_gemm", 0)
+    try:
+        sess.configure("fuse_conv12", 1)
+        mu1, lv1 = sess.encoder_forward(x)
+        sess.configure("fuse_conv12", 0)
+        mu0, lv0 = sess.encoder_forward(x)
+        sess.configure("fuse_conv12", 1)
+    finally:
+        sess.configure("split_gemm", 1)
     assert torch.equal(mu1, mu0) and torch.equal(lv1, lv0)
     with torch.no_grad():
         _assert_latents(mu1.cpu().numpy(), tenc(x)[0].numpy(), 1e-5)
+
+
+def test_split_operand_gemm_layers_are_fp32_accurate_and_batch_independent(env, capsys):
+    """The GEMM layers behind the fused pair run on the bf16 matrix cores with three-term split operands ("split_gemm",
+    default on; csrc/k_encoder_split.hip): x = h + m + l exactly, six bf16 MFMAs per K = 16, fp32 accumulation.  Against the
+    torch-CPU fp32 oracle they must be as close as the f32-MFMA kernels are (1e-5 bar; both measure ~1e-6), must not depend
+    on batch composition, and the two forms must agree to fp32 rounding noise.  Shapes: thesis-shape at 64 x 64 and at the
+    reference's 192 x 64 image, `tiny` (C_in % 32 != 0 in layer 2: the split kernel only takes the head there)."""
+    for preset, name in (("bench-1s", "thesis-shape"), ("ref-default", "thesis-shape"), ("bench-1s", "tiny")):
+        cfg = env.PRESETS[preset]
+        enc, tenc, spec = _encoders(env, name, cfg=cfg, max_batch=32)
+        sess = enc.session(cfg)
+        x = torch.from_numpy(np.random.default_rng(3).standard_normal((45, 1, cfg.target_frames, cfg.n_mels)).astype(np.float32))
+        with torch.no_grad():
+            mu_o, lv_o = tenc(x)
+        out = {}
+        try:
+            for v in (0, 1):
+                sess.configure("split_gemm", v)
+                mu, lv = sess.encoder_forward(x)
+                out[v] = (mu.cpu().numpy(), lv.cpu().numpy())
+                assert torch.equal(sess.encoder_forward(x[7:20])[0], mu[7:20])           # other batch, same bits
+                sess.configure("fuse_conv12", 0)                                         # layer 2 through the same kernel family
+                mu_u, _ = sess.encoder_forward(x)
+                sess.configure("fuse_conv12", 1)
+                _assert_latents(mu_u.cpu().numpy(), mu_o.numpy(), 1e-5)
+        finally:
+            sess.configure("split_gemm", 1)
+            sess.configure("fuse_conv12", 1)
+        for v in (0, 1):
+            _assert_latents(out[v][0], mu_o.numpy(), 1e-5)
+            _assert_latents(out[v][1], lv_o.numpy(), 1e-5)
+        _assert_latents(out[1][0], out[0][0], 5e-6)
+        e = [max(rel_l2(out[v][0][r], mu_o.numpy()[r]) for r in range(45)) for v in (0, 1)]
+        with capsys.disabled():
+            print(f"\n[split GEMM, {preset}/{name}] max rel L2 of mu vs torch-CPU fp32: f32 MFMA {e[0]:.2e}, bf16 x 3 MFMA {e[1]:.2e}")
 
 
 def test_encoder_odd_shapes_generic_path(env):
