@@ -107,6 +107,7 @@ struct amph_ctx {
     bool fuse_conv12 = true;               // recompute layer 1 inside layer 2's A staging when the tiling allows
     bool stft_prenorm = true;              // PCM16 + RMS: write the normalised PCM16 rows once, STFT reads those
     bool stft_prepad = true;               // ... fix_length'd and centre padded (independent-wave STFT kernel only)
+    bool split_fused = true;               // ... the fused conv1 + conv2 kernel too (k_conv_gemm_f3s)
     bool split_gemm = true;                // GEMM layers on the bf16 matrix cores with three-term split operands (fp32-accurate)
     int rms_f64_scale = 1;                 // RMS gate + scale in the scalar arithmetic of numpy 1.26 (reference pin) instead of numpy 2.x's
     // radial scratch
@@ -675,6 +676,12 @@ int run_encoder(amph_ctx* c, Workspace& w, const float* d_x, int nb, float* d_mu
 #endif
         StageTimer t(c, head ? stage_head_gemm(c) : ST_CONV0 + 1 + gi, s);
         const bool fused_here = fuse && gi == 0;
+        if (c->split_gemm && c->split_fused && fused_here && c->gemm[gi].d_w_s3 && conv_gemm_f3s_ok(prm[gi])) {
+            ConvGemmParams ps = prm[gi];
+            ps.w = reinterpret_cast<const float*>(c->gemm[gi].d_w_s3);
+            launch_conv_gemm_f3s(ps, s);
+            continue;
+        }
         // GEMM layers on the bf16 matrix cores with three-term split operands (fp32-accurate): k_encoder_split.hip
         if (c->split_gemm && !fused_here && c->gemm[gi].d_w_s3 && conv_gemm_s3_ok(prm[gi])) {
             ConvGemmParams ps = prm[gi];
@@ -921,6 +928,7 @@ int amph_configure(amph_ctx* c, const char* key, int value) {
     if (!std::strcmp(key, "stft_prenorm")) { c->stft_prenorm = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "stft_prepad")) { c->stft_prepad = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "split_gemm")) { c->split_gemm = value != 0; return AMPH_OK; }
+    if (!std::strcmp(key, "split_fused")) { c->split_fused = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "rms_numpy2")) { c->rms_f64_scale = value ? 0 : 1; return AMPH_OK; }
 #ifdef AMPH_STAMPS
     if (!std::strcmp(key, "dump_gemm_stamps")) {

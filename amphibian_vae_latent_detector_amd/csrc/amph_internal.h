@@ -155,6 +155,9 @@ void launch_head_reduce(const HeadReduceParams& p, int n_rows, hipStream_t s);
 bool conv_gemm_s3_ok(const ConvGemmParams& p);
 void launch_conv_gemm_s3(const ConvGemmParams& p, hipStream_t s);
 void conv_gemm_s3_split_weights(const float* w, int n_pad, int K_pad, uint16_t* out);
+// ... and the fused first-layer pair in the same arithmetic (p.img etc. as for k_conv_gemm_f3, p.w = split weights)
+bool conv_gemm_f3s_ok(const ConvGemmParams& p);
+void launch_conv_gemm_f3s(const ConvGemmParams& p, hipStream_t s);
 // bf16 encoder path (k_encoder_bf16.hip): x / w are bf16, y bf16 (epilogue 0) or fp32 partials (epilogue 1);
 // K, K_pad and C_in count bf16 elements, K_pad % 64 == 0, C_in % 8 == 0
 void launch_conv_first_bf16(const ConvFirstParams& p, int n_rows, hipStream_t s);

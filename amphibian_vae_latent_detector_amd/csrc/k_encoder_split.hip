@@ -31,6 +31,8 @@
 #include "amph_internal.h"
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace amph {
@@ -363,6 +365,390 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm_s3(ConvGemmParams p) {
         o[6] = q_t3 - q_t2; o[7] = q_rt0;
     }
 #endif
+}
+
+// ----------------------------------------------------------------------------
+// Fused conv1 -> conv2 on the bf16 matrix cores ("f3s"): k_conv_gemm_f3's structure - persistent over the M tiles, layer 1
+// (C_in == 1 direct 3x3 conv + BN + ReLU, k_conv_first's FMA order in fp32) recomputed from an image patch in LDS for the
+// 2 x 4 A-tile values a thread stages per slice, continuous slice stream across tiles, cyclic B pointer - with the
+// multiply of k_conv_gemm_s3: the recomputed fp32 A values are split into three bf16 terms on their way into LDS, the
+// weights come pre-split, twelve v_mfma_f32_32x32x16_bf16 per slice instead of sixteen v_mfma_f32_32x32x2_f32
+// (384 instead of 1 024 matrix-pipe cycles) and, unlike the f32 MFMAs, they leave the SIMD's VALU issue to the recompute.
+// LDS rows are packed (192 B, no pad) with the 16-byte slots XOR-swizzled by (row >> 2) & 3 - conflict-free like the padded
+// form - so that three A + three B slice buffers and the patch stay under 80 KB: two workgroups per CU.
+// ----------------------------------------------------------------------------
+constexpr int kFRow = 192;               // packed LDS row: [h | m | l] x 32 bf16, slot j at 16 (j ^ ((row >> 2) & 3))
+constexpr int kFBuf = 64 * kFRow;        // 12 288 B per operand per slice buffer
+
+template <int PU>                        // patch elements per thread (n_patch <= 256 PU)
+__global__ __launch_bounds__(256, 2) void k_conv_gemm_f3s(ConvGemmParams p) {
+    constexpr int BM = 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* As = smem;                                                    // [3][64][192]
+    char* Bs = smem + 3 * kFBuf;                                        // [3][64][192]
+    float* patch = reinterpret_cast<float*>(smem + 6 * kFBuf);          // [rows][W0 + 2 p1]: ONE buffer (see the tile loop)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c4 = tid & 7, r0 = tid >> 3;
+    const int n_blk = blockIdx.y * 64;
+    const int ohw = p.OH * p.OW;
+    const int PW = p.W0 + 2 * p.p1;
+    const float rcp_pw = 1.0f / (float)PW, rcp_ow = 1.0f / (float)p.OW, rcp_ohw = 1.0f / (float)ohw;
+    const int n_tiles = (p.M + BM - 1) / BM;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    // this thread's 4 first-layer channels: 9 tap weights + BN constants, as channel pairs (v_pk_fma_f32), for the whole kernel
+    f32x2 wl_0, wl_1, wl_2, wl_3, wl_4, wl_5, wl_6, wl_7, wl_8, wh_0, wh_1, wh_2, wh_3, wh_4, wh_5, wh_6, wh_7, wh_8, sc1l, sc1h, sh1l, sh1h;
+    {
+        const float* wt = p.w1 + 4 * c4;
+#define AMPH_FS_W(t) { const float4 v_ = *reinterpret_cast<const float4*>(wt + t * p.C_in); wl_##t = f32x2{v_.x, v_.y}; wh_##t = f32x2{v_.z, v_.w}; }
+        AMPH_FS_W(0) AMPH_FS_W(1) AMPH_FS_W(2) AMPH_FS_W(3) AMPH_FS_W(4) AMPH_FS_W(5) AMPH_FS_W(6) AMPH_FS_W(7) AMPH_FS_W(8)
+#undef AMPH_FS_W
+        const float4 sc1 = *reinterpret_cast<const float4*>(p.scale1 + 4 * c4), sh1 = *reinterpret_cast<const float4*>(p.shift1 + 4 * c4);
+        sc1l = f32x2{sc1.x, sc1.y}; sc1h = f32x2{sc1.z, sc1.w}; sh1l = f32x2{sh1.x, sh1.y}; sh1h = f32x2{sh1.z, sh1.w};
+    }
+    // patch slots of this thread (the same for every tile): element i = tid + 256 u of the [rows][PW] patch
+    const int n_oh = s3_div_small(BM, p.OW, rcp_ow);
+    const int r1_cnt = (n_oh - 1) * p.stride + p.k;
+    const int n_patch = ((r1_cnt - 1) * p.s1 + 3) * PW;            // <= 256 * PU (host check)
+    float pf[PU];                                                    // the NEXT tile's patch values, prefetched
+    // (row / column of a slot are recomputed per fetch - twice per workgroup - rather than kept in 16 registers: the kernel
+    // sits at the 256-register limit of two waves per SIMD)
+#define AMPH_FS_FETCH_PATCH(tile_)                                                         \
+    {                                                                                      \
+        const int mb_ = (tile_) * BM;                                                      \
+        const int b_ = s3_div_small(mb_, ohw, rcp_ohw), ohf_ = s3_div_small(mb_ - b_ * ohw, p.OW, rcp_ow); \
+        const int plo_ = (ohf_ * p.stride - p.pad) * p.s1 - p.p1;                          \
+        const float* img_ = p.img + (long long)b_ * p.H0 * p.W0;                           \
+        _Pragma("unroll") for (int u = 0; u < PU; ++u) {                                   \
+            const int i_ = tid + 256 * u;                                                  \
+            const int r_ = s3_div_small(i_, PW, rcp_pw), ic_ = i_ - r_ * PW - p.p1;        \
+            const int ir_ = plo_ + r_;                                                     \
+            pf[u] = *((i_ < n_patch && ir_ >= 0 && ir_ < p.H0 && ic_ >= 0 && ic_ < p.W0) ? img_ + ir_ * p.W0 + ic_ : p.zeros); \
+        }                                                                                  \
+    }
+    if ((int)blockIdx.x < n_tiles) AMPH_FS_FETCH_PATCH(blockIdx.x)
+    const int ohl0 = s3_div_small(r0, p.OW, rcp_ow), owl0 = r0 - ohl0 * p.OW, ohl1 = s3_div_small(r0 + 32, p.OW, rcp_ow), owl1 = (r0 + 32) - ohl1 * p.OW;
+    const int rowbase0 = (ohl0 * p.stride * p.s1) * PW + (owl0 * p.stride - p.pad) * p.s1;
+    const int rowbase1 = (ohl1 * p.stride * p.s1) * PW + (owl1 * p.stride - p.pad) * p.s1;
+    unsigned hm0, hm1;                                   // k == 3 (host check): bit kh * 3 + kw
+    {
+        const int iwA = owl0 * p.stride - p.pad, iwB = owl1 * p.stride - p.pad;
+        hm0 = ((unsigned)iwA < (unsigned)p.W ? 0x049u : 0u) | ((unsigned)(iwA + 1) < (unsigned)p.W ? 0x092u : 0u) |
+              ((unsigned)(iwA + 2) < (unsigned)p.W ? 0x124u : 0u);
+        hm1 = ((unsigned)iwB < (unsigned)p.W ? 0x049u : 0u) | ((unsigned)(iwB + 1) < (unsigned)p.W ? 0x092u : 0u) |
+              ((unsigned)(iwB + 2) < (unsigned)p.W ? 0x124u : 0u);
+    }
+    // B: the split weight block of (n tile, slice) is 64 x 192 B contiguous; the pointer runs CYCLICALLY over the K slices
+    const int n_slices = p.K_pad / kSBK;                 // == k * k taps (C_in == 32), splits == 1
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, -1, 0x00020000);
+    const unsigned woff = 16u * (unsigned)tid;
+    const int w_base = blockIdx.y * n_slices * (64 * kSWRow);
+    int w_soff = w_base;
+    int l_left = n_slices;                               // slices until the offset wraps
+    uint4 sb0a, sb0b, sb0c, sb1a, sb1b, sb1c, sb2a, sb2b, sb2c;
+    float* const patch_c = patch;                        // patch of the tile being COMPUTED
+    unsigned vmc0 = 0, vmc1 = 0;
+#define AMPH_FS_MASKS(t_)                                                                  \
+    {                                                                                      \
+        const int mb_ = (t_) * BM;                                                         \
+        const int b_ = s3_div_small(mb_, ohw, rcp_ohw), ohf_ = s3_div_small(mb_ - b_ * ohw, p.OW, rcp_ow); \
+        const int ihA = (ohf_ + ohl0) * p.stride - p.pad, ihB = (ohf_ + ohl1) * p.stride - p.pad; \
+        const unsigned rbA = ((unsigned)(ihA) < (unsigned)p.H ? 0x007u : 0u) | ((unsigned)(ihA + 1) < (unsigned)p.H ? 0x038u : 0u) | \
+                             ((unsigned)(ihA + 2) < (unsigned)p.H ? 0x1c0u : 0u);          \
+        const unsigned rbB = ((unsigned)(ihB) < (unsigned)p.H ? 0x007u : 0u) | ((unsigned)(ihB + 1) < (unsigned)p.H ? 0x038u : 0u) | \
+                             ((unsigned)(ihB + 2) < (unsigned)p.H ? 0x1c0u : 0u);          \
+        vmc0 = mb_ + r0 < p.M ? hm0 & rbA : 0u;                                            \
+        vmc1 = mb_ + r0 + 32 < p.M ? hm1 & rbB : 0u;                                       \
+    }
+#define AMPH_FS_WRITE_PATCH(dst_)                                                          \
+    {                                                                                      \
+        _Pragma("unroll") for (int u = 0; u < PU; ++u)                                     \
+            if (tid + 256 * u < n_patch) (dst_)[tid + 256 * u] = pf[u];                    \
+    }
+    int c_kpos = 0, c_kh = 0, c_kw = 0;                  // tap of the next slice to COMPUTE (wave-uniform)
+    f32x2 a0l, a0h, a1l, a1h;                            // the A stage being computed (rows r0, r0 + 32; channel pairs)
+    float pv0_0, pv0_1, pv0_2, pv0_3, pv0_4, pv0_5, pv0_6, pv0_7, pv0_8;
+    float pv1_0, pv1_1, pv1_2, pv1_3, pv1_4, pv1_5, pv1_6, pv1_7, pv1_8;
+    float cap0 = 0.0f, cap1 = 0.0f;                      // +inf for a tap inside the image, 0 for a padded one
+#define AMPH_FS_LOADB(q)                                                                   \
+    {                                                                                      \
+        sb##q##a = __builtin_bit_cast(uint4, AMPH_S3_BUFLOAD(rs_w, woff, w_soff));          \
+        sb##q##b = __builtin_bit_cast(uint4, AMPH_S3_BUFLOAD(rs_w, woff + 4096u, w_soff));  \
+        sb##q##c = __builtin_bit_cast(uint4, AMPH_S3_BUFLOAD(rs_w, woff + 8192u, w_soff));  \
+        --l_left;                                                                          \
+        w_soff = __builtin_amdgcn_readfirstlane(l_left == 0 ? w_base : w_soff + 64 * kSWRow);   /* wrap to slice 0 */ \
+        l_left = l_left == 0 ? n_slices : l_left;                                          \
+    }
+#define AMPH_FS_WINDOW(i)                                                                  \
+    {                                                                                      \
+        const bool ok_ = (vmc##i >> c_kpos) & 1u;                                          \
+        cap##i = ok_ ? __builtin_inff() : 0.0f;                                            \
+        const float* pp_ = patch_c + (ok_ ? rowbase##i + (c_kh * p.s1 * PW + c_kw * p.s1) : 0); \
+        pv##i##_0 = pp_[0]; pv##i##_1 = pp_[1]; pv##i##_2 = pp_[2];                        \
+        pv##i##_3 = pp_[PW]; pv##i##_4 = pp_[PW + 1]; pv##i##_5 = pp_[PW + 2];             \
+        pv##i##_6 = pp_[2 * PW]; pv##i##_7 = pp_[2 * PW + 1]; pv##i##_8 = pp_[2 * PW + 2]; \
+    }
+#define AMPH_FS_TAP(i, t)                                                                  \
+    a##i##l.x = fmaf(pv##i##_##t, wl_##t.x, a##i##l.x); a##i##l.y = fmaf(pv##i##_##t, wl_##t.y, a##i##l.y); \
+    a##i##h.x = fmaf(pv##i##_##t, wh_##t.x, a##i##h.x); a##i##h.y = fmaf(pv##i##_##t, wh_##t.y, a##i##h.y);
+#define AMPH_FS_ZERO(i) a##i##l = f32x2{0.f, 0.f}; a##i##h = f32x2{0.f, 0.f};
+#define AMPH_FS_FIN(i)                                                                     \
+    a##i##l.x = fmaf(a##i##l.x, sc1l.x, sh1l.x); a##i##l.y = fmaf(a##i##l.y, sc1l.y, sh1l.y); \
+    a##i##h.x = fmaf(a##i##h.x, sc1h.x, sh1h.x); a##i##h.y = fmaf(a##i##h.y, sc1h.y, sh1h.y); \
+    a##i##l.x = __builtin_amdgcn_fmed3f(a##i##l.x, 0.0f, cap##i); a##i##l.y = __builtin_amdgcn_fmed3f(a##i##l.y, 0.0f, cap##i); \
+    a##i##h.x = __builtin_amdgcn_fmed3f(a##i##h.x, 0.0f, cap##i); a##i##h.y = __builtin_amdgcn_fmed3f(a##i##h.y, 0.0f, cap##i);
+#define AMPH_FS_NEXT_TAP()                                                                 \
+    {                                                                                      \
+        ++c_kpos; ++c_kw;                                                                  \
+        const int wrap_ = c_kw >= p.k ? 1 : 0;                                             \
+        c_kw -= wrap_ * p.k;                                                               \
+        c_kh += wrap_;                                                                     \
+    }
+    // LDS offsets.  A: row r0 (+32), the thread's 4 k = 8 bytes of slot (c4 >> 1) of each term; B: byte o of the block
+    const int sw0 = (r0 >> 2) & 3;                       // == ((r0 + 32) >> 2) & 3
+    const int st_a = r0 * kFRow + 16 * ((c4 >> 1) ^ sw0) + 8 * (c4 & 1);
+    int st_b0, st_b1, st_b2;
+    {
+        const int o0 = 16 * tid, o1 = o0 + 4096, o2 = o0 + 8192;
+#define AMPH_FS_SW(o_) (((o_) / kFRow) * kFRow + 16 * ((((o_) % kFRow) >> 4) ^ ((((o_) / kFRow) >> 2) & 3)))
+        st_b0 = AMPH_FS_SW(o0); st_b1 = AMPH_FS_SW(o1); st_b2 = AMPH_FS_SW(o2);
+#undef AMPH_FS_SW
+    }
+    // (slot 4 t + u of term t: the swizzle only touches u, so the three terms of a split row are 64 bytes apart as in s3)
+#define AMPH_FS_SPLIT_STORE(lo_, hi_, dst_)                                                \
+    {                                                                                      \
+        uint32_t h0, m0, l0, h1, m1, l1;                                                   \
+        s3_split2(lo_.x, lo_.y, h0, m0, l0);                                               \
+        s3_split2(hi_.x, hi_.y, h1, m1, l1);                                               \
+        *reinterpret_cast<uint2*>(dst_) = make_uint2(h0, h1);                              \
+        *reinterpret_cast<uint2*>(dst_ + 64) = make_uint2(m0, m1);                         \
+        *reinterpret_cast<uint2*>(dst_ + 128) = make_uint2(l0, l1);                        \
+    }
+#define AMPH_FS_STORE_A0(buf_) { char* a_ = As + (buf_) * kFBuf + st_a; AMPH_FS_SPLIT_STORE(a0l, a0h, a_) }
+#define AMPH_FS_STORE_A1(buf_) { char* a_ = As + (buf_) * kFBuf + st_a + 32 * kFRow; AMPH_FS_SPLIT_STORE(a1l, a1h, a_) }
+#define AMPH_FS_STORE_B(q, buf_)                                                           \
+    {                                                                                      \
+        char* b_ = Bs + (buf_) * kFBuf;                                                    \
+        *reinterpret_cast<uint4*>(b_ + st_b0) = sb##q##a;                                  \
+        *reinterpret_cast<uint4*>(b_ + st_b1) = sb##q##b;                                  \
+        *reinterpret_cast<uint4*>(b_ + st_b2) = sb##q##c;                                  \
+    }
+#define AMPH_FS_COMPUTE_ALL()                                                              \
+    {                                                                                      \
+        AMPH_FS_WINDOW(0) AMPH_FS_WINDOW(1)                                                \
+        AMPH_FS_ZERO(0) AMPH_FS_ZERO(1)                                                    \
+        AMPH_FS_TAP(0, 0) AMPH_FS_TAP(0, 1) AMPH_FS_TAP(0, 2) AMPH_FS_TAP(0, 3) AMPH_FS_TAP(0, 4) \
+        AMPH_FS_TAP(0, 5) AMPH_FS_TAP(0, 6) AMPH_FS_TAP(0, 7) AMPH_FS_TAP(0, 8) AMPH_FS_FIN(0) \
+        AMPH_FS_TAP(1, 0) AMPH_FS_TAP(1, 1) AMPH_FS_TAP(1, 2) AMPH_FS_TAP(1, 3) AMPH_FS_TAP(1, 4) \
+        AMPH_FS_TAP(1, 5) AMPH_FS_TAP(1, 6) AMPH_FS_TAP(1, 7) AMPH_FS_TAP(1, 8) AMPH_FS_FIN(1) \
+        AMPH_FS_NEXT_TAP()                                                                 \
+    }
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    const int row_tile = wave >> 1, col_tile = wave & 1;
+    // fragment addresses: lane l holds row (l & 31), k = 16 kstep + 8 (l >> 5) + j of each term = slot 4 t + 2 kstep + (l >> 5)
+    const int swl = ((lane & 31) >> 2) & 3;              // (the row tile offset, a multiple of 32, does not change the swizzle)
+    const char* a_rd0 = As + (row_tile * 32 + (lane & 31)) * kFRow + 16 * ((lane >> 5) ^ swl);
+    const char* a_rd1 = As + (row_tile * 32 + (lane & 31)) * kFRow + 16 * ((2 + (lane >> 5)) ^ swl);
+    const char* b_rd0 = Bs + (col_tile * 32 + (lane & 31)) * kFRow + 16 * ((lane >> 5) ^ swl);
+    const char* b_rd1 = Bs + (col_tile * 32 + (lane & 31)) * kFRow + 16 * ((2 + (lane >> 5)) ^ swl);
+#define AMPH_FS_FRAG(base_, buf_, t_) __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>((base_) + (buf_) * kFBuf + 64 * (t_)))
+#define AMPH_FS_READ6(pre_, buf_, ks_)                                                     \
+    pre_##xh = AMPH_FS_FRAG(a_rd##ks_, buf_, 0); pre_##xm = AMPH_FS_FRAG(a_rd##ks_, buf_, 1); pre_##xl = AMPH_FS_FRAG(a_rd##ks_, buf_, 2); \
+    pre_##wh = AMPH_FS_FRAG(b_rd##ks_, buf_, 0); pre_##wm = AMPH_FS_FRAG(b_rd##ks_, buf_, 1); pre_##wl = AMPH_FS_FRAG(b_rd##ks_, buf_, 2);
+#define AMPH_FS_M(w_, x_) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_, x_, acc, 0, 0, 0);
+    // One slice from LDS buffer R.  B stage QL receives slice s + 3; slice s + 2 (A recomputed here, B stage QS) goes to buffer
+    // (R + 2) % 3.  bf16 MFMAs leave the VALU to the same wave (an MFMA holds the vector issue for 8 of its 32 cycles), so the
+    // recompute is spread over the MFMA gaps instead of being packed into two of them as in the f32 kernel.  The kernel sits at
+    // the 256-register limit of two waves per SIMD: each k-step's six fragments are read when the previous six are dead (no
+    // read-ahead across the barrier as in k_conv_gemm_s3); the recompute's VALU work covers the two LDS round trips.
+#define AMPH_FS_STEP(R, QL, QS)                                                            \
+    {                                                                                      \
+        bf16x8 f0xh, f0xm, f0xl, f0wh, f0wm, f0wl, f1xh, f1xm, f1xl, f1wh, f1wm, f1wl;     \
+        AMPH_FS_READ6(f0, R, 0)                                                            \
+        AMPH_FS_LOADB(QL)                                                                  \
+        AMPH_S3_SB();                                                                      \
+        AMPH_FS_ZERO(0) AMPH_FS_ZERO(1)                                                    \
+        AMPH_FS_TAP(0, 0) AMPH_FS_TAP(1, 0) AMPH_FS_TAP(0, 1) AMPH_FS_TAP(1, 1) AMPH_FS_TAP(0, 2) AMPH_FS_TAP(1, 2) \
+        AMPH_S3_SB();                                                                      \
+        AMPH_S3_T(fq_a)                                                                    \
+        AMPH_FS_M(f0wl, f0xh)                                                              \
+        AMPH_FS_M(f0wh, f0xl)                                                              \
+        AMPH_S3_SB();                                                                      \
+        AMPH_FS_TAP(0, 3) AMPH_FS_TAP(1, 3) AMPH_FS_TAP(0, 4) AMPH_FS_TAP(1, 4) AMPH_FS_TAP(0, 5) AMPH_FS_TAP(1, 5) \
+        AMPH_S3_SB();                                                                      \
+        AMPH_FS_M(f0wm, f0xm)                                                              \
+        AMPH_FS_M(f0wm, f0xh)                                                              \
+        AMPH_S3_SB();                                                                      \
+        AMPH_FS_TAP(0, 6) AMPH_FS_TAP(1, 6) AMPH_FS_TAP(0, 7) AMPH_FS_TAP(1, 7) AMPH_FS_TAP(0, 8) AMPH_FS_TAP(1, 8) \
+        AMPH_FS_FIN(0) AMPH_FS_FIN(1)                                                      \
+        AMPH_FS_NEXT_TAP()                                                                 \
+        AMPH_S3_SB();                                                                      \
+        AMPH_FS_M(f0wh, f0xm)                                                              \
+        AMPH_FS_M(f0wh, f0xh)                                                              \
+        AMPH_S3_SB();                                                                      \
+        AMPH_S3_T(fq_m)                                                                    \
+        AMPH_FS_READ6(f1, R, 1)                                                            \
+        AMPH_FS_WINDOW(0)           /* the NEXT step's image windows: the window registers are dead, the patch is read-only */ \
+        AMPH_FS_WINDOW(1)           /* between two patch writes, and an LDS round trip right behind a barrier is the slowest  */ \
+        AMPH_FS_STORE_A0((R + 2) % 3)                                                      \
+        AMPH_S3_SB();                                                                      \
+        AMPH_FS_M(f1wl, f1xh)                                                              \
+        AMPH_FS_M(f1wh, f1xl)                                                              \
+        AMPH_S3_SB();                                                                      \
+        AMPH_FS_STORE_A1((R + 2) % 3)                                                      \
+        AMPH_S3_SB();                                                                      \
+        AMPH_FS_M(f1wm, f1xm)                                                              \
+        AMPH_FS_M(f1wm, f1xh)                                                              \
+        AMPH_S3_SB();                                                                      \
+        AMPH_FS_STORE_B(QS, (R + 2) % 3)                                                   \
+        AMPH_S3_SB();                                                                      \
+        AMPH_FS_M(f1wh, f1xm)                                                              \
+        AMPH_FS_M(f1wh, f1xh)                                                              \
+        AMPH_S3_SB();                                                                      \
+        AMPH_S3_T(fq_b0)                                                                   \
+        __syncthreads();                                                                   \
+        AMPH_S3_T(fq_b1)                                                                   \
+        AMPH_FS_ACC()                                                                      \
+    }
+#ifdef AMPH_STAMPS
+    unsigned long long fq_b0 = 0, fq_b1 = 0, fq_prev = 0, fq_bar = 0, fq_work = 0, fq_t0 = 0, fq_t1 = 0, fq_a = 0, fq_m = 0, fq_p1 = 0, fq_p2 = 0;
+    const unsigned long long fq_rt0 = __builtin_amdgcn_s_memrealtime();
+    AMPH_S3_T(fq_t0)
+#define AMPH_FS_ACC() { fq_bar += fq_b1 - fq_b0; if (fq_prev) { fq_work += fq_b0 - fq_prev; fq_p1 += fq_a - fq_prev; fq_p2 += fq_m - fq_a; } fq_prev = fq_b1; }
+#else
+#define AMPH_FS_ACC()
+#endif
+
+    // ---- first tile: patch, masks, B slices 0..2, A of slices 0 and 1, on to LDS buffers 0 and 1
+    AMPH_FS_LOADB(0)
+    AMPH_FS_LOADB(1)
+    AMPH_FS_LOADB(2)
+    if ((int)blockIdx.x < n_tiles) {
+        AMPH_FS_WRITE_PATCH(patch)
+        AMPH_FS_MASKS(blockIdx.x)
+    }
+    __syncthreads();                                     // the patch is staged
+    if ((int)(blockIdx.x + gridDim.x) < n_tiles) AMPH_FS_FETCH_PATCH(blockIdx.x + gridDim.x)
+    AMPH_FS_COMPUTE_ALL()
+    AMPH_FS_STORE_A0(0) AMPH_FS_STORE_A1(0) AMPH_FS_STORE_B(0, 0)
+    AMPH_FS_COMPUTE_ALL()
+    AMPH_FS_STORE_A0(1) AMPH_FS_STORE_A1(1) AMPH_FS_STORE_B(1, 1)
+    AMPH_FS_WINDOW(0) AMPH_FS_WINDOW(1)                  // the windows of the first step (every step reads the next one's)
+    __syncthreads();
+
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int m_blk = tile * BM;
+        const int nt = tile + (int)gridDim.x;
+        const bool has_next = nt < n_tiles;
+        AMPH_FS_STEP(0, 0, 2)                            // slices 0..2 multiplied, 2..4 recomputed
+        AMPH_FS_STEP(1, 1, 0)
+        AMPH_FS_STEP(2, 2, 1)
+        AMPH_FS_STEP(0, 0, 2)
+        AMPH_FS_STEP(1, 1, 0)
+        AMPH_FS_STEP(2, 2, 1)
+        AMPH_FS_STEP(0, 0, 2)                            // slice 6 multiplied, 8 recomputed: the last read of this tile's patch
+        // The next tile's patch (in registers since the previous tile) replaces it - the barrier that ended the step above is
+        // behind every wave's last read, one more barrier publishes the new patch - and the patch after it is requested.
+        // (One patch buffer, not two as in the f32 kernel: with the 19-row patch of a 64 x 64 image two of them put the
+        // workgroup over 80 KB, i.e. one workgroup per CU; the extra barrier per tile is ~0.1 % of it.)
+        if (has_next) AMPH_FS_WRITE_PATCH(patch)
+        __syncthreads();
+        if (nt + (int)gridDim.x < n_tiles) AMPH_FS_FETCH_PATCH(nt + gridDim.x)
+        // the compute side moves on to the next tile (no tile: empty masks -> all-zero stages, never multiplied)
+        c_kpos = 0; c_kh = 0; c_kw = 0;
+        if (has_next) { AMPH_FS_MASKS(nt) }
+        else { vmc0 = 0; vmc1 = 0; }
+        AMPH_FS_WINDOW(0) AMPH_FS_WINDOW(1)              // (what the step above read ahead belonged to the old patch and masks)
+        AMPH_FS_STEP(1, 1, 0)                            // slices 7, 8 multiplied; the NEXT tile's 0, 1 recomputed
+        AMPH_FS_STEP(2, 2, 1)
+        // BN constants of the epilogue: loaded here (L1 / L2 hits), not held in 32 registers for the whole kernel
+        float4 e_sc0, e_sc1, e_sc2, e_sc3, e_sh0, e_sh1, e_sh2, e_sh3;
+        {
+            const int nb = n_blk + (wave & 1) * 32 + 4 * (lane >> 5);
+            e_sc0 = *reinterpret_cast<const float4*>(nb + 0 < p.N ? p.scale + nb + 0 : p.zeros);
+            e_sc1 = *reinterpret_cast<const float4*>(nb + 8 < p.N ? p.scale + nb + 8 : p.zeros);
+            e_sc2 = *reinterpret_cast<const float4*>(nb + 16 < p.N ? p.scale + nb + 16 : p.zeros);
+            e_sc3 = *reinterpret_cast<const float4*>(nb + 24 < p.N ? p.scale + nb + 24 : p.zeros);
+            e_sh0 = *reinterpret_cast<const float4*>(nb + 0 < p.N ? p.shift + nb + 0 : p.zeros);
+            e_sh1 = *reinterpret_cast<const float4*>(nb + 8 < p.N ? p.shift + nb + 8 : p.zeros);
+            e_sh2 = *reinterpret_cast<const float4*>(nb + 16 < p.N ? p.shift + nb + 16 : p.zeros);
+            e_sh3 = *reinterpret_cast<const float4*>(nb + 24 < p.N ? p.shift + nb + 24 : p.zeros);
+        }
+        {
+            const int m = m_blk + row_tile * 32 + (lane & 31);
+            if (m < p.M) {
+#define AMPH_FS_OUT(g)                                                                     \
+                {                                                                          \
+                    const int n0 = n_blk + col_tile * 32 + 8 * g + 4 * (lane >> 5);        \
+                    if (n0 < p.N) {                                                        \
+                        float4 v;                                                          \
+                        v.x = fmaxf(fmaf(acc[4 * g], e_sc##g.x, e_sh##g.x), 0.0f);         \
+                        v.y = fmaxf(fmaf(acc[4 * g + 1], e_sc##g.y, e_sh##g.y), 0.0f);     \
+                        v.z = fmaxf(fmaf(acc[4 * g + 2], e_sc##g.z, e_sh##g.z), 0.0f);     \
+                        v.w = fmaxf(fmaf(acc[4 * g + 3], e_sc##g.w, e_sh##g.w), 0.0f);     \
+                        *reinterpret_cast<float4*>(p.y + (long long)m * p.N + n0) = v;     \
+                    }                                                                      \
+                }
+                AMPH_FS_OUT(0) AMPH_FS_OUT(1) AMPH_FS_OUT(2) AMPH_FS_OUT(3)
+#undef AMPH_FS_OUT
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    }
+#ifdef AMPH_STAMPS
+    AMPH_S3_T(fq_t1)
+    if (tid == 0 && p.stamps) {       // cycles of wave 0: between barriers (work) | at the step barriers | - | - | total | lifetime ticks
+        unsigned long long* o = p.stamps + (size_t)blockIdx.x * 8;
+        o[0] = fq_work; o[1] = fq_p1; o[2] = fq_bar; o[3] = fq_p2; o[4] = fq_t1 - fq_t0;   // o[1]: step start -> 6 taps done; o[3]: -> k-step 0 done
+        o[5] = __builtin_amdgcn_s_memrealtime() - fq_rt0;
+        o[6] = 0; o[7] = fq_rt0 & 0xffffffffull;
+    }
+#endif
+}
+
+static size_t conv_gemm_f3s_lds(const ConvGemmParams& p) {
+    const int n_oh = 64 / p.OW;
+    const int rows = ((n_oh - 1) * p.stride + p.k - 1) * p.s1 + p.k1;
+    const size_t patch = ((size_t)rows * (p.W0 + 2 * p.p1) + 3) & ~(size_t)3;
+    return (size_t)6 * kFBuf + patch * sizeof(float);
+}
+// the shapes k_conv_gemm_f3 covers (host: conv_gemm_f3_ok) with split weights at hand; both kernels need n_slices % 3 == 0
+bool conv_gemm_f3s_ok(const ConvGemmParams& p) {
+    return conv_gemm_f3_ok(p, 64) && p.N <= 64 * 65535 && conv_gemm_f3s_lds(p) <= 80 * 1024 &&
+           (unsigned long long)((p.N + 63) / 64 * 64) * (p.K_pad / kSBK) * kSWRow < (1ull << 31);
+}
+// p.w = the split weight matrix (conv_gemm_s3_split_weights)
+void launch_conv_gemm_f3s(const ConvGemmParams& p, hipStream_t s) {
+    static bool raised[64] = {false};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !raised[dev]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_gemm_f3s<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_gemm_f3s<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        raised[dev] = true;
+    }
+    const unsigned n_tiles = (unsigned)((p.M + 63) / 64);
+    const dim3 grid(std::min(n_tiles, (unsigned)(2 * g_num_cus)), (unsigned)((p.N + 63) / 64), 1);      // persistent: one resident round
+    const int n_oh = 64 / p.OW;
+    const int n_patch = (((n_oh - 1) * p.stride + p.k - 1) * p.s1 + p.k1) * (p.W0 + 2 * p.p1);
+    if (getenv("AMPH_DEBUG_OCC")) {
+        static bool said = false;
+        if (!said) {
+            said = true;
+            int nb8 = -1, nb4 = -1, nbs = -1;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb8, k_conv_gemm_f3s<8>, 256, conv_gemm_f3s_lds(p));
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb4, k_conv_gemm_f3s<4>, 256, conv_gemm_f3s_lds(p));
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbs, k_conv_gemm_s3, 256, (size_t)6 * kSBuf);
+            fprintf(stderr, "[amph] occupancy (workgroups per CU): f3s<8> %d, f3s<4> %d (lds %zu, n_patch %d), s3 %d (lds %zu)\n", nb8, nb4,
+                    conv_gemm_f3s_lds(p), n_patch, nbs, (size_t)6 * kSBuf);
+        }
+    }
+    if (n_patch <= 256 * 4) hipLaunchKernelGGL(k_conv_gemm_f3s<4>, grid, dim3(256), conv_gemm_f3s_lds(p), s, p);
+    else hipLaunchKernelGGL(k_conv_gemm_f3s<8>, grid, dim3(256), conv_gemm_f3s_lds(p), s, p);
 }
 
 constexpr size_t kS3Lds = (size_t)6 * kSBuf;           // 79 872 B: two workgroups per CU
