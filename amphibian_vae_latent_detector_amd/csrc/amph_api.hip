@@ -107,6 +107,7 @@ struct amph_ctx {
     bool fuse_conv12 = true;               // recompute layer 1 inside layer 2's A staging when the tiling allows
     bool stft_prenorm = true;              // PCM16 + RMS: write the normalised PCM16 rows once, STFT reads those
     bool stft_prepad = true;               // ... fix_length'd and centre padded (independent-wave STFT kernel only)
+    bool stft_fuse_db = true;              // dB / z-score / crop-pad inside the STFT kernel when a row's mel power fits its LDS
     bool split_fused = true;               // ... the fused conv1 + conv2 kernel too (k_conv_gemm_f3s)
     bool split_gemm = true;                // GEMM layers on the bf16 matrix cores with three-term split operands (fp32-accurate)
     int rms_f64_scale = 1;                 // RMS gate + scale in the scalar arithmetic of numpy 1.26 (reference pin) instead of numpy 2.x's
@@ -701,12 +702,25 @@ int run_encoder(amph_ctx* c, Workspace& w, const float* d_x, int nb, float* d_mu
     return AMPH_OK;
 }
 
-StftParams make_stft(amph_ctx* c, const WaveSrc& src, float* melpow) {
+// can this context run the dB / z-score stage inside the STFT kernel (one workgroup per row, the row's mel power in LDS)?
+bool can_fuse_db(const amph_ctx* c) {
+    return c->stft_fuse_db && amph::g_stft_indep &&
+           stft_mel_can_fuse_db(c->cfg.n_fft, c->n_frames, c->cfg.n_mels, c->mel_w_floats, c->stft_waves);
+}
+
+// db_out (nullable): the standardised image is written by the STFT kernel itself (fused dB stage), melpow is not
+StftParams make_stft(amph_ctx* c, const WaveSrc& src, float* melpow, float* db_out = nullptr, int db_layout = 1) {
     StftParams p{};
     p.src = src;
     p.n_samples = c->cfg.n_samples; p.n_fft = c->cfg.n_fft; p.hop = c->cfg.hop_length; p.n_frames = c->n_frames;
     p.pad_mode = c->cfg.pad_mode; p.frames_per_block = c->frames_per_block;
     p.tiles_per_row = (c->n_frames + c->frames_per_block - 1) / c->frames_per_block;
+    p.db_out = db_out; p.db_layout = db_layout; p.db_target_frames = c->cfg.target_frames;
+    if (db_out) {                                  // one tile = one whole row: its frames go round-robin over the waves
+        const int round = c->stft_waves * (c->cfg.n_fft == 2048 ? 1 : 2);
+        p.frames_per_block = (c->n_frames + round - 1) / round * round;
+        p.tiles_per_row = 1;
+    }
     p.tables = c->d_tables; p.tw_a = c->d_tw_a; p.mel_w_floats = c->mel_w_floats; p.p_tail = c->mel_p_tail;
     p.n_mels = c->cfg.n_mels; p.mel_start = c->d_mel_start; p.mel_len = c->d_mel_len; p.mel_wofs = c->d_mel_wofs;
     p.mel_w = c->d_mel_w; p.melpow = melpow;
@@ -718,8 +732,9 @@ StftParams make_stft(amph_ctx* c, const WaveSrc& src, float* melpow) {
 }
 
 // front end for one batch: wave rows -> melpow (-> image)
+// db_out != nullptr (only with can_fuse_db): the kernel writes the standardised image there and melpow stays untouched
 int run_frontend(amph_ctx* c, Workspace& w, const void* d_wave, bool pcm16, int nb, int n_in, const int32_t* d_len,
-                 int apply_rms, int32_t* d_rms_ok, float* melpow, hipStream_t s) {
+                 int apply_rms, int32_t* d_rms_ok, float* melpow, hipStream_t s, float* db_out = nullptr, int db_layout = 1) {
     WaveSrc src{};
     src.wave = d_wave; src.row_stride = n_in; src.lengths = d_len; src.n_in = n_in;
     src.scale = nullptr; src.requant = 0;
@@ -767,7 +782,7 @@ int run_frontend(amph_ctx* c, Workspace& w, const void* d_wave, bool pcm16, int 
     }
     {
         StageTimer t(c, ST_STFT, s);
-        launch_stft_mel(make_stft(c, src, melpow), nb, pcm16 ? 1 : 0, c->stft_waves, s);
+        launch_stft_mel(make_stft(c, src, melpow, db_out, db_layout), nb, pcm16 ? 1 : 0, c->stft_waves, s);
     }
     return AMPH_OK;
 }
@@ -814,9 +829,10 @@ int encode_common(amph_ctx* c, const void* d_wave, bool pcm16, int64_t n_rows, i
         hipStream_t ls = (bi % L == 0) ? s : w.stream;
         const char* wv = (const char*)d_wave + (size_t)off * n_in * esz;
         // a stage that fails (an allocation, a launch) stops the call: the later stages of the batch would read stale buffers
+        const bool fdb = can_fuse_db(c);               // dB / z-score / crop-pad inside the STFT kernel: no mel power in HBM
         rc = run_frontend(c, w, wv, pcm16, nb, n_in, d_len ? d_len + off : nullptr, apply_rms, d_rms_ok ? d_rms_ok + off : nullptr,
-                          w.melpow, ls);
-        if (rc == AMPH_OK) rc = run_dbnorm(c, w.melpow, nb, 1, w.image, ls);
+                          w.melpow, ls, fdb ? w.image : nullptr, 1);
+        if (rc == AMPH_OK && !fdb) rc = run_dbnorm(c, w.melpow, nb, 1, w.image, ls);
         if (rc == AMPH_OK) rc = run_encoder(c, w, w.image, nb, d_mu + off * D, d_logvar ? d_logvar + off * D : nullptr, ls);
         if (rc == AMPH_OK) rc = check_launch(c, "encode");
     }
@@ -878,9 +894,14 @@ int amph_create(const amph_frontend_config* cfg, const amph_encoder_spec* spec, 
             const size_t l12 = stft_mel_lds_bytes(c->cfg.n_fft, c->cfg.hop_length, 12 * slots, c->cfg.n_mels, c->mel_w_floats, 12);
             if (l12 <= 160 * 1024) { c->stft_waves = 12; c->frames_per_block = 12 * slots; }
         }
-        const int lds = (int)stft_mel_lds_bytes(c->cfg.n_fft, c->cfg.hop_length, c->frames_per_block, c->cfg.n_mels, c->mel_w_floats, c->stft_waves);
+        int lds = (int)stft_mel_lds_bytes(c->cfg.n_fft, c->cfg.hop_length, c->frames_per_block, c->cfg.n_mels, c->mel_w_floats, c->stft_waves);
         if (lds > 160 * 1024) rc = fail(c, AMPH_ERR_UNSUPPORTED, "frame tile needs %d bytes of LDS", lds);
-        else rc = amph::stft_mel_configure(lds) == hipSuccess ? AMPH_OK : fail(c, AMPH_ERR_HIP, "hipFuncSetAttribute failed");
+        else {
+            for (int nw : {4, 12})                  // the fused dB stage keeps a row's mel power in LDS too
+                if (stft_mel_can_fuse_db(c->cfg.n_fft, c->n_frames, c->cfg.n_mels, c->mel_w_floats, nw))
+                    lds = std::max(lds, (int)stft_mel_fused_lds_bytes(c->cfg.n_fft, c->n_frames, c->cfg.n_mels, c->mel_w_floats, nw));
+            rc = amph::stft_mel_configure(lds) == hipSuccess ? AMPH_OK : fail(c, AMPH_ERR_HIP, "hipFuncSetAttribute failed");
+        }
     }
     if (rc != AMPH_OK) {
         g_create_error = c->err;
@@ -927,6 +948,7 @@ int amph_configure(amph_ctx* c, const char* key, int value) {
     if (!std::strcmp(key, "fuse_conv12")) { c->fuse_conv12 = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "stft_prenorm")) { c->stft_prenorm = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "stft_prepad")) { c->stft_prepad = value != 0; return AMPH_OK; }
+    if (!std::strcmp(key, "stft_fuse_db")) { c->stft_fuse_db = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "split_gemm")) { c->split_gemm = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "split_fused")) { c->split_fused = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "rms_numpy2")) { c->rms_f64_scale = value ? 0 : 1; return AMPH_OK; }
@@ -1101,9 +1123,10 @@ int amph_mel_f32(amph_ctx* c, const float* d_wave, int n_rows, int n_in, const i
     const size_t per = (size_t)c->cfg.target_frames * c->cfg.n_mels;
     for (int off = 0; off < n_rows; off += c->max_batch) {
         const int nb = std::min(c->max_batch, n_rows - off);
+        const bool fdb = can_fuse_db(c);
         int rc = run_frontend(c, c->lanes[0], d_wave + (size_t)off * n_in, false, nb, n_in, d_lengths ? d_lengths + off : nullptr, 0,
-                              nullptr, c->lanes[0].melpow, s);
-        if (rc == AMPH_OK) rc = run_dbnorm(c, c->lanes[0].melpow, nb, layout, d_mel_out + (size_t)off * per, s);
+                              nullptr, c->lanes[0].melpow, s, fdb ? d_mel_out + (size_t)off * per : nullptr, layout);
+        if (rc == AMPH_OK && !fdb) rc = run_dbnorm(c, c->lanes[0].melpow, nb, layout, d_mel_out + (size_t)off * per, s);
         if (rc != AMPH_OK) return rc;
     }
     return check_launch(c, "mel_f32");

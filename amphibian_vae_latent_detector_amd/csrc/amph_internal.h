@@ -47,6 +47,10 @@ struct StftParams {
     int mel_w_floats;          // total, a multiple of 16
     int p_tail;                // floats past bin n_fft/2 the padded rows may read (zeroed per frame)
     float* melpow;           // [B][n_frames][n_mels]
+    // fused dB / z-score / crop-pad (k_stft_mel_w only; tiles_per_row == 1, i.e. one workgroup owns a whole row): when db_out is
+    // set the mel power of a row stays in LDS and the workgroup writes the standardised image itself (melpow is not written)
+    float* db_out;           // nullable: [B][target][n_mels] (layout 1) or [B][n_mels][target] (layout 0)
+    int db_layout, db_target_frames;
 #ifdef AMPH_STAMPS
     unsigned long long* stamps;   // diagnostic build: [grid][16] s_memtime stamps
 #endif
@@ -74,6 +78,10 @@ void launch_rms_apply_pcm16(const int16_t* in, int n_rows, int n, const float* s
 // sample_is_pcm16: 1 -> src.wave is int16_t, 0 -> float
 void launch_stft_mel(const StftParams& p, int n_rows, int sample_is_pcm16, int n_waves, hipStream_t s);
 size_t stft_mel_lds_bytes(int n_fft, int hop, int frames_per_block, int n_mels, int mel_w_floats, int n_waves);
+// LDS of the independent-wave kernel with the fused dB stage (no sample span; + the row's mel power), and whether a
+// configuration can run it (every wave must own a frame of every row: the row-end barriers are workgroup barriers)
+size_t stft_mel_fused_lds_bytes(int n_fft, int n_frames, int n_mels, int mel_w_floats, int n_waves);
+bool stft_mel_can_fuse_db(int n_fft, int n_frames, int n_mels, int mel_w_floats, int n_waves);
 int stft_mel_table_bytes(int n_fft);
 int stft_mel_scratch_floats(int n_fft);   // floats of per-frame scratch the power spectrum + tail may use
 hipError_t stft_mel_configure(int lds_bytes);   // raises the dynamic-LDS limit of the STFT kernels

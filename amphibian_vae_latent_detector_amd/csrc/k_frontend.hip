@@ -847,6 +847,66 @@ __global__ __launch_bounds__(64 * NW) void k_stft_mel(StftParams p, int n_tiles)
 #endif
 }
 
+// K3 inside the STFT kernel: power_to_db(ref=max, amin=1e-10, top_db=80) -> z-score over the whole [M, T_raw] array
+// (population std) -> centre crop / zero pad -> [T, M] or [M, T] (map_detector_core.py:229-237, 185-195) for ONE row whose
+// mel power [n_frames][n_mels] the workgroup holds in LDS.  Same arithmetic as k_dbnorm (separately rounded dB terms, sums
+// in double, two-pass std); the mel power never reaches HBM (-3.7 MB written, -1.9 MB read and one launch less per 256 rows).
+__device__ __forceinline__ float to_db(float s, float ref_db);
+template <int NT>
+__device__ __attribute__((noinline)) void db_row_from_lds(const float* mp, int T, int M, int TT, int layout, float* out, double* red) {
+    constexpr int NWV = NT / 64;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int n = T * M;
+    float* redf = reinterpret_cast<float*>(red + 16);
+    constexpr int C = 8;                                 // values kept in registers per thread; beyond that recomputed per pass
+    float v[C];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < C; ++j) { const int i = tid + NT * j; v[j] = i < n ? mp[i] : -INFINITY; mx = fmaxf(mx, v[j]); }
+    for (int i = tid + NT * C; i < n; i += NT) mx = fmaxf(mx, mp[i]);
+    mx = wave_max(mx);
+    if (lane == 0) redf[w] = mx;
+    __syncthreads();
+    mx = redf[0];
+#pragma unroll
+    for (int g = 1; g < NWV; ++g) mx = fmaxf(mx, redf[g]);
+    const float ref_db = 10.0f * log10f(fmaxf(1e-10f, mx));             // same two operations as to_db (no FMA)
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < C; ++j) if (tid + NT * j < n) { v[j] = to_db(v[j], ref_db); acc += (double)v[j]; }
+    for (int i = tid + NT * C; i < n; i += NT) acc += (double)to_db(mp[i], ref_db);
+    acc = wave_sum(acc);
+    if (lane == 0) red[w] = acc;
+    __syncthreads();
+    double tot = 0.0;
+#pragma unroll
+    for (int g = 0; g < NWV; ++g) tot += red[g];
+    const float mean = (float)(tot / (double)n);
+    acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < C; ++j) if (tid + NT * j < n) { const float dlt = v[j] - mean; acc += (double)(dlt * dlt); }
+    for (int i = tid + NT * C; i < n; i += NT) { const float dlt = to_db(mp[i], ref_db) - mean; acc += (double)(dlt * dlt); }
+    acc = wave_sum(acc);
+    __syncthreads();                                     // every wave has read the first sums
+    if (lane == 0) red[w] = acc;
+    __syncthreads();
+    tot = 0.0;
+#pragma unroll
+    for (int g = 0; g < NWV; ++g) tot += red[g];
+    const float sd = sqrtf((float)(tot / (double)n));
+    const float den = sd + 1e-8f;
+    // crop_or_pad_time (map_detector_core.py:185-195): destination frame = source frame - shift
+    const int shift = (T >= TT) ? (T - TT) / 2 : -((TT - T) / 2);
+    for (int i = tid; i < TT * M; i += NT) {
+        int tt, m;
+        if (layout == 1) { tt = i / M; m = i - tt * M; } else { m = i / TT; tt = i - m * TT; }
+        const int src = tt + shift;
+        float z = 0.0f;                                  // literal zero padding
+        if (src >= 0 && src < T) z = (to_db(mp[src * M + m], ref_db) - mean) / den;     // (recomputed: the same value the sums used)
+        out[i] = z;
+    }
+}
+
 // ----------------------------------------------------------------------------
 // The same transform with INDEPENDENT waves ("w"): no shared sample span, no workgroup barrier after the tables are
 // staged.  See the comment at the frame list below.  Same arithmetic on the same values as k_stft_mel: bit-identical.
@@ -887,6 +947,9 @@ __global__ __launch_bounds__(64 * NW) void k_stft_mel_w(StftParams p, int n_tile
     char* wbase = smem + kTableBytes + meta_bytes + melw_bytes + wave * kWaveScratch;   // no shared sample span here
     float2* ex = reinterpret_cast<float2*>(wbase + slot * G::SLOT_BYTES);   // this frame slot's scratch
     float* P = reinterpret_cast<float*>(wbase + slot * G::SLOT_BYTES);
+    // fused dB stage (p.db_out): the row's mel power [n_frames][n_mels] stays here, behind the wave scratches
+    float* mp_row = reinterpret_cast<float*>(smem + kTableBytes + meta_bytes + melw_bytes + NW * kWaveScratch);
+    const bool fuse_db = p.db_out != nullptr;
 
     // ---- once per workgroup: tables (one packed global array = the LDS image) and the mel rows
     {
@@ -899,7 +962,7 @@ __global__ __launch_bounds__(64 * NW) void k_stft_mel_w(StftParams p, int n_tile
         for (int i = tid; i < (p.mel_w_floats >> 2); i += kThreads) wdst[i] = wsrc[i];
     }
 
-    __syncthreads();                                  // tables and mel rows staged: the ONLY workgroup barrier of the kernel
+    __syncthreads();                                  // tables and mel rows staged: the only workgroup barrier of the unfused kernel
 
     // ---- per-wave frame list: wave w of the workgroup takes frame slots w * SLOTS (+ NW * SLOTS ...) of the tiles
     //      blockIdx.x, + gridDim.x, ... - the tile order keeps the overlapping frames of a row on one CU (L1 hits) - but
@@ -1104,7 +1167,7 @@ __global__ __launch_bounds__(64 * NW) void k_stft_mel_w(StftParams p, int n_tile
         for (int sl = 0; sl < SLOTS; ++sl) {            // all 64 lanes work on one frame slot at a time
             const int fr = cur_fr0 + sl;
             if (fr >= p.n_frames) break;                      // wave-uniform
-            float* out = p.melpow + ((long long)row * p.n_frames + fr) * p.n_mels;
+            float* out = fuse_db ? mp_row + fr * p.n_mels : p.melpow + ((long long)row * p.n_frames + fr) * p.n_mels;
             const float* Ps = reinterpret_cast<const float*>(wbase + sl * G::SLOT_BYTES);
             const int q = lane & 3;
             for (int m0 = 0; m0 < p.n_mels; m0 += 16) {
@@ -1138,6 +1201,16 @@ __global__ __launch_bounds__(64 * NW) void k_stft_mel_w(StftParams p, int n_tile
         (void)fvalid;
         wave_lds_sync();                              // the scratch is rewritten by the next frame
         AMPH_STAMP(9)
+        // ---- fused dB stage: this wave's last frame of the row (tile == row here).  Every wave owns a frame of every row
+        //      (host check), so all of them arrive: power_to_db + z-score + crop / pad on the row held in LDS, by the whole
+        //      workgroup, while the samples of the waves' next frames are already in flight.
+        if (fuse_db && (!more || d.row != row)) {
+            __syncthreads();
+            db_row_from_lds<kThreads>(mp_row, p.n_frames, p.n_mels, p.db_target_frames, p.db_layout,
+                                      p.db_out + (long long)row * p.db_target_frames * p.n_mels,
+                                      reinterpret_cast<double*>(mp_row + ((p.n_frames * p.n_mels + 3) & ~3)));
+            __syncthreads();                          // the next row's frames overwrite mp_row
+        }
     }
 #ifdef AMPH_STAMPS
     if (tid == 0) {       // per-workgroup timeline (wave 0): where the tiles' time goes, and the in-kernel clock
@@ -1162,6 +1235,15 @@ size_t stft_mel_lds_bytes(int n_fft, int hop, int frames_per_block, int n_mels, 
     const size_t span = (((size_t)(frames_per_block - 1) * hop + n_fft) * 4 + 15) & ~(size_t)15;
     const size_t meta = ((size_t)n_mels * 12 + 15) & ~(size_t)15;
     return (size_t)table_bytes_for(n_fft) + meta + (size_t)mel_w_floats * 4 + span + (size_t)n_waves * kWaveScratch;
+}
+size_t stft_mel_fused_lds_bytes(int n_fft, int n_frames, int n_mels, int mel_w_floats, int n_waves) {
+    const size_t meta = ((size_t)n_mels * 12 + 15) & ~(size_t)15;
+    const size_t mp = (((size_t)n_frames * n_mels + 3) & ~(size_t)3) * 4 + 16 * 8 + 16 * 4;      // the row's mel power + reduction scratch
+    return (size_t)table_bytes_for(n_fft) + meta + (size_t)mel_w_floats * 4 + (size_t)n_waves * kWaveScratch + mp;
+}
+bool stft_mel_can_fuse_db(int n_fft, int n_frames, int n_mels, int mel_w_floats, int n_waves) {
+    const int slots = n_fft == 2048 ? 1 : 2;
+    return n_frames >= n_waves * slots && stft_mel_fused_lds_bytes(n_fft, n_frames, n_mels, mel_w_floats, n_waves) <= 160 * 1024;
 }
 int stft_mel_table_bytes(int n_fft) { return table_bytes_for(n_fft); }
 int stft_mel_scratch_floats(int n_fft) { return (n_fft == 2048 ? FftGeo<4>::SLOT_BYTES : FftGeo<2>::SLOT_BYTES) / 4; }
@@ -1197,7 +1279,8 @@ int g_stft_grid = 0;     // persistent workgroups; 0 = fill the chip (2 per CU w
 
 template <int NW>
 static void launch_stft_mel_nw(const StftParams& p, int n_tiles, int sample_is_pcm16, hipStream_t s) {
-    const size_t lds = stft_mel_lds_bytes(p.n_fft, p.hop, p.frames_per_block, p.n_mels, p.mel_w_floats, NW);
+    const size_t lds = p.db_out ? stft_mel_fused_lds_bytes(p.n_fft, p.n_frames, p.n_mels, p.mel_w_floats, NW)
+                                : stft_mel_lds_bytes(p.n_fft, p.hop, p.frames_per_block, p.n_mels, p.mel_w_floats, NW);
     const int fill = NW == 4 ? 512 : 256;
     const dim3 grid((unsigned)std::min(n_tiles, g_stft_grid > 0 ? g_stft_grid : fill)), block(64 * NW);
     if (g_stft_indep) {
