@@ -47,6 +47,8 @@ struct Workspace {
     float* partial = nullptr;
     int16_t* norm16 = nullptr;             // RMS-normalised PCM16 rows of the batch (what 00_normalize writes to disk), input of the STFT
     size_t norm16_cap = 0;                 // samples
+    float* chunk_sums = nullptr;           // K0 on long rows: per-row sums of the numpy chunks (8192 samples each)
+    size_t chunk_sums_cap = 0;             // floats
 };
 
 struct GemmLayer {
@@ -486,6 +488,17 @@ int ensure_norm16(amph_ctx* c, Workspace& w, size_t need, hipStream_t s) {
     return AMPH_OK;
 }
 
+// K0's per-row chunk sums (rows longer than one LDS pass take the two-kernel path): max_batch x ceil(n_in / 8192) floats
+int ensure_chunk_sums(amph_ctx* c, Workspace& w, int n_in, hipStream_t s) {
+    const size_t need = (size_t)c->max_batch * (size_t)rms_scale_chunks(n_in);
+    if (w.chunk_sums_cap >= need) return AMPH_OK;
+    if (w.chunk_sums) { HIP_TRY(c, hipStreamSynchronize(s)); (void)hipFree(w.chunk_sums); }
+    w.chunk_sums = nullptr; w.chunk_sums_cap = 0;
+    HIP_TRY(c, hipMalloc((void**)&w.chunk_sums, need * sizeof(float)));
+    w.chunk_sums_cap = need;
+    return AMPH_OK;
+}
+
 int alloc_lane(amph_ctx* c, Workspace& w, bool own_stream) {
     const int MB = c->max_batch;
     const amph_frontend_config& f = c->cfg;
@@ -523,7 +536,7 @@ int alloc_lane(amph_ctx* c, Workspace& w, bool own_stream) {
 
 void free_lane(Workspace& w) {
     auto fr = [](void* p) { if (p) (void)hipFree(p); };
-    fr(w.scale); fr(w.ok); fr(w.melpow); fr(w.image);
+    fr(w.scale); fr(w.ok); fr(w.melpow); fr(w.image); fr(w.chunk_sums);
     for (auto p : w.act_raw) fr(p);
     fr(w.partial);
     fr(w.norm16);
@@ -758,7 +771,11 @@ int run_frontend(amph_ctx* c, Workspace& w, const void* d_wave, bool pcm16, int 
             if (rc != AMPH_OK) return rc;
             norm = w.norm16;
         }
-        if (pcm16) launch_rms_scale_pcm16((const int16_t*)d_wave, n_in, d_len, n_in, nb, w.scale, okp, c->rms_f64_scale, norm, pad, s);
+        if (pcm16) {
+            const int rcs = ensure_chunk_sums(c, w, n_in, s);
+            if (rcs != AMPH_OK) return rcs;
+            launch_rms_scale_pcm16((const int16_t*)d_wave, n_in, d_len, n_in, nb, w.scale, okp, c->rms_f64_scale, norm, pad, w.chunk_sums, s);
+        }
         else launch_rms_scale_f32((const float*)d_wave, n_in, d_len, n_in, nb, w.scale, okp, c->rms_f64_scale, s);
         src.scale = w.scale;
         src.requant = 1;
@@ -1091,7 +1108,14 @@ int amph_rms_normalize_pcm16(amph_ctx* c, const int16_t* d_in, int n_rows, int n
         const int nb = std::min(c->max_batch, n_rows - off);
         Workspace& w = c->lanes[0];
         int32_t* okp = d_ok ? d_ok + off : w.ok;
-        launch_rms_scale_pcm16(d_in + (size_t)off * n, n, nullptr, n, nb, w.scale, okp, c->rms_f64_scale, nullptr, NormPad{}, s);
+        const int rcs = ensure_chunk_sums(c, w, n, s);
+        if (rcs != AMPH_OK) return rcs;
+        // (rows longer than one LDS pass: the two-kernel path writes the normalised rows itself)
+        if (rms_scale_chunks(n) > 4) {
+            launch_rms_scale_pcm16(d_in + (size_t)off * n, n, nullptr, n, nb, w.scale, okp, c->rms_f64_scale, d_out + (size_t)off * n, NormPad{}, w.chunk_sums, s);
+            continue;
+        }
+        launch_rms_scale_pcm16(d_in + (size_t)off * n, n, nullptr, n, nb, w.scale, okp, c->rms_f64_scale, nullptr, NormPad{}, nullptr, s);
         launch_rms_apply_pcm16(d_in + (size_t)off * n, nb, n, w.scale, okp, d_out + (size_t)off * n, s);
     }
     return check_launch(c, "rms_normalize_pcm16");

@@ -65,8 +65,12 @@ struct DbNormParams {
 
 // scale_f64: 1 = the scalar arithmetic of numpy 1.26 (the reference's pin: float64 gate compare and scale, one cast), 0 = numpy 2.x (float32)
 // norm_out (nullable): also write the normalised, re-quantised PCM16 rows (same row stride)
+// chunk_sums (nullable): workspace of n_rows * rms_scale_chunks(n_in) floats; with it, rows longer than one LDS pass take the
+// two-kernel path (chunk sums by (row, pass) workgroups, then fold + normalise + pad by (row, tile) workgroups)
+int rms_scale_chunks(int n_in);
 void launch_rms_scale_pcm16(const int16_t* in, long long row_stride, const int32_t* lengths, int n_in,
-                            int n_rows, float* scale, int32_t* ok, int scale_f64, int16_t* norm_out, const NormPad& pad, hipStream_t s);
+                            int n_rows, float* scale, int32_t* ok, int scale_f64, int16_t* norm_out, const NormPad& pad, float* chunk_sums,
+                            hipStream_t s);
 void launch_pad_rows_pcm16(const int16_t* in, long long row_stride, const int32_t* lengths, int n_in, int n_rows, int16_t* out,
                            const NormPad& pad, hipStream_t s);
 void launch_rms_scale_f32(const float* in, long long row_stride, const int32_t* lengths, int n_in,

@@ -147,13 +147,17 @@ __device__ __forceinline__ float sq_of(float y) {
 // (rms stage 18.4 -> 16.1 us with 512, 14.8 us with 1024 threads; same bits)
 constexpr int kRmsThreads = 1024, kRmsTree = 256;
 
-template <typename T>
-__global__ __launch_bounds__(kRmsThreads) void k_rms_scale(const T* __restrict__ in, long long row_stride,
+// TH threads per workgroup, CH numpy chunks staged per pass: <T, 1024, 4 | 2> for whole rows (one workgroup per row), <int16_t, 256, 1>
+// for the chunk-sums mode on long rows (one workgroup per chunk: 8 x the workgroups, each a fraction of the latency chain)
+template <typename T, int TH, int CH>
+__global__ __launch_bounds__(TH) void k_rms_scale(const T* __restrict__ in, long long row_stride,
                                                    const int32_t* __restrict__ lengths, int n_in,
                                                    float* __restrict__ scale, int32_t* __restrict__ ok, int16_t* __restrict__ norm_out,
-                                                   NormPad pad, int scale_f64) {
+                                                   NormPad pad, int scale_f64, float* __restrict__ chunk_sums, int chunk_stride) {
 #pragma clang fp contract(off)
-    constexpr int kChunksPerPass = NpPass<T>::kChunks;
+    // chunk_sums != nullptr (rows longer than one pass): workgroup (row, y) sums ONE pass - numpy chunks CH y .. CH y + CH - 1 -
+    // and writes their sums; k_rms_fold_apply folds them in order.  Same leaves, same tree.
+    constexpr int kChunksPerPass = CH, kRmsThreads = TH;
     constexpr int kPassElems = kChunksPerPass * kNpChunk;
     constexpr int kVec = 16 / (int)sizeof(T);            // elements per 16-byte LDS read
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -164,12 +168,14 @@ __global__ __launch_bounds__(kRmsThreads) void k_rms_scale(const T* __restrict__
     const int n = lengths ? min(lengths[row], n_in) : n_in;
     const int n_chunks = (n + kNpChunk - 1) / kNpChunk;
     float total = 0.0f;                                  // thread 0 only
-    for (int c0 = 0; c0 < n_chunks; c0 += kChunksPerPass) {
+    const int c_first = chunk_sums ? (int)blockIdx.y * kChunksPerPass : 0;
+    const int c_last = chunk_sums ? min(n_chunks, c_first + kChunksPerPass) : n_chunks;
+    for (int c0 = c_first; c0 < c_last; c0 += kChunksPerPass) {
         // ---- stage this pass's samples, coalesced (dword granules when the row is 4-byte aligned)
         const int e0 = c0 * kNpChunk, ne = min(kPassElems, n - e0);
         // every load of a batch is issued before the first LDS write: a 1 s / 22.05 kHz row (11 025 dwords) is ONE batch,
         // i.e. one global round trip (batches of 8 loads per thread were six serialised round trips: 16 -> 10 us)
-        constexpr int U = (sizeof(T) == 2 ? 44 : 32) / (kRmsThreads / kRmsTree);
+        constexpr int U = sizeof(T) == 2 ? (kPassElems / 2 + kRmsThreads - 1) / kRmsThreads : (kPassElems + kRmsThreads - 1) / kRmsThreads;   // one batch per pass
         if (sizeof(T) == 2 && (((uintptr_t)(x + e0)) & 3u) == 0) {
             const uint32_t* src = reinterpret_cast<const uint32_t*>(x + e0);
             const int nd = ne >> 1;
@@ -258,12 +264,17 @@ __global__ __launch_bounds__(kRmsThreads) void k_rms_scale(const T* __restrict__
             }
             __syncthreads();
         }
+        if (chunk_sums) {
+            if (tid < kChunksPerPass && c0 + tid < n_chunks) chunk_sums[(long long)row * chunk_stride + c0 + tid] = heap[tid * 128 + 1];
+            return;
+        }
         if (tid == 0) {
             for (int cl = 0; cl < kChunksPerPass && c0 + cl < n_chunks; ++cl)
                 total = (c0 + cl == 0) ? heap[cl * 128 + 1] : total + heap[cl * 128 + 1];
         }
         __syncthreads();
     }
+    if (chunk_sums) return;                              // (a pass past the row's end: nothing to sum)
     if (tid == 0) {
         float sc = 1.0f;
         int good = 0;
@@ -377,9 +388,9 @@ __global__ __launch_bounds__(kRmsThreads) void k_rms_scale(const T* __restrict__
     }
 }
 
-template <typename T>
+template <typename T, int CH = NpPass<T>::kChunks>
 static size_t rms_scale_lds() {
-    constexpr int kChunksPerPass = NpPass<T>::kChunks;
+    constexpr int kChunksPerPass = CH;
     return (size_t)kChunksPerPass * 128 * 4 + (size_t)kChunksPerPass * kNpChunk * sizeof(T) + (size_t)kChunksPerPass * 64 * 16;
 }
 
@@ -406,6 +417,86 @@ __global__ __launch_bounds__(256) void k_rms_apply_pcm16(const int16_t* __restri
         float x = (float)in[base + i] * (1.0f / 32768.0f);
         if (scaled) x = fminf(fmaxf(x * sc, -1.0f), 1.0f);
         out[base + i] = (int16_t)(int)rintf(x * 32767.0f);     // libsndfile float -> PCM_16
+    }
+}
+
+// Long rows (more than one LDS pass of k_rms_scale: the reference's 5 s / 48 kHz default, 240 000 samples = 30 numpy
+// chunks): the single-workgroup-per-row kernel walked its 8 passes one after the other and then read the row from global
+// memory again for the normalised copy - 181 us per 256 rows, 1.4 TB/s.  Here the chunk sums come from (row, pass)
+// workgroups of k_rms_scale (chunk_sums mode) and THIS kernel, on (row, tile) workgroups, folds them in numpy's order
+// (sequentially, chunk 0 first: the same float32 additions thread 0 of the one-kernel form does), derives the scale with the
+// same expressions, and writes its tile of the normalised / padded row (the arithmetic of k_rms_scale's write pass).
+// out == nullptr (float32 input): blockIdx.y == 0 only writes scale / ok.
+__global__ __launch_bounds__(256) void k_rms_fold_apply(const int16_t* __restrict__ in, long long row_stride, const int32_t* __restrict__ lengths,
+                                                        int n_in, const float* __restrict__ chunk_sums, int chunk_stride, int scale_f64,
+                                                        float* __restrict__ scale, int32_t* __restrict__ ok, int16_t* __restrict__ norm_out,
+                                                        NormPad pad) {
+#pragma clang fp contract(off)
+    __shared__ float sh[2];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const int n = lengths ? min(lengths[row], n_in) : n_in;
+    if (tid == 0) {
+        const int n_chunks = (n + kNpChunk - 1) / kNpChunk;
+        float total = 0.0f, sc = 1.0f;
+        int good = 0;
+        for (int c = 0; c < n_chunks; ++c) total = c == 0 ? chunk_sums[(long long)row * chunk_stride] : total + chunk_sums[(long long)row * chunk_stride + c];
+        if (n > 0) {
+            const float rms = sqrtf(total / (float)n);
+            if (scale_f64) { if (!((double)rms < 1e-4)) { sc = (float)(0.05 / ((double)rms + 1e-8)); good = 1; } }
+            else if (!(rms < 1e-4f)) { sc = 0.05f / (rms + 1e-8f); good = 1; }
+        }
+        if (blockIdx.y == 0) { scale[row] = sc; if (ok) ok[row] = good; }
+        sh[0] = sc; sh[1] = good ? 1.0f : 0.0f;
+    }
+    if (!norm_out) return;
+    __syncthreads();
+    const float sc = sh[0];
+    const bool scaled = sh[1] != 0.0f;
+    const int16_t* x = in + (long long)row * row_stride;
+    int16_t* o = norm_out + (long long)row * (pad.lead > 0 ? pad.out_stride : row_stride);
+    auto conv = [&](int q) {
+        float v = (float)q * (1.0f / 32768.0f);
+        if (scaled) v = fminf(fmaxf(v * sc, -1.0f), 1.0f);
+        return (int)rintf(v * 32767.0f);
+    };
+    const int lead = pad.lead, n_fix = pad.lead > 0 ? pad.n_fix : n_in, nv = min(n, n_fix), total_out = n_fix + 2 * lead;
+    auto sample = [&](int idx) {                         // output sample idx of the (padded) row
+        int sidx = idx - lead;
+        if (lead > 0 && pad.mode == 0) {                 // reflect (np.pad mode="reflect")
+            if (sidx < 0) sidx = -sidx;
+            if (sidx >= n_fix) sidx = 2 * (n_fix - 1) - sidx;
+        }
+        if (sidx < 0 || sidx >= nv) return lead > 0 ? 0 : (sidx >= 0 && sidx < n_in ? conv((int)x[sidx]) : 0);
+        return conv((int)x[sidx]);
+    };
+    // this workgroup's share of the output dwords; the body - output dword i = input dword i - lead / 2 - is the fast path
+    const int nd = total_out >> 1;
+    const int per = (nd + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int d0 = blockIdx.y * per, d1 = min(nd, d0 + per);
+    const bool al = ((reinterpret_cast<uintptr_t>(o) | reinterpret_cast<uintptr_t>(x)) & 3u) == 0 && (lead & 1) == 0;
+    const int i_lo = lead >> 1, i_hi = i_lo + (nv >> 1);
+    if (al) {
+        uint32_t* o2 = reinterpret_cast<uint32_t*>(o);
+        const uint32_t* x2 = reinterpret_cast<const uint32_t*>(x);
+        constexpr int UW = 8;
+        for (int base = d0; base < d1; base += 256 * UW) {
+            uint32_t v[UW];
+#pragma unroll
+            for (int u = 0; u < UW; ++u) { const int i = base + tid + 256 * u; v[u] = (i < d1 && i >= i_lo && i < i_hi) ? x2[i - i_lo] : 0u; }
+#pragma unroll
+            for (int u = 0; u < UW; ++u) {
+                const int i = base + tid + 256 * u;
+                if (i < d1) {
+                    int lo, hi;
+                    if (i >= i_lo && i < i_hi) { lo = conv((int)(short)(v[u] & 0xFFFFu)); hi = conv((int)v[u] >> 16); }
+                    else { lo = sample(2 * i); hi = sample(2 * i + 1); }
+                    o2[i] = ((uint32_t)lo & 0xFFFFu) | ((uint32_t)hi << 16);
+                }
+            }
+        }
+        if ((total_out & 1) && blockIdx.y == gridDim.y - 1 && tid == 0) o[total_out - 1] = (int16_t)sample(total_out - 1);
+    } else {
+        for (int i = 2 * d0 + tid; i < min(total_out, 2 * d1 + ((blockIdx.y == gridDim.y - 1) ? 1 : 0)); i += 256) o[i] = (int16_t)sample(i);
     }
 }
 
@@ -853,7 +944,7 @@ __global__ __launch_bounds__(64 * NW) void k_stft_mel(StftParams p, int n_tiles)
 // in double, two-pass std); the mel power never reaches HBM (-3.7 MB written, -1.9 MB read and one launch less per 256 rows).
 __device__ __forceinline__ float to_db(float s, float ref_db);
 template <int NT>
-__device__ __attribute__((noinline)) void db_row_from_lds(const float* mp, int T, int M, int TT, int layout, float* out, double* red) {
+__device__ __forceinline__ void db_row_from_lds(const float* mp, int T, int M, int TT, int layout, float* out, double* red) {
     constexpr int NWV = NT / 64;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int n = T * M;
@@ -897,14 +988,38 @@ __device__ __attribute__((noinline)) void db_row_from_lds(const float* mp, int T
     const float den = sd + 1e-8f;
     // crop_or_pad_time (map_detector_core.py:185-195): destination frame = source frame - shift
     const int shift = (T >= TT) ? (T - TT) / 2 : -((TT - T) / 2);
-    for (int i = tid; i < TT * M; i += NT) {
-        int tt, m;
-        if (layout == 1) { tt = i / M; m = i - tt * M; } else { m = i / TT; tt = i - m * TT; }
-        const int src = tt + shift;
-        float z = 0.0f;                                  // literal zero padding
-        if (src >= 0 && src < T) z = (to_db(mp[src * M + m], ref_db) - mean) / den;     // (recomputed: the same value the sums used)
-        out[i] = z;
+    // source-major, like k_dbnorm's cached form: the dB values of passes 2 and 3 are still in registers (no third log10)
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        const int e = tid + NT * j;
+        if (e < n) {
+            const int fr = e / M, m = e - fr * M, tt = fr - shift;
+            if (tt >= 0 && tt < TT) {
+                const float z = (v[j] - mean) / den;
+                if (layout == 1) out[tt * M + m] = z; else out[m * TT + tt] = z;
+            }
+        }
     }
+    for (int e = tid + NT * C; e < n; e += NT) {         // rows larger than the register cache
+        const int fr = e / M, m = e - fr * M, tt = fr - shift;
+        if (tt >= 0 && tt < TT) {
+            const float z = (to_db(mp[e], ref_db) - mean) / den;
+            if (layout == 1) out[tt * M + m] = z; else out[m * TT + tt] = z;
+        }
+    }
+    if (T < TT) {                                        // literal zero padding, left then right
+        const int left = -shift, right0 = left + T;
+        for (int i = tid; i < (TT - T) * M; i += NT) {
+            const int fr = i / M, m = i - fr * M;
+            const int tt = fr < left ? fr : right0 + (fr - left);
+            if (layout == 1) out[tt * M + m] = 0.0f; else out[m * TT + tt] = 0.0f;
+        }
+    }
+}
+
+template <int NT>
+__device__ __attribute__((noinline)) void db_row_call(const float* mp, int T, int M, int TT, int layout, float* out, double* red) {
+    db_row_from_lds<NT>(mp, T, M, TT, layout, out, red);
 }
 
 // ----------------------------------------------------------------------------
@@ -1021,6 +1136,7 @@ __global__ __launch_bounds__(64 * NW) void k_stft_mel_w(StftParams p, int n_tile
     const float sgn_a = t_lo < 2 ? 1.0f : -1.0f;          // first butterfly (lanes 2 apart): x + p or p - x
     const float sgn_b = (t_lo & 1) == 0 ? 1.0f : -1.0f;   // second butterfly (adjacent lanes)
     const bool rot3 = T_LO == 4 && t_lo == 3;
+    int last_row = -1;
     while (more) {
         const int row = d.row;
         const int fl = 0; (void)fl;                   // (stamps: every frame of wave 0)
@@ -1163,39 +1279,43 @@ __global__ __launch_bounds__(64 * NW) void k_stft_mel_w(StftParams p, int n_tile
         }
         // ---- mel rows: 4 lanes per filter, each lane 4 consecutive bins per step (aligned float4).
         //      The host pads every filter of a 16-filter round to the round's longest row (zero
-        //      weights), so the step count is wave-uniform: no per-lane predication, no branches.
-        for (int sl = 0; sl < SLOTS; ++sl) {            // all 64 lanes work on one frame slot at a time
-            const int fr = cur_fr0 + sl;
-            if (fr >= p.n_frames) break;                      // wave-uniform
-            float* out = fuse_db ? mp_row + fr * p.n_mels : p.melpow + ((long long)row * p.n_frames + fr) * p.n_mels;
-            const float* Ps = reinterpret_cast<const float*>(wbase + sl * G::SLOT_BYTES);
+        //      weights), so the step count is wave-uniform: no per-lane predication.
+        //      The stage was a chain of LDS round trips (descriptor -> first operands -> ... per round, 2.7 k of a frame's
+        //      ~10 k cycles): a round's descriptor is requested one round ahead.  Same accumulation order as before (even steps -> acc0, odd -> acc1).
+        {
             const int q = lane & 3;
-            for (int m0 = 0; m0 < p.n_mels; m0 += 16) {
-                const int m = min(m0 + (lane >> 2), p.n_mels - 1);
-                const int3 meta = mel_meta[m];                                // (start4, steps of the round, wofs)
-                const int steps = __builtin_amdgcn_readfirstlane(meta.y);
-                const float4* w = reinterpret_cast<const float4*>(mel_w + meta.z) + q;    // (from global / L1 instead: +1 us)
-                const float4* pp = reinterpret_cast<const float4*>(Ps + meta.x) + q;
-                float acc0 = 0.0f, acc1 = 0.0f;
-                int i = 0;
-                for (; i + 1 < steps; i += 2) {
-                    const float4 a0 = w[4 * i], b0 = pp[4 * i], a1 = w[4 * i + 4], b1 = pp[4 * i + 4];
-                    acc0 = fmaf(a0.x, b0.x, acc0); acc1 = fmaf(a1.x, b1.x, acc1);
-                    acc0 = fmaf(a0.y, b0.y, acc0); acc1 = fmaf(a1.y, b1.y, acc1);
-                    acc0 = fmaf(a0.z, b0.z, acc0); acc1 = fmaf(a1.z, b1.z, acc1);
-                    acc0 = fmaf(a0.w, b0.w, acc0); acc1 = fmaf(a1.w, b1.w, acc1);
+            const int n_rounds = (p.n_mels + 15) >> 4;
+            // (hoisting the descriptors of all rounds into registers spilled: the frame's FFT state leaves no room at three waves
+            // per SIMD; the next round's descriptor is requested before the current round's operands instead)
+            for (int sl = 0; sl < SLOTS; ++sl) {            // all 64 lanes work on one frame slot at a time
+                const int fr = cur_fr0 + sl;
+                if (fr >= p.n_frames) break;                      // wave-uniform
+                float* out = fuse_db ? mp_row + fr * p.n_mels : p.melpow + ((long long)row * p.n_frames + fr) * p.n_mels;
+                const float* Ps = reinterpret_cast<const float*>(wbase + sl * G::SLOT_BYTES);
+                int3 mt = mel_meta[min(lane >> 2, p.n_mels - 1)];                             // (start4, steps of the round, wofs)
+                for (int r = 0; r < n_rounds; ++r) {
+                    const int steps = __builtin_amdgcn_readfirstlane(mt.y);
+                    const float4* w = reinterpret_cast<const float4*>(mel_w + mt.z) + q;    // (from global / L1 instead: +1 us)
+                    const float4* pp = reinterpret_cast<const float4*>(Ps + mt.x) + q;
+                    if (r + 1 < n_rounds) mt = mel_meta[min(16 * (r + 1) + (lane >> 2), p.n_mels - 1)];
+                    float acc0 = 0.0f, acc1 = 0.0f;
+#define AMPH_MEL_FMA(acc_, a_, b_)                                                         \
+    acc_ = fmaf(a_.x, b_.x, acc_); acc_ = fmaf(a_.y, b_.y, acc_); acc_ = fmaf(a_.z, b_.z, acc_); acc_ = fmaf(a_.w, b_.w, acc_);
+                    for (int i0 = 0; i0 < steps; i0 += 2) {         // two steps (four 16-byte requests) per trip: more spilled
+                        const bool two = i0 + 1 < steps;            // wave-uniform
+                        const float4 a0 = w[4 * i0], b0 = pp[4 * i0];
+                        float4 a1 = a0, b1 = b0;
+                        if (two) { a1 = w[4 * i0 + 4]; b1 = pp[4 * i0 + 4]; }
+                        AMPH_MEL_FMA(acc0, a0, b0)
+                        if (two) { AMPH_MEL_FMA(acc1, a1, b1) }
+                    }
+#undef AMPH_MEL_FMA
+                    float acc = acc0 + acc1;
+                    acc += dpp_xor1(acc);
+                    acc += dpp_xor2(acc);
+                    const int m = 16 * r + (lane >> 2);
+                    if (q == 0 && m < p.n_mels) out[m] = acc;
                 }
-                if (i < steps) {
-                    const float4 a0 = w[4 * i], b0 = pp[4 * i];
-                    acc0 = fmaf(a0.x, b0.x, acc0);
-                    acc0 = fmaf(a0.y, b0.y, acc0);
-                    acc0 = fmaf(a0.z, b0.z, acc0);
-                    acc0 = fmaf(a0.w, b0.w, acc0);
-                }
-                float acc = acc0 + acc1;
-                acc += dpp_xor1(acc);
-                acc += dpp_xor2(acc);
-                if (q == 0 && m0 + (lane >> 2) < p.n_mels) out[m] = acc;
             }
         }
         (void)fvalid;
@@ -1204,13 +1324,23 @@ __global__ __launch_bounds__(64 * NW) void k_stft_mel_w(StftParams p, int n_tile
         // ---- fused dB stage: this wave's last frame of the row (tile == row here).  Every wave owns a frame of every row
         //      (host check), so all of them arrive: power_to_db + z-score + crop / pad on the row held in LDS, by the whole
         //      workgroup, while the samples of the waves' next frames are already in flight.
-        if (fuse_db && (!more || d.row != row)) {
+        //      The LAST row of the workgroup (with a 256-row batch: its only one) is finished behind the loop, where nothing of
+        //      the frame loop is live any more: as a call from inside the loop the stage cost ~5 us per row in register saves
+        //      (scratch traffic of 12 waves x ~170 registers), inlined here it spilled the frame loop.
+        if (fuse_db && more && d.row != row) {
             __syncthreads();
-            db_row_from_lds<kThreads>(mp_row, p.n_frames, p.n_mels, p.db_target_frames, p.db_layout,
-                                      p.db_out + (long long)row * p.db_target_frames * p.n_mels,
-                                      reinterpret_cast<double*>(mp_row + ((p.n_frames * p.n_mels + 3) & ~3)));
+            db_row_call<kThreads>(mp_row, p.n_frames, p.n_mels, p.db_target_frames, p.db_layout,
+                                  p.db_out + (long long)row * p.db_target_frames * p.n_mels,
+                                  reinterpret_cast<double*>(mp_row + ((p.n_frames * p.n_mels + 3) & ~3)));
             __syncthreads();                          // the next row's frames overwrite mp_row
         }
+        last_row = row;
+    }
+    if (fuse_db && last_row >= 0) {
+        __syncthreads();
+        db_row_from_lds<kThreads>(mp_row, p.n_frames, p.n_mels, p.db_target_frames, p.db_layout,
+                                  p.db_out + (long long)last_row * p.db_target_frames * p.n_mels,
+                                  reinterpret_cast<double*>(mp_row + ((p.n_frames * p.n_mels + 3) & ~3)));
     }
 #ifdef AMPH_STAMPS
     if (tid == 0) {       // per-workgroup timeline (wave 0): where the tiles' time goes, and the in-kernel clock
@@ -1253,10 +1383,10 @@ hipError_t stft_mel_configure(int lds_bytes) {
     // contexts with different LDS images (n_fft 2048 and 1024 presets side by side): only ever raise it
     static int s_lds_max = 0;
     if (lds_bytes <= s_lds_max) return hipSuccess;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rms_scale<float>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rms_scale<float, kRmsThreads, NpPass<float>::kChunks>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)rms_scale_lds<float>());
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rms_scale<int16_t>),
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rms_scale<int16_t, kRmsThreads, NpPass<int16_t>::kChunks>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)rms_scale_lds<int16_t>());
     if (e != hipSuccess) return e;
     const void* fns[16] = {reinterpret_cast<const void*>(&k_stft_mel_w<true, 4, 4>), reinterpret_cast<const void*>(&k_stft_mel_w<false, 4, 4>),
@@ -1411,10 +1541,23 @@ void launch_dbnorm(const DbNormParams& p, int n_rows, hipStream_t s) {
     else hipLaunchKernelGGL((k_dbnorm<0, 256>), dim3(n_rows), dim3(256), 0, s, p);                          // anything longer: recompute per pass
 }
 
+int rms_scale_chunks(int n_in) { return (n_in + kNpChunk - 1) / kNpChunk; }
+
 void launch_rms_scale_pcm16(const int16_t* in, long long row_stride, const int32_t* lengths, int n_in, int n_rows,
-                            float* scale, int32_t* ok, int scale_f64, int16_t* norm_out, const NormPad& pad, hipStream_t s) {
-    hipLaunchKernelGGL(k_rms_scale<int16_t>, dim3(n_rows), dim3(kRmsThreads), rms_scale_lds<int16_t>(), s, in, row_stride, lengths, n_in, scale, ok, norm_out,
-                       pad, scale_f64);
+                            float* scale, int32_t* ok, int scale_f64, int16_t* norm_out, const NormPad& pad, float* chunk_sums, hipStream_t s) {
+    const int n_chunks = rms_scale_chunks(n_in);
+    if (chunk_sums && n_chunks > NpPass<int16_t>::kChunks) {
+        // rows longer than one LDS pass: (row, chunk) workgroups sum the chunks, (row, tile) workgroups fold + normalise + pad
+        hipLaunchKernelGGL((k_rms_scale<int16_t, 256, 1>), dim3(n_rows, n_chunks), dim3(256), (rms_scale_lds<int16_t, 1>()), s, in, row_stride, lengths, n_in,
+                           scale, ok, static_cast<int16_t*>(nullptr), NormPad{}, scale_f64, chunk_sums, n_chunks);
+        const int total_out = (pad.lead > 0 ? pad.n_fix : n_in) + 2 * pad.lead;
+        const int tiles = norm_out ? std::max(1, std::min(64, total_out / (2 * 256 * 16))) : 1;      // ~16 dwords per thread
+        hipLaunchKernelGGL(k_rms_fold_apply, dim3(n_rows, tiles), dim3(256), 0, s, in, row_stride, lengths, n_in, chunk_sums, n_chunks, scale_f64,
+                           scale, ok, norm_out, pad);
+        return;
+    }
+    hipLaunchKernelGGL((k_rms_scale<int16_t, kRmsThreads, NpPass<int16_t>::kChunks>), dim3(n_rows), dim3(kRmsThreads), rms_scale_lds<int16_t>(), s, in, row_stride,
+                       lengths, n_in, scale, ok, norm_out, pad, scale_f64, static_cast<float*>(nullptr), 0);
 }
 // Rows that are NOT RMS-normalised here (apply_rms == 0: files 00_normalize_dataset_rms.py already processed), PCM16: the
 // same fix_length'd, centre-padded copy K0 writes, so that the independent-wave STFT kernel has no edge frames in this mode
@@ -1462,8 +1605,8 @@ void launch_pad_rows_pcm16(const int16_t* in, long long row_stride, const int32_
 }
 void launch_rms_scale_f32(const float* in, long long row_stride, const int32_t* lengths, int n_in, int n_rows,
                           float* scale, int32_t* ok, int scale_f64, hipStream_t s) {
-    hipLaunchKernelGGL(k_rms_scale<float>, dim3(n_rows), dim3(kRmsThreads), rms_scale_lds<float>(), s, in, row_stride, lengths, n_in, scale, ok,
-                       static_cast<int16_t*>(nullptr), NormPad{}, scale_f64);
+    hipLaunchKernelGGL((k_rms_scale<float, kRmsThreads, NpPass<float>::kChunks>), dim3(n_rows), dim3(kRmsThreads), rms_scale_lds<float>(), s, in, row_stride, lengths,
+                       n_in, scale, ok, static_cast<int16_t*>(nullptr), NormPad{}, scale_f64, static_cast<float*>(nullptr), 0);
 }
 void launch_rms_apply_f32(const float* in, int n_rows, int n, const float* scale, const int32_t* ok, float* out,
                           hipStream_t s) {

@@ -123,7 +123,7 @@ def test_rms_normalize_pcm16_bit_exact(env, fe):
     in numpy's own summation order.  Lengths straddle numpy's 8192-element buffer chunks
     and its 128-element pairwise blocks."""
     rng = np.random.default_rng(3)
-    for n in (env.cfg.n_samples, 8192, 8193, 16385, 129, 100, 7, 48000):
+    for n in (env.cfg.n_samples, 8192, 8193, 16385, 129, 100, 7, 48000, 32769, 240000):     # > 32 768: K0's two-kernel path
         idx = list(range(20)) + [49] if n == env.cfg.n_samples else [int(v) for v in rng.integers(0, 5000, 5)]
         pcm = env.synth(idx, n, env.cfg.sr)
         for numpy2, promotion in ((0, "numpy1"), (1, "numpy2")):       # each mode against its oracle twin
@@ -186,6 +186,18 @@ def test_mel_image_against_oracle_both_pad_modes(env, pad_mode):
     assert np.abs(got - want).max() <= 1e-4
     assert np.array_equal(got_t, got.transpose(0, 2, 1))
     assert not got[:, :, :3].any() and not got[:, :, 61:].any()         # zero pad 3 left / 3 right (58 -> 64)
+    # the dB / z-score stage runs inside the STFT kernel (one workgroup per row); the separate kernel must give the same image,
+    # and so must a launch whose workgroups own several rows each (3 persistent workgroups for 9 rows: the in-loop form)
+    try:
+        sess.configure("stft_fuse_db", 0)
+        assert np.array_equal(sess.mel(y, layout=0).cpu().numpy(), got)
+        sess.configure("stft_fuse_db", 1)
+        sess.configure("stft_grid", 3)
+        assert np.array_equal(sess.mel(y, layout=0).cpu().numpy(), got)
+        assert np.array_equal(sess.mel(y, layout=1).cpu().numpy(), got_t)
+    finally:
+        sess.configure("stft_grid", 0)
+        sess.configure("stft_fuse_db", 1)
     sess.close()
     # the PCM16 paths in the same pad mode: rows padded by K0 (apply_rms) / by the copy kernel, against the STFT kernel
     # padding on the fly (stft_prepad 0), ragged lengths included - same bits; and against the CPU restatement
