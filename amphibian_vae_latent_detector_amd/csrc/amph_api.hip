@@ -95,6 +95,10 @@ struct amph_ctx {
     size_t rs_cap = 0;
     std::vector<double> rs_host;
     float* d_zeros = nullptr;              // 256 bytes of zeros: the source of padded taps (k_conv_gemm_p3)
+    // radial fit scratch (amph_fit_radial)
+    long long* d_fit_off = nullptr;        // [kMaxSpecies + 1] offsets, then [kMaxSpecies][16] ranks
+    float *d_fit_mu = nullptr, *d_fit_stats = nullptr, *d_fit_rho = nullptr;
+    size_t fit_rho_cap = 0;
     int head_splits = 1;
     int flat = 0, latent = 0;
 
@@ -943,6 +947,7 @@ void amph_destroy(amph_ctx* c) {
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     fr(c->d_centroids); fr(c->d_thr); fr(c->d_rank);
     fr(c->d_rs_win); fr(c->d_rs_delta);
+    fr(c->d_fit_off); fr(c->d_fit_mu); fr(c->d_fit_stats); fr(c->d_fit_rho);
     fr(c->d_map_means); fr(c->d_map_prec); fr(c->d_map_logdet); fr(c->d_map_lprior);
     for (int i = 0; i < 2; ++i) {
         if (c->pin_in[i]) (void)hipHostFree(c->pin_in[i]);
@@ -1312,6 +1317,103 @@ int amph_decide_map(amph_ctx* c, const float* d_z, int64_t n_rows, int dim, cons
     p.pred = d_pred; p.best_score = d_best_score; p.scores = d_scores;
     if (n_rows > 0) launch_score_map(p, n_rows, s);
     return check_launch(c, "decide_map");
+}
+
+// np.quantile's interpolation between the order statistics a = x_(lo), b = x_(lo + 1) (method "linear"), in the scalar
+// arithmetic of numpy 1.26 (float64 virtual index / weight / sum, the difference b - a in float32) or numpy 2.x (all float32)
+static void quantile_ranks(long long n, double q, int numpy2, long long* lo, long long* hi) {
+#pragma clang fp contract(off)
+    double vi;
+    if (numpy2) vi = (double)((float)(n - 1) * (float)q);
+    else vi = (double)(n - 1) * q;
+    if (vi >= (double)(n - 1)) { *lo = *hi = n - 1; return; }
+    if (vi < 0) { *lo = *hi = 0; return; }
+    *lo = (long long)std::floor(vi);
+    *hi = *lo + 1;
+}
+static double quantile_lerp(float a, float b, long long n, double q, int numpy2) {
+#pragma clang fp contract(off)
+    const float diff = b - a;
+    if (numpy2) {
+        const float vi = (float)(n - 1) * (float)q;
+        const float t = vi - std::floor(vi);
+        if (t >= 0.5f) { const float u = 1.0f - t; const float m = diff * u; return (double)(b - m); }
+        const float m = diff * t;
+        return (double)(a + m);
+    }
+    const double vi = (double)(n - 1) * q;
+    const double t = vi - std::floor(vi);
+    if (t >= 0.5) return (double)b - (double)diff * (1.0 - t);
+    return (double)a + (double)diff * t;
+}
+
+int amph_fit_radial(amph_ctx* c, const float* d_z, const int64_t* h_offsets, int n_species, int dim, double q_in, double q_out,
+                    int numpy2, float* h_centroids, double* h_rk_in, double* h_rk_out, double* h_rk, double* h_summaries, void* stream) {
+    if (!c) return AMPH_ERR_INVALID_ARG;
+    if (n_species < 1 || n_species > kMaxSpecies || dim < 1 || dim > kMaxRadialDim || !d_z || !h_offsets || !h_centroids || !h_rk_in ||
+        !h_rk_out || !h_rk || !(q_in >= 0.0 && q_in <= 1.0) || !(q_out >= 0.0 && q_out <= 1.0))
+        return fail(c, AMPH_ERR_INVALID_ARG, "bad radial-fit arguments (dim <= %d, species <= %d, quantiles in [0, 1])", kMaxRadialDim, kMaxSpecies);
+    for (int k = 0; k < n_species; ++k)
+        if (h_offsets[k + 1] <= h_offsets[k] || h_offsets[0] != 0)
+            return fail(c, AMPH_ERR_INVALID_ARG, "radial fit: species %d has no rows (offsets must start at 0 and increase)", k);
+    const long long n = h_offsets[n_species];
+    if (n >= (1ll << 24)) return fail(c, AMPH_ERR_UNSUPPORTED, "radial fit: more than 2^24 rows");     // (float)(n - 1) must be exact
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    if (!c->d_fit_off) {
+        HIP_TRY(c, hipMalloc((void**)&c->d_fit_off, (size_t)(kMaxSpecies + 1 + 16 * kMaxSpecies) * sizeof(long long)));
+        HIP_TRY(c, hipMalloc((void**)&c->d_fit_mu, (size_t)kMaxSpecies * kMaxRadialDim * sizeof(float)));
+        HIP_TRY(c, hipMalloc((void**)&c->d_fit_stats, (size_t)kMaxSpecies * 16 * sizeof(float)));
+    }
+    const size_t need = (size_t)n_species * (size_t)n;
+    if (c->fit_rho_cap < need) {
+        HIP_TRY(c, hipStreamSynchronize(s));
+        if (c->d_fit_rho) (void)hipFree(c->d_fit_rho);
+        c->d_fit_rho = nullptr; c->fit_rho_cap = 0;
+        HIP_TRY(c, hipMalloc((void**)&c->d_fit_rho, need * sizeof(float)));
+        c->fit_rho_cap = need;
+    }
+    std::vector<long long> meta((size_t)kMaxSpecies + 1 + 16 * kMaxSpecies, -1);
+    for (int k = 0; k <= n_species; ++k) meta[k] = h_offsets[k];
+    auto class_ranks = [&](long long* r, long long cnt, double q) {      // q lo, hi | min | p50 lo, hi | p90 lo, hi | max
+        quantile_ranks(cnt, q, numpy2, &r[0], &r[1]);
+        r[2] = 0;
+        quantile_ranks(cnt, 0.50, numpy2, &r[3], &r[4]);
+        quantile_ranks(cnt, 0.90, numpy2, &r[5], &r[6]);
+        r[7] = cnt - 1;
+    };
+    for (int k = 0; k < n_species; ++k) {
+        long long* r = meta.data() + kMaxSpecies + 1 + 16 * k;
+        const long long n_in = h_offsets[k + 1] - h_offsets[k], n_out = n - n_in;
+        class_ranks(r, n_in, q_in);
+        if (n_out > 0) class_ranks(r + 8, n_out, q_out);
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->d_fit_off, meta.data(), meta.size() * sizeof(long long), hipMemcpyHostToDevice, s));
+    FitParams p;
+    p.z = d_z; p.offsets = c->d_fit_off; p.K = n_species; p.D = dim; p.n = n; p.mu = c->d_fit_mu; p.rho = c->d_fit_rho;
+    p.ranks = c->d_fit_off + kMaxSpecies + 1; p.stats = c->d_fit_stats;
+    launch_fit_radial(p, s);
+    std::vector<float> st((size_t)n_species * 16);
+    HIP_TRY(c, hipMemcpyAsync(h_centroids, c->d_fit_mu, (size_t)n_species * dim * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(st.data(), c->d_fit_stats, st.size() * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));               // host outputs (and `meta`, a pageable source) are complete
+    for (int k = 0; k < n_species; ++k) {
+        const long long n_in = h_offsets[k + 1] - h_offsets[k], n_out = n - n_in;
+        const float* t = st.data() + 16 * k;
+        h_rk_in[k] = quantile_lerp(t[0], t[1], n_in, q_in, numpy2);
+        h_rk_out[k] = n_out > 0 ? quantile_lerp(t[8], t[9], n_out, q_out, numpy2) : INFINITY;
+        h_rk[k] = std::min(h_rk_in[k], h_rk_out[k]);
+        if (h_summaries) {                              // summarize_dist of rho_in / rho_out: min, p50, p90, max (NaN x 4: empty)
+            double* o = h_summaries + 8 * k;
+            o[0] = t[2]; o[1] = quantile_lerp(t[3], t[4], n_in, 0.50, numpy2); o[2] = quantile_lerp(t[5], t[6], n_in, 0.90, numpy2); o[3] = t[7];
+            for (int u = 0; u < 4; ++u) o[4 + u] = NAN;
+            if (n_out > 0) {
+                o[4] = t[10]; o[5] = quantile_lerp(t[11], t[12], n_out, 0.50, numpy2); o[6] = quantile_lerp(t[13], t[14], n_out, 0.90, numpy2);
+                o[7] = t[15];
+            }
+        }
+    }
+    return check_launch(c, "fit_radial");
 }
 
 int amph_resample_length(int n_in, int orig_sr, int target_sr) {

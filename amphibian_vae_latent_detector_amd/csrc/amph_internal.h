@@ -176,6 +176,30 @@ void launch_conv_first_bf16(const ConvFirstParams& p, int n_rows, hipStream_t s)
 void launch_conv_gemm_bf16(const ConvGemmParams& p, int bm, hipStream_t s);
 
 #ifdef __HIPCC__
+// sum((z - mu)^2) over n <= 128 elements in numpy's float32 pairwise order (n < 8 sequential; else eight strided accumulators
+// combined ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) plus a sequential tail): np.sum(a * a) of 09_evaluate_wav_detection.py:354-355 and
+// each row of l2_norm_rows, 08_fit_radial_detector.py:105-106
+__device__ __forceinline__ float np_pairwise_sumsq(const float* z, const float* mu, int n) {
+#pragma clang fp contract(off)   // numpy rounds a = z - mu, a * a and every add separately; no FMA
+    if (n < 8) {
+        float r = 0.0f;
+        for (int i = 0; i < n; ++i) { const float a = z[i] - mu[i]; r = r + a * a; }
+        return r;
+    }
+    float r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float a = z[j] - mu[j]; r[j] = a * a; }
+    int i = 8;
+    for (; i < n - (n % 8); i += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float a = z[i + j] - mu[i + j]; r[j] = r[j] + a * a; }
+    }
+    float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) { const float a = z[i] - mu[i]; res = res + a * a; }
+    return res;
+}
+
+
 // x = h + m + l exactly, h = bf16(x), m = bf16(x - h), l = bf16(x - h - m) (RNE; every subtraction is exact): packed pairs
 typedef __bf16 amph_bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void s3_split2(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
@@ -224,5 +248,20 @@ struct MapParams {
     double* scores;          // nullable [B][K]
 };
 void launch_score_map(const MapParams& p, long long n_rows, hipStream_t s);
+
+// ----------------------------------------------------------------------------
+// Radial fit on the device (k_fit.hip): 08_fit_radial_detector.py:310-333 on latents resident in HBM
+// ----------------------------------------------------------------------------
+struct FitParams {
+    const float* z;            // [n][D] rows grouped by species (species k = rows offsets[k] .. offsets[k + 1] - 1)
+    const long long* offsets;  // device [K + 1]
+    int K, D;
+    long long n;
+    float* mu;                 // device [K][D]
+    float* rho;                // device [K][n]: distance of EVERY row to centroid k
+    const long long* ranks;    // device [K][16]: order statistics wanted, 8 per class (in, out): q lo, q hi, min, p50 lo, hi, p90 lo, hi, max; -1 = none
+    float* stats;              // device [K][16]
+};
+void launch_fit_radial(const FitParams& p, hipStream_t s);
 
 }  // namespace amph

@@ -1253,26 +1253,6 @@ void launch_head_reduce(const HeadReduceParams& p, int n_rows, hipStream_t s) {
 // numpy's float32 pairwise summation order (n < 8 sequential; 8 <= n <= 128 eight
 // strided accumulators), accept if (double)d_k <= thr_k; tie -> smallest rank.
 // ----------------------------------------------------------------------------
-__device__ __forceinline__ float np_pairwise_sumsq(const float* z, const float* mu, int n) {
-#pragma clang fp contract(off)   // numpy rounds a = z - mu, a * a and every add separately; no FMA
-    if (n < 8) {
-        float r = 0.0f;
-        for (int i = 0; i < n; ++i) { const float a = z[i] - mu[i]; r = r + a * a; }
-        return r;
-    }
-    float r[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { const float a = z[j] - mu[j]; r[j] = a * a; }
-    int i = 8;
-    for (; i < n - (n % 8); i += 8) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { const float a = z[i + j] - mu[i + j]; r[j] = r[j] + a * a; }
-    }
-    float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-    for (; i < n; ++i) { const float a = z[i] - mu[i]; res = res + a * a; }
-    return res;
-}
-
 __global__ __launch_bounds__(256) void k_decide_radial(RadialParams p, long long n_rows) {
     const long long b = (long long)blockIdx.x * 256 + threadIdx.x;
     if (b >= n_rows) return;

@@ -262,6 +262,25 @@ class AmphSession:
             torch.cuda.current_stream(self.device).synchronize()   # host arrays above must outlive the async copies
         return pred, best
 
+    def fit_radial(self, z: torch.Tensor, offsets, q_in: float, q_out: float, numpy2: bool = False):
+        """fit_species_with_fp_control (08_fit_radial_detector.py:310-333) for every species at once on resident latents
+        (K9, amph_fit_radial).  z: [n, D] device tensor, rows of species k at offsets[k]:offsets[k + 1].
+        -> (centroids float32 [K, D], rk_in, rk_out, rk float64 [K], summaries float64 [K, 2, 4])."""
+        z = self._dev(z, torch.float32)
+        off = np.ascontiguousarray(offsets, dtype=np.int64)
+        K, D = off.shape[0] - 1, z.shape[1]
+        if int(off[-1]) != z.shape[0]:
+            raise RuntimeError(f"offsets end at {int(off[-1])}, z has {z.shape[0]} rows")
+        cent = np.empty((K, D), dtype=np.float32)
+        rk_in, rk_out, rk = (np.empty(K, dtype=np.float64) for _ in range(3))
+        summ = np.empty((K, 2, 4), dtype=np.float64)
+        with torch.cuda.device(self.device):
+            self._chk(N.lib.amph_fit_radial(self._ctx, _ptr(z), off.ctypes.data_as(C.c_void_p), K, D, float(q_in), float(q_out),
+                                            1 if numpy2 else 0, cent.ctypes.data_as(C.c_void_p), rk_in.ctypes.data_as(C.c_void_p),
+                                            rk_out.ctypes.data_as(C.c_void_p), rk.ctypes.data_as(C.c_void_p),
+                                            summ.ctypes.data_as(C.c_void_p), self._stream()))
+        return cent, rk_in, rk_out, rk, summ
+
     def resample(self, y, orig_sr: int, target_sr: int) -> torch.Tensor:
         """librosa.load's rate conversion (resampy kaiser_best + fix_length) for rows of float32 samples, on the GPU
         (K8, amph_resample_f32).  y: [n] or [B, n] -> device tensor [B, ceil(n * target_sr / orig_sr)]."""

@@ -94,7 +94,10 @@ def fit_radial_from_folder(encoder, chunks_dir: Path, config_path: Path, fe: Fro
     if not Z_by:
         raise RuntimeError("No se codificó ninguna especie. Revisa root y/o pipeline.")
     rank = _folder._dist_info(group)[0]
-    rd = _radial.fit_radial_detector(Z_by, q_in, q_out, failed=failed, verbose=verbose and rank == 0)
+    # the fit's array work (centroids, distances, order statistics) on the GPU when the encoder is the HIP one (K9); the
+    # result equals the host fit bit for bit, so the other ranks of a sharded run may take either
+    session = encoder.session(fe2) if hasattr(encoder, "session") else None
+    rd = _radial.fit_radial_detector(Z_by, q_in, q_out, failed=failed, verbose=verbose and rank == 0, session=session)
     if rank == 0:
         write_radial_config(config_path, rd, chunks_dir=Path(chunks_dir).resolve(), q_in=q_in, q_out=q_out,
                             chunk_seconds=chunk_seconds, fe=fe2, max_per_class=max_per_class, seed=seed)

@@ -122,9 +122,10 @@ def detect_leg(enc, sess, cfg, pcm, mu, args, dev):
                     "includes the per-call upload of centroids / thresholds and a stream sync; decisions stay on the device"}
 
 
-def config3_fit(mu, plan, args):
-    """08's fit on the gathered latent matrix (host numpy, 08_fit_radial_detector.py:310-333,525-587): q_in 0.95,
-    q_out 0.10, max_per_class 0 (all chunks) and 400 (seed 123: rows of the same matrix)."""
+def config3_fit(mu, plan, args, sess=None):
+    """08's fit on the gathered latent matrix (08_fit_radial_detector.py:310-333,525-587): q_in 0.95, q_out 0.10,
+    max_per_class 0 (all chunks) and 400 (seed 123: rows of the same matrix); on the host (numpy) and on the device
+    (K9, amph_fit_radial, latents stay in HBM) - the two must agree to the last bit."""
     from amphibian_vae_latent_detector_amd import radial as prad
     from amphibian_vae_latent_detector_amd.synth import SPECIES, synth_folder_plan
     Z = mu.cpu().numpy()
@@ -144,8 +145,16 @@ def config3_fit(mu, plan, args):
         else:
             Zs = Zby
         rd = prad.fit_radial_detector(Zs, 0.95, 0.10, verbose=False)
-        out[f"max_per_class_{mpc}"] = {"thresholds": {k: round(v, 6) for k, v in rd["thresholds"].items()},
-                                       "fit_seconds_host": round(time.perf_counter() - t0, 3)}
+        e = {"thresholds": {k: round(v, 6) for k, v in rd["thresholds"].items()}, "fit_seconds_host": round(time.perf_counter() - t0, 4)}
+        if sess is not None:
+            dev_parts = {sp: (mu[torch.as_tensor([pos[c] for c in p400[sp]], device=mu.device)] if mpc else
+                              mu[pos[plan[sp][0]]:pos[plan[sp][0]] + len(plan[sp])]) for sp in SPECIES}
+            prad.fit_radial_detector(dev_parts, 0.95, 0.10, verbose=False, session=sess)          # warm
+            t0 = time.perf_counter()
+            rd2 = prad.fit_radial_detector(dev_parts, 0.95, 0.10, verbose=False, session=sess)
+            e["fit_seconds_device"] = round(time.perf_counter() - t0, 4)
+            e["device_equals_host"] = rd2["thresholds"] == rd["thresholds"] and rd2["centroids"] == rd["centroids"]
+        out[f"max_per_class_{mpc}"] = e
     return out
 
 
@@ -387,7 +396,7 @@ def main():
         if world == 1 and not args.no_detect and not args.config3:
             line["detect"] = detect_leg(enc, sess, cfg, pcm, mu, args, dev)
         if args.config3:
-            line["config3_fit"] = config3_fit(mu, plan, args)
+            line["config3_fit"] = config3_fit(mu, plan, args, sess)
         if world == 1 and args.pcie:
             # host-resident PCM16 -> pinned staging -> H2D on a copy stream overlapped with compute -> latents back
             sess.encode_host(pcm_host[:args.batch * 4], apply_rms=True)

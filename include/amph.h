@@ -202,6 +202,22 @@ int amph_decide_radial(amph_ctx* ctx, const float* d_z, int64_t n_rows, int dim,
                        int32_t* d_pred, float* d_best_d, void* stream);
 
 /* -------------------------------------------------------------------------
+ * Radial fit - fit_species_with_fp_control, 08_fit_radial_detector.py:310-333, for every species at once on latents that
+ * are resident in HBM: d_z is [n][dim] float32 with the rows of species k at h_offsets[k] .. h_offsets[k + 1] - 1
+ * (h_offsets[0] == 0, every species non-empty; n < 2^24).  For species k:
+ *   centroid  = np.mean(Z_k, axis=0)                      (numpy's float32 order: row after row, then / N)
+ *   rk_in     = np.quantile(||Z_k - centroid||, q_in)     rk_out = np.quantile(||Z_others - centroid||, q_out)  (+inf when
+ *   there are no other rows);   rk = min(rk_in, rk_out)
+ * numpy2 = 0: np.quantile's scalar arithmetic of numpy 1.26.4, the reference's pin (float64 interpolation); 1: numpy 2.x
+ * (float32).  Host outputs h_centroids [K][dim], h_rk_in / h_rk_out / h_rk [K] and (nullable) h_summaries [K][2][4] =
+ * summarize_dist (08:115-123: min, p50, p90, max) of the in-class and of the out-class distances (NaN when there are
+ * none); synchronises `stream`.
+ * ------------------------------------------------------------------------- */
+int amph_fit_radial(amph_ctx* ctx, const float* d_z, const int64_t* h_offsets, int n_species, int dim,
+                    double q_in, double q_out, int numpy2,
+                    float* h_centroids, double* h_rk_in, double* h_rk_out, double* h_rk, double* h_summaries, void* stream);
+
+/* -------------------------------------------------------------------------
  * Gaussian-MAP decision - MapDetectorSession.predict_one,
  * 10b_benchmark_folder_detection_map.py:143-169, with gaussian_logpdf_from_precision
  * (map_detector_core.py:319-323).  K species in the caller's order (the reference

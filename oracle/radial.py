@@ -52,22 +52,56 @@ def l2_norm_rows(x):
     return np.sqrt(np.sum(x * x, axis=1))
 
 
-def quantile_safe(x, q):
+QUANTILE_PROMOTION = "numpy1"    # the reference's pinned numpy 1.26.4 (requirements-thesis-baseline-macos-arm64.txt:46)
+
+
+def quantile_linear(x, q, promotion=None):
+    """float(np.quantile(x, q)) for a 1-D float32 array, method "linear", restated with the scalar arithmetic spelled out:
+      "numpy1"  numpy 1.26: q, the virtual index (n - 1) q and the weight t stay float64; a + (b - a) t with the difference
+                taken in float32 and the rest in float64 (t >= 0.5: b - (b - a)(1 - t));
+      "numpy2"  numpy 2.x: a Python-float q is cast to float32 first, everything in float32.
+    Pinned both ways by tests/golden/radial_fit.npz (rk1_* / rk_*), "numpy2" also against the installed numpy."""
+    promotion = promotion or QUANTILE_PROMOTION
+    x = np.asarray(x)
+    n = x.shape[0]
+    f = np.float64 if (promotion == "numpy1" or x.dtype != np.float32) else np.float32
+    if promotion not in ("numpy1", "numpy2"):
+        raise ValueError(promotion)
+    vi = f(n - 1) * f(q)
+    if vi >= n - 1:
+        lo = hi = n - 1
+    elif vi < 0:
+        lo = hi = 0
+    else:
+        lo = int(np.floor(vi))
+        hi = lo + 1
+    s = np.sort(x)
+    a, b = s[lo], s[hi]
+    t = f(vi - f(np.floor(vi)))
+    diff = b - a                                       # array dtype (float32)
+    if t >= 0.5:
+        r = f(b) - f(diff) * (f(1) - t)
+    else:
+        r = f(a) + f(diff) * t
+    return float(r)
+
+
+def quantile_safe(x, q, promotion=None):
     if x.size == 0:
         return 0.0
-    return float(np.quantile(x, q))
+    return quantile_linear(x, q, promotion)
 
 
-def fit_species_with_fp_control(Z_in, Z_out, q_in, q_out):
+def fit_species_with_fp_control(Z_in, Z_out, q_in, q_out, promotion=None):
     """08_fit_radial_detector.py:310-333 -> (mu, rk, rk_in, rk_out)."""
     mu = np.mean(Z_in, axis=0).astype(np.float32)
     rho_in = l2_norm_rows(Z_in - mu[None, :])
-    rk_in = quantile_safe(rho_in, q_in)
+    rk_in = quantile_safe(rho_in, q_in, promotion)
     if Z_out is None or Z_out.size == 0:
         rk_out = float("inf")
     else:
         rho_out = l2_norm_rows(Z_out - mu[None, :])
-        rk_out = quantile_safe(rho_out, q_out)
+        rk_out = quantile_safe(rho_out, q_out, promotion)
     rk = float(min(rk_in, rk_out))
     return mu, rk, rk_in, rk_out
 

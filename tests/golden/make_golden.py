@@ -183,6 +183,32 @@ def main():
             out[f"rk_{i}_{q_out:.2f}"] = np.array([rk, rk_in, rk_out], dtype=np.float64)
     mu, rk, rk_in, rk_out, extra = m08.fit_species_with_fp_control(Z[species[0]], None, 0.95, 0.1)
     out["rk_noout"] = np.array([rk, rk_in, rk_out], dtype=np.float64)
+    # np.quantile(x_float32, q) under the reference's pinned numpy 1.26.4 keeps q, the virtual index and the interpolation weight
+    # in float64 and evaluates a + (b - a) * t in float64 (0-d float32 array x 0-d float64 array -> float64); numpy 2.x casts a
+    # Python-float q to the array's dtype first and does all of it in float32 (numpy/lib/_function_base_impl.py, quantile():
+    # "Use dtype of array if possible").  rk1_* = the reference function with np.quantile routed PAST that one cast, into
+    # numpy's own unchanged implementation (q as a float64 array): operation for operation the 1.26 arithmetic.
+    from numpy.lib import _function_base_impl as _fb
+
+    class _LegacyQuantileNumpy:
+        def __getattr__(self, name):
+            return getattr(np, name)
+
+        @staticmethod
+        def quantile(a, q):
+            return _fb._quantile_unchecked(np.asanyarray(a), np.asanyarray(q, dtype=np.float64))
+
+    m08.np = _LegacyQuantileNumpy()
+    try:
+        for q_out in (0.10, 0.15, 0.20, 0.25):
+            for i, sp in enumerate(species):
+                Z_out = np.concatenate([Z[o] for o in species if o != sp], axis=0)
+                mu, rk, rk_in, rk_out, extra = m08.fit_species_with_fp_control(Z[sp], Z_out, 0.95, q_out)
+                assert isinstance(rk_in, float)
+                out[f"rk1_{i}_{q_out:.2f}"] = np.array([rk, rk_in, rk_out], dtype=np.float64)
+    finally:
+        m08.np = np
+    out["promotion"] = np.array("rk_* = numpy 2.x as run; rk1_* = numpy 1.26 quantile arithmetic (see make_golden.py)")
     out["species_json"] = np.array(json.dumps(species))
     np.savez_compressed(HERE / "radial_fit.npz", **out)
 

@@ -721,6 +721,44 @@ def test_radial_decisions_bit_identical_to_reference(env, fe, golden):
             assert (det.names[pred[r]] if pred[r] >= 0 else None) == sp and float(best[r]) == bd
 
 
+# ----------------------------------------------------------------------------- K9: radial fit on the device
+def test_radial_fit_on_device_bit_equal_to_host_and_reference(env, fe, golden):
+    """amph_fit_radial: centroids (numpy's axis-0 order), distances (numpy's pairwise row sums) and the
+    order statistics behind every np.quantile on the GPU.  Thresholds and centroids must equal the reference's own outputs
+    (radial_fit.npz: rk1_* = numpy 1.26 arithmetic, rk_* = numpy 2.x) and the host fit on other shapes TO THE LAST BIT,
+    summaries (min / p50 / p90 / max) included; single species -> rk_out = inf; ties; a one-row species."""
+    from amphibian_vae_latent_detector_amd import radial as prad
+    g = golden("radial_fit.npz")
+    species = json.loads(str(g["species_json"]))
+    Zs = {sp: g[f"Z_{i}"] for i, sp in enumerate(species)}
+    for q_out in (0.10, 0.15, 0.20, 0.25):
+        for numpy2, pre in ((False, "rk1_"), (True, "rk_")):
+            rd = prad.fit_radial_detector(Zs, 0.95, q_out, verbose=False, session=fe, numpy2=numpy2)
+            rh = prad.fit_radial_detector(Zs, 0.95, q_out, verbose=False, numpy2=numpy2)
+            for i, sp in enumerate(species):
+                rk, rk_in, rk_out = g[f"{pre}{i}_{q_out:.2f}"].tolist()
+                assert rd["centroids"][sp] == g[f"mu_{i}_{q_out:.2f}"].tolist()
+                m = rd["per_species"][sp]
+                assert (rd["thresholds"][sp], m["rk_in"], m["rk_out"]) == (rk, rk_in, rk_out), (q_out, numpy2, sp)
+                assert m == rh["per_species"][sp], (q_out, numpy2, sp)          # N_in / N_out / summaries too
+    rng = np.random.default_rng(11)
+    for D, sizes in ((32, (2500, 1, 333, 4096)), (5, (17, 9)), (100, (300,)), (8, (2, 2, 2))):
+        Z = {f"s{k}": (rng.standard_normal((n, D)) * (1 + k) + k).astype(np.float32) for k, n in enumerate(sizes)}
+        Z["s0"][1] = Z["s0"][0]                                                   # duplicate rows: tied distances
+        dev = {k: torch.from_numpy(v).to(DEV) for k, v in Z.items()}               # latents already on the device
+        for q_in, q_out in ((0.95, 0.01), (0.5, 0.5), (1.0, 0.0)):
+            rd = prad.fit_radial_detector(dev, q_in, q_out, verbose=False, session=fe)
+            rh = prad.fit_radial_detector(Z, q_in, q_out, verbose=False)
+            assert rd["centroids"] == rh["centroids"] and rd["thresholds"] == rh["thresholds"], (D, sizes, q_in, q_out)
+            for sp in Z:
+                a, b = rd["per_species"][sp], rh["per_species"][sp]
+                assert a["rk_in"] == b["rk_in"] and a["rk_out"] == b["rk_out"] and a["N_out"] == b["N_out"]
+                for key in ("rho_in_summary", "rho_out_summary"):
+                    assert all((a[key][s] == b[key][s]) or (np.isnan(a[key][s]) and np.isnan(b[key][s])) for s in a[key]), (sp, key, a[key], b[key])
+    with pytest.raises(RuntimeError):
+        fe.fit_radial(torch.zeros((4, 8)), [0, 4, 4], 0.9, 0.1)                  # an empty species
+
+
 # ----------------------------------------------------------------------------- K7: Gaussian-MAP decision
 def test_map_scores_and_decisions_against_reference(env, fe, golden):
     """Scores within 1e-5 relative of the reference's (its quadratic form is float32 BLAS with an unspecified

@@ -91,17 +91,34 @@ def test_adapter_matches_reference(golden):
 
 
 def test_radial_fit_matches_reference(golden):
+    """Both scalar-promotion environments of np.quantile inside the reference's fit_species_with_fp_control
+    (tests/golden/make_golden.py): rk1_* = numpy 1.26 (the reference's pin and the default here: float64 interpolation),
+    rk_* = numpy 2.x as run (float32); the restatement must hit both to the last bit, and so must the product's host fit."""
+    from amphibian_vae_latent_detector_amd import radial as prad
     g = golden("radial_fit.npz")
     species = json.loads(str(g["species_json"]))
     Z = [g[f"Z_{i}"] for i in range(len(species))]
+    differ = 0
     for q_out in (0.10, 0.15, 0.20, 0.25):
         for i in range(len(species)):
             Z_out = np.concatenate([Z[j] for j in range(len(species)) if j != i], axis=0)
-            mu, rk, rk_in, rk_out = orad.fit_species_with_fp_control(Z[i], Z_out, 0.95, q_out)
-            assert np.array_equal(mu, g[f"mu_{i}_{q_out:.2f}"])
-            assert [rk, rk_in, rk_out] == g[f"rk_{i}_{q_out:.2f}"].tolist()
-    mu, rk, rk_in, rk_out = orad.fit_species_with_fp_control(Z[0], None, 0.95, 0.1)
+            for promotion, pre in (("numpy1", "rk1_"), ("numpy2", "rk_")):
+                mu, rk, rk_in, rk_out = orad.fit_species_with_fp_control(Z[i], Z_out, 0.95, q_out, promotion=promotion)
+                assert np.array_equal(mu, g[f"mu_{i}_{q_out:.2f}"])
+                assert [rk, rk_in, rk_out] == g[f"{pre}{i}_{q_out:.2f}"].tolist(), (promotion, i, q_out)
+                pm, prk, prk_in, prk_out, _ = prad.fit_species_with_fp_control(Z[i], Z_out, 0.95, q_out, numpy2=promotion == "numpy2")
+                assert np.array_equal(pm, mu) and [prk, prk_in, prk_out] == [rk, rk_in, rk_out]
+            differ += g[f"rk_{i}_{q_out:.2f}"].tolist() != g[f"rk1_{i}_{q_out:.2f}"].tolist()
+    assert differ > 0                                                    # the environments do give different thresholds
+    mu, rk, rk_in, rk_out = orad.fit_species_with_fp_control(Z[0], None, 0.95, 0.1, promotion="numpy2")
     assert [rk, rk_in, rk_out] == g["rk_noout"].tolist() and rk_out == float("inf")
+    assert orad.fit_species_with_fp_control(Z[0], None, 0.95, 0.1)[1:] == orad.fit_species_with_fp_control(Z[0], None, 0.95, 0.1, promotion="numpy1")[1:]
+    rng = np.random.default_rng(1)                                       # "numpy2" is what the installed numpy 2.x computes
+    if int(np.__version__.split(".")[0]) >= 2:
+        for n in (1, 2, 3, 10, 101, 25000):
+            x = rng.standard_normal(n).astype(np.float32)
+            for q in (0.0, 0.01, 0.1, 0.5, 0.95, 0.999, 1.0):
+                assert orad.quantile_linear(x, q, "numpy2") == float(np.quantile(x, q)) == prad.quantile_safe(x, q, numpy2=True), (n, q)
 
 
 def test_radial_decide_matches_reference(golden):
