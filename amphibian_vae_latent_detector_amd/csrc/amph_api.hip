@@ -602,14 +602,31 @@ void build_stages(amph_ctx* c) {
 int run_encoder(amph_ctx* c, Workspace& w, const float* d_x, int nb, float* d_mu, float* d_logvar, hipStream_t s) {
     const int n_gemm = (int)c->gemm.size();
     if (c->bf16_encoder) {
-        {
+        // layers 1 + 2: the fused split-operand kernel (fp32 layer 1 recomputed in the staging, fp32-accurate layer 2 on the bf16
+        // matrix cores) with a bf16 epilogue - the layer-1 activation, the largest tensor of the path, never exists; the
+        // unfused bf16 pair (k_conv_first_bf16 24 us + its GEMM 19 us per 256 chunks) only where that kernel does not apply
+        int gi0 = 0;
+        if (c->fuse_conv12 && c->split_fused && n_gemm >= 2 && c->gemm[0].d_w_s3) {
+            ConvGemmParams p = c->gemm[0].prm;
+            p.x = w.act[0]; p.x_guard = w.act_guard[0]; p.M = nb * p.OH * p.OW; p.zeros = c->d_zeros; p.y = w.act[1];
+            p.img = d_x; p.w1 = c->first.w; p.scale1 = c->first.scale; p.shift1 = c->first.shift;
+            p.H0 = c->first.H; p.W0 = c->first.W; p.k1 = c->first.k; p.s1 = c->first.stride; p.p1 = c->first.pad;
+            if (conv_gemm_f3s_ok(p)) {
+                StageTimer t(c, ST_CONV0 + 1, s);
+                p.w = reinterpret_cast<const float*>(c->gemm[0].d_w_s3);
+                p.y_bf16 = 1;
+                launch_conv_gemm_f3s(p, s);
+                gi0 = 1;
+            }
+        }
+        if (gi0 == 0) {
             StageTimer t(c, ST_CONV0, s);
             ConvFirstParams p = c->first;
             p.x = d_x;
             p.y = w.act[0];                            // bf16 NHWC in the (fp32-sized) activation buffer
             launch_conv_first_bf16(p, nb, s);
         }
-        for (int gi = 0; gi < n_gemm; ++gi) {
+        for (int gi = gi0; gi < n_gemm; ++gi) {
             const bool head = gi == n_gemm - 1;
             ConvGemmParams p = c->gemm[gi].prm;
             p.x = w.act[gi];

@@ -689,7 +689,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm_f3s(ConvGemmParams p) {
                         v.y = fmaxf(fmaf(acc[4 * g + 1], e_sc##g.y, e_sh##g.y), 0.0f);     \
                         v.z = fmaxf(fmaf(acc[4 * g + 2], e_sc##g.z, e_sh##g.z), 0.0f);     \
                         v.w = fmaxf(fmaf(acc[4 * g + 3], e_sc##g.w, e_sh##g.w), 0.0f);     \
-                        *reinterpret_cast<float4*>(p.y + (long long)m * p.N + n0) = v;     \
+                        if (p.y_bf16) {                                                    \
+                            const amph_bf16x2 lo_ = {(__bf16)v.x, (__bf16)v.y}, hi_ = {(__bf16)v.z, (__bf16)v.w};   /* RNE */ \
+                            *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.y) + (long long)m * p.N + n0) =       \
+                                make_uint2(__builtin_bit_cast(uint32_t, lo_), __builtin_bit_cast(uint32_t, hi_));          \
+                        } else *reinterpret_cast<float4*>(p.y + (long long)m * p.N + n0) = v; \
                     }                                                                      \
                 }
                 AMPH_FS_OUT(0) AMPH_FS_OUT(1) AMPH_FS_OUT(2) AMPH_FS_OUT(3)

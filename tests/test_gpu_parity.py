@@ -636,13 +636,19 @@ def test_bf16_encoder_path(env, preset, name, capsys):
     mel = np.stack([env.ofe.wave_to_mel(env.ofe.normalize_pcm16_chunk(q, True)[0], **cfg.mel_kwargs()) for q in pcm])
     x = torch.from_numpy(mel).transpose(1, 2).unsqueeze(1).contiguous()
     bf = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    # thesis-shape: layers 1 + 2 run in the fused split-operand kernel (fp32 layer 1, fp32-accurate layer 2, bf16 epilogue):
+    # the first bf16 rounding is layer 2's OUTPUT; `tiny` (8 channels after layer 1) takes the unfused bf16 pair
+    fused12 = name == "thesis-shape"
     with torch.no_grad():
         mu32, _ = tenc(x)
         h = x
-        for conv, bn in zip(tenc.conv, tenc.bn):
-            y = torch.nn.functional.conv2d(h, bf(conv.weight) if conv is not tenc.conv[0] else conv.weight, conv.bias,
+        for li, (conv, bn) in enumerate(zip(tenc.conv, tenc.bn)):
+            exact_w = li == 0 or (fused12 and li == 1)
+            y = torch.nn.functional.conv2d(h, conv.weight if exact_w else bf(conv.weight), conv.bias,
                                            stride=conv.stride, padding=conv.padding)
-            h = bf(torch.relu(bn(y)))
+            h = torch.relu(bn(y))
+            if not (fused12 and li == 0):
+                h = bf(h)
         flat = h.flatten(1)
         mu_emu = flat @ bf(tenc.fc_mu.weight).T + tenc.fc_mu.bias
     sess.configure("bf16_encoder", 1)
