@@ -25,7 +25,7 @@
 // staging a pure copy, no VALU) - 50 % more A bytes and 12 epilogue stores per lane instead of 4 cost more than the VALU
 // work they removed (conv2 33.2 -> 37.9, conv3 22.8 -> 24.6, conv4 25.0 -> 24.1 us); four register stages instead of three
 // (no change: the loop is not latency-bound).
-// LDS row = 3 x 64 B + 16 B pad = 208 B: ds_read_b128 of any 16 rows of a 32-row fragment covers all 64 banks.
+// LDS rows are packed (192 B) with XOR-swizzled 16-byte slots: fragment reads and staging stores are conflict-free.
 // Geometry, addressing (buffer loads, zero guard for padded taps, scalar tap state) and the transposed-accumulator
 // epilogue are k_conv_gemm_p3's.
 #include "amph_internal.h"
@@ -41,7 +41,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kSBK = 32;                 // K elements per slice (one tap's 32-channel group)
-constexpr int kSRow = 208;               // LDS bytes per row: [h | m | l] x 32 bf16 + 16 B pad
+constexpr int kSRow = 192;               // LDS bytes per row: [h | m | l] x 32 bf16, packed; the 16-byte slot j of row r sits at
+                                         // 16 (j ^ ((r >> 2) & 3)): conflict-free 16-byte fragment reads AND conflict-free stores (the padded
+                                         // 208-byte rows of the first version showed 26 % of its LDS cycles as bank conflicts)
 constexpr int kSBuf = 64 * kSRow;        // bytes per operand per slice buffer
 constexpr int kSWRow = 192;              // bytes per (n, slice) in the split weight matrix
 
@@ -73,8 +75,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm_s3(ConvGemmParams p) {
     const unsigned long long q_rt0 = __builtin_amdgcn_s_memrealtime();
     AMPH_S3_T(q_t0)
 #endif
-    char* As = smem;                                   // [3][64][208]
-    char* Bs = smem + 3 * kSBuf;                       // [3][64][208]
+    char* As = smem;                                   // [3][64][192]
+    char* Bs = smem + 3 * kSBuf;                       // [3][64][192]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c4 = tid & 7, r0 = tid >> 3;             // A staging: rows r0, r0 + 32; k = 4 c4 .. 4 c4 + 3 of the slice
@@ -183,13 +185,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm_s3(ConvGemmParams p) {
 #define AMPH_S3_LOADA_ADV(q) { AMPH_S3_LOADA(q) AMPH_S3_ADV() }
 
     // stage q -> LDS buffer buf_: B rows are the LDS image already; A rows are split here
-    const int st_a = r0 * kSRow + 8 * c4;
-    int st_b0, st_b1, st_b2;                           // byte o of the block -> LDS row o / 192, column o % 192
+    const int st_a = r0 * kSRow + 16 * ((c4 >> 1) ^ ((r0 >> 2) & 3)) + 8 * (c4 & 1);     // (row r0 + 32 has the same swizzle)
+    int st_b0, st_b1, st_b2;                           // byte o of the block -> LDS row o / 192, swizzled slot of column o % 192
     {
         const int o0 = 16 * tid, o1 = o0 + 4096, o2 = o0 + 8192;
-        st_b0 = (o0 / kSWRow) * kSRow + o0 % kSWRow;
-        st_b1 = (o1 / kSWRow) * kSRow + o1 % kSWRow;
-        st_b2 = (o2 / kSWRow) * kSRow + o2 % kSWRow;
+#define AMPH_S3_SW(o_) (((o_) / kSWRow) * kSRow + 16 * ((((o_) % kSWRow) >> 4) ^ ((((o_) / kSWRow) >> 2) & 3)))
+        st_b0 = AMPH_S3_SW(o0); st_b1 = AMPH_S3_SW(o1); st_b2 = AMPH_S3_SW(o2);
+#undef AMPH_S3_SW
     }
 #define AMPH_S3_SPLIT_ROW(v_, dst_)                                                        \
     {                                                                                      \
@@ -227,9 +229,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm_s3(ConvGemmParams p) {
 #undef AMPH_S3_BN
     }
     // fragment addresses: lane l holds row (l & 31), k = 16 kstep + 8 (l >> 5) + j of each term
-    const char* a_rd = As + (row_tile * 32 + (lane & 31)) * kSRow + 16 * (lane >> 5);
-    const char* b_rd = Bs + (col_tile * 32 + (lane & 31)) * kSRow + 16 * (lane >> 5);
-#define AMPH_S3_FRAG(base_, buf_, ks_, t_) __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>((base_) + (buf_) * kSBuf + 64 * (t_) + 32 * (ks_)))
+    // (slot 4 t + 2 kstep + (l >> 5) of the row; the swizzle touches the low two bits only, so the terms stay 64 bytes apart)
+    const int swl = ((lane & 31) >> 2) & 3;
+    const char* a_rd0 = As + (row_tile * 32 + (lane & 31)) * kSRow + 16 * ((lane >> 5) ^ swl);
+    const char* a_rd1 = As + (row_tile * 32 + (lane & 31)) * kSRow + 16 * ((2 + (lane >> 5)) ^ swl);
+    const char* b_rd0 = Bs + (col_tile * 32 + (lane & 31)) * kSRow + 16 * ((lane >> 5) ^ swl);
+    const char* b_rd1 = Bs + (col_tile * 32 + (lane & 31)) * kSRow + 16 * ((2 + (lane >> 5)) ^ swl);
+#define AMPH_S3_FRAG(base_, buf_, ks_, t_) __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>((base_##ks_) + (buf_) * kSBuf + 64 * (t_)))
     // weights as the FIRST operand: transposed accumulator (lane = output row m, registers 4g .. 4g + 3 = channels), see p3
 #define AMPH_S3_MFMA(w_, x_) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_, x_, acc, 0, 0, 0);
 #define AMPH_S3_READ6(pre_, buf_, ks_)                                                     \
@@ -755,7 +761,7 @@ void launch_conv_gemm_f3s(const ConvGemmParams& p, hipStream_t s) {
     else hipLaunchKernelGGL(k_conv_gemm_f3s<8>, grid, dim3(256), conv_gemm_f3s_lds(p), s, p);
 }
 
-constexpr size_t kS3Lds = (size_t)6 * kSBuf;           // 79 872 B: two workgroups per CU
+constexpr size_t kS3Lds = (size_t)6 * kSBuf;           // 73 728 B: two workgroups per CU
 
 bool conv_gemm_s3_ok(const ConvGemmParams& p) {
     const unsigned long long span = (unsigned long long)p.M / (p.OH * p.OW) * p.H * p.W * p.C_in * 4ull + p.x_guard;     // 32-bit lane offsets
