@@ -100,6 +100,14 @@ const char* amph_last_error(const amph_ctx* ctx);   /* ctx may be NULL: create-t
  *                            evaluated in double, the scale cast to float32 once; 1 = numpy 2.x (NEP 50):
  *                            float32 throughout.  The scales differ by 1 ulp on about a third of all chunks,
  *                            which the PCM16 re-quantisation behind it turns into whole LSBs
+ *   "split_gemm"       0/1   GEMM-shaped layers behind the fused pair (and the head) on the bf16 matrix cores with three-term
+ *                            split operands: x = h + m + l exactly, six v_mfma_f32_32x32x16_bf16 per K = 16, fp32
+ *                            accumulation - as close to the torch-CPU fp32 result as the f32-MFMA kernels (1e-6), which 0
+ *                            selects; results differ from those in the last bits (default 1)
+ *   "split_fused"      0/1   ... the fused conv1 + conv2 kernel too (default 1)
+ *   "stft_fuse_db"     0/1   power_to_db + z-score + crop / pad inside the STFT kernel (one workgroup per row, the row's mel
+ *                            power stays in LDS) when it fits; 0 = the separate kernel (default 1; same image up to the last
+ *                            bit of the float32 mean in a few rows)
  *   "stft_waves"       4/12  waves per STFT workgroup: 12 = one 768-thread workgroup per CU (three waves
  *                            per SIMD; the default when its LDS image fits 160 KB), 4 = two 256-thread ones
  *   "frames_per_block" 4..32 STFT frames per workgroup tile (multiple of 4; default 12 with 12 waves
