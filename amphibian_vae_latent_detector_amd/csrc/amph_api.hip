@@ -58,6 +58,7 @@ struct GemmLayer {
     int bm = 128;
     float* d_w = nullptr;
     uint16_t* d_w_s3 = nullptr;     // three-term bf16 split [n_pad / 64][K_pad / 32][64][3][32] for k_conv_gemm_s3 (nullptr: shape not covered)
+    uint16_t* d_w_f4 = nullptr;     // the same split in MFMA fragment order for k_conv_gemm_f4s (first GEMM layer, K_pad == 288 only)
     uint16_t* d_w_bf16 = nullptr;   // bf16 copy [n_pad][K_pad_b] for the bf16 encoder path
     int K_pad_b = 0;                // K rounded up to 64 elements
     float* d_scale = nullptr;
@@ -117,6 +118,8 @@ struct amph_ctx {
     bool stft_prepad = true;               // ... fix_length'd and centre padded (independent-wave STFT kernel only)
     bool stft_fuse_db = true;              // dB / z-score / crop-pad inside the STFT kernel when a row's mel power fits its LDS
     bool split_fused = true;               // ... the fused conv1 + conv2 kernel too (k_conv_gemm_f3s)
+    bool patch_fused = true;               // ... in its patch-resident form where the shape allows (k_conv_gemm_f4s)
+    int patch_wgs = 0;                     // workgroups of that kernel (0: one per CU)
     bool split_gemm = true;                // GEMM layers on the bf16 matrix cores with three-term split operands (fp32-accurate)
     int rms_f64_scale = 1;                 // RMS gate + scale in the scalar arithmetic of numpy 1.26 (reference pin) instead of numpy 2.x's
     // radial scratch
@@ -423,6 +426,10 @@ int build_encoder(amph_ctx* c, const float* hw, size_t n_floats) {
                 std::vector<uint16_t> w3((size_t)n_pad * K_pad * 3);
                 conv_gemm_s3_split_weights(wg.data(), n_pad, K_pad, w3.data());
                 HIP_TRY(c, upload(&gl.d_w_s3, w3));
+                if (i == 1 && K_pad == 288) {
+                    conv_gemm_f4s_fragment_weights(wg.data(), n_pad, K_pad, w3.data());
+                    HIP_TRY(c, upload(&gl.d_w_f4, w3));
+                }
             }
             gl.K_pad_b = (K + 63) / 64 * 64;
             HIP_TRY(c, upload_bf16(&gl.d_w_bf16, wg, n_pad, K_pad, gl.K_pad_b));
@@ -611,7 +618,12 @@ int run_encoder(amph_ctx* c, Workspace& w, const float* d_x, int nb, float* d_mu
             p.x = w.act[0]; p.x_guard = w.act_guard[0]; p.M = nb * p.OH * p.OW; p.zeros = c->d_zeros; p.y = w.act[1];
             p.img = d_x; p.w1 = c->first.w; p.scale1 = c->first.scale; p.shift1 = c->first.shift;
             p.H0 = c->first.H; p.W0 = c->first.W; p.k1 = c->first.k; p.s1 = c->first.stride; p.p1 = c->first.pad;
-            if (conv_gemm_f3s_ok(p)) {
+            if (c->patch_fused && c->gemm[0].d_w_f4 && conv_gemm_f4s_ok(p)) {
+                StageTimer t(c, ST_CONV0 + 1, s);
+                p.y_bf16 = 1;
+                launch_conv_gemm_f4s(p, c->gemm[0].d_w_f4, c->patch_wgs, s);
+                gi0 = 1;
+            } else if (conv_gemm_f3s_ok(p)) {
                 StageTimer t(c, ST_CONV0 + 1, s);
                 p.w = reinterpret_cast<const float*>(c->gemm[0].d_w_s3);
                 p.y_bf16 = 1;
@@ -713,6 +725,13 @@ int run_encoder(amph_ctx* c, Workspace& w, const float* d_x, int nb, float* d_mu
 #endif
         StageTimer t(c, head ? stage_head_gemm(c) : ST_CONV0 + 1 + gi, s);
         const bool fused_here = fuse && gi == 0;
+        if (c->split_gemm && c->split_fused && c->patch_fused && fused_here && c->gemm[gi].d_w_f4 && conv_gemm_f4s_ok(prm[gi])) {
+#ifdef AMPH_STAMPS
+            c->gstamp_wgs[gi] = std::min(prm[gi].M / 64, c->patch_wgs > 0 ? c->patch_wgs : amph::g_num_cus);
+#endif
+            launch_conv_gemm_f4s(prm[gi], c->gemm[gi].d_w_f4, c->patch_wgs, s);
+            continue;
+        }
         if (c->split_gemm && c->split_fused && fused_here && c->gemm[gi].d_w_s3 && conv_gemm_f3s_ok(prm[gi])) {
             ConvGemmParams ps = prm[gi];
             ps.w = reinterpret_cast<const float*>(c->gemm[gi].d_w_s3);
@@ -960,7 +979,7 @@ void amph_destroy(amph_ctx* c) {
     fr(c->d_tables); fr(c->d_tw_a);
     fr(c->d_mel_start); fr(c->d_mel_len); fr(c->d_mel_wofs); fr(c->d_mel_w);
     fr(c->d_first_w); fr(c->d_first_scale); fr(c->d_first_shift);
-    for (auto& g : c->gemm) { fr(g.d_w); fr(g.d_w_s3); fr(g.d_w_bf16); fr(g.d_scale); fr(g.d_shift); }
+    for (auto& g : c->gemm) { fr(g.d_w); fr(g.d_w_s3); fr(g.d_w_f4); fr(g.d_w_bf16); fr(g.d_scale); fr(g.d_shift); }
     fr(c->d_head_bias); fr(c->d_zeros);
     for (auto& w : c->lanes) free_lane(w);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -992,6 +1011,8 @@ int amph_configure(amph_ctx* c, const char* key, int value) {
     if (!std::strcmp(key, "stft_fuse_db")) { c->stft_fuse_db = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "split_gemm")) { c->split_gemm = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "split_fused")) { c->split_fused = value != 0; return AMPH_OK; }
+    if (!std::strcmp(key, "patch_fused")) { c->patch_fused = value != 0; return AMPH_OK; }
+    if (!std::strcmp(key, "patch_wgs")) { if (value < 0) return AMPH_ERR_INVALID_ARG; c->patch_wgs = value; return AMPH_OK; }
     if (!std::strcmp(key, "rms_numpy2")) { c->rms_f64_scale = value ? 0 : 1; return AMPH_OK; }
 #ifdef AMPH_STAMPS
     if (!std::strcmp(key, "dump_gemm_stamps")) {

@@ -171,6 +171,11 @@ void conv_gemm_s3_split_weights(const float* w, int n_pad, int K_pad, uint16_t* 
 // ... and the fused first-layer pair in the same arithmetic (p.img etc. as for k_conv_gemm_f3, p.w = split weights)
 bool conv_gemm_f3s_ok(const ConvGemmParams& p);
 void launch_conv_gemm_f3s(const ConvGemmParams& p, hipStream_t s);
+// ... and with the layer-1 activation of a tile resident in LDS, weights in registers (k_encoder_patch.hip):
+// wfrag = split weights in MFMA fragment order [n_pad / 64][2][K_pad / 16][3][64 lanes][8] bf16, wgs = workgroups (0: one per CU)
+bool conv_gemm_f4s_ok(const ConvGemmParams& p);
+void launch_conv_gemm_f4s(const ConvGemmParams& p, const void* wfrag, int wgs, hipStream_t s);
+void conv_gemm_f4s_fragment_weights(const float* w, int n_pad, int K_pad, uint16_t* out);
 // bf16 encoder path (k_encoder_bf16.hip): x / w are bf16, y bf16 (epilogue 0) or fp32 partials (epilogue 1);
 // K, K_pad and C_in count bf16 elements, K_pad % 64 == 0, C_in % 8 == 0
 void launch_conv_first_bf16(const ConvFirstParams& p, int n_rows, hipStream_t s);
@@ -209,6 +214,20 @@ __device__ __forceinline__ void s3_split2(float x0, float x1, uint32_t& h, uint3
     const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xFFFF0000u);
     const amph_bf16x2 mp = {(__bf16)r0, (__bf16)r1};
     m = __builtin_bit_cast(uint32_t, mp);
+    const float t0 = r0 - __uint_as_float(m << 16), t1 = r1 - __uint_as_float(m & 0xFFFF0000u);
+    const amph_bf16x2 lp = {(__bf16)t0, (__bf16)t1};
+    l = __builtin_bit_cast(uint32_t, lp);
+}
+// the same with the packed pairs made opaque to the optimiser: h << 16 is then a shift of h, not a second conversion of x0 alone
+// (8 instructions fewer per 8 values; costs registers where the caller is at its limit - k_conv_gemm_f3s keeps the form above)
+__device__ __forceinline__ void s3_split2_o(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
+    const amph_bf16x2 hp = {(__bf16)x0, (__bf16)x1};
+    h = __builtin_bit_cast(uint32_t, hp);
+    asm("" : "+v"(h));
+    const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xFFFF0000u);
+    const amph_bf16x2 mp = {(__bf16)r0, (__bf16)r1};
+    m = __builtin_bit_cast(uint32_t, mp);
+    asm("" : "+v"(m));
     const float t0 = r0 - __uint_as_float(m << 16), t1 = r1 - __uint_as_float(m & 0xFFFF0000u);
     const amph_bf16x2 lp = {(__bf16)t0, (__bf16)t1};
     l = __builtin_bit_cast(uint32_t, lp);

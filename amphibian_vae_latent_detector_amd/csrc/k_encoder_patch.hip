@@ -1,0 +1,409 @@
+// Fused conv1 -> conv2 with the layer-1 activation of a tile RESIDENT in LDS ("f4s"), wave-specialised.
+//
+// Replaces, like k_conv_gemm_f3 / _f3s, layers 1 and 2 of `encoder(x)` at
+// latent_space_exploration/map_detector_core.py:270 (module built at :175-179): C_in == 1 3x3 stride-2 conv + BN + ReLU, then
+// 3x3 stride-2 conv (32 -> N channels) + BN + ReLU.  Same arithmetic as k_conv_gemm_f3s - layer 1 in fp32 with
+// k_conv_first's FMA order, three-term bf16 split of both operands, six v_mfma_f32_32x32x16_bf16 per K = 16 in the same
+// order - except that the K = 288 sum is formed as (k-steps 0..8) + (k-steps 9..17) by two waves instead of in one chain.
+//
+// Why another form: f3 / f3s recompute layer 1 for every (tap, output pixel) pair a K slice needs - 576 pixel evaluations
+// per 64-pixel tile for 297 distinct pixels -, push each value through LDS staging once per tap and re-stage the weight
+// slice for every tile; in-kernel stamps show the three resources of a step (VALU recompute, LDS staging, MFMA) used one
+// after the other (profiles/r02_f3s_stamps.txt).  Here a 512-thread workgroup, one per CU, has two roles:
+//   producer waves 4..7  compute the tile's layer-1 patch ONCE - (2 n_oh + 1) rows x (2 OW + 1) columns x 32 channels -
+//                        from image rows staged in LDS, split it and leave it as [column parity][row][column / 2][term][32 ch]
+//                        bf16 (208-byte pixels: odd multiple of 16, conflict-free for the gather below);
+//   consumer waves 0..3  = (channel tile ct, K half th).  A wave keeps ITS HALF OF THE WEIGHTS IN REGISTERS for the whole
+//                        kernel (9 k-steps x 3 terms x 16 B per lane = 108 VGPRs) and reads the MFMA activation fragments
+//                        STRAIGHT from the patch: for output pixel (oh, ow) and tap (kh, kw) the layer-1 pixel is patch row
+//                        2 oh + kh, parity kw & 1, index ow + (kw >> 1): a per-lane base plus a wave-uniform constant per
+//                        k-step - no im2col staging, no weight traffic at all in the tile loop.  It multiplies all 64 pixels
+//                        of the tile (two accumulators), hands the partial sum of the row tile it does not own to its partner
+//                        wave through LDS and writes the other one out.
+// Two patch buffers: the producers build tile i + 1 while the consumers multiply tile i.  Barriers per tile: X (patch i + 1
+// complete, patch i free, partial sums published) and Y (partial sums consumed).
+#include "amph_internal.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+
+namespace amph {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kPPix = 208;               // bytes per patch pixel: [h | m | l] x 32 bf16 + 16 B pad (13 slots: odd)
+constexpr int kPImgU = 6;                // staged image elements per producer lane (host check)
+constexpr int kPItemU = 6;               // (patch pixel, 8-channel group) items per producer lane (host check)
+
+struct PatchGeo {                        // derived on the host, passed by value
+    int n_oh;                            // output rows per 64-pixel tile (64 / OW)
+    int PR, PC;                          // patch rows 2 n_oh + 1, columns 2 OW + 1
+    int RS;                              // bytes per plane row: OW + 1 pixels, rounded up to 128
+    int plane;                           // bytes per parity plane: PR * RS + 64 (pixels xi, xi + 1 of one store on different banks)
+    int img_row;                         // floats per staged image row: 2 PC + 1 rounded up to even (element c = image column c - 3)
+    int n_img;                           // staged image elements of a tile: (2 PR + 1) rows
+    int n_items;                         // (patch pixel, channel group of 8) pairs of a tile: PR * PC * 4
+    int tiles_per_image, n_tiles;
+    int rt1_off;                         // patch byte offset of output pixel m + 32 relative to pixel m
+};
+
+__device__ __forceinline__ int f4_div_small(int n, int d, float rcp) {
+    int q = (int)((float)n * rcp);
+    int r = n - q * d;
+    if (r < 0) { --q; r += d; }
+    if (r >= d) ++q;
+    return q;
+}
+
+#ifdef AMPH_STAMPS
+#define AMPH_F4_T(v_)                                                                      \
+    {                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v_)::"memory");         \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+    }
+#else
+#define AMPH_F4_T(v_)
+#endif
+
+__global__ __launch_bounds__(512, 2) void k_conv_gemm_f4s(ConvGemmParams p, PatchGeo g, const uint4* __restrict__ wfrag) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const patch0 = smem;                                                       // [2 parity][PR][RS]
+    char* const patch1 = smem + 2 * g.plane;
+    float* const img_stage = reinterpret_cast<float*>(smem + 4 * g.plane);           // [2][2 PR + 1][img_row]
+    const int img_buf = (g.n_img + 3) & ~3;
+    char* const part = smem + 4 * g.plane + 2 * img_buf * 4;                         // [4 consumer waves][4][64] float4
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);                       // the role branch below is scalar
+    const int n_blk = blockIdx.y * 64;
+    const float rcp_tpi = 1.0f / (float)g.tiles_per_image;
+#ifdef AMPH_STAMPS
+    unsigned long long q_t0 = 0, q_a = 0, q_b = 0, q_c = 0, q_d = 0, q_s0 = 0, q_s1 = 0, q_s2 = 0, q_s3 = 0;
+    const unsigned long long q_rt0 = __builtin_amdgcn_s_memrealtime();
+    AMPH_F4_T(q_t0)
+#endif
+
+    if (wave >= 4) {
+        // ================================================================ producers
+        const int ptid = tid - 256;
+        const int cg = ptid & 3;                                   // this lane's 8 layer-1 channels (256 % 4 == 0: the same for all its items)
+        float4 w1a[9], w1b[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            w1a[t] = *reinterpret_cast<const float4*>(p.w1 + t * p.C_in + 8 * cg);
+            w1b[t] = *reinterpret_cast<const float4*>(p.w1 + t * p.C_in + 8 * cg + 4);
+        }
+        const float4 sc1a = *reinterpret_cast<const float4*>(p.scale1 + 8 * cg), sc1b = *reinterpret_cast<const float4*>(p.scale1 + 8 * cg + 4);
+        const float4 sh1a = *reinterpret_cast<const float4*>(p.shift1 + 8 * cg), sh1b = *reinterpret_cast<const float4*>(p.shift1 + 8 * cg + 4);
+        const float rcp_ir = 1.0f / (float)g.img_row, rcp_pc = 1.0f / (float)g.PC;
+        // this lane's items (patch pixel, channel group), the same for every tile: staged-image offset of the 3 x 3 window,
+        // patch byte offset of the split pixel, and whether the pixel is layer-2 padding (column -1 always; row -1 on an image's first tile)
+        int it_src[kPItemU], it_dst[kPItemU];
+        unsigned it_live = 0, it_pad_always = 0, it_pad_top = 0;
+#pragma unroll
+        for (int u = 0; u < kPItemU; ++u) {
+            const int idx = ptid + 256 * u, pix = idx >> 2;
+            const int yl = f4_div_small(pix, g.PC, rcp_pc), xi = pix - yl * g.PC;
+            it_src[u] = 2 * yl * g.img_row + 2 * xi;
+            it_dst[u] = (xi & 1) * g.plane + yl * g.RS + (xi >> 1) * kPPix + 16 * cg;
+            if (idx < g.n_items) it_live |= 1u << u;
+            if (xi == 0) it_pad_always |= 1u << u;
+            if (yl == 0) it_pad_top |= 1u << u;
+        }
+        float pf[kPImgU];
+        // staged row r of a tile starting at output row oh0 = image row 4 oh0 - 3 + r (conv1 row 2 oh0 - 1 + yl reads staged
+        // rows 2 yl + {0, 1, 2}); staged column c = image column c - 3 (patch column xi = conv1 column xi - 1 reads 2 xi + {0, 1, 2})
+#define AMPH_F4_FETCH_IMG(tile_)                                                           \
+        {                                                                                  \
+            const int b_ = f4_div_small(tile_, g.tiles_per_image, rcp_tpi), tr_ = (tile_) - b_ * g.tiles_per_image; \
+            const int ir0_ = 4 * tr_ * g.n_oh - 3;                                         \
+            const float* img_ = p.img + (long long)b_ * p.H0 * p.W0;                       \
+            _Pragma("unroll") for (int u = 0; u < kPImgU; ++u) {                           \
+                const int e_ = ptid + 256 * u;                                             \
+                const int r_ = f4_div_small(e_, g.img_row, rcp_ir), ic_ = e_ - r_ * g.img_row - 3, ir_ = ir0_ + r_; \
+                pf[u] = *((e_ < g.n_img && ir_ >= 0 && ir_ < p.H0 && ic_ >= 0 && ic_ < p.W0) ? img_ + ir_ * p.W0 + ic_ : p.zeros); \
+            }                                                                              \
+        }
+#define AMPH_F4_WRITE_IMG(dst_)                                                            \
+        {                                                                                  \
+            _Pragma("unroll") for (int u = 0; u < kPImgU; ++u)                             \
+                if (ptid + 256 * u < g.n_img) (dst_)[ptid + 256 * u] = pf[u];              \
+        }
+        int tile = blockIdx.x;
+        if (tile < g.n_tiles) {
+            AMPH_F4_FETCH_IMG(tile)
+            AMPH_F4_WRITE_IMG(img_stage)
+        }
+        __syncthreads();                                             // A: the first tile's image rows are staged
+        for (int i = 0; tile < g.n_tiles; tile += gridDim.x, ++i) {
+            const int nt = tile + (int)gridDim.x;
+            AMPH_F4_T(q_a)
+            if (nt < g.n_tiles) AMPH_F4_FETCH_IMG(nt)                // lands under the arithmetic below
+            const float* sbuf = img_stage + (i & 1) * img_buf;
+            char* patch = (i & 1) ? patch1 : patch0;
+            const int tr = tile - f4_div_small(tile, g.tiles_per_image, rcp_tpi) * g.tiles_per_image;
+            const unsigned it_pad = it_pad_always | (tr == 0 ? it_pad_top : 0u);
+            // (conv1 rows 2 oh0 - 1 + yl, yl < PR, and columns xi - 1, xi < PC, never pass the bottom / right edge: host check)
+#pragma unroll
+            for (int u = 0; u < kPItemU; ++u) {
+                if (!((it_live >> u) & 1u)) continue;
+                const float cap = ((it_pad >> u) & 1u) ? 0.0f : __builtin_inff();
+                const float* s0 = sbuf + it_src[u];                  // even float index, rows of even length: 8-byte aligned
+                float pv[9];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const float2 v2 = *reinterpret_cast<const float2*>(s0 + r * g.img_row);
+                    pv[3 * r] = v2.x; pv[3 * r + 1] = v2.y; pv[3 * r + 2] = s0[r * g.img_row + 2];
+                }
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    a0 = fmaf(pv[t], w1a[t].x, a0); a1 = fmaf(pv[t], w1a[t].y, a1); a2 = fmaf(pv[t], w1a[t].z, a2); a3 = fmaf(pv[t], w1a[t].w, a3);
+                    a4 = fmaf(pv[t], w1b[t].x, a4); a5 = fmaf(pv[t], w1b[t].y, a5); a6 = fmaf(pv[t], w1b[t].z, a6); a7 = fmaf(pv[t], w1b[t].w, a7);
+                }
+                a0 = __builtin_amdgcn_fmed3f(fmaf(a0, sc1a.x, sh1a.x), 0.0f, cap); a1 = __builtin_amdgcn_fmed3f(fmaf(a1, sc1a.y, sh1a.y), 0.0f, cap);
+                a2 = __builtin_amdgcn_fmed3f(fmaf(a2, sc1a.z, sh1a.z), 0.0f, cap); a3 = __builtin_amdgcn_fmed3f(fmaf(a3, sc1a.w, sh1a.w), 0.0f, cap);
+                a4 = __builtin_amdgcn_fmed3f(fmaf(a4, sc1b.x, sh1b.x), 0.0f, cap); a5 = __builtin_amdgcn_fmed3f(fmaf(a5, sc1b.y, sh1b.y), 0.0f, cap);
+                a6 = __builtin_amdgcn_fmed3f(fmaf(a6, sc1b.z, sh1b.z), 0.0f, cap); a7 = __builtin_amdgcn_fmed3f(fmaf(a7, sc1b.w, sh1b.w), 0.0f, cap);
+                uint32_t h0, m0, l0, h1, m1, l1, h2, m2, l2, h3, m3, l3;
+                s3_split2_o(a0, a1, h0, m0, l0);
+                s3_split2_o(a2, a3, h1, m1, l1);
+                s3_split2_o(a4, a5, h2, m2, l2);
+                s3_split2_o(a6, a7, h3, m3, l3);
+                char* dst = patch + it_dst[u];
+                *reinterpret_cast<uint4*>(dst) = make_uint4(h0, h1, h2, h3);
+                *reinterpret_cast<uint4*>(dst + 64) = make_uint4(m0, m1, m2, m3);
+                *reinterpret_cast<uint4*>(dst + 128) = make_uint4(l0, l1, l2, l3);
+            }
+            if (nt < g.n_tiles) AMPH_F4_WRITE_IMG(img_stage + ((i + 1) & 1) * img_buf)     // last read before the previous X
+            AMPH_F4_T(q_b)
+            __syncthreads();                                         // X: patch i complete (the consumers are done with patch i - 1)
+            __syncthreads();                                         // Y
+#ifdef AMPH_STAMPS
+            AMPH_F4_T(q_c)
+            q_s0 += q_b - q_a; q_s1 += q_c - q_b;
+#endif
+        }
+        __syncthreads();                                             // the consumers' last X
+        __syncthreads();                                             // ... and Y
+#ifdef AMPH_STAMPS
+        if (tid == 256 && p.stamps) { unsigned long long* o = p.stamps + (size_t)blockIdx.x * 8; o[4] = q_s0; o[6] = q_s1; }   // producer: build | at the barriers
+#endif
+#undef AMPH_F4_FETCH_IMG
+#undef AMPH_F4_WRITE_IMG
+        return;
+    }
+
+    // ==================================================================== consumers
+    const int ct = wave & 1, th = wave >> 1;                         // channel tile, K half (k-steps 9 th .. 9 th + 8); owner of row tile th
+    uint4 breg[27];                                                  // [k-step][term]: this wave's weights, for the whole kernel
+    {
+        const uint4* wf = wfrag + (((size_t)blockIdx.y * 2 + ct) * 18 + 9 * th) * (3 * 64) + lane;
+#pragma unroll
+        for (int f = 0; f < 27; ++f) breg[f] = wf[f * 64];
+    }
+    int aoff[9];                                                     // patch offset of k-step 9 th + i: tap (kh, kw), channel half
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int s = 9 * th + i, tap = s >> 1, kh = tap / 3, kw = tap - 3 * kh;
+        aoff[i] = (kw & 1) * g.plane + kh * g.RS + (kw >> 1) * kPPix + 32 * (s & 1);
+    }
+    const int m0 = lane & 31;
+    const int ohl = m0 / p.OW, ow = m0 - ohl * p.OW;
+    const int a_base = ohl * 2 * g.RS + ow * kPPix + 16 * (lane >> 5);
+    float4 e_sc0, e_sc1, e_sc2, e_sc3, e_sh0, e_sh1, e_sh2, e_sh3;
+    {
+        const int nb = n_blk + ct * 32 + 4 * (lane >> 5);
+        e_sc0 = *reinterpret_cast<const float4*>(nb + 0 < p.N ? p.scale + nb + 0 : p.zeros);
+        e_sc1 = *reinterpret_cast<const float4*>(nb + 8 < p.N ? p.scale + nb + 8 : p.zeros);
+        e_sc2 = *reinterpret_cast<const float4*>(nb + 16 < p.N ? p.scale + nb + 16 : p.zeros);
+        e_sc3 = *reinterpret_cast<const float4*>(nb + 24 < p.N ? p.scale + nb + 24 : p.zeros);
+        e_sh0 = *reinterpret_cast<const float4*>(nb + 0 < p.N ? p.shift + nb + 0 : p.zeros);
+        e_sh1 = *reinterpret_cast<const float4*>(nb + 8 < p.N ? p.shift + nb + 8 : p.zeros);
+        e_sh2 = *reinterpret_cast<const float4*>(nb + 16 < p.N ? p.shift + nb + 16 : p.zeros);
+        e_sh3 = *reinterpret_cast<const float4*>(nb + 24 < p.N ? p.shift + nb + 24 : p.zeros);
+    }
+    float4* const part_out = reinterpret_cast<float4*>(part + (wave ^ 2) * 4096) + lane;      // the partner's inbox
+    const float4* const part_in = reinterpret_cast<const float4*>(part + wave * 4096) + lane;
+    __syncthreads();                                                 // A
+    __syncthreads();                                                 // X: the first patch is complete
+    __syncthreads();                                                 // Y (nothing to consume yet)
+#ifdef AMPH_STAMPS
+    AMPH_F4_T(q_d)
+    const unsigned long long q_start = q_d - q_t0;
+#endif
+    int i = 0;
+    for (int tile = blockIdx.x; tile < g.n_tiles; tile += gridDim.x, ++i) {
+        const char* pb = ((i & 1) ? patch1 : patch0) + a_base;
+        AMPH_F4_T(q_a)
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+#define AMPH_F4_FR(ptr_) __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ptr_))
+        bf16x8 c0h, c0m, c0l, c1h, c1m, c1l, n0h, n0m, n0l, n1h, n1m, n1l;
+        {
+            const char* pa = pb + aoff[0];
+            c0h = AMPH_F4_FR(pa); c0m = AMPH_F4_FR(pa + 64); c0l = AMPH_F4_FR(pa + 128);
+            c1h = AMPH_F4_FR(pa + g.rt1_off); c1m = AMPH_F4_FR(pa + g.rt1_off + 64); c1l = AMPH_F4_FR(pa + g.rt1_off + 128);
+        }
+#pragma unroll
+        for (int s = 0; s < 9; ++s) {
+            if (s < 8) {
+                const char* pa = pb + aoff[s + 1];
+                n0h = AMPH_F4_FR(pa); n0m = AMPH_F4_FR(pa + 64); n0l = AMPH_F4_FR(pa + 128);
+                n1h = AMPH_F4_FR(pa + g.rt1_off); n1m = AMPH_F4_FR(pa + g.rt1_off + 64); n1l = AMPH_F4_FR(pa + g.rt1_off + 128);
+            }
+            const bf16x8 wh = __builtin_bit_cast(bf16x8, breg[3 * s]), wm = __builtin_bit_cast(bf16x8, breg[3 * s + 1]),
+                         wl = __builtin_bit_cast(bf16x8, breg[3 * s + 2]);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, c0h, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, c1h, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, c0l, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, c1l, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, c0m, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, c1m, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, c0h, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, c1h, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, c0m, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, c1m, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, c0h, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, c1h, acc1, 0, 0, 0);
+            if (s < 8) { c0h = n0h; c0m = n0m; c0l = n0l; c1h = n1h; c1m = n1m; c1l = n1l; }
+        }
+#undef AMPH_F4_FR
+        // the partial sum of the row tile this wave does not own goes to the partner (same ct, other K half)
+        AMPH_F4_T(q_b)
+        f32x16 keep, send;
+        if (th) { keep = acc1; send = acc0; } else { keep = acc0; send = acc1; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) part_out[q * 64] = make_float4(send[4 * q], send[4 * q + 1], send[4 * q + 2], send[4 * q + 3]);
+        __syncthreads();                                             // X: partial sums published; patch i + 1 complete; patch i free
+        float4 rv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rv[q] = part_in[q * 64];
+        AMPH_F4_T(q_c)
+        __syncthreads();                                             // Y: partial sums consumed
+        AMPH_F4_T(q_d)
+        {
+            const int m = tile * 64 + th * 32 + m0;
+            if (m < p.M) {
+                // K halves added low + high whichever wave holds which
+#define AMPH_F4_SUM(q_, c_) (th ? rv[q_].c_ + keep[4 * q_ + AMPH_F4_IX_##c_] : keep[4 * q_ + AMPH_F4_IX_##c_] + rv[q_].c_)
+#define AMPH_F4_IX_x 0
+#define AMPH_F4_IX_y 1
+#define AMPH_F4_IX_z 2
+#define AMPH_F4_IX_w 3
+#define AMPH_F4_OUT(gq)                                                                    \
+                {                                                                          \
+                    const int n0 = n_blk + ct * 32 + 8 * gq + 4 * (lane >> 5);             \
+                    if (n0 < p.N) {                                                        \
+                        float4 v;                                                          \
+                        v.x = fmaxf(fmaf(AMPH_F4_SUM(gq, x), e_sc##gq.x, e_sh##gq.x), 0.0f); \
+                        v.y = fmaxf(fmaf(AMPH_F4_SUM(gq, y), e_sc##gq.y, e_sh##gq.y), 0.0f); \
+                        v.z = fmaxf(fmaf(AMPH_F4_SUM(gq, z), e_sc##gq.z, e_sh##gq.z), 0.0f); \
+                        v.w = fmaxf(fmaf(AMPH_F4_SUM(gq, w), e_sc##gq.w, e_sh##gq.w), 0.0f); \
+                        if (p.y_bf16) {                                                    \
+                            const amph_bf16x2 lo_ = {(__bf16)v.x, (__bf16)v.y}, hi_ = {(__bf16)v.z, (__bf16)v.w};   /* RNE */ \
+                            *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.y) + (long long)m * p.N + n0) =       \
+                                make_uint2(__builtin_bit_cast(uint32_t, lo_), __builtin_bit_cast(uint32_t, hi_));          \
+                        } else *reinterpret_cast<float4*>(p.y + (long long)m * p.N + n0) = v; \
+                    }                                                                      \
+                }
+                AMPH_F4_OUT(0) AMPH_F4_OUT(1) AMPH_F4_OUT(2) AMPH_F4_OUT(3)
+#undef AMPH_F4_OUT
+#undef AMPH_F4_SUM
+            }
+        }
+#ifdef AMPH_STAMPS
+        {
+            unsigned long long q_e;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            AMPH_F4_T(q_e)
+            q_s0 += q_b - q_a; q_s1 += q_c - q_b; q_s2 += q_d - q_c; q_s3 += q_e - q_d;
+        }
+#endif
+    }
+#ifdef AMPH_STAMPS
+    if (tid == 0 && p.stamps) {       // consumer wave 0: start-up | multiply | partial sums + barrier X | barrier Y | (producer: build) | lifetime ticks | (producer: barriers) | start
+        unsigned long long* o = p.stamps + (size_t)blockIdx.x * 8;
+        o[0] = q_start; o[1] = q_s0; o[2] = q_s1; o[3] = q_s2 + q_s3;
+        o[5] = __builtin_amdgcn_s_memrealtime() - q_rt0; o[7] = q_rt0;
+    }
+#endif
+}
+
+static PatchGeo f4s_geo(const ConvGemmParams& p) {
+    PatchGeo g{};
+    g.n_oh = 64 / p.OW;
+    g.PR = 2 * g.n_oh + 1;
+    g.PC = 2 * p.OW + 1;
+    g.RS = ((p.OW + 1) * kPPix + 127) & ~127;
+    g.plane = g.PR * g.RS + 64;
+    g.img_row = (2 * g.PC + 2) & ~1;
+    g.n_img = (2 * g.PR + 1) * g.img_row;
+    g.n_items = g.PR * g.PC * 4;
+    g.tiles_per_image = p.OH / g.n_oh;
+    g.n_tiles = p.M / 64;
+    g.rt1_off = (32 / p.OW) * 2 * g.RS;
+    return g;
+}
+static size_t f4s_lds(const PatchGeo& g) { return (size_t)4 * g.plane + (size_t)2 * ((g.n_img + 3) & ~3) * sizeof(float) + 4 * 4096; }
+
+// the shapes it covers: 3x3 stride-2 pad-1 twice, 32 layer-1 channels, whole output rows per 64-pixel tile (OW 16 or 32)
+bool conv_gemm_f4s_ok(const ConvGemmParams& p) {
+    if (!(p.img && p.zeros && p.k == 3 && p.stride == 2 && p.pad == 1 && p.k1 == 3 && p.s1 == 2 && p.p1 == 1 && p.C_in == 32 &&
+          p.K == 288 && p.K_pad == 288 && p.splits == 1 && p.epilogue == 0 && (p.N % 4) == 0))
+        return false;
+    if ((p.OW != 16 && p.OW != 32) || (p.OH % (64 / p.OW)) || (p.M % 64) || p.M <= 0) return false;
+    if (p.H != (p.H0 + 2 - 3) / 2 + 1 || p.W != (p.W0 + 2 - 3) / 2 + 1 || p.OH != (p.H + 2 - 3) / 2 + 1 || p.OW != (p.W + 2 - 3) / 2 + 1) return false;
+    const PatchGeo g = f4s_geo(p);
+    return g.n_img <= 256 * kPImgU && g.n_items <= 256 * kPItemU && p.W == 2 * p.OW && p.H == 2 * p.OH && f4s_lds(g) <= 160 * 1024 && p.M < (1 << 22);
+}
+
+// split weights in MFMA fragment order: [n tile][channel tile][k-step (K_pad / 16)][term][lane][8 bf16];
+// lane l holds row (l & 31), k = 16 kstep + 8 (l >> 5) + j
+void conv_gemm_f4s_fragment_weights(const float* w, int n_pad, int K_pad, uint16_t* out) {
+    auto rne = [](float f) {
+        uint32_t u;
+        std::memcpy(&u, &f, 4);
+        if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
+        u += 0x7fffu + ((u >> 16) & 1u);
+        return (uint16_t)(u >> 16);
+    };
+    auto up = [](uint16_t h) { const uint32_t u = (uint32_t)h << 16; float f; std::memcpy(&f, &u, 4); return f; };
+    const int ksteps = K_pad / 16;
+    for (int nt = 0; nt < n_pad / 64; ++nt)
+        for (int ct = 0; ct < 2; ++ct)
+            for (int ks = 0; ks < ksteps; ++ks)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int n = nt * 64 + ct * 32 + (lane & 31), k = 16 * ks + 8 * (lane >> 5) + j;
+                        const float x = w[(size_t)n * K_pad + k];
+                        const uint16_t h = rne(x);
+                        const float r = x - up(h);
+                        const uint16_t m = rne(r);
+                        const uint16_t l = rne(r - up(m));
+                        const size_t base = (((size_t)(nt * 2 + ct) * ksteps + ks) * 3) * 64 * 8;
+                        out[base + (0 * 64 + lane) * 8 + j] = h;
+                        out[base + (1 * 64 + lane) * 8 + j] = m;
+                        out[base + (2 * 64 + lane) * 8 + j] = l;
+                    }
+}
+
+// wfrag = conv_gemm_f4s_fragment_weights' output on the device; wgs = workgroups to launch (0: one per CU)
+void launch_conv_gemm_f4s(const ConvGemmParams& p, const void* wfrag, int wgs, hipStream_t s) {
+    static bool raised[64] = {false};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !raised[dev]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_gemm_f4s), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        raised[dev] = true;
+    }
+    const PatchGeo g = f4s_geo(p);
+    if (wgs <= 0) wgs = g_num_cus;
+    const dim3 grid((unsigned)std::min(g.n_tiles, wgs), (unsigned)((p.N + 63) / 64), 1);      // persistent
+    hipLaunchKernelGGL(k_conv_gemm_f4s, grid, dim3(512), f4s_lds(g), s, p, g, reinterpret_cast<const uint4*>(wfrag));
+}
+
+}  // namespace amph

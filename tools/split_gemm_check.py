@@ -25,16 +25,22 @@ for preset, name in (("bench-1s", "thesis-shape"), ("bench-1s-128", "thesis-shap
     with torch.no_grad():
         mu_o, lv_o = tenc(x)
     out = {}
-    for v in (0, 1, 2):
+    for v in (0, 1, 2, 3, 4):                                    # 3: patch-resident fused pair (k_conv_gemm_f4s); 4: with 7 workgroups
         sess.configure("split_gemm", 1 if v else 0)
-        sess.configure("split_fused", 1 if v == 2 else 0)
+        sess.configure("split_fused", 1 if v >= 2 else 0)
+        sess.configure("patch_fused", 1 if v >= 3 else 0)
+        sess.configure("patch_wgs", 7 if v == 4 else 0)
         mu, lv = sess.encoder_forward(x)
         out[v] = (mu.cpu().numpy(), lv.cpu().numpy())
         mu2, _ = sess.encoder_forward(x[:13])
         assert torch.equal(mu2.cpu(), mu[:13].cpu()), "batch dependence"
+    assert np.array_equal(out[3][0], out[4][0]), "workgroup-count dependence"
+    print(f"   + patch-resident fused pair: mu {rel(out[3][0], mu_o.numpy()):.2e} lv {rel(out[3][1], lv_o.numpy()):.2e} vs f3s {rel(out[3][0], out[2][0]):.2e}")
     print(f"   + fused pair on bf16x3: mu {rel(out[2][0], mu_o.numpy()):.2e} lv {rel(out[2][1], lv_o.numpy()):.2e} vs f32 MFMA {rel(out[2][0], out[0][0]):.2e}")
     print(f"[{preset}] encoder vs torch-CPU fp32: f32 MFMA mu {rel(out[0][0], mu_o.numpy()):.2e} lv {rel(out[0][1], lv_o.numpy()):.2e} | "
           f"bf16x3 mu {rel(out[1][0], mu_o.numpy()):.2e} lv {rel(out[1][1], lv_o.numpy()):.2e} | bf16x3 vs f32 MFMA {rel(out[1][0], out[0][0]):.2e}")
     sess.configure("split_gemm", 1)
     sess.configure("split_fused", 1)
+    sess.configure("patch_fused", 1)
+    sess.configure("patch_wgs", 0)
 print("ok")
