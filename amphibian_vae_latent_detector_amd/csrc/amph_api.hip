@@ -111,6 +111,7 @@ struct amph_ctx {
     unsigned long long* d_stamps = nullptr;   // AMPH_STAMPS builds only
     unsigned long long* d_gstamps = nullptr;
     int gstamp_wgs[16] = {0};
+    bool gstamp_f4s = false;
     int gemm_min_wg128 = 512;
     bool bf16_encoder = false;             // BASELINE config 4: bf16 weights/activations, bf16 MFMA, fp32 accumulate
     bool fuse_conv12 = true;               // recompute layer 1 inside layer 2's A staging when the tiling allows
@@ -728,6 +729,7 @@ int run_encoder(amph_ctx* c, Workspace& w, const float* d_x, int nb, float* d_mu
         if (c->split_gemm && c->split_fused && c->patch_fused && fused_here && c->gemm[gi].d_w_f4 && conv_gemm_f4s_ok(prm[gi])) {
 #ifdef AMPH_STAMPS
             c->gstamp_wgs[gi] = std::min(prm[gi].M / 64, c->patch_wgs > 0 ? c->patch_wgs : amph::g_num_cus);
+            c->gstamp_f4s = true;                               // rows of 16: consumer wave 0 in [0..7], producer wave 4 in [8..15]
 #endif
             launch_conv_gemm_f4s(prm[gi], c->gemm[gi].d_w_f4, c->patch_wgs, s);
             continue;
@@ -1018,6 +1020,18 @@ int amph_configure(amph_ctx* c, const char* key, int value) {
     if (!std::strcmp(key, "dump_gemm_stamps")) {
         (void)hipDeviceSynchronize();
         for (int gi = 0; gi < (int)c->gemm.size(); ++gi) {
+            if (gi == 0 && c->gstamp_f4s) {
+                const int nw = std::min(c->gstamp_wgs[0], 4096);
+                std::vector<unsigned long long> h((size_t)nw * 16);
+                (void)hipMemcpy(h.data(), c->d_gstamps, h.size() * 8, hipMemcpyDeviceToHost);
+                double m[16] = {0};
+                for (int w = 0; w < nw; ++w) for (int k = 0; k < 16; ++k) m[k] += (double)h[(size_t)w * 16 + k] / nw;
+                fprintf(stderr, "  f4s (%d workgroups) mean cycles per workgroup: consumer start-up %.0f multiply %.0f partial+X %.0f Y+epilogue %.0f | lifetime %.0f ticks\n"
+                                "      producer build %.0f (image fetch issue %.0f, groups %.0f, image write %.0f) barriers %.0f\n",
+                        nw, m[0], m[1], m[2], m[3], m[5], m[8], m[10], m[11], m[8] - m[10] - m[11], m[9]);
+                c->gstamp_f4s = false;
+                continue;
+            }
             const int nwg = std::min(c->gstamp_wgs[gi], 8192);
             std::vector<unsigned long long> h((size_t)nwg * 8);
             (void)hipMemcpy(h.data(), c->d_gstamps + (size_t)gi * 8192 * 8, h.size() * 8, hipMemcpyDeviceToHost);

@@ -11,8 +11,10 @@
 // slice for every tile; in-kernel stamps show the three resources of a step (VALU recompute, LDS staging, MFMA) used one
 // after the other (profiles/r02_f3s_stamps.txt).  Here a 512-thread workgroup, one per CU, has two roles:
 //   producer waves 4..7  compute the tile's layer-1 patch ONCE - (2 n_oh + 1) rows x (2 OW + 1) columns x 32 channels -
-//                        from image rows staged in LDS, split it and leave it as [column parity][row][column / 2][term][32 ch]
-//                        bf16 (208-byte pixels: odd multiple of 16, conflict-free for the gather below);
+//                        from image rows staged in LDS (as three bf16 term planes), on the matrix cores too: per group of 32 patch
+//                        pixels a K = 16 product (9 taps + zero weights) with both operands split, six MFMAs; BN + ReLU + split of
+//                        the result go to LDS as [column parity][row][column / 2][term][32 ch] bf16 (208-byte pixels: odd
+//                        multiple of 16, conflict-free for the gather below);
 //   consumer waves 0..3  = (channel tile ct, K half th).  A wave keeps ITS HALF OF THE WEIGHTS IN REGISTERS for the whole
 //                        kernel (9 k-steps x 3 terms x 16 B per lane = 108 VGPRs) and reads the MFMA activation fragments
 //                        STRAIGHT from the patch: for output pixel (oh, ow) and tap (kh, kw) the layer-1 pixel is patch row
@@ -22,6 +24,15 @@
 //                        wave through LDS and writes the other one out.
 // Two patch buffers: the producers build tile i + 1 while the consumers multiply tile i.  Barriers per tile: X (patch i + 1
 // complete, patch i free, partial sums published) and Y (partial sums consumed).
+//
+// Where the time goes (in-kernel stamps, profiles/r02_f4s_stamps_*.txt; issue-cost probe profiles/r02_probe_mfma_bf16_valu.txt):
+// the consumers multiply a tile in 3 950 cycles (3 456 = MFMA bound) and then wait ~1 500 for the producers, whose wave gets only
+// what the consumer wave on its SIMD leaves of the vector issue - about 2.6 instructions per MFMA gap (a gap's issue budget is
+// 32 cycles: MFMA 8, independent VALU 4, dependent VALU / v_cvt_pk / v_accvgpr 8, an LDS access 8..17).  Doing layer 1 with
+// scalar FMAs in the producers (first form of this kernel) or on the matrix cores (this form) costs the same 7 000 cycles per
+// tile for that reason; giving every wave both roles in ONE instruction stream (4 waves, 512 registers, the patch work placed in
+// the MFMA gaps with sched_group_barrier; tried, removed) ran 6 700 cycles per tile + barriers = slower: its ~650 VALU and ~120
+// LDS instructions per tile sum to more issue cycles than the 126 MFMAs leave.  25 us per 256 chunks against 32 for k_conv_gemm_f3s.
 #include "amph_internal.h"
 
 #include <algorithm>
@@ -35,7 +46,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kPPix = 208;               // bytes per patch pixel: [h | m | l] x 32 bf16 + 16 B pad (13 slots: odd)
 constexpr int kPImgU = 6;                // staged image elements per producer lane (host check)
-constexpr int kPItemU = 6;               // (patch pixel, 8-channel group) items per producer lane (host check)
+constexpr int kPGroupU = 3;              // 32-pixel groups of a tile's patch per producer wave (host check)
 
 struct PatchGeo {                        // derived on the host, passed by value
     int n_oh;                            // output rows per 64-pixel tile (64 / OW)
@@ -44,7 +55,7 @@ struct PatchGeo {                        // derived on the host, passed by value
     int plane;                           // bytes per parity plane: PR * RS + 64 (pixels xi, xi + 1 of one store on different banks)
     int img_row;                         // floats per staged image row: 2 PC + 1 rounded up to even (element c = image column c - 3)
     int n_img;                           // staged image elements of a tile: (2 PR + 1) rows
-    int n_items;                         // (patch pixel, channel group of 8) pairs of a tile: PR * PC * 4
+    int n_pix;                           // patch pixels of a tile: PR * PC
     int tiles_per_image, n_tiles;
     int rt1_off;                         // patch byte offset of output pixel m + 32 relative to pixel m
 };
@@ -72,9 +83,9 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_f4s(ConvGemmParams p, Patc
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const patch0 = smem;                                                       // [2 parity][PR][RS]
     char* const patch1 = smem + 2 * g.plane;
-    float* const img_stage = reinterpret_cast<float*>(smem + 4 * g.plane);           // [2][2 PR + 1][img_row]
-    const int img_buf = (g.n_img + 3) & ~3;
-    char* const part = smem + 4 * g.plane + 2 * img_buf * 4;                         // [4 consumer waves][4][64] float4
+    uint16_t* const img_stage = reinterpret_cast<uint16_t*>(smem + 4 * g.plane);     // [2][3 terms][2 PR + 1][img_row] bf16
+    const int img_pl = (g.n_img + 8) & ~7;                                           // elements per term plane
+    char* const part = smem + 4 * g.plane + 2 * 3 * img_pl * 2;                      // [4 consumer waves][4][64] float4
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);                       // the role branch below is scalar
     const int n_blk = blockIdx.y * 64;
@@ -87,34 +98,53 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_f4s(ConvGemmParams p, Patc
 
     if (wave >= 4) {
         // ================================================================ producers
-        const int ptid = tid - 256;
-        const int cg = ptid & 3;                                   // this lane's 8 layer-1 channels (256 % 4 == 0: the same for all its items)
-        float4 w1a[9], w1b[9];
+        const int ptid = tid - 256, pw = wave - 4;
+        const int px = lane & 31, kh2 = lane >> 5;                 // pixel within a group of 32, K half of the MFMA operands
+        // Layer 1 as a K = 16 product on the matrix cores: 32 channels x 32 patch pixels per group, both operands split in three
+        // bf16 terms (six MFMAs, as in layer 2).  k = 8 kh2 + j pairs with the dwords a lane reads from the staged image: lanes < 32
+        // read columns (c0, c1) of the pixel's three window rows, lanes >= 32 (c2, c3): k 0..5 = taps (r, 0), (r, 1), k 8 / 10 / 12
+        // = taps (r, 2); the slots that see c3 or nothing carry zero weights.
+        bf16x8 w1h, w1m, w1l;
+        {
+            uint32_t hh[4], mm[4], ll[4];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            w1a[t] = *reinterpret_cast<const float4*>(p.w1 + t * p.C_in + 8 * cg);
-            w1b[t] = *reinterpret_cast<const float4*>(p.w1 + t * p.C_in + 8 * cg + 4);
+            for (int d = 0; d < 4; ++d) {
+                const int tap0 = d < 3 ? (kh2 ? 3 * d + 2 : 3 * d) : -1, tap1 = (d < 3 && !kh2) ? 3 * d + 1 : -1;
+                const float v0 = tap0 >= 0 ? p.w1[tap0 * p.C_in + px] : 0.0f, v1 = tap1 >= 0 ? p.w1[tap1 * p.C_in + px] : 0.0f;
+                s3_split2_o(v0, v1, hh[d], mm[d], ll[d]);
+            }
+            w1h = __builtin_bit_cast(bf16x8, make_uint4(hh[0], hh[1], hh[2], hh[3]));
+            w1m = __builtin_bit_cast(bf16x8, make_uint4(mm[0], mm[1], mm[2], mm[3]));
+            w1l = __builtin_bit_cast(bf16x8, make_uint4(ll[0], ll[1], ll[2], ll[3]));
         }
-        const float4 sc1a = *reinterpret_cast<const float4*>(p.scale1 + 8 * cg), sc1b = *reinterpret_cast<const float4*>(p.scale1 + 8 * cg + 4);
-        const float4 sh1a = *reinterpret_cast<const float4*>(p.shift1 + 8 * cg), sh1b = *reinterpret_cast<const float4*>(p.shift1 + 8 * cg + 4);
+        float4 sc1[4], sh1[4];                                     // BN of this lane's accumulator channels 8 q + 4 kh2 + r
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            sc1[q] = *reinterpret_cast<const float4*>(p.scale1 + 8 * q + 4 * kh2);
+            sh1[q] = *reinterpret_cast<const float4*>(p.shift1 + 8 * q + 4 * kh2);
+        }
         const float rcp_ir = 1.0f / (float)g.img_row, rcp_pc = 1.0f / (float)g.PC;
-        // this lane's items (patch pixel, channel group), the same for every tile: staged-image offset of the 3 x 3 window,
-        // patch byte offset of the split pixel, and whether the pixel is layer-2 padding (column -1 always; row -1 on an image's first tile)
-        int it_src[kPItemU], it_dst[kPItemU];
+        // this wave's pixel groups pw, pw + 4, ... (the same for every tile): byte offset of the lane's window in a staged term plane,
+        // patch byte offset of its pixel, and whether that pixel is layer-2 padding (column -1 always; row -1 on an image's first tile)
+        int it_src[kPGroupU], it_dst[kPGroupU];
         unsigned it_live = 0, it_pad_always = 0, it_pad_top = 0;
 #pragma unroll
-        for (int u = 0; u < kPItemU; ++u) {
-            const int idx = ptid + 256 * u, pix = idx >> 2;
-            const int yl = f4_div_small(pix, g.PC, rcp_pc), xi = pix - yl * g.PC;
-            it_src[u] = 2 * yl * g.img_row + 2 * xi;
-            it_dst[u] = (xi & 1) * g.plane + yl * g.RS + (xi >> 1) * kPPix + 16 * cg;
-            if (idx < g.n_items) it_live |= 1u << u;
+        for (int u = 0; u < kPGroupU; ++u) {
+            const int pix = (pw + 4 * u) * 32 + px;
+            const bool live = pix < g.n_pix;
+            const int pc = live ? pix : 0;
+            const int yl = f4_div_small(pc, g.PC, rcp_pc), xi = pc - yl * g.PC;
+            it_src[u] = 2 * (2 * yl * g.img_row + 2 * xi + 2 * kh2);
+            it_dst[u] = (xi & 1) * g.plane + yl * g.RS + (xi >> 1) * kPPix + 8 * kh2;
+            if (live) it_live |= 1u << u;
             if (xi == 0) it_pad_always |= 1u << u;
             if (yl == 0) it_pad_top |= 1u << u;
         }
+        const int n_groups = (g.n_pix + 31) >> 5;
         float pf[kPImgU];
         // staged row r of a tile starting at output row oh0 = image row 4 oh0 - 3 + r (conv1 row 2 oh0 - 1 + yl reads staged
-        // rows 2 yl + {0, 1, 2}); staged column c = image column c - 3 (patch column xi = conv1 column xi - 1 reads 2 xi + {0, 1, 2})
+        // rows 2 yl + {0, 1, 2}); staged column c = image column c - 3 (patch column xi = conv1 column xi - 1 reads 2 xi + {0, 1, 2});
+        // staged as three bf16 term planes
 #define AMPH_F4_FETCH_IMG(tile_)                                                           \
         {                                                                                  \
             const int b_ = f4_div_small(tile_, g.tiles_per_image, rcp_tpi), tr_ = (tile_) - b_ * g.tiles_per_image; \
@@ -129,7 +159,12 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_f4s(ConvGemmParams p, Patc
 #define AMPH_F4_WRITE_IMG(dst_)                                                            \
         {                                                                                  \
             _Pragma("unroll") for (int u = 0; u < kPImgU; ++u)                             \
-                if (ptid + 256 * u < g.n_img) (dst_)[ptid + 256 * u] = pf[u];              \
+                if (ptid + 256 * u < g.n_img) {                                            \
+                    uint32_t h_, m_, l_;                                                   \
+                    s3_split2_o(pf[u], 0.0f, h_, m_, l_);                                  \
+                    uint16_t* d_ = (dst_) + ptid + 256 * u;                                \
+                    d_[0] = (uint16_t)h_; d_[img_pl] = (uint16_t)m_; d_[2 * img_pl] = (uint16_t)l_; \
+                }                                                                          \
         }
         int tile = blockIdx.x;
         if (tile < g.n_tiles) {
@@ -141,43 +176,60 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_f4s(ConvGemmParams p, Patc
             const int nt = tile + (int)gridDim.x;
             AMPH_F4_T(q_a)
             if (nt < g.n_tiles) AMPH_F4_FETCH_IMG(nt)                // lands under the arithmetic below
-            const float* sbuf = img_stage + (i & 1) * img_buf;
+#ifdef AMPH_STAMPS
+            unsigned long long q_f, q_g;
+            AMPH_F4_T(q_f)
+#endif
+            const char* sbuf = reinterpret_cast<const char*>(img_stage + (i & 1) * 3 * img_pl);
             char* patch = (i & 1) ? patch1 : patch0;
             const int tr = tile - f4_div_small(tile, g.tiles_per_image, rcp_tpi) * g.tiles_per_image;
             const unsigned it_pad = it_pad_always | (tr == 0 ? it_pad_top : 0u);
             // (conv1 rows 2 oh0 - 1 + yl, yl < PR, and columns xi - 1, xi < PC, never pass the bottom / right edge: host check)
 #pragma unroll
-            for (int u = 0; u < kPItemU; ++u) {
-                if (!((it_live >> u) & 1u)) continue;
+            for (int u = 0; u < kPGroupU; ++u) {
+                if (pw + 4 * u >= n_groups) break;                   // wave-uniform
                 const float cap = ((it_pad >> u) & 1u) ? 0.0f : __builtin_inff();
-                const float* s0 = sbuf + it_src[u];                  // even float index, rows of even length: 8-byte aligned
-                float pv[9];
+                const char* sp = sbuf + it_src[u];
+                uint32_t xw[3][3];                                   // [term][window row]
 #pragma unroll
-                for (int r = 0; r < 3; ++r) {
-                    const float2 v2 = *reinterpret_cast<const float2*>(s0 + r * g.img_row);
-                    pv[3 * r] = v2.x; pv[3 * r + 1] = v2.y; pv[3 * r + 2] = s0[r * g.img_row + 2];
-                }
-                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f;
+                for (int t = 0; t < 3; ++t)
 #pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    a0 = fmaf(pv[t], w1a[t].x, a0); a1 = fmaf(pv[t], w1a[t].y, a1); a2 = fmaf(pv[t], w1a[t].z, a2); a3 = fmaf(pv[t], w1a[t].w, a3);
-                    a4 = fmaf(pv[t], w1b[t].x, a4); a5 = fmaf(pv[t], w1b[t].y, a5); a6 = fmaf(pv[t], w1b[t].z, a6); a7 = fmaf(pv[t], w1b[t].w, a7);
-                }
-                a0 = __builtin_amdgcn_fmed3f(fmaf(a0, sc1a.x, sh1a.x), 0.0f, cap); a1 = __builtin_amdgcn_fmed3f(fmaf(a1, sc1a.y, sh1a.y), 0.0f, cap);
-                a2 = __builtin_amdgcn_fmed3f(fmaf(a2, sc1a.z, sh1a.z), 0.0f, cap); a3 = __builtin_amdgcn_fmed3f(fmaf(a3, sc1a.w, sh1a.w), 0.0f, cap);
-                a4 = __builtin_amdgcn_fmed3f(fmaf(a4, sc1b.x, sh1b.x), 0.0f, cap); a5 = __builtin_amdgcn_fmed3f(fmaf(a5, sc1b.y, sh1b.y), 0.0f, cap);
-                a6 = __builtin_amdgcn_fmed3f(fmaf(a6, sc1b.z, sh1b.z), 0.0f, cap); a7 = __builtin_amdgcn_fmed3f(fmaf(a7, sc1b.w, sh1b.w), 0.0f, cap);
-                uint32_t h0, m0, l0, h1, m1, l1, h2, m2, l2, h3, m3, l3;
-                s3_split2_o(a0, a1, h0, m0, l0);
-                s3_split2_o(a2, a3, h1, m1, l1);
-                s3_split2_o(a4, a5, h2, m2, l2);
-                s3_split2_o(a6, a7, h3, m3, l3);
+                    for (int r = 0; r < 3; ++r) xw[t][r] = *reinterpret_cast<const uint32_t*>(sp + 2 * (t * img_pl + r * g.img_row));
+                const bf16x8 xh = __builtin_bit_cast(bf16x8, make_uint4(xw[0][0], xw[0][1], xw[0][2], 0u));
+                const bf16x8 xm = __builtin_bit_cast(bf16x8, make_uint4(xw[1][0], xw[1][1], xw[1][2], 0u));
+                const bf16x8 xl = __builtin_bit_cast(bf16x8, make_uint4(xw[2][0], xw[2][1], xw[2][2], 0u));
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1l, xh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1h, xl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1m, xm, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1m, xh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1h, xm, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1h, xh, acc, 0, 0, 0);
                 char* dst = patch + it_dst[u];
-                *reinterpret_cast<uint4*>(dst) = make_uint4(h0, h1, h2, h3);
-                *reinterpret_cast<uint4*>(dst + 64) = make_uint4(m0, m1, m2, m3);
-                *reinterpret_cast<uint4*>(dst + 128) = make_uint4(l0, l1, l2, l3);
+                const bool live = (it_live >> u) & 1u;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float a0 = __builtin_amdgcn_fmed3f(fmaf(acc[4 * q], sc1[q].x, sh1[q].x), 0.0f, cap);
+                    const float a1 = __builtin_amdgcn_fmed3f(fmaf(acc[4 * q + 1], sc1[q].y, sh1[q].y), 0.0f, cap);
+                    const float a2 = __builtin_amdgcn_fmed3f(fmaf(acc[4 * q + 2], sc1[q].z, sh1[q].z), 0.0f, cap);
+                    const float a3 = __builtin_amdgcn_fmed3f(fmaf(acc[4 * q + 3], sc1[q].w, sh1[q].w), 0.0f, cap);
+                    uint32_t h0, m0, l0, h1, m1, l1;
+                    s3_split2_o(a0, a1, h0, m0, l0);
+                    s3_split2_o(a2, a3, h1, m1, l1);
+                    if (live) {
+                        *reinterpret_cast<uint2*>(dst + 16 * q) = make_uint2(h0, h1);
+                        *reinterpret_cast<uint2*>(dst + 16 * q + 64) = make_uint2(m0, m1);
+                        *reinterpret_cast<uint2*>(dst + 16 * q + 128) = make_uint2(l0, l1);
+                    }
+                }
             }
-            if (nt < g.n_tiles) AMPH_F4_WRITE_IMG(img_stage + ((i + 1) & 1) * img_buf)     // last read before the previous X
+#ifdef AMPH_STAMPS
+            AMPH_F4_T(q_g)
+            q_s2 += q_f - q_a; q_s3 += q_g - q_f;
+#endif
+            if (nt < g.n_tiles) AMPH_F4_WRITE_IMG(img_stage + ((i + 1) & 1) * 3 * img_pl)   // last read before the previous X
             AMPH_F4_T(q_b)
             __syncthreads();                                         // X: patch i complete (the consumers are done with patch i - 1)
             __syncthreads();                                         // Y
@@ -189,7 +241,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_f4s(ConvGemmParams p, Patc
         __syncthreads();                                             // the consumers' last X
         __syncthreads();                                             // ... and Y
 #ifdef AMPH_STAMPS
-        if (tid == 256 && p.stamps) { unsigned long long* o = p.stamps + (size_t)blockIdx.x * 8; o[4] = q_s0; o[6] = q_s1; }   // producer: build | at the barriers
+        if (tid == 256 && p.stamps) { unsigned long long* o = p.stamps + (size_t)blockIdx.x * 16; o[8] = q_s0; o[9] = q_s1; o[10] = q_s2; o[11] = q_s3; }   // producer: build | at the barriers | build: image fetch issue | build: groups
 #endif
 #undef AMPH_F4_FETCH_IMG
 #undef AMPH_F4_WRITE_IMG
@@ -326,7 +378,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_f4s(ConvGemmParams p, Patc
     }
 #ifdef AMPH_STAMPS
     if (tid == 0 && p.stamps) {       // consumer wave 0: start-up | multiply | partial sums + barrier X | barrier Y | (producer: build) | lifetime ticks | (producer: barriers) | start
-        unsigned long long* o = p.stamps + (size_t)blockIdx.x * 8;
+        unsigned long long* o = p.stamps + (size_t)blockIdx.x * 16;
         o[0] = q_start; o[1] = q_s0; o[2] = q_s1; o[3] = q_s2 + q_s3;
         o[5] = __builtin_amdgcn_s_memrealtime() - q_rt0; o[7] = q_rt0;
     }
@@ -342,13 +394,13 @@ static PatchGeo f4s_geo(const ConvGemmParams& p) {
     g.plane = g.PR * g.RS + 64;
     g.img_row = (2 * g.PC + 2) & ~1;
     g.n_img = (2 * g.PR + 1) * g.img_row;
-    g.n_items = g.PR * g.PC * 4;
+    g.n_pix = g.PR * g.PC;
     g.tiles_per_image = p.OH / g.n_oh;
     g.n_tiles = p.M / 64;
     g.rt1_off = (32 / p.OW) * 2 * g.RS;
     return g;
 }
-static size_t f4s_lds(const PatchGeo& g) { return (size_t)4 * g.plane + (size_t)2 * ((g.n_img + 3) & ~3) * sizeof(float) + 4 * 4096; }
+static size_t f4s_lds(const PatchGeo& g) { return (size_t)4 * g.plane + (size_t)2 * 3 * ((g.n_img + 8) & ~7) * sizeof(uint16_t) + 4 * 4096; }
 
 // the shapes it covers: 3x3 stride-2 pad-1 twice, 32 layer-1 channels, whole output rows per 64-pixel tile (OW 16 or 32)
 bool conv_gemm_f4s_ok(const ConvGemmParams& p) {
@@ -358,7 +410,7 @@ bool conv_gemm_f4s_ok(const ConvGemmParams& p) {
     if ((p.OW != 16 && p.OW != 32) || (p.OH % (64 / p.OW)) || (p.M % 64) || p.M <= 0) return false;
     if (p.H != (p.H0 + 2 - 3) / 2 + 1 || p.W != (p.W0 + 2 - 3) / 2 + 1 || p.OH != (p.H + 2 - 3) / 2 + 1 || p.OW != (p.W + 2 - 3) / 2 + 1) return false;
     const PatchGeo g = f4s_geo(p);
-    return g.n_img <= 256 * kPImgU && g.n_items <= 256 * kPItemU && p.W == 2 * p.OW && p.H == 2 * p.OH && f4s_lds(g) <= 160 * 1024 && p.M < (1 << 22);
+    return g.n_img <= 256 * kPImgU && g.n_pix <= 128 * kPGroupU && g.n_img <= 256 * kPImgU - 256 * (kPImgU & 1) && p.W == 2 * p.OW && p.H == 2 * p.OH && f4s_lds(g) <= 160 * 1024 && p.M < (1 << 22);
 }
 
 // split weights in MFMA fragment order: [n tile][channel tile][k-step (K_pad / 16)][term][lane][8 bf16];
