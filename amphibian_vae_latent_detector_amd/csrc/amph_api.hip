@@ -120,7 +120,7 @@ struct amph_ctx {
     bool stft_fuse_db = true;              // dB / z-score / crop-pad inside the STFT kernel when a row's mel power fits its LDS
     bool split_fused = true;               // ... the fused conv1 + conv2 kernel too (k_conv_gemm_f3s)
     bool patch_fused = true;               // ... in its patch-resident form where the shape allows (k_conv_gemm_f4s)
-    int patch_wgs = 0;                     // workgroups of that kernel (0: one per CU)
+    int patch_wgs = 0;                     // workgroups of that kernel (0: eight tiles each, at most half the CUs)
     bool split_gemm = true;                // GEMM layers on the bf16 matrix cores with three-term split operands (fp32-accurate)
     int rms_f64_scale = 1;                 // RMS gate + scale in the scalar arithmetic of numpy 1.26 (reference pin) instead of numpy 2.x's
     // radial scratch
@@ -728,7 +728,7 @@ int run_encoder(amph_ctx* c, Workspace& w, const float* d_x, int nb, float* d_mu
         const bool fused_here = fuse && gi == 0;
         if (c->split_gemm && c->split_fused && c->patch_fused && fused_here && c->gemm[gi].d_w_f4 && conv_gemm_f4s_ok(prm[gi])) {
 #ifdef AMPH_STAMPS
-            c->gstamp_wgs[gi] = std::min(prm[gi].M / 64, c->patch_wgs > 0 ? c->patch_wgs : amph::g_num_cus);
+            c->gstamp_wgs[gi] = std::min(prm[gi].M / 64, c->patch_wgs > 0 ? c->patch_wgs : std::max(1, std::min(amph::g_num_cus / 2, (prm[gi].M / 64 + 7) / 8)));
             c->gstamp_f4s = true;                               // rows of 16: consumer wave 0 in [0..7], producer wave 4 in [8..15]
 #endif
             launch_conv_gemm_f4s(prm[gi], c->gemm[gi].d_w_f4, c->patch_wgs, s);
@@ -1027,8 +1027,10 @@ int amph_configure(amph_ctx* c, const char* key, int value) {
                 double m[16] = {0};
                 for (int w = 0; w < nw; ++w) for (int k = 0; k < 16; ++k) m[k] += (double)h[(size_t)w * 16 + k] / nw;
                 fprintf(stderr, "  f4s (%d workgroups) mean cycles per workgroup: consumer start-up %.0f multiply %.0f partial+X %.0f Y+epilogue %.0f | lifetime %.0f ticks\n"
-                                "      producer build %.0f (image fetch issue %.0f, groups %.0f, image write %.0f) barriers %.0f\n",
-                        nw, m[0], m[1], m[2], m[3], m[5], m[8], m[10], m[11], m[8] - m[10] - m[11], m[9]);
+                                "      producer build %.0f (image fetch issue %.0f, groups %.0f, image write %.0f) barriers %.0f\n"
+                                "      start-up: consumer loads issued at %.0f, landed %.0f, barrier A (image staged) passed %.0f, first patch built %.0f\n"
+                                "      producer groups: window reads %.0f, layer-1 MFMAs %.0f, BN + split + stores %.0f\n",
+                        nw, m[0], m[1], m[2], m[3], m[5], m[8], m[10], m[11], m[8] - m[10] - m[11], m[9], m[4], m[6], m[12], m[0], m[13], m[14], m[15]);
                 c->gstamp_f4s = false;
                 continue;
             }

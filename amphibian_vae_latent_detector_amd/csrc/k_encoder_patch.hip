@@ -91,7 +91,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_f4s(ConvGemmParams p, Patc
     const int n_blk = blockIdx.y * 64;
     const float rcp_tpi = 1.0f / (float)g.tiles_per_image;
 #ifdef AMPH_STAMPS
-    unsigned long long q_t0 = 0, q_a = 0, q_b = 0, q_c = 0, q_d = 0, q_s0 = 0, q_s1 = 0, q_s2 = 0, q_s3 = 0;
+    unsigned long long q_t0 = 0, q_a = 0, q_b = 0, q_c = 0, q_d = 0, q_s0 = 0, q_s1 = 0, q_s2 = 0, q_s3 = 0, q_p0 = 0, q_p1 = 0, q_p2 = 0;
     const unsigned long long q_rt0 = __builtin_amdgcn_s_memrealtime();
     AMPH_F4_T(q_t0)
 #endif
@@ -123,61 +123,109 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_f4s(ConvGemmParams p, Patc
             sc1[q] = *reinterpret_cast<const float4*>(p.scale1 + 8 * q + 4 * kh2);
             sh1[q] = *reinterpret_cast<const float4*>(p.shift1 + 8 * q + 4 * kh2);
         }
-        const float rcp_ir = 1.0f / (float)g.img_row, rcp_pc = 1.0f / (float)g.PC;
-        // this wave's pixel groups pw, pw + 4, ... (the same for every tile): byte offset of the lane's window in a staged term plane,
-        // patch byte offset of its pixel, and whether that pixel is layer-2 padding (column -1 always; row -1 on an image's first tile)
+        // (the constants above are needed from the first group on: wait for them HERE and re-define the registers, or the
+        // compiler's wait-count bookkeeping carries their loads into the tile loop and waits for the image prefetch in every group)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            asm volatile("v_mov_b32 %0, %0\n\tv_mov_b32 %1, %1\n\tv_mov_b32 %2, %2\n\tv_mov_b32 %3, %3" : "+v"(sc1[q].x), "+v"(sc1[q].y), "+v"(sc1[q].z), "+v"(sc1[q].w));
+            asm volatile("v_mov_b32 %0, %0\n\tv_mov_b32 %1, %1\n\tv_mov_b32 %2, %2\n\tv_mov_b32 %3, %3" : "+v"(sh1[q].x), "+v"(sh1[q].y), "+v"(sh1[q].z), "+v"(sh1[q].w));
+        }
+        // this wave's pixel groups pw, pw + 4, pw + 8 of ppg <= 32 patch pixels each (the same for every tile; 12 groups cover the
+        // patch): byte offset of the lane's window in a staged term plane, patch byte offset of its pixel, and whether that pixel
+        // is layer-2 padding (column -1 always; row -1 on an image's first tile)
         int it_src[kPGroupU], it_dst[kPGroupU];
         unsigned it_live = 0, it_pad_always = 0, it_pad_top = 0;
+        {
+            const float rcp_pc = 1.0f / (float)g.PC;
+            const int ppg = (g.n_pix + 11) / 12;
 #pragma unroll
-        for (int u = 0; u < kPGroupU; ++u) {
-            const int pix = (pw + 4 * u) * 32 + px;
-            const bool live = pix < g.n_pix;
-            const int pc = live ? pix : 0;
-            const int yl = f4_div_small(pc, g.PC, rcp_pc), xi = pc - yl * g.PC;
-            it_src[u] = 2 * (2 * yl * g.img_row + 2 * xi + 2 * kh2);
-            it_dst[u] = (xi & 1) * g.plane + yl * g.RS + (xi >> 1) * kPPix + 8 * kh2;
-            if (live) it_live |= 1u << u;
-            if (xi == 0) it_pad_always |= 1u << u;
-            if (yl == 0) it_pad_top |= 1u << u;
+            for (int u = 0; u < kPGroupU; ++u) {
+                const int pix = (pw + 4 * u) * ppg + px;
+                const bool live = px < ppg && pix < g.n_pix;
+                const int pc = live ? pix : 0;
+                const int yl = f4_div_small(pc, g.PC, rcp_pc), xi = pc - yl * g.PC;
+                it_src[u] = 2 * (2 * yl * g.img_row + 2 * xi + 2 * kh2);
+                it_dst[u] = (xi & 1) * g.plane + yl * g.RS + (xi >> 1) * kPPix + 8 * kh2;
+                if (live) it_live |= 1u << u;
+                if (xi == 0) it_pad_always |= 1u << u;
+                if (yl == 0) it_pad_top |= 1u << u;
+            }
         }
-        const int n_groups = (g.n_pix + 31) >> 5;
-        float pf[kPImgU];
         // staged row r of a tile starting at output row oh0 = image row 4 oh0 - 3 + r (conv1 row 2 oh0 - 1 + yl reads staged
         // rows 2 yl + {0, 1, 2}); staged column c = image column c - 3 (patch column xi = conv1 column xi - 1 reads 2 xi + {0, 1, 2});
-        // staged as three bf16 term planes
+        // staged as three bf16 term planes.  This lane's elements (the same for every tile): row, and row * W0 + column or -1
+        int io_r[kPImgU], io_off[kPImgU], io_w[kPImgU];
+        {
+            const float rcp_ir = 1.0f / (float)g.img_row;
+#pragma unroll
+            for (int u = 0; u < kPImgU; ++u) {
+                const int e = ptid + 256 * u;
+                const int r = f4_div_small(e, g.img_row, rcp_ir), ic = e - r * g.img_row - 3;
+                io_r[u] = r;
+                io_off[u] = (e < g.n_img && ic >= 0 && ic < p.W0) ? r * p.W0 + ic : -1;
+                io_w[u] = e < g.n_img ? e : g.n_img;                 // lanes past the last element store to the plane's pad element
+            }
+        }
+        float pf[kPImgU];
 #define AMPH_F4_FETCH_IMG(tile_)                                                           \
         {                                                                                  \
-            const int b_ = f4_div_small(tile_, g.tiles_per_image, rcp_tpi), tr_ = (tile_) - b_ * g.tiles_per_image; \
+            const int t_ = (tile_);                                                        \
+            const int b_ = f4_div_small(t_, g.tiles_per_image, rcp_tpi), tr_ = t_ - b_ * g.tiles_per_image; \
             const int ir0_ = 4 * tr_ * g.n_oh - 3;                                         \
-            const float* img_ = p.img + (long long)b_ * p.H0 * p.W0;                       \
-            _Pragma("unroll") for (int u = 0; u < kPImgU; ++u) {                           \
-                const int e_ = ptid + 256 * u;                                             \
-                const int r_ = f4_div_small(e_, g.img_row, rcp_ir), ic_ = e_ - r_ * g.img_row - 3, ir_ = ir0_ + r_; \
-                pf[u] = *((e_ < g.n_img && ir_ >= 0 && ir_ < p.H0 && ic_ >= 0 && ic_ < p.W0) ? img_ + ir_ * p.W0 + ic_ : p.zeros); \
+            const float* img_ = p.img + ((long long)b_ * p.H0 + ir0_) * p.W0;              \
+            _Pragma("unroll") for (int u = 0; u < kPImgU; ++u)                             \
+                pf[u] = *((io_off[u] >= 0 && (unsigned)(ir0_ + io_r[u]) < (unsigned)p.H0) ? img_ + io_off[u] : p.zeros); \
+        }
+        // the three-term split of n pairs, stage by stage over all the pairs: every instruction's inputs are n instructions old
+        // (one after the other the eleven instructions of a pair form a dependent chain at ~8 cycles apiece)
+#define AMPH_F4_SPLIT_PAIRS(n_, x_, h_, m_, l_)                                            \
+        {                                                                                  \
+            float r_[2 * (n_)];                                                            \
+            _Pragma("unroll") for (int k = 0; k < (n_); ++k) {                             \
+                const amph_bf16x2 hp_ = {(__bf16)x_[2 * k], (__bf16)x_[2 * k + 1]};        \
+                h_[k] = __builtin_bit_cast(uint32_t, hp_);                                 \
+                asm volatile("" : "+v"(h_[k]));                                            \
+            }                                                                              \
+            _Pragma("unroll") for (int k = 0; k < (n_); ++k) {                             \
+                r_[2 * k] = x_[2 * k] - __uint_as_float(h_[k] << 16);                      \
+                r_[2 * k + 1] = x_[2 * k + 1] - __uint_as_float(h_[k] & 0xFFFF0000u);      \
+            }                                                                              \
+            _Pragma("unroll") for (int k = 0; k < (n_); ++k) {                             \
+                const amph_bf16x2 mp_ = {(__bf16)r_[2 * k], (__bf16)r_[2 * k + 1]};        \
+                m_[k] = __builtin_bit_cast(uint32_t, mp_);                                 \
+                asm volatile("" : "+v"(m_[k]));                                            \
+            }                                                                              \
+            _Pragma("unroll") for (int k = 0; k < (n_); ++k) {                             \
+                r_[2 * k] = r_[2 * k] - __uint_as_float(m_[k] << 16);                      \
+                r_[2 * k + 1] = r_[2 * k + 1] - __uint_as_float(m_[k] & 0xFFFF0000u);      \
+            }                                                                              \
+            _Pragma("unroll") for (int k = 0; k < (n_); ++k) {                             \
+                const amph_bf16x2 lp_ = {(__bf16)r_[2 * k], (__bf16)r_[2 * k + 1]};        \
+                l_[k] = __builtin_bit_cast(uint32_t, lp_);                                 \
             }                                                                              \
         }
 #define AMPH_F4_WRITE_IMG(dst_)                                                            \
         {                                                                                  \
-            _Pragma("unroll") for (int u = 0; u < kPImgU; ++u)                             \
-                if (ptid + 256 * u < g.n_img) {                                            \
-                    uint32_t h_, m_, l_;                                                   \
-                    s3_split2_o(pf[u], 0.0f, h_, m_, l_);                                  \
-                    uint16_t* d_ = (dst_) + ptid + 256 * u;                                \
-                    d_[0] = (uint16_t)h_; d_[img_pl] = (uint16_t)m_; d_[2 * img_pl] = (uint16_t)l_; \
-                }                                                                          \
+            uint32_t h_[kPImgU / 2], m_[kPImgU / 2], l_[kPImgU / 2];                       \
+            AMPH_F4_SPLIT_PAIRS(kPImgU / 2, pf, h_, m_, l_)                                \
+            _Pragma("unroll") for (int k = 0; k < kPImgU / 2; ++k) {                       \
+                uint16_t* d0_ = (dst_) + io_w[2 * k];                                      \
+                uint16_t* d1_ = (dst_) + io_w[2 * k + 1];                                  \
+                d0_[0] = (uint16_t)h_[k]; d0_[img_pl] = (uint16_t)m_[k]; d0_[2 * img_pl] = (uint16_t)l_[k]; \
+                d1_[0] = (uint16_t)(h_[k] >> 16); d1_[img_pl] = (uint16_t)(m_[k] >> 16); d1_[2 * img_pl] = (uint16_t)(l_[k] >> 16); \
+            }                                                                              \
         }
         int tile = blockIdx.x;
-        if (tile < g.n_tiles) {
-            AMPH_F4_FETCH_IMG(tile)
-            AMPH_F4_WRITE_IMG(img_stage)
-        }
+        AMPH_F4_FETCH_IMG(tile)
+        AMPH_F4_WRITE_IMG(img_stage)
         __syncthreads();                                             // A: the first tile's image rows are staged
         for (int i = 0; tile < g.n_tiles; tile += gridDim.x, ++i) {
             const int nt = tile + (int)gridDim.x;
             AMPH_F4_T(q_a)
-            if (nt < g.n_tiles) AMPH_F4_FETCH_IMG(nt)                // lands under the arithmetic below
+            AMPH_F4_FETCH_IMG(nt < g.n_tiles ? nt : tile)            // lands under the arithmetic below
 #ifdef AMPH_STAMPS
-            unsigned long long q_f, q_g;
+            unsigned long long q_f, q_g, q_g1, q_g2;
             AMPH_F4_T(q_f)
 #endif
             const char* sbuf = reinterpret_cast<const char*>(img_stage + (i & 1) * 3 * img_pl);
@@ -185,51 +233,66 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_f4s(ConvGemmParams p, Patc
             const int tr = tile - f4_div_small(tile, g.tiles_per_image, rcp_tpi) * g.tiles_per_image;
             const unsigned it_pad = it_pad_always | (tr == 0 ? it_pad_top : 0u);
             // (conv1 rows 2 oh0 - 1 + yl, yl < PR, and columns xi - 1, xi < PC, never pass the bottom / right edge: host check)
+            // all the window reads of the three groups, then their MFMAs interleaved (three independent accumulation chains)
+            uint32_t xw[kPGroupU][3][3];                             // [group][term][window row]
 #pragma unroll
             for (int u = 0; u < kPGroupU; ++u) {
-                if (pw + 4 * u >= n_groups) break;                   // wave-uniform
-                const float cap = ((it_pad >> u) & 1u) ? 0.0f : __builtin_inff();
                 const char* sp = sbuf + it_src[u];
-                uint32_t xw[3][3];                                   // [term][window row]
 #pragma unroll
                 for (int t = 0; t < 3; ++t)
 #pragma unroll
-                    for (int r = 0; r < 3; ++r) xw[t][r] = *reinterpret_cast<const uint32_t*>(sp + 2 * (t * img_pl + r * g.img_row));
-                const bf16x8 xh = __builtin_bit_cast(bf16x8, make_uint4(xw[0][0], xw[0][1], xw[0][2], 0u));
-                const bf16x8 xm = __builtin_bit_cast(bf16x8, make_uint4(xw[1][0], xw[1][1], xw[1][2], 0u));
-                const bf16x8 xl = __builtin_bit_cast(bf16x8, make_uint4(xw[2][0], xw[2][1], xw[2][2], 0u));
-                f32x16 acc;
+                    for (int r = 0; r < 3; ++r) xw[u][t][r] = *reinterpret_cast<const uint32_t*>(sp + 2 * (t * img_pl + r * g.img_row));
+            }
+#ifdef AMPH_STAMPS
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            AMPH_F4_T(q_g1)
+#endif
+            f32x16 acc[kPGroupU];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1l, xh, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1h, xl, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1m, xm, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1m, xh, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1h, xm, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1h, xh, acc, 0, 0, 0);
-                char* dst = patch + it_dst[u];
-                const bool live = (it_live >> u) & 1u;
+            for (int u = 0; u < kPGroupU; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[u][r] = 0.0f;
+#define AMPH_F4_XT(u_, t_) __builtin_bit_cast(bf16x8, make_uint4(xw[u_][t_][0], xw[u_][t_][1], xw[u_][t_][2], 0u))
+#define AMPH_F4_M3(w_, t_)                                                                 \
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_, AMPH_F4_XT(0, t_), acc[0], 0, 0, 0); \
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_, AMPH_F4_XT(1, t_), acc[1], 0, 0, 0); \
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_, AMPH_F4_XT(2, t_), acc[2], 0, 0, 0);
+            AMPH_F4_M3(w1l, 0) AMPH_F4_M3(w1h, 2) AMPH_F4_M3(w1m, 1) AMPH_F4_M3(w1m, 0) AMPH_F4_M3(w1h, 1) AMPH_F4_M3(w1h, 0)
+#undef AMPH_F4_M3
+#undef AMPH_F4_XT
+#ifdef AMPH_STAMPS
+            asm volatile("v_mov_b32 %0, %0" : "+v"(acc[2][0]));      // waits for the last MFMA
+            AMPH_F4_T(q_g2)
+#endif
+#pragma unroll
+            for (int u = 0; u < kPGroupU; ++u) {
+                const float cap = ((it_pad >> u) & 1u) ? 0.0f : __builtin_inff();
+                float a[16];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float a0 = __builtin_amdgcn_fmed3f(fmaf(acc[4 * q], sc1[q].x, sh1[q].x), 0.0f, cap);
-                    const float a1 = __builtin_amdgcn_fmed3f(fmaf(acc[4 * q + 1], sc1[q].y, sh1[q].y), 0.0f, cap);
-                    const float a2 = __builtin_amdgcn_fmed3f(fmaf(acc[4 * q + 2], sc1[q].z, sh1[q].z), 0.0f, cap);
-                    const float a3 = __builtin_amdgcn_fmed3f(fmaf(acc[4 * q + 3], sc1[q].w, sh1[q].w), 0.0f, cap);
-                    uint32_t h0, m0, l0, h1, m1, l1;
-                    s3_split2_o(a0, a1, h0, m0, l0);
-                    s3_split2_o(a2, a3, h1, m1, l1);
-                    if (live) {
-                        *reinterpret_cast<uint2*>(dst + 16 * q) = make_uint2(h0, h1);
-                        *reinterpret_cast<uint2*>(dst + 16 * q + 64) = make_uint2(m0, m1);
-                        *reinterpret_cast<uint2*>(dst + 16 * q + 128) = make_uint2(l0, l1);
+                    a[4 * q] = fmaf(acc[u][4 * q], sc1[q].x, sh1[q].x); a[4 * q + 1] = fmaf(acc[u][4 * q + 1], sc1[q].y, sh1[q].y);
+                    a[4 * q + 2] = fmaf(acc[u][4 * q + 2], sc1[q].z, sh1[q].z); a[4 * q + 3] = fmaf(acc[u][4 * q + 3], sc1[q].w, sh1[q].w);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a[r] = __builtin_amdgcn_fmed3f(a[r], 0.0f, cap);
+                uint32_t hh[8], mm[8], ll[8];
+                AMPH_F4_SPLIT_PAIRS(8, a, hh, mm, ll)
+                if ((it_live >> u) & 1u) {
+                    char* dst = patch + it_dst[u];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        *reinterpret_cast<uint2*>(dst + 16 * q) = make_uint2(hh[2 * q], hh[2 * q + 1]);
+                        *reinterpret_cast<uint2*>(dst + 16 * q + 64) = make_uint2(mm[2 * q], mm[2 * q + 1]);
+                        *reinterpret_cast<uint2*>(dst + 16 * q + 128) = make_uint2(ll[2 * q], ll[2 * q + 1]);
                     }
                 }
             }
 #ifdef AMPH_STAMPS
             AMPH_F4_T(q_g)
             q_s2 += q_f - q_a; q_s3 += q_g - q_f;
+            q_p0 += q_g1 - q_f; q_p1 += q_g2 - q_g1; q_p2 += q_g - q_g2;
 #endif
-            if (nt < g.n_tiles) AMPH_F4_WRITE_IMG(img_stage + ((i + 1) & 1) * 3 * img_pl)   // last read before the previous X
+            AMPH_F4_WRITE_IMG(img_stage + ((i + 1) & 1) * 3 * img_pl)   // that buffer's last read came before the previous X
             AMPH_F4_T(q_b)
             __syncthreads();                                         // X: patch i complete (the consumers are done with patch i - 1)
             __syncthreads();                                         // Y
@@ -241,8 +304,9 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_f4s(ConvGemmParams p, Patc
         __syncthreads();                                             // the consumers' last X
         __syncthreads();                                             // ... and Y
 #ifdef AMPH_STAMPS
-        if (tid == 256 && p.stamps) { unsigned long long* o = p.stamps + (size_t)blockIdx.x * 16; o[8] = q_s0; o[9] = q_s1; o[10] = q_s2; o[11] = q_s3; }   // producer: build | at the barriers | build: image fetch issue | build: groups
+        if (tid == 256 && p.stamps) { unsigned long long* o = p.stamps + (size_t)blockIdx.x * 16; o[8] = q_s0; o[9] = q_s1; o[10] = q_s2; o[11] = q_s3; o[13] = q_p0; o[14] = q_p1; o[15] = q_p2; }   // producer: build | at the barriers | build: image fetch issue | build: groups | groups: window reads | MFMAs | BN + split + stores
 #endif
+#undef AMPH_F4_SPLIT_PAIRS
 #undef AMPH_F4_FETCH_IMG
 #undef AMPH_F4_WRITE_IMG
         return;
@@ -279,7 +343,16 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_f4s(ConvGemmParams p, Patc
     }
     float4* const part_out = reinterpret_cast<float4*>(part + (wave ^ 2) * 4096) + lane;      // the partner's inbox
     const float4* const part_in = reinterpret_cast<const float4*>(part + wave * 4096) + lane;
+#ifdef AMPH_STAMPS
+    unsigned long long q_u0 = 0, q_u1 = 0, q_u2 = 0;
+    AMPH_F4_T(q_u0)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    AMPH_F4_T(q_u1)
+#endif
     __syncthreads();                                                 // A
+#ifdef AMPH_STAMPS
+    AMPH_F4_T(q_u2)
+#endif
     __syncthreads();                                                 // X: the first patch is complete
     __syncthreads();                                                 // Y (nothing to consume yet)
 #ifdef AMPH_STAMPS
@@ -380,6 +453,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_f4s(ConvGemmParams p, Patc
     if (tid == 0 && p.stamps) {       // consumer wave 0: start-up | multiply | partial sums + barrier X | barrier Y | (producer: build) | lifetime ticks | (producer: barriers) | start
         unsigned long long* o = p.stamps + (size_t)blockIdx.x * 16;
         o[0] = q_start; o[1] = q_s0; o[2] = q_s1; o[3] = q_s2 + q_s3;
+        o[4] = q_u0 - q_t0; o[6] = q_u1 - q_t0; o[12] = q_u2 - q_t0;      // start-up: own loads issued | landed | barrier A passed
         o[5] = __builtin_amdgcn_s_memrealtime() - q_rt0; o[7] = q_rt0;
     }
 #endif
@@ -410,7 +484,7 @@ bool conv_gemm_f4s_ok(const ConvGemmParams& p) {
     if ((p.OW != 16 && p.OW != 32) || (p.OH % (64 / p.OW)) || (p.M % 64) || p.M <= 0) return false;
     if (p.H != (p.H0 + 2 - 3) / 2 + 1 || p.W != (p.W0 + 2 - 3) / 2 + 1 || p.OH != (p.H + 2 - 3) / 2 + 1 || p.OW != (p.W + 2 - 3) / 2 + 1) return false;
     const PatchGeo g = f4s_geo(p);
-    return g.n_img <= 256 * kPImgU && g.n_pix <= 128 * kPGroupU && g.n_img <= 256 * kPImgU - 256 * (kPImgU & 1) && p.W == 2 * p.OW && p.H == 2 * p.OH && f4s_lds(g) <= 160 * 1024 && p.M < (1 << 22);
+    return g.n_img <= 256 * kPImgU && g.n_pix <= 12 * 32 && (kPImgU % 2) == 0 && g.n_img <= 256 * kPImgU - 256 * (kPImgU & 1) && p.W == 2 * p.OW && p.H == 2 * p.OH && f4s_lds(g) <= 160 * 1024 && p.M < (1 << 22);
 }
 
 // split weights in MFMA fragment order: [n tile][channel tile][k-step (K_pad / 16)][term][lane][8 bf16];
@@ -443,7 +517,7 @@ void conv_gemm_f4s_fragment_weights(const float* w, int n_pad, int K_pad, uint16
                     }
 }
 
-// wfrag = conv_gemm_f4s_fragment_weights' output on the device; wgs = workgroups to launch (0: one per CU)
+// wfrag = conv_gemm_f4s_fragment_weights' output on the device; wgs = workgroups to launch (0: the rule below)
 void launch_conv_gemm_f4s(const ConvGemmParams& p, const void* wfrag, int wgs, hipStream_t s) {
     static bool raised[64] = {false};
     int dev = 0;
@@ -453,7 +527,9 @@ void launch_conv_gemm_f4s(const ConvGemmParams& p, const void* wfrag, int wgs, h
         raised[dev] = true;
     }
     const PatchGeo g = f4s_geo(p);
-    if (wgs <= 0) wgs = g_num_cus;
+    // eight tiles per workgroup amortise its start-up (weights, first patch: ~10 k cycles, 2.5 tiles' worth); half the CUs at most -
+    // the other lanes' kernels fill the rest (tools/sweep.py patch_wgs=...: 64..128 workgroups 2.41 M chunks/s, 256: 2.37 M)
+    if (wgs <= 0) wgs = std::max(1, std::min(g_num_cus / 2, (g.n_tiles + 7) / 8));
     const dim3 grid((unsigned)std::min(g.n_tiles, wgs), (unsigned)((p.N + 63) / 64), 1);      // persistent
     hipLaunchKernelGGL(k_conv_gemm_f4s, grid, dim3(512), f4s_lds(g), s, p, g, reinterpret_cast<const uint4*>(wfrag));
 }

@@ -105,6 +105,12 @@ const char* amph_last_error(const amph_ctx* ctx);   /* ctx may be NULL: create-t
  *                            accumulation - as close to the torch-CPU fp32 result as the f32-MFMA kernels (1e-6), which 0
  *                            selects; results differ from those in the last bits (default 1)
  *   "split_fused"      0/1   ... the fused conv1 + conv2 kernel too (default 1)
+ *   "patch_fused"      0/1   ... in its patch-resident form where the shape allows (3x3 stride-2 pad-1 twice, 32 layer-1 channels,
+ *                            conv2 output 16 wide): the layer-1 activation of a 64-pixel tile is built once in LDS (layer 1 itself
+ *                            on the matrix cores, split operands) and the conv2 weights stay in registers (default 1; 0 = the
+ *                            staged kernel; the two agree to fp32 rounding, ~7e-7)
+ *   "patch_wgs"        0..   persistent workgroups of that kernel (0 = eight tiles each, at most half the CUs; results do not
+ *                            depend on it)
  *   "stft_fuse_db"     0/1   power_to_db + z-score + crop / pad inside the STFT kernel (one workgroup per row, the row's mel
  *                            power stays in LDS) when it fits; 0 = the separate kernel (default 1; same image up to the last
  *                            bit of the float32 mean in a few rows)

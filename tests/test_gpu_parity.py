@@ -312,6 +312,47 @@ def test_split_operand_gemm_layers_are_fp32_accurate_and_batch_independent(env, 
             print(f"\n[split GEMM, {preset}/{name}] max rel L2 of mu vs torch-CPU fp32: f32 MFMA {e[0]:.2e}, bf16 x 3 MFMA {e[1]:.2e}")
 
 
+def test_patch_resident_fused_pair_matches_oracle_and_other_forms(env, capsys):
+    """conv1 + conv2 with the layer-1 tile resident in LDS and the conv2 weights in registers ("patch_fused", default on;
+    csrc/k_encoder_patch.hip).  Against the torch-CPU fp32 oracle it must meet the same 1e-5 bar as the other forms (all ~1e-6),
+    must not depend on the batch (ragged sizes: 1 chunk = 4 tiles ... 45 chunks), on the number of persistent workgroups
+    (1, 7, the default rule, one per tile) or on where in the batch a chunk sits, and must agree with the staged split kernel
+    (k_conv_gemm_f3s, "patch_fused" 0) to fp32 rounding noise.  Both 64 x 64 (bench) and 192 x 64 (reference default) images."""
+    for preset in ("bench-1s", "ref-default"):
+        cfg = env.PRESETS[preset]
+        enc, tenc, spec = _encoders(env, "thesis-shape", cfg=cfg, max_batch=48)
+        sess = enc.session(cfg)
+        x = torch.from_numpy(np.random.default_rng(11).standard_normal((45, 1, cfg.target_frames, cfg.n_mels)).astype(np.float32))
+        x[3] = 0.0                                                                       # an all-zero image (silence after z-score)
+        x[4, 0, :2, :] = 6.0                                                             # large values (for a z-scored image) on the padded top edge
+        with torch.no_grad():
+            mu_o, lv_o = tenc(x)
+        try:
+            sess.configure("patch_fused", 0)
+            mu_s, lv_s = sess.encoder_forward(x)
+            sess.configure("patch_fused", 1)
+            mu, lv = sess.encoder_forward(x)
+            for wgs in (1, 7, 4096):
+                sess.configure("patch_wgs", wgs)
+                mu_w, lv_w = sess.encoder_forward(x)
+                assert torch.equal(mu_w, mu) and torch.equal(lv_w, lv), f"result depends on the workgroup count ({wgs})"
+            sess.configure("patch_wgs", 0)
+            for lo, hi in ((0, 1), (7, 20), (44, 45)):
+                mu_b, _ = sess.encoder_forward(x[lo:hi])
+                assert torch.equal(mu_b, mu[lo:hi]), "result depends on the batch"
+        finally:
+            sess.configure("patch_fused", 1)
+            sess.configure("patch_wgs", 0)
+        _assert_latents(mu.cpu().numpy(), mu_o.numpy(), 1e-5)
+        _assert_latents(lv.cpu().numpy(), lv_o.numpy(), 1e-5)
+        _assert_latents(mu.cpu().numpy(), mu_s.cpu().numpy(), 5e-6)
+        _assert_latents(lv.cpu().numpy(), lv_s.cpu().numpy(), 5e-6)
+        e = max(rel_l2(mu.cpu().numpy()[r], mu_o.numpy()[r]) for r in range(45))
+        d = max(rel_l2(mu.cpu().numpy()[r], mu_s.cpu().numpy()[r]) for r in range(45))
+        with capsys.disabled():
+            print(f"\n[patch-resident conv1+conv2, {preset}] max rel L2 of mu vs torch-CPU fp32 {e:.2e}, vs the staged split kernel {d:.2e}")
+
+
 def test_encoder_odd_shapes_generic_path(env):
     """Non power-of-two geometry: 5x5 stride-1 first layer, C_out not a multiple of 64, K padded to 32."""
     from amphibian_vae_latent_detector_amd import EncoderSpec
