@@ -30,7 +30,7 @@
 // what the consumer wave on its SIMD leaves of the vector issue - about 2.6 instructions per MFMA gap (a gap's issue budget is
 // 32 cycles: MFMA 8, independent VALU 4, dependent VALU / v_cvt_pk / v_accvgpr 8, an LDS access 8..17).  Doing layer 1 with
 // scalar FMAs in the producers (first form of this kernel) or on the matrix cores (this form) costs the same 7 000 cycles per
-// tile for that reason; giving every wave both roles in ONE instruction stream (4 waves, 512 registers, the patch work placed in
+// tile for that reason (raising the producers' s_setprio moves the wait from one role to the other, same period); giving every wave both roles in ONE instruction stream (4 waves, 512 registers, the patch work placed in
 // the MFMA gaps with sched_group_barrier; tried, removed) ran 6 700 cycles per tile + barriers = slower: its ~650 VALU and ~120
 // LDS instructions per tile sum to more issue cycles than the 126 MFMAs leave.  25 us per 256 chunks against 32 for k_conv_gemm_f3s.
 #include "amph_internal.h"
