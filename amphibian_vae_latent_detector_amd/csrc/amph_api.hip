@@ -47,6 +47,7 @@ struct Workspace {
     std::vector<void*> act_raw;            // the allocations
     std::vector<int> act_guard;
     float* partial = nullptr;
+    int* fold_counters = nullptr;          // head: one per output tile of the split-K GEMM (k_conv_gemm_s3's fold), zero between launches
     int16_t* norm16 = nullptr;             // RMS-normalised PCM16 rows of the batch (what 00_normalize writes to disk), input of the STFT
     size_t norm16_cap = 0;                 // samples
     float* chunk_sums = nullptr;           // K0 on long rows: per-row sums of the numpy chunks (8192 samples each)
@@ -119,6 +120,8 @@ struct amph_ctx {
     bool stft_prepad = true;               // ... fix_length'd and centre padded (independent-wave STFT kernel only)
     bool stft_fuse_db = true;              // dB / z-score / crop-pad inside the STFT kernel when a row's mel power fits its LDS
     bool split_fused = true;               // ... the fused conv1 + conv2 kernel too (k_conv_gemm_f3s)
+    bool head_fold = false;                // head: the last split-K workgroup of a tile sums the partials (no k_head_reduce launch); measured SLOWER:
+                                           // the agent-scope release / acquire around the counter write back and invalidate L2 (include/amph.h)
     bool patch_fused = true;               // ... in its patch-resident form where the shape allows (k_conv_gemm_f4s)
     int patch_wgs = 0;                     // workgroups of that kernel (0: eight tiles each, at most half the CUs)
     bool split_gemm = true;                // GEMM layers on the bf16 matrix cores with three-term split operands (fp32-accurate)
@@ -544,6 +547,11 @@ int alloc_lane(amph_ctx* c, Workspace& w, bool own_stream) {
             w.act.push_back(reinterpret_cast<float*>(raw + guard));
         }
         HIP_TRY(c, hipMalloc((void**)&w.partial, (size_t)c->head_splits * MB * 2 * c->latent * sizeof(float)));
+        {
+            const size_t n_cnt = (size_t)((MB + 63) / 64) * ((2 * c->latent + 63) / 64);
+            HIP_TRY(c, hipMalloc((void**)&w.fold_counters, n_cnt * sizeof(int)));
+            HIP_TRY(c, hipMemset(w.fold_counters, 0, n_cnt * sizeof(int)));
+        }
     }
     return AMPH_OK;
 }
@@ -552,7 +560,7 @@ void free_lane(Workspace& w) {
     auto fr = [](void* p) { if (p) (void)hipFree(p); };
     fr(w.scale); fr(w.ok); fr(w.melpow); fr(w.image); fr(w.chunk_sums);
     for (auto p : w.act_raw) fr(p);
-    fr(w.partial);
+    fr(w.partial); fr(w.fold_counters);
     fr(w.norm16);
     if (w.done) (void)hipEventDestroy(w.done);
     if (w.stream) (void)hipStreamDestroy(w.stream);
@@ -716,6 +724,7 @@ int run_encoder(amph_ctx* c, Workspace& w, const float* d_x, int nb, float* d_mu
         p.y = w.act[0];
         launch_conv_first(p, nb, s);
     }
+    bool head_folded = false;
     for (int gi = 0; gi < n_gemm; ++gi) {
         const bool head = gi == n_gemm - 1;
 #ifdef AMPH_STAMPS
@@ -744,12 +753,17 @@ int run_encoder(amph_ctx* c, Workspace& w, const float* d_x, int nb, float* d_mu
         if (c->split_gemm && !fused_here && c->gemm[gi].d_w_s3 && conv_gemm_s3_ok(prm[gi])) {
             ConvGemmParams ps = prm[gi];
             ps.w = reinterpret_cast<const float*>(c->gemm[gi].d_w_s3);
+            if (head && c->head_fold && w.fold_counters) {
+                ps.fold_counters = w.fold_counters; ps.fold_bias = c->d_head_bias; ps.fold_D = c->latent;
+                ps.fold_mu = d_mu; ps.fold_logvar = d_logvar;
+                head_folded = true;
+            }
             launch_conv_gemm_s3(ps, s);
             continue;
         }
         launch_conv_gemm(prm[gi], bms[gi], fused_here, s);
     }
-    {
+    if (!head_folded) {
         StageTimer t(c, stage_head_reduce(c), s);
         HeadReduceParams p;
         p.partial = w.partial; p.bias = c->d_head_bias; p.splits = c->head_splits; p.D = c->latent;
@@ -1013,6 +1027,7 @@ int amph_configure(amph_ctx* c, const char* key, int value) {
     if (!std::strcmp(key, "stft_fuse_db")) { c->stft_fuse_db = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "split_gemm")) { c->split_gemm = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "split_fused")) { c->split_fused = value != 0; return AMPH_OK; }
+    if (!std::strcmp(key, "head_fold")) { c->head_fold = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "patch_fused")) { c->patch_fused = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "patch_wgs")) { if (value < 0) return AMPH_ERR_INVALID_ARG; c->patch_wgs = value; return AMPH_OK; }
     if (!std::strcmp(key, "rms_numpy2")) { c->rms_f64_scale = value ? 0 : 1; return AMPH_OK; }

@@ -137,6 +137,14 @@ struct ConvGemmParams {      // implicit GEMM: M = B*OH*OW, N = C_out, K = k*k*C
     int H0, W0, k1, s1, p1;
     const float* zeros;      // >= 16 bytes of zeros (16-byte aligned): source of masked loads in the fused kernel
     int x_guard;             // bytes of ZEROS in front of x (same allocation): padded taps of k_conv_gemm_p3 read there
+    // k_conv_gemm_s3 with epilogue 1 only (nullptr: partials are left for k_head_reduce): the split-K partials of an output tile
+    // are summed - split 0 first, then the bias: k_head_reduce's order, same bits - by whichever of the tile's workgroups
+    // finishes last (agent-scope counter per tile, reset by that workgroup)
+    int* fold_counters;      // [m tiles][n tiles], zero between launches
+    const float* fold_bias;  // [N]
+    float* fold_mu;          // [M][fold_D]
+    float* fold_logvar;      // nullable [M][fold_D]
+    int fold_D;              // N == 2 fold_D
     int y_bf16;              // k_conv_gemm_f3s only: write the output as bf16 NHWC (the bf16 encoder's layer 3 reads it)
     int flags;               // bit 1: use the first-generation kernel; bit 0: static issue priority from the wave's slot on its SIMD (see k_conv_gemm)
 #ifdef AMPH_STAMPS

@@ -105,6 +105,12 @@ const char* amph_last_error(const amph_ctx* ctx);   /* ctx may be NULL: create-t
  *                            accumulation - as close to the torch-CPU fp32 result as the f32-MFMA kernels (1e-6), which 0
  *                            selects; results differ from those in the last bits (default 1)
  *   "split_fused"      0/1   ... the fused conv1 + conv2 kernel too (default 1)
+ *   "head_fold"        0/1   head (fc_mu | fc_logvar as one split-K GEMM): 1 = the partial sums of an output tile are added - in split
+ *                            order, then the bias: the reduce kernel's order, same bits - by the tile's last workgroup instead of by
+ *                            a separate k_head_reduce launch.  Default 0: the agent-scope release / acquire fences the hand-off
+ *                            needs (L2 write-back and invalidate on a multi-XCD part) cost more than the launch they save, and the
+ *                            invalidate hits the other lanes' kernels too: head 10.5 + 6.3 -> 22.2 us, end to end -7 %
+ *                            (profiles/r02_head_fold_sweep.txt)
  *   "patch_fused"      0/1   ... in its patch-resident form where the shape allows (3x3 stride-2 pad-1 twice, 32 layer-1 channels,
  *                            conv2 output 16 wide): the layer-1 activation of a 64-pixel tile is built once in LDS (layer 1 itself
  *                            on the matrix cores, split operands) and the conv2 weights stay in registers (default 1; 0 = the

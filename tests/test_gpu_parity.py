@@ -353,6 +353,45 @@ def test_patch_resident_fused_pair_matches_oracle_and_other_forms(env, capsys):
             print(f"\n[patch-resident conv1+conv2, {preset}] max rel L2 of mu vs torch-CPU fp32 {e:.2e}, vs the staged split kernel {d:.2e}")
 
 
+def test_head_fold_equals_reduce_kernel_bitwise(env):
+    """The split-K head GEMM's partial sums can be added by the last workgroup of each output tile ("head_fold" 1; default 0, it
+    measured slower: an agent-scope counter per tile, release / acquire fences around it) instead of by a separate reduce kernel.  Same order of
+    additions (split 0 first, then the bias), so the latents must be bit-identical to the two-kernel form - on every one of many
+    repeated runs (which workgroup comes last changes from run to run), ragged batches, and with all lanes busy."""
+    cfg = env.PRESETS["bench-1s"]
+    enc, tenc, spec = _encoders(env, "thesis-shape", cfg=cfg, max_batch=64)
+    sess = enc.session(cfg)
+    rng = np.random.default_rng(5)
+    x = torch.from_numpy(rng.standard_normal((150, 1, cfg.target_frames, cfg.n_mels)).astype(np.float32))
+    try:
+        sess.configure("head_fold", 0)
+        mu0, lv0 = sess.encoder_forward(x)
+        sess.configure("head_fold", 1)
+        for rep in range(40):
+            mu1, lv1 = sess.encoder_forward(x)
+            assert torch.equal(mu1, mu0) and torch.equal(lv1, lv0), f"run {rep}"
+        for nb in (1, 63, 65, 128):
+            mu1, lv1 = sess.encoder_forward(x[:nb])
+            assert torch.equal(mu1, mu0[:nb]) and torch.equal(lv1, lv0[:nb]), nb
+    finally:
+        sess.configure("head_fold", 0)
+    with torch.no_grad():
+        _assert_latents(mu0.cpu().numpy(), tenc(x)[0].numpy(), 1e-5)
+    # end to end, four lanes, 40 batches per call
+    pcm = torch.from_numpy(np.tile(env.synth(list(range(250)), cfg.n_samples, cfg.sr), (10, 1))).to(DEV)
+    big = env.HipEncoder(spec, env.random_init_state(spec, seed=0), DEV, max_batch=64).session(cfg)
+    try:
+        big.configure("head_fold", 0)
+        ref_mu, _, _ = big.encode(pcm, apply_rms=True)
+        ref_mu = ref_mu.clone()
+        big.configure("head_fold", 1)
+        for rep in range(5):
+            mu, _, _ = big.encode(pcm, apply_rms=True)
+            assert torch.equal(mu, ref_mu), f"end to end, run {rep}"
+    finally:
+        big.configure("head_fold", 0)
+
+
 def test_encoder_odd_shapes_generic_path(env):
     """Non power-of-two geometry: 5x5 stride-1 first layer, C_out not a multiple of 64, K padded to 32."""
     from amphibian_vae_latent_detector_amd import EncoderSpec
