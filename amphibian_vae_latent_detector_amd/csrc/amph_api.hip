@@ -667,8 +667,10 @@ int run_encoder(amph_ctx* c, Workspace& w, const float* d_x, int nb, float* d_mu
                 const long long wg128 = (long long)((p.M + 127) / 128) * ((p.N + 63) / 64);
                 if (wg128 < c->gemm_min_wg128) bm = 64;
             }
-            StageTimer t(c, head ? stage_head_gemm(c) : ST_CONV0 + 1 + gi, s);
-            launch_conv_gemm_bf16(p, bm, s);
+            {
+                StageTimer t(c, head ? stage_head_gemm(c) : ST_CONV0 + 1 + gi, s);
+                launch_conv_gemm_bf16(p, bm, s);
+            }
             if (head) {
                 StageTimer t2(c, stage_head_reduce(c), s);
                 HeadReduceParams hp;
