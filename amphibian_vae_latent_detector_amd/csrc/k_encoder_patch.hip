@@ -25,14 +25,18 @@
 // Two patch buffers: the producers build tile i + 1 while the consumers multiply tile i.  Barriers per tile: X (patch i + 1
 // complete, patch i free, partial sums published) and Y (partial sums consumed).
 //
-// Where the time goes (in-kernel stamps, profiles/r02_f4s_stamps_*.txt; issue-cost probe profiles/r02_probe_mfma_bf16_valu.txt):
-// the consumers multiply a tile in 3 950 cycles (3 456 = MFMA bound) and then wait ~1 500 for the producers, whose wave gets only
-// what the consumer wave on its SIMD leaves of the vector issue - about 2.6 instructions per MFMA gap (a gap's issue budget is
-// 32 cycles: MFMA 8, independent VALU 4, dependent VALU / v_cvt_pk / v_accvgpr 8, an LDS access 8..17).  Doing layer 1 with
-// scalar FMAs in the producers (first form of this kernel) or on the matrix cores (this form) costs the same 7 000 cycles per
-// tile for that reason (raising the producers' s_setprio moves the wait from one role to the other, same period); giving every wave both roles in ONE instruction stream (4 waves, 512 registers, the patch work placed in
-// the MFMA gaps with sched_group_barrier; tried, removed) ran 6 700 cycles per tile + barriers = slower: its ~650 VALU and ~120
-// LDS instructions per tile sum to more issue cycles than the 126 MFMAs leave.  25 us per 256 chunks against 32 for k_conv_gemm_f3s.
+// Where the time goes (in-kernel stamps, profiles/r02_f4s_stamps_*.txt; issue-cost probe profiles/r02_probe_mfma_bf16_valu.txt),
+// cycles per 64-pixel tile: the consumers multiply in 3.95 k (3.46 k = MFMA bound) and then wait for the producers, who build in
+// 5.0 k: window reads 0.6 k, the eighteen layer-1 MFMAs 0.64 k (behind the consumer wave's MFMA stream on the same SIMD), BN + split
+// + stores 2.7 k, image fetch + staging 1.4 k.  A wave beside an MFMA-streaming wave gets what that wave leaves of the SIMD's vector
+// issue (a gap's budget is 32 cycles: MFMA 8, independent VALU 4, dependent VALU / v_cvt_pk / v_accvgpr 8, an LDS access 8..17), and a
+// lone wave pays ~8 cycles per DEPENDENT instruction: hence all window reads first, three interleaved MFMA chains, and the splits
+// done stage by stage over eight pairs (7.0 k -> 5.0 k; layer 1 by scalar FMAs instead of MFMAs built in the same 7.0 k before that).
+// Raising the producers' s_setprio moves the wait from one role to the other, same period.  Every wave in both roles in ONE
+// instruction stream (4 waves, 512 registers, the patch work placed in the MFMA gaps with sched_group_barrier; tried, removed): 6.7 k
+// cycles per tile - its ~650 VALU and ~120 LDS instructions per tile sum to more issue cycles than the 126 MFMAs leave.
+// Start-up 11 k cycles (weights 1.7 k, first image staged 5 k, first patch 11 k): eight tiles per workgroup.  21 us per 256 chunks with one
+// workgroup per CU against 30.7 for k_conv_gemm_f3s; the default (128 workgroups, 31 us alone) leaves half the chip to the other lanes.
 #include "amph_internal.h"
 
 #include <algorithm>

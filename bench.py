@@ -179,6 +179,9 @@ def main():
     ap.add_argument("--bf16", action="store_true", help="BASELINE.json configs[3]: encoder in bf16 (weights, activations, "
                                                         "bf16 MFMA, fp32 accumulate); relaxes the parity bar to ~5e-3, "
                                                         "so it is never the default / headline configuration")
+    ap.add_argument("--knob", action="append", default=[], metavar="KEY=VALUE",
+                    help="amph_configure(KEY, VALUE) on the session before anything is timed (include/amph.h lists the keys); "
+                         "recorded in the JSON line's config - a line with knobs is a tuning experiment, not the headline")
     args = ap.parse_args()
     if args.config3 and args.chunks == 10000:
         args.chunks = 100000
@@ -217,6 +220,9 @@ def main():
     sess = enc.session(cfg)
     if args.bf16:
         sess.configure("bf16_encoder", 1)
+    for kv in args.knob:
+        k, v = kv.split("=")
+        sess.configure(k, int(v))
     D = spec.latent_dim
 
     # synthetic chunks of this rank's shard (distinct per rank), resident in HBM before timing
@@ -380,6 +386,7 @@ def main():
                                    f"preset {args.preset}, {args.spec} VAE encoder (latent_dim {D}), "
                                    f"batch {args.batch}, RMS normalise + mel + encoder, " + ("bf16 encoder" if args.bf16 else "fp32"),
                        "chunks_per_gpu": args.chunks, "batch": args.batch, "lanes": n_lanes,
+                       **({"knobs": list(args.knob)} if args.knob else {}),
                        "parallelism": f"dp{world} (chunk shards, 1 all-gather)" if not args.config3 else f"1 GPU, {args.shards} virtual shards"},
             "roofline": roof,
             "fp32_roofline": {"algorithmic_flops_per_chunk": int(alg_flops), "achieved_TFLOPs_per_gpu": round(per_gpu * alg_flops / 1e12, 2),

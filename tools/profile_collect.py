@@ -27,7 +27,7 @@ def stage_of(kernel: str, grid: int) -> str:
     if k.startswith("k_rms_scale"): return "rms_scale"
     if k.startswith("k_stft_mel"): return "stft_mel"
     if k.startswith("k_dbnorm"): return "dbnorm"
-    if k.startswith("k_conv_gemm_f3") or (k.startswith("k_conv_gemm<") and "true" in k): return "conv2"
+    if k.startswith("k_conv_gemm_f3") or k.startswith("k_conv_gemm_f4") or (k.startswith("k_conv_gemm<") and "true" in k): return "conv2"
     if k.startswith("k_conv_gemm_p3") or k.startswith("k_conv_gemm_s3") or k.startswith("k_conv_gemm<"):
         return {131072: "conv3", 65536: "conv4", 16384: "head_gemm"}.get(grid, f"gemm_grid{grid}")
     if k.startswith("k_head_reduce"): return "head_reduce"
