@@ -59,7 +59,7 @@ struct GemmLayer {
     int bm = 128;
     float* d_w = nullptr;
     uint16_t* d_w_s3 = nullptr;     // three-term bf16 split [n_pad / 64][K_pad / 32][64][3][32] for k_conv_gemm_s3 (nullptr: shape not covered)
-    uint16_t* d_w_f4 = nullptr;     // the same split in MFMA fragment order for k_conv_gemm_f4s (first GEMM layer, K_pad == 288 only)
+    uint16_t* d_w_f4 = nullptr;     // the same split in MFMA fragment order for k_conv_gemm_f4s (first GEMM layer) / k_conv_gemm_g4 (C_in 64 / 128)
     uint16_t* d_w_bf16 = nullptr;   // bf16 copy [n_pad][K_pad_b] for the bf16 encoder path
     int K_pad_b = 0;                // K rounded up to 64 elements
     float* d_scale = nullptr;
@@ -122,6 +122,9 @@ struct amph_ctx {
     bool split_fused = true;               // ... the fused conv1 + conv2 kernel too (k_conv_gemm_f3s)
     bool head_fold = false;                // head: the last split-K workgroup of a tile sums the partials (no k_head_reduce launch); measured SLOWER:
                                            // the agent-scope release / acquire around the counter write back and invalidate L2 (include/amph.h)
+    int patch_gemm = 1;                    // bit 0 / 1: conv3 / conv4 of the thesis shape with weights in registers and the input resident in LDS (k_conv_gemm_g4);
+                                           // conv4 in that form is 2 us faster alone and 1 % slower end to end (two images = 127 KB of LDS per workgroup): off
+    int patch_gemm_wgs = 0;                // workgroups of that kernel (0: four tiles each, at most half the CUs)
     bool patch_fused = true;               // ... in its patch-resident form where the shape allows (k_conv_gemm_f4s)
     int patch_wgs = 0;                     // workgroups of that kernel (0: eight tiles each, at most half the CUs)
     bool split_gemm = true;                // GEMM layers on the bf16 matrix cores with three-term split operands (fp32-accurate)
@@ -430,7 +433,7 @@ int build_encoder(amph_ctx* c, const float* hw, size_t n_floats) {
                 std::vector<uint16_t> w3((size_t)n_pad * K_pad * 3);
                 conv_gemm_s3_split_weights(wg.data(), n_pad, K_pad, w3.data());
                 HIP_TRY(c, upload(&gl.d_w_s3, w3));
-                if (i == 1 && K_pad == 288) {
+                if ((i == 1 && K_pad == 288) || (i > 1 && (l.c_in == 64 || l.c_in == 128) && K_pad == 9 * l.c_in)) {   // k_conv_gemm_f4s / _g4
                     conv_gemm_f4s_fragment_weights(wg.data(), n_pad, K_pad, w3.data());
                     HIP_TRY(c, upload(&gl.d_w_f4, w3));
                 }
@@ -752,6 +755,13 @@ int run_encoder(amph_ctx* c, Workspace& w, const float* d_x, int nb, float* d_mu
             continue;
         }
         // GEMM layers on the bf16 matrix cores with three-term split operands (fp32-accurate): k_encoder_split.hip
+        if (c->split_gemm && !fused_here && !head && c->gemm[gi].d_w_f4) {
+            const int kind = conv_gemm_g4_kind(prm[gi]);
+            if ((kind == 3 && (c->patch_gemm & 1)) || (kind == 4 && (c->patch_gemm & 2))) {
+                launch_conv_gemm_g4(prm[gi], c->gemm[gi].d_w_f4, c->patch_gemm_wgs, s);
+                continue;
+            }
+        }
         if (c->split_gemm && !fused_here && c->gemm[gi].d_w_s3 && conv_gemm_s3_ok(prm[gi])) {
             ConvGemmParams ps = prm[gi];
             ps.w = reinterpret_cast<const float*>(c->gemm[gi].d_w_s3);
@@ -1030,6 +1040,8 @@ int amph_configure(amph_ctx* c, const char* key, int value) {
     if (!std::strcmp(key, "split_gemm")) { c->split_gemm = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "split_fused")) { c->split_fused = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "head_fold")) { c->head_fold = value != 0; return AMPH_OK; }
+    if (!std::strcmp(key, "patch_gemm")) { c->patch_gemm = value & 3; return AMPH_OK; }
+    if (!std::strcmp(key, "patch_gemm_wgs")) { if (value < 0) return AMPH_ERR_INVALID_ARG; c->patch_gemm_wgs = value; return AMPH_OK; }
     if (!std::strcmp(key, "patch_fused")) { c->patch_fused = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "patch_wgs")) { if (value < 0) return AMPH_ERR_INVALID_ARG; c->patch_wgs = value; return AMPH_OK; }
     if (!std::strcmp(key, "rms_numpy2")) { c->rms_f64_scale = value ? 0 : 1; return AMPH_OK; }

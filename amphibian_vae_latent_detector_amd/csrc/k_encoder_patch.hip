@@ -538,4 +538,290 @@ void launch_conv_gemm_f4s(const ConvGemmParams& p, const void* wfrag, int wgs, h
     hipLaunchKernelGGL(k_conv_gemm_f4s, grid, dim3(512), f4s_lds(g), s, p, g, reinterpret_cast<const uint4*>(wfrag));
 }
 
+// ----------------------------------------------------------------------------
+// 3x3 stride-2 layers behind the fused pair with the WEIGHTS IN REGISTERS and the input image(s) of a tile resident in LDS ("g4"):
+// k_conv_gemm_f4s's consumer side as a whole kernel.  A 512-thread workgroup owns a slice of the output channels for all its tiles:
+// wave = (channel tile ct, K part kq) keeps its 9 k-steps x 3 terms of the split weights in 108 registers for the whole kernel, so the
+// multiply loop has no weight traffic, no staging and NO barrier: 6 MFMAs per k-step and row tile on fragments read straight from the
+// patch.  Per tile: (1) all eight waves split the fp32 NHWC input of the tile into the patch [image][row][column parity][column / 2]
+// [term][C_in] bf16 (once per element, not once per tap); (2) multiply; (3) the K parts are added through LDS (the retired patch) in
+// part order, BN + ReLU, out.  conv3 (16 x 16 x 64 -> 8 x 8 x 128): tile = one image, 64 channels per workgroup, K in 4 parts;
+// conv4 (8 x 8 x 128 -> 4 x 4 x 256): tile = two images, 32 channels per workgroup, K in 8 parts.
+// ----------------------------------------------------------------------------
+struct G4Geo {
+    int PXB, PL, RS, IMG_B;   // bytes per patch pixel (3 terms x C_in bf16 + 16), per even-column plane of a row, per row, per image
+    int n_tiles;              // tiles of IM images
+    int patch_bytes;
+};
+
+// C_IN input channels; KW K parts x CT channel tiles of 32 = 8 waves; RT row tiles of 32 output pixels per tile; IM images per tile;
+// OWL = log2(output width); the input is (2 OW) x (2 OW) x C_IN per image
+template <int C_IN, int KW, int CT, int RT, int IM, int OWL>
+__global__ __launch_bounds__(512, 2) void k_conv_gemm_g4(ConvGemmParams p, G4Geo g, const uint4* __restrict__ wfrag) {
+    constexpr int OW = 1 << OWL, W = 2 * OW, PR = W + 1, PC = W + 1;
+    constexpr int KSTEPS = 9 * C_IN / 16, KPW = KSTEPS / KW;            // k-steps of 16 in all, per wave (9)
+    constexpr int SPT = C_IN / 16;                                       // k-steps per tap
+    constexpr int TERM_B = 2 * C_IN;
+    constexpr int CQ = C_IN / 4;                                         // float4 per input pixel
+    constexpr int NV = IM * W * W * CQ / 512;                            // float4 per thread and tile (8)
+    constexpr int RPO = 16 / KW;                                         // accumulator registers per owner and row tile
+    static_assert(KW * CT == 8 && KPW == 9 && RT * 32 == IM * OW * OW && NV * 512 == IM * W * W * CQ, "shape");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const patch = smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ct = CT == 2 ? (wave & 1) : 0, kq = CT == 2 ? (wave >> 1) : wave;
+    const int px = lane & 31, kh2 = lane >> 5;
+    // ---- this wave's weights: k-steps 9 kq .. 9 kq + 8 of channel tile (64-wide n tile, half) in fragment order
+    const int n_tile = CT == 2 ? blockIdx.y : (blockIdx.y >> 1), half = CT == 2 ? ct : (blockIdx.y & 1);
+    uint4 breg[27];
+    {
+        const uint4* wf = wfrag + (((size_t)n_tile * 2 + half) * KSTEPS + KPW * kq) * (3 * 64) + lane;
+#pragma unroll
+        for (int f = 0; f < 27; ++f) breg[f] = wf[f * 64];
+    }
+    int aoff[9];                                                         // patch offset of k-step 9 kq + i: tap, channel group
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int s = KPW * kq + i, tap = s / SPT, kh = tap / 3, kw = tap - 3 * kh;
+        aoff[i] = kh * g.RS + (kw & 1) * g.PL + (kw >> 1) * g.PXB + 32 * (s % SPT);
+    }
+    // lane -> output pixel of row tile 0: image, row, column; row tile 1 (RT == 2) is OW * OW / 2 ... i.e. 32 pixels further
+    const int im0 = px >> (2 * OWL), oh0 = (px >> OWL) & (OW - 1), ow0 = px & (OW - 1);
+    const int a_base = im0 * g.IMG_B + oh0 * 2 * g.RS + ow0 * g.PXB + 16 * kh2;
+    constexpr int RT1_ROWS = 32 >> OWL;                                  // output rows between the two row tiles of an image (RT == 2: IM == 1)
+    const int rt1_off = RT1_ROWS * 2 * g.RS;
+    const int n_base = blockIdx.y * (32 * CT) + ct * 32;                 // first output channel of this wave
+    // ---- input elements of this thread (the same for every tile): float4 index tid + 512 u = (image, y, x, channel group)
+    int in_dst[NV];
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        const int i = tid + 512 * u, c4 = i % CQ, pix = i / CQ, im = pix / (W * W), y = (pix / W) % W, x = pix % W;
+        in_dst[u] = im * g.IMG_B + (y + 1) * g.RS + ((x + 1) & 1) * g.PL + ((x + 1) >> 1) * g.PXB + 8 * c4;
+    }
+    float4 v[NV];
+    const int n_v_total = (p.M >> (2 * OWL)) * (W * W * CQ);             // float4 of all the batch's images (a last tile may be short of images)
+#define AMPH_G4_FETCH(tile_)                                                               \
+    {                                                                                      \
+        const int base_ = (tile_) * (IM * W * W * CQ) + tid;                               \
+        const float4* src_ = reinterpret_cast<const float4*>(p.x);                         \
+        _Pragma("unroll") for (int u = 0; u < NV; ++u)                                     \
+            v[u] = (IM == 1 || base_ + 512 * u < n_v_total) ? src_[base_ + 512 * u] : make_float4(0.f, 0.f, 0.f, 0.f); \
+    }
+    int tile = blockIdx.x;
+    if (tile < g.n_tiles) AMPH_G4_FETCH(tile)
+    // zero padding of the patch (row 0 and column 0 of every image): written once, never overwritten
+    {
+        constexpr int CH = 3 * TERM_B / 16, NPAD = IM * (PC + PR - 1) * CH;
+        for (int i = tid; i < NPAD; i += 512) {
+            const int j = i / CH, ch = i - j * CH, im = j / (PC + PR - 1), jj = j - im * (PC + PR - 1);
+            const int row = jj < PC ? 0 : jj - PC + 1, xi = jj < PC ? jj : 0;
+            *reinterpret_cast<uint4*>(patch + im * g.IMG_B + row * g.RS + (xi & 1) * g.PL + (xi >> 1) * g.PXB + 16 * ch) = make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+    float4* const inbox = reinterpret_cast<float4*>(patch);             // [8 waves][RT][KW - 1 senders][64 lanes] (RPO == 4) after the multiply
+    for (; tile < g.n_tiles; tile += gridDim.x) {
+        // ---- (1) the tile's input, split, into the patch: stage by stage over the 2 NV pairs of this thread
+        {
+            float x_[4 * NV], r_[4 * NV];
+            uint32_t h_[2 * NV], m_[2 * NV], l_[2 * NV];
+#pragma unroll
+            for (int u = 0; u < NV; ++u) { x_[4 * u] = v[u].x; x_[4 * u + 1] = v[u].y; x_[4 * u + 2] = v[u].z; x_[4 * u + 3] = v[u].w; }
+#pragma unroll
+            for (int k = 0; k < 2 * NV; ++k) {
+                const amph_bf16x2 hp = {(__bf16)x_[2 * k], (__bf16)x_[2 * k + 1]};
+                h_[k] = __builtin_bit_cast(uint32_t, hp);
+                asm volatile("" : "+v"(h_[k]));
+            }
+#pragma unroll
+            for (int k = 0; k < 2 * NV; ++k) { r_[2 * k] = x_[2 * k] - __uint_as_float(h_[k] << 16); r_[2 * k + 1] = x_[2 * k + 1] - __uint_as_float(h_[k] & 0xFFFF0000u); }
+#pragma unroll
+            for (int k = 0; k < 2 * NV; ++k) {
+                const amph_bf16x2 mp = {(__bf16)r_[2 * k], (__bf16)r_[2 * k + 1]};
+                m_[k] = __builtin_bit_cast(uint32_t, mp);
+                asm volatile("" : "+v"(m_[k]));
+            }
+#pragma unroll
+            for (int k = 0; k < 2 * NV; ++k) { r_[2 * k] = r_[2 * k] - __uint_as_float(m_[k] << 16); r_[2 * k + 1] = r_[2 * k + 1] - __uint_as_float(m_[k] & 0xFFFF0000u); }
+#pragma unroll
+            for (int k = 0; k < 2 * NV; ++k) {
+                const amph_bf16x2 lp = {(__bf16)r_[2 * k], (__bf16)r_[2 * k + 1]};
+                l_[k] = __builtin_bit_cast(uint32_t, lp);
+            }
+#pragma unroll
+            for (int u = 0; u < NV; ++u) {
+                char* dst = patch + in_dst[u];
+                *reinterpret_cast<uint2*>(dst) = make_uint2(h_[2 * u], h_[2 * u + 1]);
+                *reinterpret_cast<uint2*>(dst + TERM_B) = make_uint2(m_[2 * u], m_[2 * u + 1]);
+                *reinterpret_cast<uint2*>(dst + 2 * TERM_B) = make_uint2(l_[2 * u], l_[2 * u + 1]);
+            }
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < g.n_tiles) AMPH_G4_FETCH(tile + gridDim.x)      // lands under the multiply
+        // ---- (2) multiply: 9 k-steps, fragments of the next one read while this one is multiplied
+        f32x16 acc[RT];
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+#define AMPH_G4_FR(ptr_) __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ptr_))
+        bf16x8 fc[RT][3], fn[RT][3];
+        {
+            const char* pa = patch + a_base + aoff[0];
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) fc[t][q] = AMPH_G4_FR(pa + t * rt1_off + q * TERM_B);
+        }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            if (i < 8) {
+                const char* pa = patch + a_base + aoff[i + 1];
+#pragma unroll
+                for (int t = 0; t < RT; ++t)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) fn[t][q] = AMPH_G4_FR(pa + t * rt1_off + q * TERM_B);
+            }
+            const bf16x8 wh = __builtin_bit_cast(bf16x8, breg[3 * i]), wm = __builtin_bit_cast(bf16x8, breg[3 * i + 1]),
+                         wl = __builtin_bit_cast(bf16x8, breg[3 * i + 2]);
+#define AMPH_G4_M(w_, q_)                                                                  \
+            _Pragma("unroll") for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_, fc[t][q_], acc[t], 0, 0, 0);
+            AMPH_G4_M(wl, 0) AMPH_G4_M(wh, 2) AMPH_G4_M(wm, 1) AMPH_G4_M(wm, 0) AMPH_G4_M(wh, 1) AMPH_G4_M(wh, 0)
+#undef AMPH_G4_M
+            if (i < 8) {
+#pragma unroll
+                for (int t = 0; t < RT; ++t)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) fc[t][q] = fn[t][q];
+            }
+        }
+#undef AMPH_G4_FR
+        __syncthreads();                                                 // every wave is done with the patch: it becomes the inbox
+        // ---- (3) K parts -> their owners: wave kq owns accumulator registers RPO kq .. RPO kq + RPO - 1 (RPO consecutive channels x 32 pixels)
+        // of its channel tile; it sends the others' registers to their inboxes: [owner wave][row tile][sender kq][lane] x RPO floats
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+            for (int o = 0; o < KW; ++o) {
+                if (o == kq) continue;
+                const int ow_ = CT == 2 ? (2 * o + ct) : o;                   // the owner's wave index
+                float* dst = reinterpret_cast<float*>(inbox) + ((((size_t)ow_ * RT + t) * KW + kq) * 64 + lane) * RPO;
+#pragma unroll
+                for (int r = 0; r < RPO; ++r) dst[r] = acc[t][RPO * o + r];
+            }
+        __syncthreads();
+        {
+            const int m_img = tile * IM;
+#pragma unroll
+            for (int t = 0; t < RT; ++t) {
+                float sum[RPO];
+#pragma unroll
+                for (int r = 0; r < RPO; ++r) sum[r] = 0.0f;
+#pragma unroll
+                for (int sdr = 0; sdr < KW; ++sdr) {                      // part 0 first: a fixed order
+                    if (sdr == kq) {
+#pragma unroll
+                        for (int r = 0; r < RPO; ++r) sum[r] += acc[t][RPO * kq + r];
+                    } else {
+                        const float* src = reinterpret_cast<const float*>(inbox) + ((((size_t)wave * RT + t) * KW + sdr) * 64 + lane) * RPO;
+#pragma unroll
+                        for (int r = 0; r < RPO; ++r) sum[r] += src[r];
+                    }
+                }
+                // accumulator register j of a lane = channel 8 (j / 4) + 4 kh2 + (j % 4) of pixel px (+ 32 t)
+                const int j0 = RPO * kq, n0 = n_base + 8 * (j0 >> 2) + 4 * kh2 + (j0 & 3);
+                const int m = m_img * (OW * OW) + 32 * t + px;          // output pixel index: tiles are whole images
+                if (n0 < p.N && m < p.M) {
+#pragma unroll
+                    for (int r = 0; r < RPO; ++r) sum[r] = fmaxf(fmaf(sum[r], p.scale[n0 + r], p.shift[n0 + r]), 0.0f);
+                    if (RPO == 4) *reinterpret_cast<float4*>(p.y + (long long)m * p.N + n0) = make_float4(sum[0], sum[1], sum[2 % RPO], sum[3 % RPO]);
+                    else *reinterpret_cast<float2*>(p.y + (long long)m * p.N + n0) = make_float2(sum[0], sum[1]);
+                }
+            }
+        }
+        __syncthreads();                                                 // the inbox is read: the next tile's patch may be written
+        // (the zero padding of the patch was overwritten by the inbox: restore it)
+        {
+            constexpr int CH = 3 * TERM_B / 16, NPAD = IM * (PC + PR - 1) * CH;
+            for (int i = tid; i < NPAD; i += 512) {
+                const int j = i / CH, ch = i - j * CH, im = j / (PC + PR - 1), jj = j - im * (PC + PR - 1);
+                const int row = jj < PC ? 0 : jj - PC + 1, xi = jj < PC ? jj : 0;
+                *reinterpret_cast<uint4*>(patch + im * g.IMG_B + row * g.RS + (xi & 1) * g.PL + (xi >> 1) * g.PXB + 16 * ch) = make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+    }
+#undef AMPH_G4_FETCH
+}
+
+template <int C_IN, int IM, int OWL>
+static G4Geo g4_geo(const ConvGemmParams& p) {
+    constexpr int OW = 1 << OWL, W = 2 * OW;
+    G4Geo g{};
+    g.PXB = 6 * C_IN + 16;
+    g.PL = (OW + 1) * g.PXB;
+    // row stride / image stride: the 16 lanes of every ds_read_b128 group (lane -> image, output row, output column) on 16 different
+    // 16-byte slots: searched, not derived (OW = 8: 2 RS = 128 mod 256; OW = 4: 2 RS = 64 mod 256 and whole 256-byte images)
+    static const int groups[4][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27}, {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31},
+                                      {0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27}, {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31}};
+    const int rs0 = (W + 1) * g.PXB;
+    for (int rs = rs0; rs < rs0 + 512; rs += 16)
+        for (int ib = (W + 1) * rs; ib < (W + 1) * rs + 512; ib += 16) {
+            bool ok = true;
+            for (int gi = 0; gi < 2 && ok; ++gi) {
+                unsigned used = 0;
+                for (int k = 0; k < 16; ++k) {
+                    const int px = groups[gi][k], im = px >> (2 * OWL), oh = (px >> OWL) & (OW - 1), ow = px & (OW - 1);
+                    const int slot = ((im * ib + oh * 2 * rs + ow * g.PXB) >> 4) & 15;
+                    if (used & (1u << slot)) { ok = false; break; }
+                    used |= 1u << slot;
+                }
+            }
+            if (ok) { g.RS = rs; g.IMG_B = ib; goto found; }
+        }
+    g.RS = rs0; g.IMG_B = (W + 1) * rs0;                                 // (no conflict-free stride in range: correct, slower)
+found:
+    g.patch_bytes = IM * g.IMG_B;
+    g.n_tiles = (p.M + IM * OW * OW - 1) / (IM * OW * OW);
+    return g;
+}
+
+// 0: not covered; 3: conv3's shape (16 x 16 x 64 -> 8 x 8 x 128k); 4: conv4's (8 x 8 x 128 -> 4 x 4 x 64k)
+int conv_gemm_g4_kind(const ConvGemmParams& p) {
+    if (!(p.k == 3 && p.stride == 2 && p.pad == 1 && p.K == 9 * p.C_in && p.K_pad == p.K && p.splits == 1 && p.epilogue == 0 && !p.img && !p.y_bf16 && p.M > 0))
+        return 0;
+    if (p.C_in == 64 && p.OW == 8 && p.OH == 8 && p.W == 16 && p.H == 16 && (p.N % 64) == 0 && (p.M % 64) == 0) return 3;
+    if (p.C_in == 128 && p.OW == 4 && p.OH == 4 && p.W == 8 && p.H == 8 && (p.N % 64) == 0 && (p.M % 16) == 0) return 4;
+    return 0;
+}
+
+// wfrag = conv_gemm_f4s_fragment_weights' output for this layer
+void launch_conv_gemm_g4(const ConvGemmParams& p, const void* wfrag, int wgs, hipStream_t s) {
+    static bool raised[64] = {false};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !raised[dev]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_gemm_g4<64, 4, 2, 2, 1, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_gemm_g4<128, 8, 1, 1, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        raised[dev] = true;
+    }
+    const int kind = conv_gemm_g4_kind(p);
+    // workgroups: four tiles each amortise the 221 KB of weights a workgroup loads (one per CU: 57 MB through L2 per launch), half the
+    // CUs at most - the other lanes' kernels fill the rest (tools/sweep.py patch_gemm_wgs=...: 64..128 workgroups 2.48 M chunks/s, 256: 2.47 M)
+    if (kind == 3) {
+        const G4Geo g = g4_geo<64, 1, 3>(p);
+        const int ny = p.N / 64;
+        if (wgs <= 0) wgs = std::min(g_num_cus / 2, (g.n_tiles * ny + 3) / 4);
+        const int per = std::max(1, wgs / ny);
+        hipLaunchKernelGGL((k_conv_gemm_g4<64, 4, 2, 2, 1, 3>), dim3((unsigned)std::min(g.n_tiles, per), (unsigned)ny), dim3(512), (size_t)g.patch_bytes, s, p, g,
+                           reinterpret_cast<const uint4*>(wfrag));
+    } else if (kind == 4) {
+        const G4Geo g = g4_geo<128, 2, 2>(p);
+        const int ny = p.N / 32;
+        if (wgs <= 0) wgs = std::min(g_num_cus / 2, (g.n_tiles * ny + 3) / 4);
+        const int per = std::max(1, wgs / ny);
+        hipLaunchKernelGGL((k_conv_gemm_g4<128, 8, 1, 1, 2, 2>), dim3((unsigned)std::min(g.n_tiles, per), (unsigned)ny), dim3(512), (size_t)g.patch_bytes, s, p, g,
+                           reinterpret_cast<const uint4*>(wfrag));
+    }
+}
+
 }  // namespace amph

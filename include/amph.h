@@ -115,8 +115,14 @@ const char* amph_last_error(const amph_ctx* ctx);   /* ctx may be NULL: create-t
  *                            conv2 output 16 wide): the layer-1 activation of a 64-pixel tile is built once in LDS (layer 1 itself
  *                            on the matrix cores, split operands) and the conv2 weights stay in registers (default 1; 0 = the
  *                            staged kernel; the two agree to fp32 rounding, ~7e-7)
- *   "patch_wgs"        0..   persistent workgroups of that kernel (0 = eight tiles each, at most half the CUs; results do not
- *                            depend on it)
+ *   "patch_gemm"       0..3  bit 0: conv3 (16 x 16 x 64 -> 8 x 8 x 128), bit 1: conv4 (8 x 8 x 128 -> 4 x 4 x 256) of the thesis-shape
+ *                            encoder as k_conv_gemm_g4: a workgroup's slice of the split weights stays in registers, the tile's input
+ *                            image(s) are split once into an LDS patch, no barrier in the multiply loop.  Default 1 (conv4 in that form
+ *                            is faster alone and slower beside the other lanes' kernels); other shapes use k_conv_gemm_s3.  Same 1e-6
+ *                            agreement with the fp32 encoder; last bits differ (K is summed in 4 / 8 parts)
+ *   "patch_gemm_wgs"   0..   workgroups of that kernel (0 = four tiles each, at most half the CUs; results do not depend on it)
+ *   "patch_wgs"        0..   persistent workgroups of the "patch_fused" kernel (0 = eight tiles each, at most half the CUs; results do
+ *                            not depend on it)
  *   "stft_fuse_db"     0/1   power_to_db + z-score + crop / pad inside the STFT kernel (one workgroup per row, the row's mel
  *                            power stays in LDS) when it fits; 0 = the separate kernel (default 1; same image up to the last
  *                            bit of the float32 mean in a few rows)

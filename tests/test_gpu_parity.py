@@ -353,6 +353,46 @@ def test_patch_resident_fused_pair_matches_oracle_and_other_forms(env, capsys):
             print(f"\n[patch-resident conv1+conv2, {preset}] max rel L2 of mu vs torch-CPU fp32 {e:.2e}, vs the staged split kernel {d:.2e}")
 
 
+def test_register_resident_weight_conv_layers_match_oracle_and_staged_kernel(env, capsys):
+    """conv3 / conv4 of the thesis-shape encoder with a workgroup's slice of the split weights in registers and the tile's input
+    image(s) resident in LDS ("patch_gemm" bits 0 / 1; csrc/k_encoder_patch.hip, k_conv_gemm_g4).  Against the torch-CPU fp32 oracle
+    each combination must meet the 1e-5 bar of the staged kernel (k_conv_gemm_s3; all measure ~1e-6), agree with it to fp32 rounding,
+    and must not depend on the batch (1 image: conv4's tile is two images, the second missing; odd counts), on the position in the
+    batch or on the number of workgroups."""
+    cfg = env.PRESETS["bench-1s"]
+    enc, tenc, spec = _encoders(env, "thesis-shape", cfg=cfg, max_batch=48)
+    sess = enc.session(cfg)
+    x = torch.from_numpy(np.random.default_rng(17).standard_normal((45, 1, cfg.target_frames, cfg.n_mels)).astype(np.float32))
+    x[5] = 0.0
+    with torch.no_grad():
+        mu_o, lv_o = tenc(x)
+    res = {}
+    try:
+        for bits in (0, 1, 2, 3):
+            sess.configure("patch_gemm", bits)
+            mu, lv = sess.encoder_forward(x)
+            res[bits] = (mu.cpu().numpy(), lv.cpu().numpy())
+            for wgs in (1, 5, 4096):
+                sess.configure("patch_gemm_wgs", wgs)
+                mu_w, lv_w = sess.encoder_forward(x)
+                assert torch.equal(mu_w, mu) and torch.equal(lv_w, lv), f"patch_gemm {bits}: result depends on the workgroup count ({wgs})"
+            sess.configure("patch_gemm_wgs", 0)
+            for lo, hi in ((0, 1), (2, 5), (7, 20), (44, 45)):
+                mu_b, _ = sess.encoder_forward(x[lo:hi])
+                assert torch.equal(mu_b, mu[lo:hi]), f"patch_gemm {bits}: result depends on the batch"
+    finally:
+        sess.configure("patch_gemm", 1)
+        sess.configure("patch_gemm_wgs", 0)
+    for bits in (0, 1, 2, 3):
+        _assert_latents(res[bits][0], mu_o.numpy(), 1e-5)
+        _assert_latents(res[bits][1], lv_o.numpy(), 1e-5)
+        _assert_latents(res[bits][0], res[0][0], 5e-6)
+    e = {bits: max(rel_l2(res[bits][0][r], mu_o.numpy()[r]) for r in range(45)) for bits in res}
+    with capsys.disabled():
+        print("\n[weights-in-registers conv3 / conv4] max rel L2 of mu vs torch-CPU fp32: staged %.2e, conv3 %.2e, conv4 %.2e, both %.2e"
+              % (e[0], e[1], e[2], e[3]))
+
+
 def test_head_fold_equals_reduce_kernel_bitwise(env):
     """The split-K head GEMM's partial sums can be added by the last workgroup of each output tile ("head_fold" 1; default 0, it
     measured slower: an agent-scope counter per tile, release / acquire fences around it) instead of by a separate reduce kernel.  Same order of

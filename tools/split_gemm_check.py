@@ -35,6 +35,12 @@ for preset, name in (("bench-1s", "thesis-shape"), ("bench-1s-128", "thesis-shap
         mu2, _ = sess.encoder_forward(x[:13])
         assert torch.equal(mu2.cpu(), mu[:13].cpu()), "batch dependence"
     assert np.array_equal(out[3][0], out[4][0]), "workgroup-count dependence"
+    for pg in (0, 1, 2):
+        sess.configure("patch_gemm", pg)
+        mu_g, lv_g = sess.encoder_forward(x)
+        assert torch.equal(sess.encoder_forward(x[:13])[0], mu_g[:13]), "batch dependence"
+        print(f"   + patch_gemm={pg}: mu {rel(mu_g.cpu().numpy(), mu_o.numpy()):.2e} lv {rel(lv_g.cpu().numpy(), lv_o.numpy()):.2e} vs patch_gemm=3 {rel(mu_g.cpu().numpy(), out[4][0]):.2e}")
+    sess.configure("patch_gemm", 3)
     print(f"   + patch-resident fused pair: mu {rel(out[3][0], mu_o.numpy()):.2e} lv {rel(out[3][1], lv_o.numpy()):.2e} vs f3s {rel(out[3][0], out[2][0]):.2e}")
     print(f"   + fused pair on bf16x3: mu {rel(out[2][0], mu_o.numpy()):.2e} lv {rel(out[2][1], lv_o.numpy()):.2e} vs f32 MFMA {rel(out[2][0], out[0][0]):.2e}")
     print(f"[{preset}] encoder vs torch-CPU fp32: f32 MFMA mu {rel(out[0][0], mu_o.numpy()):.2e} lv {rel(out[0][1], lv_o.numpy()):.2e} | "
