@@ -758,6 +758,9 @@ int run_encoder(amph_ctx* c, Workspace& w, const float* d_x, int nb, float* d_mu
         if (c->split_gemm && !fused_here && !head && c->gemm[gi].d_w_f4) {
             const int kind = conv_gemm_g4_kind(prm[gi]);
             if ((kind == 3 && (c->patch_gemm & 1)) || (kind == 4 && (c->patch_gemm & 2))) {
+#ifdef AMPH_STAMPS
+                c->gstamp_wgs[gi] = c->patch_gemm_wgs > 0 ? c->patch_gemm_wgs : 128;
+#endif
                 launch_conv_gemm_g4(prm[gi], c->gemm[gi].d_w_f4, c->patch_gemm_wgs, s);
                 continue;
             }

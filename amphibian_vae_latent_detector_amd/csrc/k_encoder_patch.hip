@@ -570,6 +570,11 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_g4(ConvGemmParams p, G4Geo
     char* const patch = smem;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef AMPH_STAMPS
+    unsigned long long q_t0 = 0, q_a = 0, q_b = 0, q_c = 0, q_d = 0, q_e = 0, q_f = 0, q_s0 = 0, q_s1 = 0, q_s2 = 0, q_s3 = 0, q_s4 = 0, q_start = 0;
+    const unsigned long long q_rt0 = __builtin_amdgcn_s_memrealtime();
+    AMPH_F4_T(q_t0)
+#endif
     const int ct = CT == 2 ? (wave & 1) : 0, kq = CT == 2 ? (wave >> 1) : wave;
     const int px = lane & 31, kh2 = lane >> 5;
     // ---- this wave's weights: k-steps 9 kq .. 9 kq + 8 of channel tile (64-wide n tile, half) in fragment order
@@ -592,6 +597,11 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_g4(ConvGemmParams p, G4Geo
     constexpr int RT1_ROWS = 32 >> OWL;                                  // output rows between the two row tiles of an image (RT == 2: IM == 1)
     const int rt1_off = RT1_ROWS * 2 * g.RS;
     const int n_base = blockIdx.y * (32 * CT) + ct * 32;                 // first output channel of this wave
+    // BN constants of the RPO channels this wave writes out (accumulator register j of a lane = channel 8 (j / 4) + 4 kh2 + (j % 4))
+    const int n_own = n_base + 8 * ((RPO * kq) >> 2) + 4 * kh2 + ((RPO * kq) & 3);
+    float e_sc[RPO], e_sh[RPO];
+#pragma unroll
+    for (int r = 0; r < RPO; ++r) { e_sc[r] = n_own < p.N ? p.scale[n_own + r] : 0.0f; e_sh[r] = n_own < p.N ? p.shift[n_own + r] : 0.0f; }
     // ---- input elements of this thread (the same for every tile): float4 index tid + 512 u = (image, y, x, channel group)
     int in_dst[NV];
 #pragma unroll
@@ -620,8 +630,14 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_g4(ConvGemmParams p, G4Geo
         }
     }
     float4* const inbox = reinterpret_cast<float4*>(patch);             // [8 waves][RT][KW - 1 senders][64 lanes] (RPO == 4) after the multiply
+#ifdef AMPH_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    AMPH_F4_T(q_a)
+    q_start = q_a - q_t0;
+#endif
     for (; tile < g.n_tiles; tile += gridDim.x) {
         // ---- (1) the tile's input, split, into the patch: stage by stage over the 2 NV pairs of this thread
+        AMPH_F4_T(q_a)
         {
             float x_[4 * NV], r_[4 * NV];
             uint32_t h_[2 * NV], m_[2 * NV], l_[2 * NV];
@@ -656,7 +672,9 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_g4(ConvGemmParams p, G4Geo
                 *reinterpret_cast<uint2*>(dst + 2 * TERM_B) = make_uint2(l_[2 * u], l_[2 * u + 1]);
             }
         }
+        AMPH_F4_T(q_b)
         __syncthreads();
+        AMPH_F4_T(q_c)
         if (tile + (int)gridDim.x < g.n_tiles) AMPH_G4_FETCH(tile + gridDim.x)      // lands under the multiply
         // ---- (2) multiply: 9 k-steps, fragments of the next one read while this one is multiplied
         f32x16 acc[RT];
@@ -696,7 +714,9 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_g4(ConvGemmParams p, G4Geo
             }
         }
 #undef AMPH_G4_FR
+        AMPH_F4_T(q_d)
         __syncthreads();                                                 // every wave is done with the patch: it becomes the inbox
+        AMPH_F4_T(q_e)
         // ---- (3) K parts -> their owners: wave kq owns accumulator registers RPO kq .. RPO kq + RPO - 1 (RPO consecutive channels x 32 pixels)
         // of its channel tile; it sends the others' registers to their inboxes: [owner wave][row tile][sender kq][lane] x RPO floats
 #pragma unroll
@@ -706,8 +726,8 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_g4(ConvGemmParams p, G4Geo
                 if (o == kq) continue;
                 const int ow_ = CT == 2 ? (2 * o + ct) : o;                   // the owner's wave index
                 float* dst = reinterpret_cast<float*>(inbox) + ((((size_t)ow_ * RT + t) * KW + kq) * 64 + lane) * RPO;
-#pragma unroll
-                for (int r = 0; r < RPO; ++r) dst[r] = acc[t][RPO * o + r];
+                if (RPO == 4) *reinterpret_cast<float4*>(dst) = make_float4(acc[t][RPO * o], acc[t][RPO * o + 1], acc[t][RPO * o + 2 % RPO], acc[t][RPO * o + 3 % RPO]);
+                else *reinterpret_cast<float2*>(dst) = make_float2(acc[t][RPO * o], acc[t][RPO * o + 1]);
             }
         __syncthreads();
         {
@@ -724,21 +744,27 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_g4(ConvGemmParams p, G4Geo
                         for (int r = 0; r < RPO; ++r) sum[r] += acc[t][RPO * kq + r];
                     } else {
                         const float* src = reinterpret_cast<const float*>(inbox) + ((((size_t)wave * RT + t) * KW + sdr) * 64 + lane) * RPO;
+                        float in_[4];
+                        if (RPO == 4) { const float4 q4 = *reinterpret_cast<const float4*>(src); in_[0] = q4.x; in_[1] = q4.y; in_[2] = q4.z; in_[3] = q4.w; }
+                        else { const float2 q2 = *reinterpret_cast<const float2*>(src); in_[0] = q2.x; in_[1] = q2.y; in_[2] = 0.f; in_[3] = 0.f; }
 #pragma unroll
-                        for (int r = 0; r < RPO; ++r) sum[r] += src[r];
+                        for (int r = 0; r < RPO; ++r) sum[r] += in_[r];
                     }
                 }
-                // accumulator register j of a lane = channel 8 (j / 4) + 4 kh2 + (j % 4) of pixel px (+ 32 t)
-                const int j0 = RPO * kq, n0 = n_base + 8 * (j0 >> 2) + 4 * kh2 + (j0 & 3);
+                const int n0 = n_own;
                 const int m = m_img * (OW * OW) + 32 * t + px;          // output pixel index: tiles are whole images
                 if (n0 < p.N && m < p.M) {
 #pragma unroll
-                    for (int r = 0; r < RPO; ++r) sum[r] = fmaxf(fmaf(sum[r], p.scale[n0 + r], p.shift[n0 + r]), 0.0f);
+                    for (int r = 0; r < RPO; ++r) sum[r] = fmaxf(fmaf(sum[r], e_sc[r], e_sh[r]), 0.0f);
                     if (RPO == 4) *reinterpret_cast<float4*>(p.y + (long long)m * p.N + n0) = make_float4(sum[0], sum[1], sum[2 % RPO], sum[3 % RPO]);
                     else *reinterpret_cast<float2*>(p.y + (long long)m * p.N + n0) = make_float2(sum[0], sum[1]);
                 }
             }
         }
+        AMPH_F4_T(q_f)
+#ifdef AMPH_STAMPS
+        q_s0 += q_b - q_a; q_s1 += q_c - q_b; q_s2 += q_d - q_c; q_s3 += q_e - q_d; q_s4 += q_f - q_e;
+#endif
         __syncthreads();                                                 // the inbox is read: the next tile's patch may be written
         // (the zero padding of the patch was overwritten by the inbox: restore it)
         {
@@ -750,6 +776,13 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_g4(ConvGemmParams p, G4Geo
             }
         }
     }
+#ifdef AMPH_STAMPS
+    if (tid == 0 && p.stamps) {       // wave 0: start-up (weights + first image landed) | patch build | barrier | multiply | barrier | exchange + epilogue
+        unsigned long long* o = p.stamps + (size_t)(blockIdx.x + gridDim.x * blockIdx.y) * 8;
+        o[0] = q_start; o[1] = q_s0; o[2] = q_s1; o[3] = q_s2; o[4] = q_s3;
+        o[5] = __builtin_amdgcn_s_memrealtime() - q_rt0; o[6] = q_s4; o[7] = q_rt0;
+    }
+#endif
 #undef AMPH_G4_FETCH
 }
 
