@@ -1045,6 +1045,7 @@ int amph_configure(amph_ctx* c, const char* key, int value) {
     if (!std::strcmp(key, "head_fold")) { c->head_fold = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "patch_gemm")) { c->patch_gemm = value & 3; return AMPH_OK; }
     if (!std::strcmp(key, "patch_gemm_wgs")) { if (value < 0) return AMPH_ERR_INVALID_ARG; c->patch_gemm_wgs = value; return AMPH_OK; }
+    if (!std::strcmp(key, "rms_chunk_path_over")) { if (value < 1) return AMPH_ERR_INVALID_ARG; amph::g_rms_chunk_path_over = value; return AMPH_OK; }
     if (!std::strcmp(key, "patch_fused")) { c->patch_fused = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "patch_wgs")) { if (value < 0) return AMPH_ERR_INVALID_ARG; c->patch_wgs = value; return AMPH_OK; }
     if (!std::strcmp(key, "rms_numpy2")) { c->rms_f64_scale = value ? 0 : 1; return AMPH_OK; }

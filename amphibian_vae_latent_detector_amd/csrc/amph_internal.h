@@ -166,6 +166,7 @@ extern int g_gemm_flags;
 extern int g_num_cus;
 extern int g_stft_grid;
 extern int g_stft_indep;
+extern int g_rms_chunk_path_over;
 bool conv_gemm_can_fuse(const ConvGemmParams& p, int bm);
 size_t conv_gemm_x_guard(int k, int W, int C_in);          // zero guard k_conv_gemm_p3 needs in front of its input
 bool conv_gemm_f3_ok(const ConvGemmParams& p, int bm);   // second-generation fused kernel (64-row tiles, 32 first-layer channels)

@@ -1542,11 +1542,16 @@ void launch_dbnorm(const DbNormParams& p, int n_rows, hipStream_t s) {
 }
 
 int rms_scale_chunks(int n_in) { return (n_in + kNpChunk - 1) / kNpChunk; }
+// Rows of more numpy chunks (8 192 samples) than this take the (row, chunk) + (row, tile) kernels.  A one-pass row fits the single kernel
+// up to 4 chunks, and alone on the GPU that form is faster (15 vs 20 us per 256 one-second rows), but its 1024-thread, 70 KB workgroups wait
+// for a free CU behind the other lanes' persistent kernels (49 us in the four-lane trace), the 256-thread ones of the two-kernel form
+// fit beside them: +0.8 % end to end at 3 chunks per row (profiles/r02_rms_chunk_path_sweep.txt)
+int g_rms_chunk_path_over = 2;
 
 void launch_rms_scale_pcm16(const int16_t* in, long long row_stride, const int32_t* lengths, int n_in, int n_rows,
                             float* scale, int32_t* ok, int scale_f64, int16_t* norm_out, const NormPad& pad, float* chunk_sums, hipStream_t s) {
     const int n_chunks = rms_scale_chunks(n_in);
-    if (chunk_sums && n_chunks > NpPass<int16_t>::kChunks) {
+    if (chunk_sums && n_chunks > g_rms_chunk_path_over) {
         // rows longer than one LDS pass: (row, chunk) workgroups sum the chunks, (row, tile) workgroups fold + normalise + pad
         hipLaunchKernelGGL((k_rms_scale<int16_t, 256, 1>), dim3(n_rows, n_chunks), dim3(256), (rms_scale_lds<int16_t, 1>()), s, in, row_stride, lengths, n_in,
                            scale, ok, static_cast<int16_t*>(nullptr), NormPad{}, scale_f64, chunk_sums, n_chunks);

@@ -111,6 +111,8 @@ const char* amph_last_error(const amph_ctx* ctx);   /* ctx may be NULL: create-t
  *                            needs (L2 write-back and invalidate on a multi-XCD part) cost more than the launch they save, and the
  *                            invalidate hits the other lanes' kernels too: head 10.5 + 6.3 -> 22.2 us, end to end -7 %
  *                            (profiles/r02_head_fold_sweep.txt)
+ *   "rms_chunk_path_over" 1.. PCM16 rows of more than this many numpy chunks (8 192 samples) are normalised by the (row, chunk) + (row, tile)
+ *                            kernel pair instead of one workgroup per row (default 2; same bits; PROCESS-wide)
  *   "patch_fused"      0/1   ... in its patch-resident form where the shape allows (3x3 stride-2 pad-1 twice, 32 layer-1 channels,
  *                            conv2 output 16 wide): the layer-1 activation of a 64-pixel tile is built once in LDS (layer 1 itself
  *                            on the matrix cores, split operands) and the conv2 weights stay in registers (default 1; 0 = the
