@@ -24,10 +24,13 @@ src, dst = ROOT / "gpurun_out" / f"prof_{tag}", ROOT / "profiles"
 
 def stage_of(kernel: str, grid: int) -> str:
     k = kernel.split("(")[0].replace("void amph::", "").replace("amph::", "")
+    if k.startswith("k_rms_fold_apply"): return "rms_apply"             # second kernel of the chunked K0 path (bench's stage "rms_scale" = both)
     if k.startswith("k_rms_scale"): return "rms_scale"
     if k.startswith("k_stft_mel"): return "stft_mel"
     if k.startswith("k_dbnorm"): return "dbnorm"
     if k.startswith("k_conv_gemm_f3") or k.startswith("k_conv_gemm_f4") or (k.startswith("k_conv_gemm<") and "true" in k): return "conv2"
+    if k.startswith("k_conv_gemm_g4<64"): return "conv3"
+    if k.startswith("k_conv_gemm_g4<128"): return "conv4"
     if k.startswith("k_conv_gemm_p3") or k.startswith("k_conv_gemm_s3") or k.startswith("k_conv_gemm<"):
         return {131072: "conv3", 65536: "conv4", 16384: "head_gemm"}.get(grid, f"gemm_grid{grid}")
     if k.startswith("k_head_reduce"): return "head_reduce"
@@ -98,6 +101,9 @@ for st, by_g in dur.items():
     g = max(by_g, key=lambda k: len(by_g[k]))            # the full 256-chunk batches (one partial batch per step has its own grid)
     avg_us[st] = round(sum(by_g[g]) / len(by_g[g]), 3)
     n_l[st] = len(by_g[g])
+if "rms_apply" in avg_us and "rms_scale" in avg_us:      # the stage bench.py times is the pair
+    avg_us["rms_scale_sum_kernel"] = avg_us["rms_scale"]
+    avg_us["rms_scale"] = round(avg_us["rms_scale"] + avg_us["rms_apply"], 3)
 kd = {"_source": f"profiles/{rnd}_bench_kernel_stats_{tag}_lanes1.csv run (rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 "
                  f"--cpu-seconds 0 --lanes 1): mean End - Start of the full-size launches of each stage, microseconds",
       "avg_us": avg_us, "launches": n_l}
