@@ -56,10 +56,12 @@ struct Workspace {
 
 struct GemmLayer {
     ConvGemmParams prm{};   // x / y / M / splits filled per call
+    ConvGemmParams prm_m(int M) const { ConvGemmParams q = prm; q.M = M; return q; }
     int bm = 128;
     float* d_w = nullptr;
     uint16_t* d_w_s3 = nullptr;     // three-term bf16 split [n_pad / 64][K_pad / 32][64][3][32] for k_conv_gemm_s3 (nullptr: shape not covered)
     uint16_t* d_w_f4 = nullptr;     // the same split in MFMA fragment order for k_conv_gemm_f4s (first GEMM layer) / k_conv_gemm_g4 (C_in 64 / 128)
+    uint16_t* d_w_f4b = nullptr;    // bf16 weights in MFMA fragment order for k_conv_gemm_f4b (first GEMM layer, K_pad == 288 only)
     uint16_t* d_w_bf16 = nullptr;   // bf16 copy [n_pad][K_pad_b] for the bf16 encoder path
     int K_pad_b = 0;                // K rounded up to 64 elements
     float* d_scale = nullptr;
@@ -124,7 +126,9 @@ struct amph_ctx {
                                            // the agent-scope release / acquire around the counter write back and invalidate L2 (include/amph.h)
     int patch_gemm = 1;                    // bit 0 / 1: conv3 / conv4 of the thesis shape with weights in registers and the input resident in LDS (k_conv_gemm_g4);
                                            // conv4 in that form is 2 us faster alone and 1 % slower end to end (two images = 127 KB of LDS per workgroup): off
+    int patch_gemm_bf16 = 3;               // the same for the bf16 encoder (bf16 operands: patches of 42 / 44 KB)
     int patch_gemm_wgs = 0;                // workgroups of that kernel (0: four tiles each, at most half the CUs)
+    bool bf16_pair = true;                 // bf16 encoder: layers 1 + 2 in bf16 proper (k_conv_gemm_f4b) instead of fp32-accurate with a bf16 epilogue
     bool patch_fused = true;               // ... in its patch-resident form where the shape allows (k_conv_gemm_f4s)
     int patch_wgs = 0;                     // workgroups of that kernel (0: eight tiles each, at most half the CUs)
     bool split_gemm = true;                // GEMM layers on the bf16 matrix cores with three-term split operands (fp32-accurate)
@@ -433,6 +437,16 @@ int build_encoder(amph_ctx* c, const float* hw, size_t n_floats) {
                 std::vector<uint16_t> w3((size_t)n_pad * K_pad * 3);
                 conv_gemm_s3_split_weights(wg.data(), n_pad, K_pad, w3.data());
                 HIP_TRY(c, upload(&gl.d_w_s3, w3));
+                if (i == 1 && K_pad == 288) {
+                    std::vector<uint16_t> wb((size_t)n_pad * K_pad);
+                    conv_gemm_f4b_fragment_weights(wg.data(), n_pad, K_pad, wb.data());
+                    HIP_TRY(c, upload(&gl.d_w_f4b, wb));
+                }
+                if (i > 1 && (l.c_in == 64 || l.c_in == 128) && K_pad == 9 * l.c_in) {                                 // k_conv_gemm_g4, bf16 encoder
+                    std::vector<uint16_t> wb((size_t)n_pad * K_pad);
+                    conv_gemm_f4b_fragment_weights(wg.data(), n_pad, K_pad, wb.data());
+                    HIP_TRY(c, upload(&gl.d_w_f4b, wb));
+                }
                 if ((i == 1 && K_pad == 288) || (i > 1 && (l.c_in == 64 || l.c_in == 128) && K_pad == 9 * l.c_in)) {   // k_conv_gemm_f4s / _g4
                     conv_gemm_f4s_fragment_weights(wg.data(), n_pad, K_pad, w3.data());
                     HIP_TRY(c, upload(&gl.d_w_f4, w3));
@@ -630,7 +644,13 @@ int run_encoder(amph_ctx* c, Workspace& w, const float* d_x, int nb, float* d_mu
             p.x = w.act[0]; p.x_guard = w.act_guard[0]; p.M = nb * p.OH * p.OW; p.zeros = c->d_zeros; p.y = w.act[1];
             p.img = d_x; p.w1 = c->first.w; p.scale1 = c->first.scale; p.shift1 = c->first.shift;
             p.H0 = c->first.H; p.W0 = c->first.W; p.k1 = c->first.k; p.s1 = c->first.stride; p.p1 = c->first.pad;
-            if (c->patch_fused && c->gemm[0].d_w_f4 && conv_gemm_f4s_ok(p)) {
+            if (c->patch_fused && c->bf16_pair && c->gemm[0].d_w_f4b && conv_gemm_f4s_ok(p)) {
+                // layers 1 + 2 in bf16 proper: image, weights and the layer-1 activation rounded to bf16, fp32 accumulate / BN
+                StageTimer t(c, ST_CONV0 + 1, s);
+                p.y_bf16 = 1;
+                launch_conv_gemm_f4b(p, c->gemm[0].d_w_f4b, c->patch_wgs, s);
+                gi0 = 1;
+            } else if (c->patch_fused && c->gemm[0].d_w_f4 && conv_gemm_f4s_ok(p)) {
                 StageTimer t(c, ST_CONV0 + 1, s);
                 p.y_bf16 = 1;
                 launch_conv_gemm_f4s(p, c->gemm[0].d_w_f4, c->patch_wgs, s);
@@ -672,7 +692,12 @@ int run_encoder(amph_ctx* c, Workspace& w, const float* d_x, int nb, float* d_mu
             }
             {
                 StageTimer t(c, head ? stage_head_gemm(c) : ST_CONV0 + 1 + gi, s);
-                launch_conv_gemm_bf16(p, bm, s);
+                const int kind = (!head && c->gemm[gi].d_w_f4b) ? conv_gemm_g4_kind(c->gemm[gi].prm_m(p.M)) : 0;
+                if ((kind == 3 && (c->patch_gemm_bf16 & 1)) || (kind == 4 && (c->patch_gemm_bf16 & 2))) {
+                    ConvGemmParams pg = c->gemm[gi].prm;              // (fp32 element counts: K, K_pad as the layer has them)
+                    pg.x = w.act[gi]; pg.y = w.act[gi + 1]; pg.M = p.M; pg.y_bf16 = 1;
+                    launch_conv_gemm_g4(pg, c->gemm[gi].d_w_f4b, c->patch_gemm_wgs, 1, s);
+                } else launch_conv_gemm_bf16(p, bm, s);
             }
             if (head) {
                 StageTimer t2(c, stage_head_reduce(c), s);
@@ -761,7 +786,7 @@ int run_encoder(amph_ctx* c, Workspace& w, const float* d_x, int nb, float* d_mu
 #ifdef AMPH_STAMPS
                 c->gstamp_wgs[gi] = c->patch_gemm_wgs > 0 ? c->patch_gemm_wgs : 128;
 #endif
-                launch_conv_gemm_g4(prm[gi], c->gemm[gi].d_w_f4, c->patch_gemm_wgs, s);
+                launch_conv_gemm_g4(prm[gi], c->gemm[gi].d_w_f4, c->patch_gemm_wgs, 3, s);
                 continue;
             }
         }
@@ -1010,7 +1035,7 @@ void amph_destroy(amph_ctx* c) {
     fr(c->d_tables); fr(c->d_tw_a);
     fr(c->d_mel_start); fr(c->d_mel_len); fr(c->d_mel_wofs); fr(c->d_mel_w);
     fr(c->d_first_w); fr(c->d_first_scale); fr(c->d_first_shift);
-    for (auto& g : c->gemm) { fr(g.d_w); fr(g.d_w_s3); fr(g.d_w_f4); fr(g.d_w_bf16); fr(g.d_scale); fr(g.d_shift); }
+    for (auto& g : c->gemm) { fr(g.d_w); fr(g.d_w_s3); fr(g.d_w_f4); fr(g.d_w_f4b); fr(g.d_w_bf16); fr(g.d_scale); fr(g.d_shift); }
     fr(c->d_head_bias); fr(c->d_zeros);
     for (auto& w : c->lanes) free_lane(w);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -1044,8 +1069,10 @@ int amph_configure(amph_ctx* c, const char* key, int value) {
     if (!std::strcmp(key, "split_fused")) { c->split_fused = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "head_fold")) { c->head_fold = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "patch_gemm")) { c->patch_gemm = value & 3; return AMPH_OK; }
+    if (!std::strcmp(key, "patch_gemm_bf16")) { c->patch_gemm_bf16 = value & 3; return AMPH_OK; }
     if (!std::strcmp(key, "patch_gemm_wgs")) { if (value < 0) return AMPH_ERR_INVALID_ARG; c->patch_gemm_wgs = value; return AMPH_OK; }
     if (!std::strcmp(key, "rms_chunk_path_over")) { if (value < 1) return AMPH_ERR_INVALID_ARG; amph::g_rms_chunk_path_over = value; return AMPH_OK; }
+    if (!std::strcmp(key, "bf16_pair")) { c->bf16_pair = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "patch_fused")) { c->patch_fused = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "patch_wgs")) { if (value < 0) return AMPH_ERR_INVALID_ARG; c->patch_wgs = value; return AMPH_OK; }
     if (!std::strcmp(key, "rms_numpy2")) { c->rms_f64_scale = value ? 0 : 1; return AMPH_OK; }

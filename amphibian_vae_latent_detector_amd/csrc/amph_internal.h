@@ -185,10 +185,13 @@ void launch_conv_gemm_f3s(const ConvGemmParams& p, hipStream_t s);
 bool conv_gemm_f4s_ok(const ConvGemmParams& p);
 void launch_conv_gemm_f4s(const ConvGemmParams& p, const void* wfrag, int wgs, hipStream_t s);
 void conv_gemm_f4s_fragment_weights(const float* w, int n_pad, int K_pad, uint16_t* out);
+// ... and with one bf16 term per operand for the bf16 encoder (same shapes: conv_gemm_f4s_ok; bf16 NHWC output)
+void conv_gemm_f4b_fragment_weights(const float* w, int n_pad, int K_pad, uint16_t* out);
+void launch_conv_gemm_f4b(const ConvGemmParams& p, const void* wfrag, int wgs, hipStream_t s);
 // the 3x3 stride-2 layers behind the pair in the same form: weights in registers, the tile's input image(s) resident in LDS
 // (0: shape not covered; wfrag = conv_gemm_f4s_fragment_weights' output of the layer; wgs = workgroups, 0: one per CU)
 int conv_gemm_g4_kind(const ConvGemmParams& p);
-void launch_conv_gemm_g4(const ConvGemmParams& p, const void* wfrag, int wgs, hipStream_t s);
+void launch_conv_gemm_g4(const ConvGemmParams& p, const void* wfrag, int wgs, int terms, hipStream_t s);   // terms 3: fp32 in / out; 1: bf16 in / out (wfrag: conv_gemm_f4b_fragment_weights)
 // bf16 encoder path (k_encoder_bf16.hip): x / w are bf16, y bf16 (epilogue 0) or fp32 partials (epilogue 1);
 // K, K_pad and C_in count bf16 elements, K_pad % 64 == 0, C_in % 8 == 0
 void launch_conv_first_bf16(const ConvFirstParams& p, int n_rows, hipStream_t s);

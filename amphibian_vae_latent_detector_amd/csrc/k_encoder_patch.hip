@@ -539,6 +539,262 @@ void launch_conv_gemm_f4s(const ConvGemmParams& p, const void* wfrag, int wgs, h
 }
 
 // ----------------------------------------------------------------------------
+// The same pair for the bf16 encoder (BASELINE configs[3]: bf16 weights and activations, bf16 MFMA, fp32 accumulate / BN): "f4b".
+// k_conv_gemm_f4s with ONE bf16 term per operand: image and layer-1 weights rounded to bf16 (RNE), layer 1 as one MFMA per group
+// of 32 patch pixels, BN + ReLU in fp32, the activation rounded to bf16 into an 80-byte-pixel patch (5 slots: odd), layer 2 as one
+// MFMA per k-step with ALL 18 k-steps of a wave's 32 channels in 72 registers - no K split, so no partial-sum exchange: one barrier
+// per tile.  bf16 NHWC output.  56 KB of LDS, 160 registers (72 of them weights): one workgroup per CU.
+// ----------------------------------------------------------------------------
+constexpr int kBPix = 80;                // bytes per patch pixel: 32 bf16 + 16 B pad
+
+struct PatchGeoB {
+    int n_oh, PR, PC, RS, plane, img_row, n_img, n_pix, tiles_per_image, n_tiles, rt1_off;
+};
+
+__global__ __launch_bounds__(512, 2) void k_conv_gemm_f4b(ConvGemmParams p, PatchGeoB g, const uint4* __restrict__ wfrag) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const patch0 = smem;                                                       // [2 parity][PR][RS]
+    char* const patch1 = smem + 2 * g.plane;
+    const int img_pl = (g.n_img + 8) & ~7;
+    uint16_t* const img_stage = reinterpret_cast<uint16_t*>(smem + 4 * g.plane);     // [2][2 PR + 1][img_row] bf16
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_blk = blockIdx.y * 64;
+    const float rcp_tpi = 1.0f / (float)g.tiles_per_image;
+    const int px = lane & 31, kh2 = lane >> 5;
+
+    if (wave >= 4) {
+        // ================================================================ producers
+        const int ptid = tid - 256, pw = wave - 4;
+        bf16x8 w1f;                                                  // layer-1 weights as an MFMA fragment (k <-> window dwords: k_conv_gemm_f4s)
+        {
+            uint32_t d4[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const int tap0 = d < 3 ? (kh2 ? 3 * d + 2 : 3 * d) : -1, tap1 = (d < 3 && !kh2) ? 3 * d + 1 : -1;
+                const float v0 = tap0 >= 0 ? p.w1[tap0 * p.C_in + px] : 0.0f, v1 = tap1 >= 0 ? p.w1[tap1 * p.C_in + px] : 0.0f;
+                const amph_bf16x2 pk = {(__bf16)v0, (__bf16)v1};
+                d4[d] = __builtin_bit_cast(uint32_t, pk);
+            }
+            w1f = __builtin_bit_cast(bf16x8, make_uint4(d4[0], d4[1], d4[2], d4[3]));
+        }
+        float4 sc1[4], sh1[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            sc1[q] = *reinterpret_cast<const float4*>(p.scale1 + 8 * q + 4 * kh2);
+            sh1[q] = *reinterpret_cast<const float4*>(p.shift1 + 8 * q + 4 * kh2);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // (see k_conv_gemm_f4s: keeps these loads out of the tile loop's wait counts)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            asm volatile("v_mov_b32 %0, %0\n\tv_mov_b32 %1, %1\n\tv_mov_b32 %2, %2\n\tv_mov_b32 %3, %3" : "+v"(sc1[q].x), "+v"(sc1[q].y), "+v"(sc1[q].z), "+v"(sc1[q].w));
+            asm volatile("v_mov_b32 %0, %0\n\tv_mov_b32 %1, %1\n\tv_mov_b32 %2, %2\n\tv_mov_b32 %3, %3" : "+v"(sh1[q].x), "+v"(sh1[q].y), "+v"(sh1[q].z), "+v"(sh1[q].w));
+        }
+        int it_src[kPGroupU], it_dst[kPGroupU];
+        unsigned it_live = 0, it_pad_always = 0, it_pad_top = 0;
+        {
+            const float rcp_pc = 1.0f / (float)g.PC;
+            const int ppg = (g.n_pix + 11) / 12;
+#pragma unroll
+            for (int u = 0; u < kPGroupU; ++u) {
+                const int pix = (pw + 4 * u) * ppg + px;
+                const bool live = px < ppg && pix < g.n_pix;
+                const int pc = live ? pix : 0;
+                const int yl = f4_div_small(pc, g.PC, rcp_pc), xi = pc - yl * g.PC;
+                it_src[u] = 2 * (2 * yl * g.img_row + 2 * xi + 2 * kh2);
+                it_dst[u] = (xi & 1) * g.plane + yl * g.RS + (xi >> 1) * kBPix + 8 * kh2;
+                if (live) it_live |= 1u << u;
+                if (xi == 0) it_pad_always |= 1u << u;
+                if (yl == 0) it_pad_top |= 1u << u;
+            }
+        }
+        int io_r[kPImgU], io_off[kPImgU], io_w[kPImgU];
+        {
+            const float rcp_ir = 1.0f / (float)g.img_row;
+#pragma unroll
+            for (int u = 0; u < kPImgU; ++u) {
+                const int e = ptid + 256 * u;
+                const int r = f4_div_small(e, g.img_row, rcp_ir), ic = e - r * g.img_row - 3;
+                io_r[u] = r;
+                io_off[u] = (e < g.n_img && ic >= 0 && ic < p.W0) ? r * p.W0 + ic : -1;
+                io_w[u] = e < g.n_img ? e : g.n_img;
+            }
+        }
+        float pf[kPImgU];
+#define AMPH_F4B_FETCH_IMG(tile_)                                                          \
+        {                                                                                  \
+            const int t_ = (tile_);                                                        \
+            const int b_ = f4_div_small(t_, g.tiles_per_image, rcp_tpi), tr_ = t_ - b_ * g.tiles_per_image; \
+            const int ir0_ = 4 * tr_ * g.n_oh - 3;                                         \
+            const float* img_ = p.img + ((long long)b_ * p.H0 + ir0_) * p.W0;              \
+            _Pragma("unroll") for (int u = 0; u < kPImgU; ++u)                             \
+                pf[u] = *((io_off[u] >= 0 && (unsigned)(ir0_ + io_r[u]) < (unsigned)p.H0) ? img_ + io_off[u] : p.zeros); \
+        }
+#define AMPH_F4B_WRITE_IMG(dst_)                                                           \
+        {                                                                                  \
+            _Pragma("unroll") for (int k = 0; k < kPImgU / 2; ++k) {                       \
+                const amph_bf16x2 pk_ = {(__bf16)pf[2 * k], (__bf16)pf[2 * k + 1]};        \
+                const uint32_t w_ = __builtin_bit_cast(uint32_t, pk_);                     \
+                (dst_)[io_w[2 * k]] = (uint16_t)w_; (dst_)[io_w[2 * k + 1]] = (uint16_t)(w_ >> 16); \
+            }                                                                              \
+        }
+        int tile = blockIdx.x;
+        AMPH_F4B_FETCH_IMG(tile)
+        AMPH_F4B_WRITE_IMG(img_stage)
+        __syncthreads();                                             // A
+        for (int i = 0; tile < g.n_tiles; tile += gridDim.x, ++i) {
+            const int nt = tile + (int)gridDim.x;
+            AMPH_F4B_FETCH_IMG(nt < g.n_tiles ? nt : tile)
+            const char* sbuf = reinterpret_cast<const char*>(img_stage + (i & 1) * img_pl);
+            char* patch = (i & 1) ? patch1 : patch0;
+            const int tr = tile - f4_div_small(tile, g.tiles_per_image, rcp_tpi) * g.tiles_per_image;
+            const unsigned it_pad = it_pad_always | (tr == 0 ? it_pad_top : 0u);
+            uint32_t xw[kPGroupU][3];
+#pragma unroll
+            for (int u = 0; u < kPGroupU; ++u)
+#pragma unroll
+                for (int r = 0; r < 3; ++r) xw[u][r] = *reinterpret_cast<const uint32_t*>(sbuf + it_src[u] + 2 * r * g.img_row);
+            f32x16 acc[kPGroupU];
+#pragma unroll
+            for (int u = 0; u < kPGroupU; ++u) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[u][r] = 0.0f;
+                acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1f, __builtin_bit_cast(bf16x8, make_uint4(xw[u][0], xw[u][1], xw[u][2], 0u)), acc[u], 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < kPGroupU; ++u) {
+                const float cap = ((it_pad >> u) & 1u) ? 0.0f : __builtin_inff();
+                uint32_t o[8];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float a0 = __builtin_amdgcn_fmed3f(fmaf(acc[u][4 * q], sc1[q].x, sh1[q].x), 0.0f, cap);
+                    const float a1 = __builtin_amdgcn_fmed3f(fmaf(acc[u][4 * q + 1], sc1[q].y, sh1[q].y), 0.0f, cap);
+                    const float a2 = __builtin_amdgcn_fmed3f(fmaf(acc[u][4 * q + 2], sc1[q].z, sh1[q].z), 0.0f, cap);
+                    const float a3 = __builtin_amdgcn_fmed3f(fmaf(acc[u][4 * q + 3], sc1[q].w, sh1[q].w), 0.0f, cap);
+                    const amph_bf16x2 p0 = {(__bf16)a0, (__bf16)a1}, p1 = {(__bf16)a2, (__bf16)a3};
+                    o[2 * q] = __builtin_bit_cast(uint32_t, p0); o[2 * q + 1] = __builtin_bit_cast(uint32_t, p1);
+                }
+                if ((it_live >> u) & 1u) {
+                    char* dst = patch + it_dst[u];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2*>(dst + 16 * q) = make_uint2(o[2 * q], o[2 * q + 1]);
+                }
+            }
+            AMPH_F4B_WRITE_IMG(img_stage + ((i + 1) & 1) * img_pl)
+            __syncthreads();                                         // X: patch i complete (the consumers are done with patch i - 1)
+        }
+        __syncthreads();                                             // the consumers' last X
+#undef AMPH_F4B_FETCH_IMG
+#undef AMPH_F4B_WRITE_IMG
+        return;
+    }
+
+    // ==================================================================== consumers: (row tile, channel tile), all of K
+    const int rt = wave >> 1, ct = wave & 1;
+    uint4 breg[18];
+    {
+        const uint4* wf = wfrag + ((size_t)blockIdx.y * 2 + ct) * 18 * 64 + lane;
+#pragma unroll
+        for (int f = 0; f < 18; ++f) breg[f] = wf[f * 64];
+    }
+    const int m_local = rt * 32 + px;
+    const int ohl = m_local / p.OW, ow = m_local - ohl * p.OW;
+    const int a_base = ohl * 2 * g.RS + ow * kBPix + 16 * kh2;
+    float4 e_sc[4], e_sh[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int nb = n_blk + ct * 32 + 4 * kh2 + 8 * q;
+        e_sc[q] = *reinterpret_cast<const float4*>(nb < p.N ? p.scale + nb : p.zeros);
+        e_sh[q] = *reinterpret_cast<const float4*>(nb < p.N ? p.shift + nb : p.zeros);
+    }
+    __syncthreads();                                                 // A
+    __syncthreads();                                                 // X: the first patch is complete
+    int i = 0;
+    for (int tile = blockIdx.x; tile < g.n_tiles; tile += gridDim.x, ++i) {
+        const char* pb = ((i & 1) ? patch1 : patch0) + a_base;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        bf16x8 xf[18];
+#pragma unroll
+        for (int s_ = 0; s_ < 18; ++s_) {
+            const int tap = s_ >> 1, kh = tap / 3, kw = tap - 3 * kh;
+            xf[s_] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(pb + (kw & 1) * g.plane + kh * g.RS + (kw >> 1) * kBPix + 32 * (s_ & 1)));
+        }
+#pragma unroll
+        for (int s_ = 0; s_ < 18; ++s_) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, breg[s_]), xf[s_], acc, 0, 0, 0);
+        {
+            const int m = tile * 64 + m_local;
+            if (m < p.M) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n0 = n_blk + ct * 32 + 8 * q + 4 * kh2;
+                    if (n0 < p.N) {
+                        const float v0 = fmaxf(fmaf(acc[4 * q], e_sc[q].x, e_sh[q].x), 0.0f), v1 = fmaxf(fmaf(acc[4 * q + 1], e_sc[q].y, e_sh[q].y), 0.0f);
+                        const float v2 = fmaxf(fmaf(acc[4 * q + 2], e_sc[q].z, e_sh[q].z), 0.0f), v3 = fmaxf(fmaf(acc[4 * q + 3], e_sc[q].w, e_sh[q].w), 0.0f);
+                        const amph_bf16x2 lo_ = {(__bf16)v0, (__bf16)v1}, hi_ = {(__bf16)v2, (__bf16)v3};
+                        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.y) + (long long)m * p.N + n0) =
+                            make_uint2(__builtin_bit_cast(uint32_t, lo_), __builtin_bit_cast(uint32_t, hi_));
+                    }
+                }
+            }
+        }
+        __syncthreads();                                             // X: patch i + 1 complete; patch i free
+    }
+}
+
+static PatchGeoB f4b_geo(const ConvGemmParams& p) {
+    PatchGeoB g{};
+    g.n_oh = 64 / p.OW;
+    g.PR = 2 * g.n_oh + 1;
+    g.PC = 2 * p.OW + 1;
+    g.RS = ((p.OW + 1) * kBPix + 127) & ~127;
+    g.plane = g.PR * g.RS + 64;
+    g.img_row = (2 * g.PC + 2) & ~1;
+    g.n_img = (2 * g.PR + 1) * g.img_row;
+    g.n_pix = g.PR * g.PC;
+    g.tiles_per_image = p.OH / g.n_oh;
+    g.n_tiles = p.M / 64;
+    g.rt1_off = (32 / p.OW) * 2 * g.RS;
+    return g;
+}
+static size_t f4b_lds(const PatchGeoB& g) { return (size_t)4 * g.plane + (size_t)2 * ((g.n_img + 8) & ~7) * sizeof(uint16_t); }
+
+// bf16 weights of the layer in MFMA fragment order: [n tile][channel tile][k-step][lane][8 bf16] (RNE)
+void conv_gemm_f4b_fragment_weights(const float* w, int n_pad, int K_pad, uint16_t* out) {
+    auto rne = [](float f) {
+        uint32_t u;
+        std::memcpy(&u, &f, 4);
+        if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
+        u += 0x7fffu + ((u >> 16) & 1u);
+        return (uint16_t)(u >> 16);
+    };
+    const int ksteps = K_pad / 16;
+    for (int nt = 0; nt < n_pad / 64; ++nt)
+        for (int ct = 0; ct < 2; ++ct)
+            for (int ks = 0; ks < ksteps; ++ks)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j)
+                        out[((((size_t)(nt * 2 + ct) * ksteps + ks) * 64) + lane) * 8 + j] =
+                            rne(w[(size_t)(nt * 64 + ct * 32 + (lane & 31)) * K_pad + 16 * ks + 8 * (lane >> 5) + j]);
+}
+
+// same shapes as k_conv_gemm_f4s; wfrag = conv_gemm_f4b_fragment_weights' output; y is bf16 NHWC
+void launch_conv_gemm_f4b(const ConvGemmParams& p, const void* wfrag, int wgs, hipStream_t s) {
+    static bool raised[64] = {false};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !raised[dev]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_gemm_f4b), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        raised[dev] = true;
+    }
+    const PatchGeoB g = f4b_geo(p);
+    if (wgs <= 0) wgs = std::max(1, std::min(g_num_cus / 2, (g.n_tiles + 7) / 8));          // as k_conv_gemm_f4s (bf16 bench: 128 workgroups 3.27 M, 256: 3.23 M)
+    const dim3 grid((unsigned)std::min(g.n_tiles, wgs), (unsigned)((p.N + 63) / 64), 1);
+    hipLaunchKernelGGL(k_conv_gemm_f4b, grid, dim3(512), f4b_lds(g), s, p, g, reinterpret_cast<const uint4*>(wfrag));
+}
+
+// ----------------------------------------------------------------------------
 // 3x3 stride-2 layers behind the fused pair with the WEIGHTS IN REGISTERS and the input image(s) of a tile resident in LDS ("g4"):
 // k_conv_gemm_f4s's consumer side as a whole kernel.  A 512-thread workgroup owns a slice of the output channels for all its tiles:
 // wave = (channel tile ct, K part kq) keeps its 9 k-steps x 3 terms of the split weights in 108 registers for the whole kernel, so the
@@ -556,14 +812,15 @@ struct G4Geo {
 
 // C_IN input channels; KW K parts x CT channel tiles of 32 = 8 waves; RT row tiles of 32 output pixels per tile; IM images per tile;
 // OWL = log2(output width); the input is (2 OW) x (2 OW) x C_IN per image
-template <int C_IN, int KW, int CT, int RT, int IM, int OWL>
+// TERMS = 3: fp32 NHWC input split in three bf16 terms, fp32 output; TERMS = 1 (bf16 encoder): bf16 NHWC input copied, bf16 weights, bf16 output
+template <int C_IN, int KW, int CT, int RT, int IM, int OWL, int TERMS>
 __global__ __launch_bounds__(512, 2) void k_conv_gemm_g4(ConvGemmParams p, G4Geo g, const uint4* __restrict__ wfrag) {
     constexpr int OW = 1 << OWL, W = 2 * OW, PR = W + 1, PC = W + 1;
     constexpr int KSTEPS = 9 * C_IN / 16, KPW = KSTEPS / KW;            // k-steps of 16 in all, per wave (9)
     constexpr int SPT = C_IN / 16;                                       // k-steps per tap
     constexpr int TERM_B = 2 * C_IN;
-    constexpr int CQ = C_IN / 4;                                         // float4 per input pixel
-    constexpr int NV = IM * W * W * CQ / 512;                            // float4 per thread and tile (8)
+    constexpr int CQ = TERMS == 3 ? C_IN / 4 : C_IN / 8;                 // 16-byte units per input pixel: float4 (fp32) / 8 bf16
+    constexpr int NV = IM * W * W * CQ / 512;                            // units per thread and tile (8 / 4)
     constexpr int RPO = 16 / KW;                                         // accumulator registers per owner and row tile
     static_assert(KW * CT == 8 && KPW == 9 && RT * 32 == IM * OW * OW && NV * 512 == IM * W * W * CQ, "shape");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -579,11 +836,11 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_g4(ConvGemmParams p, G4Geo
     const int px = lane & 31, kh2 = lane >> 5;
     // ---- this wave's weights: k-steps 9 kq .. 9 kq + 8 of channel tile (64-wide n tile, half) in fragment order
     const int n_tile = CT == 2 ? blockIdx.y : (blockIdx.y >> 1), half = CT == 2 ? ct : (blockIdx.y & 1);
-    uint4 breg[27];
+    uint4 breg[9 * TERMS];
     {
-        const uint4* wf = wfrag + (((size_t)n_tile * 2 + half) * KSTEPS + KPW * kq) * (3 * 64) + lane;
+        const uint4* wf = wfrag + (((size_t)n_tile * 2 + half) * KSTEPS + KPW * kq) * (TERMS * 64) + lane;
 #pragma unroll
-        for (int f = 0; f < 27; ++f) breg[f] = wf[f * 64];
+        for (int f = 0; f < 9 * TERMS; ++f) breg[f] = wf[f * 64];
     }
     int aoff[9];                                                         // patch offset of k-step 9 kq + i: tap, channel group
 #pragma unroll
@@ -607,7 +864,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_g4(ConvGemmParams p, G4Geo
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
         const int i = tid + 512 * u, c4 = i % CQ, pix = i / CQ, im = pix / (W * W), y = (pix / W) % W, x = pix % W;
-        in_dst[u] = im * g.IMG_B + (y + 1) * g.RS + ((x + 1) & 1) * g.PL + ((x + 1) >> 1) * g.PXB + 8 * c4;
+        in_dst[u] = im * g.IMG_B + (y + 1) * g.RS + ((x + 1) & 1) * g.PL + ((x + 1) >> 1) * g.PXB + (TERMS == 3 ? 8 : 16) * c4;
     }
     float4 v[NV];
     const int n_v_total = (p.M >> (2 * OWL)) * (W * W * CQ);             // float4 of all the batch's images (a last tile may be short of images)
@@ -622,7 +879,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_g4(ConvGemmParams p, G4Geo
     if (tile < g.n_tiles) AMPH_G4_FETCH(tile)
     // zero padding of the patch (row 0 and column 0 of every image): written once, never overwritten
     {
-        constexpr int CH = 3 * TERM_B / 16, NPAD = IM * (PC + PR - 1) * CH;
+        constexpr int CH = TERMS * TERM_B / 16, NPAD = IM * (PC + PR - 1) * CH;
         for (int i = tid; i < NPAD; i += 512) {
             const int j = i / CH, ch = i - j * CH, im = j / (PC + PR - 1), jj = j - im * (PC + PR - 1);
             const int row = jj < PC ? 0 : jj - PC + 1, xi = jj < PC ? jj : 0;
@@ -636,9 +893,12 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_g4(ConvGemmParams p, G4Geo
     q_start = q_a - q_t0;
 #endif
     for (; tile < g.n_tiles; tile += gridDim.x) {
-        // ---- (1) the tile's input, split, into the patch: stage by stage over the 2 NV pairs of this thread
+        // ---- (1) the tile's input into the patch: split, stage by stage over the 2 NV pairs of this thread (bf16 input: copied)
         AMPH_F4_T(q_a)
-        {
+        if (TERMS == 1) {
+#pragma unroll
+            for (int u = 0; u < NV; ++u) *reinterpret_cast<float4*>(patch + in_dst[u]) = v[u];
+        } else {
             float x_[4 * NV], r_[4 * NV];
             uint32_t h_[2 * NV], m_[2 * NV], l_[2 * NV];
 #pragma unroll
@@ -683,13 +943,13 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_g4(ConvGemmParams p, G4Geo
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 #define AMPH_G4_FR(ptr_) __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ptr_))
-        bf16x8 fc[RT][3], fn[RT][3];
+        bf16x8 fc[RT][TERMS], fn[RT][TERMS];
         {
             const char* pa = patch + a_base + aoff[0];
 #pragma unroll
             for (int t = 0; t < RT; ++t)
 #pragma unroll
-                for (int q = 0; q < 3; ++q) fc[t][q] = AMPH_G4_FR(pa + t * rt1_off + q * TERM_B);
+                for (int q = 0; q < TERMS; ++q) fc[t][q] = AMPH_G4_FR(pa + t * rt1_off + q * TERM_B);
         }
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
@@ -698,19 +958,20 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_g4(ConvGemmParams p, G4Geo
 #pragma unroll
                 for (int t = 0; t < RT; ++t)
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) fn[t][q] = AMPH_G4_FR(pa + t * rt1_off + q * TERM_B);
+                    for (int q = 0; q < TERMS; ++q) fn[t][q] = AMPH_G4_FR(pa + t * rt1_off + q * TERM_B);
             }
-            const bf16x8 wh = __builtin_bit_cast(bf16x8, breg[3 * i]), wm = __builtin_bit_cast(bf16x8, breg[3 * i + 1]),
-                         wl = __builtin_bit_cast(bf16x8, breg[3 * i + 2]);
+            const bf16x8 wh = __builtin_bit_cast(bf16x8, breg[TERMS * i]), wm = __builtin_bit_cast(bf16x8, breg[TERMS * i + (TERMS == 3 ? 1 : 0)]),
+                         wl = __builtin_bit_cast(bf16x8, breg[TERMS * i + (TERMS == 3 ? 2 : 0)]);
 #define AMPH_G4_M(w_, q_)                                                                  \
             _Pragma("unroll") for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_, fc[t][q_], acc[t], 0, 0, 0);
-            AMPH_G4_M(wl, 0) AMPH_G4_M(wh, 2) AMPH_G4_M(wm, 1) AMPH_G4_M(wm, 0) AMPH_G4_M(wh, 1) AMPH_G4_M(wh, 0)
+            if (TERMS == 3) { AMPH_G4_M(wl, 0) AMPH_G4_M(wh, TERMS - 1) AMPH_G4_M(wm, TERMS / 2) AMPH_G4_M(wm, 0) AMPH_G4_M(wh, TERMS / 2) }
+            AMPH_G4_M(wh, 0)
 #undef AMPH_G4_M
             if (i < 8) {
 #pragma unroll
                 for (int t = 0; t < RT; ++t)
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) fc[t][q] = fn[t][q];
+                    for (int q = 0; q < TERMS; ++q) fc[t][q] = fn[t][q];
             }
         }
 #undef AMPH_G4_FR
@@ -756,7 +1017,12 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_g4(ConvGemmParams p, G4Geo
                 if (n0 < p.N && m < p.M) {
 #pragma unroll
                     for (int r = 0; r < RPO; ++r) sum[r] = fmaxf(fmaf(sum[r], e_sc[r], e_sh[r]), 0.0f);
-                    if (RPO == 4) *reinterpret_cast<float4*>(p.y + (long long)m * p.N + n0) = make_float4(sum[0], sum[1], sum[2 % RPO], sum[3 % RPO]);
+                    if (TERMS == 1) {                                  // bf16 NHWC
+                        uint16_t* yo = reinterpret_cast<uint16_t*>(p.y) + (long long)m * p.N + n0;
+                        const amph_bf16x2 lo_ = {(__bf16)sum[0], (__bf16)sum[1]}, hi_ = {(__bf16)sum[2 % RPO], (__bf16)sum[3 % RPO]};
+                        if (RPO == 4) *reinterpret_cast<uint2*>(yo) = make_uint2(__builtin_bit_cast(uint32_t, lo_), __builtin_bit_cast(uint32_t, hi_));
+                        else *reinterpret_cast<uint32_t*>(yo) = __builtin_bit_cast(uint32_t, lo_);
+                    } else if (RPO == 4) *reinterpret_cast<float4*>(p.y + (long long)m * p.N + n0) = make_float4(sum[0], sum[1], sum[2 % RPO], sum[3 % RPO]);
                     else *reinterpret_cast<float2*>(p.y + (long long)m * p.N + n0) = make_float2(sum[0], sum[1]);
                 }
             }
@@ -768,7 +1034,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_g4(ConvGemmParams p, G4Geo
         __syncthreads();                                                 // the inbox is read: the next tile's patch may be written
         // (the zero padding of the patch was overwritten by the inbox: restore it)
         {
-            constexpr int CH = 3 * TERM_B / 16, NPAD = IM * (PC + PR - 1) * CH;
+            constexpr int CH = TERMS * TERM_B / 16, NPAD = IM * (PC + PR - 1) * CH;
             for (int i = tid; i < NPAD; i += 512) {
                 const int j = i / CH, ch = i - j * CH, im = j / (PC + PR - 1), jj = j - im * (PC + PR - 1);
                 const int row = jj < PC ? 0 : jj - PC + 1, xi = jj < PC ? jj : 0;
@@ -786,11 +1052,11 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_g4(ConvGemmParams p, G4Geo
 #undef AMPH_G4_FETCH
 }
 
-template <int C_IN, int IM, int OWL>
+template <int C_IN, int IM, int OWL, int TERMS>
 static G4Geo g4_geo(const ConvGemmParams& p) {
     constexpr int OW = 1 << OWL, W = 2 * OW;
     G4Geo g{};
-    g.PXB = 6 * C_IN + 16;
+    g.PXB = TERMS * 2 * C_IN + 16;
     g.PL = (OW + 1) * g.PXB;
     // row stride / image stride: the 16 lanes of every ds_read_b128 group (lane -> image, output row, output column) on 16 different
     // 16-byte slots: searched, not derived (OW = 8: 2 RS = 128 mod 256; OW = 4: 2 RS = 64 mod 256 and whole 256-byte images)
@@ -820,41 +1086,46 @@ found:
 
 // 0: not covered; 3: conv3's shape (16 x 16 x 64 -> 8 x 8 x 128k); 4: conv4's (8 x 8 x 128 -> 4 x 4 x 64k)
 int conv_gemm_g4_kind(const ConvGemmParams& p) {
-    if (!(p.k == 3 && p.stride == 2 && p.pad == 1 && p.K == 9 * p.C_in && p.K_pad == p.K && p.splits == 1 && p.epilogue == 0 && !p.img && !p.y_bf16 && p.M > 0))
+    if (!(p.k == 3 && p.stride == 2 && p.pad == 1 && p.K == 9 * p.C_in && p.K_pad == p.K && p.splits == 1 && p.epilogue == 0 && !p.img && p.M > 0))
         return 0;
     if (p.C_in == 64 && p.OW == 8 && p.OH == 8 && p.W == 16 && p.H == 16 && (p.N % 64) == 0 && (p.M % 64) == 0) return 3;
     if (p.C_in == 128 && p.OW == 4 && p.OH == 4 && p.W == 8 && p.H == 8 && (p.N % 64) == 0 && (p.M % 16) == 0) return 4;
     return 0;
 }
 
-// wfrag = conv_gemm_f4s_fragment_weights' output for this layer
-void launch_conv_gemm_g4(const ConvGemmParams& p, const void* wfrag, int wgs, hipStream_t s) {
+// wfrag = conv_gemm_f4s_fragment_weights' (terms 3: fp32 in / out) or conv_gemm_f4b_fragment_weights' (terms 1: bf16 in / out) output of the layer
+template <int TERMS>
+static void launch_g4_t(const ConvGemmParams& p, const void* wfrag, int wgs, hipStream_t s) {
     static bool raised[64] = {false};
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev >= 0 && dev < 64 && !raised[dev]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_gemm_g4<64, 4, 2, 2, 1, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_gemm_g4<128, 8, 1, 1, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_gemm_g4<64, 4, 2, 2, 1, 3, TERMS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_gemm_g4<128, 8, 1, 1, 2, 2, TERMS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         raised[dev] = true;
     }
     const int kind = conv_gemm_g4_kind(p);
     // workgroups: four tiles each amortise the 221 KB of weights a workgroup loads (one per CU: 57 MB through L2 per launch), half the
     // CUs at most - the other lanes' kernels fill the rest (tools/sweep.py patch_gemm_wgs=...: 64..128 workgroups 2.48 M chunks/s, 256: 2.47 M)
     if (kind == 3) {
-        const G4Geo g = g4_geo<64, 1, 3>(p);
+        const G4Geo g = g4_geo<64, 1, 3, TERMS>(p);
         const int ny = p.N / 64;
         if (wgs <= 0) wgs = std::min(g_num_cus / 2, (g.n_tiles * ny + 3) / 4);
         const int per = std::max(1, wgs / ny);
-        hipLaunchKernelGGL((k_conv_gemm_g4<64, 4, 2, 2, 1, 3>), dim3((unsigned)std::min(g.n_tiles, per), (unsigned)ny), dim3(512), (size_t)g.patch_bytes, s, p, g,
+        hipLaunchKernelGGL((k_conv_gemm_g4<64, 4, 2, 2, 1, 3, TERMS>), dim3((unsigned)std::min(g.n_tiles, per), (unsigned)ny), dim3(512), (size_t)std::max(g.patch_bytes, 64 * 1024), s, p, g,
                            reinterpret_cast<const uint4*>(wfrag));
     } else if (kind == 4) {
-        const G4Geo g = g4_geo<128, 2, 2>(p);
+        const G4Geo g = g4_geo<128, 2, 2, TERMS>(p);
         const int ny = p.N / 32;
         if (wgs <= 0) wgs = std::min(g_num_cus / 2, (g.n_tiles * ny + 3) / 4);
         const int per = std::max(1, wgs / ny);
-        hipLaunchKernelGGL((k_conv_gemm_g4<128, 8, 1, 1, 2, 2>), dim3((unsigned)std::min(g.n_tiles, per), (unsigned)ny), dim3(512), (size_t)g.patch_bytes, s, p, g,
+        hipLaunchKernelGGL((k_conv_gemm_g4<128, 8, 1, 1, 2, 2, TERMS>), dim3((unsigned)std::min(g.n_tiles, per), (unsigned)ny), dim3(512), (size_t)std::max(g.patch_bytes, 32 * 1024), s, p, g,
                            reinterpret_cast<const uint4*>(wfrag));
     }
+}
+void launch_conv_gemm_g4(const ConvGemmParams& p, const void* wfrag, int wgs, int terms, hipStream_t s) {
+    if (terms == 1) launch_g4_t<1>(p, wfrag, wgs, s);
+    else launch_g4_t<3>(p, wfrag, wgs, s);
 }
 
 }  // namespace amph

@@ -122,6 +122,10 @@ const char* amph_last_error(const amph_ctx* ctx);   /* ctx may be NULL: create-t
  *                            image(s) are split once into an LDS patch, no barrier in the multiply loop.  Default 1 (conv4 in that form
  *                            is faster alone and slower beside the other lanes' kernels); other shapes use k_conv_gemm_s3.  Same 1e-6
  *                            agreement with the fp32 encoder; last bits differ (K is summed in 4 / 8 parts)
+ *   "patch_gemm_bf16"  0..3  the same two bits for the bf16 encoder ("bf16_encoder" 1): bf16 activations copied into the patch, bf16 weights
+ *                            in 36 registers, one MFMA per k-step (default 3)
+ *   "bf16_pair"        0/1   bf16 encoder: conv1 + conv2 in bf16 proper (k_conv_gemm_f4b: image, weights and the layer-1 activation
+ *                            rounded to bf16, fp32 accumulate / BN; default 1) instead of the fp32-accurate pair with a bf16 epilogue
  *   "patch_gemm_wgs"   0..   workgroups of that kernel (0 = four tiles each, at most half the CUs; results do not depend on it)
  *   "patch_wgs"        0..   persistent workgroups of the "patch_fused" kernel (0 = eight tiles each, at most half the CUs; results do
  *                            not depend on it)
