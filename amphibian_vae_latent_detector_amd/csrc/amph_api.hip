@@ -84,6 +84,11 @@ struct amph_ctx {
     int stft_waves = 4;                    // waves per STFT workgroup: 4 (two workgroups per CU) or 12 (one)
     float* d_tables = nullptr;             // packed LDS image of the STFT tables
     float2* d_tw_a = nullptr;              // stage-A twiddles (global memory)
+    float* d_pair_tables = nullptr;        // k_stft_pair: window pairs + stage-2 twiddles (packed LDS image); nullptr: configuration not covered
+    float2* d_pair_tw1 = nullptr;          // k_stft_pair: stage-1 twiddles (global memory)
+    bool stft_pair = true;                 // use k_stft_pair (two frames per wave as one complex FFT) where it applies
+    int stft_pair_waves = 10;              // its workgroup: 8, 10 or 12 waves (29 pairs of a 1 s row over 10 waves = 3 rounds)
+    bool stft_pair_tw_lds = true;          // its stage-1 twiddles in LDS when the image still fits
     int mel_w_floats = 0, mel_p_tail = 0;
     int32_t *d_mel_start = nullptr, *d_mel_len = nullptr, *d_mel_wofs = nullptr;
     float* d_mel_w = nullptr;
@@ -356,6 +361,33 @@ int build_frontend(amph_ctx* c) {
     HIP_TRY(c, upload(&c->d_mel_wofs, wo));
     c->mel_w_floats = (int)wv.size();
     HIP_TRY(c, upload(&c->d_mel_w, wv));
+    // k_stft_pair (n_fft 2048, hop 384): lane l reads samples 128 j' + 2 l + e and owns column col(l) = 2 (l & 31) + (l >> 5)
+    // of the first stage (tools/fft_pair_model.py)
+    if (stft_pair_ok(n_fft, f.hop_length, c->mel_p_tail)) {
+        std::vector<float> pt(stft_pair_table_bytes() / 4, 0.0f);
+        for (int j = 0; j < 16; ++j)
+            for (int l = 0; l < 64; ++l)
+                for (int e = 0; e < 2; ++e) {
+                    const int n = 128 * j + 2 * l + e;
+                    const float w = (float)(0.5 - 0.5 * std::cos(2.0 * PI * (double)n / (double)n_fft));
+                    pt[(size_t)(j * 64 + l) * 2 + e] = w * (1.0f / 32768.0f);      // x / 32768 * w == x * (w / 32768): exact scaling
+                }
+        float* tw2 = pt.data() + 16 * 64 * 2;
+        for (int mm = 0; mm < 32; ++mm) {
+            const double a = -2.0 * PI * (double)mm / 64.0;
+            tw2[2 * mm] = 1.0f; tw2[2 * mm + 1] = 0.0f;
+            tw2[2 * (32 + mm)] = (float)std::cos(a); tw2[2 * (32 + mm) + 1] = (float)std::sin(a);
+        }
+        std::vector<float2> tw1(31 * 64);
+        for (int k1 = 1; k1 < 32; ++k1)
+            for (int l = 0; l < 64; ++l) {
+                const int col = 2 * (l & 31) + (l >> 5);
+                const double a = -2.0 * PI * (double)((col * k1) % n_fft) / (double)n_fft;
+                tw1[(size_t)(k1 - 1) * 64 + l] = make_float2((float)std::cos(a), (float)std::sin(a));
+            }
+        HIP_TRY(c, upload(&c->d_pair_tables, pt));
+        HIP_TRY(c, upload(&c->d_pair_tw1, tw1));
+    }
     return AMPH_OK;
 }
 
@@ -835,6 +867,12 @@ StftParams make_stft(amph_ctx* c, const WaveSrc& src, float* melpow, float* db_o
     p.tables = c->d_tables; p.tw_a = c->d_tw_a; p.mel_w_floats = c->mel_w_floats; p.p_tail = c->mel_p_tail;
     p.n_mels = c->cfg.n_mels; p.mel_start = c->d_mel_start; p.mel_len = c->d_mel_len; p.mel_wofs = c->d_mel_wofs;
     p.mel_w = c->d_mel_w; p.melpow = melpow;
+    // the pair kernel where it applies (launch_stft_mel checks the source rows); with the fused dB stage its LDS image must fit
+    if (c->stft_pair && c->d_pair_tables &&
+        stft_pair_lds_bytes(c->n_frames, c->cfg.n_mels, c->mel_w_floats, c->stft_pair_waves, db_out != nullptr) <= 160 * 1024) {
+        p.pair_tables = c->d_pair_tables; p.pair_tw1 = c->d_pair_tw1; p.pair_waves = c->stft_pair_waves;
+        p.pair_tw_lds = c->stft_pair_tw_lds ? 1 : 0;
+    }
 #ifdef AMPH_STAMPS
     if (!c->d_stamps) (void)hipMalloc((void**)&c->d_stamps, (size_t)c->max_batch * 64 * 16 * 8);
     p.stamps = c->d_stamps;
@@ -1015,6 +1053,12 @@ int amph_create(const amph_frontend_config* cfg, const amph_encoder_spec* spec, 
             for (int nw : {4, 12})                  // the fused dB stage keeps a row's mel power in LDS too
                 if (stft_mel_can_fuse_db(c->cfg.n_fft, c->n_frames, c->cfg.n_mels, c->mel_w_floats, nw))
                     lds = std::max(lds, (int)stft_mel_fused_lds_bytes(c->cfg.n_fft, c->n_frames, c->cfg.n_mels, c->mel_w_floats, nw));
+            if (c->d_pair_tables)
+                for (int fused = 0; fused < 2; ++fused) {
+                    size_t lp = stft_pair_lds_bytes(c->n_frames, c->cfg.n_mels, c->mel_w_floats, c->stft_pair_waves, fused != 0);
+                    if (lp + stft_pair_tw1_lds_bytes() <= 160 * 1024) lp += stft_pair_tw1_lds_bytes();
+                    if (lp <= 160 * 1024) lds = std::max(lds, (int)lp);
+                }
             rc = amph::stft_mel_configure(lds) == hipSuccess ? AMPH_OK : fail(c, AMPH_ERR_HIP, "hipFuncSetAttribute failed");
         }
     }
@@ -1032,7 +1076,7 @@ void amph_destroy(amph_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     auto fr = [](void* p) { if (p) (void)hipFree(p); };
-    fr(c->d_tables); fr(c->d_tw_a);
+    fr(c->d_tables); fr(c->d_tw_a); fr(c->d_pair_tables); fr(c->d_pair_tw1);
     fr(c->d_mel_start); fr(c->d_mel_len); fr(c->d_mel_wofs); fr(c->d_mel_w);
     fr(c->d_first_w); fr(c->d_first_scale); fr(c->d_first_shift);
     for (auto& g : c->gemm) { fr(g.d_w); fr(g.d_w_s3); fr(g.d_w_f4); fr(g.d_w_f4b); fr(g.d_w_bf16); fr(g.d_scale); fr(g.d_shift); }
@@ -1065,6 +1109,22 @@ int amph_configure(amph_ctx* c, const char* key, int value) {
     if (!std::strcmp(key, "stft_prenorm")) { c->stft_prenorm = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "stft_prepad")) { c->stft_prepad = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "stft_fuse_db")) { c->stft_fuse_db = value != 0; return AMPH_OK; }
+    if (!std::strcmp(key, "stft_pair")) { c->stft_pair = value != 0; return AMPH_OK; }
+    if (!std::strcmp(key, "stft_pair_tw_lds")) { c->stft_pair_tw_lds = value != 0; return AMPH_OK; }
+    if (!std::strcmp(key, "stft_pair_waves")) {
+        if (value != 8 && value != 10 && value != 12) return fail(c, AMPH_ERR_INVALID_ARG, "stft_pair_waves must be 8, 10 or 12");
+        if (c->d_pair_tables) {
+            const size_t lds = stft_pair_lds_bytes(c->n_frames, c->cfg.n_mels, c->mel_w_floats, value, false);
+            if (lds > 160 * 1024) return fail(c, AMPH_ERR_UNSUPPORTED, "stft_pair_waves=%d needs %zu bytes of LDS", value, lds);
+            size_t need = lds;
+            const size_t lf = stft_pair_lds_bytes(c->n_frames, c->cfg.n_mels, c->mel_w_floats, value, true);
+            if (lf <= 160 * 1024) need = lf;
+            if (need + stft_pair_tw1_lds_bytes() <= 160 * 1024) need += stft_pair_tw1_lds_bytes();
+            if (amph::stft_mel_configure((int)need) != hipSuccess) return fail(c, AMPH_ERR_HIP, "hipFuncSetAttribute failed");
+        }
+        c->stft_pair_waves = value;
+        return AMPH_OK;
+    }
     if (!std::strcmp(key, "split_gemm")) { c->split_gemm = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "split_fused")) { c->split_fused = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "head_fold")) { c->head_fold = value != 0; return AMPH_OK; }
@@ -1275,6 +1335,28 @@ int amph_mel_f32(amph_ctx* c, const float* d_wave, int n_rows, int n_in, const i
         if (rc != AMPH_OK) return rc;
     }
     return check_launch(c, "mel_f32");
+}
+
+int amph_mel_pcm16(amph_ctx* c, const int16_t* d_pcm, int n_rows, int n_in, const int32_t* d_lengths, int apply_rms, int layout,
+                   float* d_mel_out, float* d_melpow_out, void* stream) {
+    if (!c) return AMPH_ERR_INVALID_ARG;
+    if (n_rows < 0 || n_in <= 0 || (layout != 0 && layout != 1) || (n_rows > 0 && (!d_pcm || (!d_mel_out && !d_melpow_out))))
+        return fail(c, AMPH_ERR_INVALID_ARG, "bad mel arguments");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    const size_t per = (size_t)c->cfg.target_frames * c->cfg.n_mels, per_pow = (size_t)c->n_frames * c->cfg.n_mels;
+    for (int off = 0; off < n_rows; off += c->max_batch) {
+        const int nb = std::min(c->max_batch, n_rows - off);
+        Workspace& w = c->lanes[0];
+        // the mel power is wanted: it has to reach memory, so the dB stage runs as its own kernel
+        const bool fdb = !d_melpow_out && can_fuse_db(c);
+        float* mp = d_melpow_out ? d_melpow_out + (size_t)off * per_pow : w.melpow;
+        int rc = run_frontend(c, w, d_pcm + (size_t)off * n_in, true, nb, n_in, d_lengths ? d_lengths + off : nullptr, apply_rms, nullptr, mp, s,
+                              fdb ? d_mel_out + (size_t)off * per : nullptr, layout);
+        if (rc == AMPH_OK && !fdb && d_mel_out) rc = run_dbnorm(c, mp, nb, layout, d_mel_out + (size_t)off * per, s);
+        if (rc != AMPH_OK) return rc;
+    }
+    return check_launch(c, "mel_pcm16");
 }
 
 int amph_encoder_forward(amph_ctx* c, const float* d_x, int n_rows, float* d_mu, float* d_logvar, void* stream) {

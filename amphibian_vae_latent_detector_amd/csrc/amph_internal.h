@@ -51,6 +51,11 @@ struct StftParams {
     // set the mel power of a row stays in LDS and the workgroup writes the standardised image itself (melpow is not written)
     float* db_out;           // nullable: [B][target][n_mels] (layout 1) or [B][n_mels][target] (layout 0)
     int db_layout, db_target_frames;
+    // k_stft_pair (two frames per wave as one complex FFT; nullptr: that kernel is not used)
+    const float* pair_tables;  // packed LDS image: window pairs [16][64][2] (x 2^-15) | stage-2 twiddles [2][32][2]
+    const float2* pair_tw1;    // [31][64] W_2048^(col(lane) k1), k1 = 1..31 (read from global memory)
+    int pair_waves;            // waves per workgroup of that kernel (8, 10 or 12)
+    int pair_tw_lds;           // keep pair_tw1 in LDS when the image still fits 160 KB
 #ifdef AMPH_STAMPS
     unsigned long long* stamps;   // diagnostic build: [grid][16] s_memtime stamps
 #endif
@@ -89,6 +94,11 @@ bool stft_mel_can_fuse_db(int n_fft, int n_frames, int n_mels, int mel_w_floats,
 int stft_mel_table_bytes(int n_fft);
 int stft_mel_scratch_floats(int n_fft);   // floats of per-frame scratch the power spectrum + tail may use
 hipError_t stft_mel_configure(int lds_bytes);   // raises the dynamic-LDS limit of the STFT kernels
+// the pair kernel (k_stft_pair): LDS image, packed table size, and the configurations it covers
+size_t stft_pair_lds_bytes(int n_frames, int n_mels, int mel_w_floats, int n_waves, bool fused);
+int stft_pair_table_bytes();
+size_t stft_pair_tw1_lds_bytes();
+bool stft_pair_ok(int n_fft, int hop, int p_tail);
 void launch_dbnorm(const DbNormParams& p, int n_rows, hipStream_t s);
 
 struct ResampleParams {      // resampy's resample_f for rows of equal length

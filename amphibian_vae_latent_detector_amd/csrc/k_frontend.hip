@@ -1356,6 +1356,365 @@ __global__ __launch_bounds__(64 * NW) void k_stft_mel_w(StftParams p, int n_tile
 #endif
 }
 
+// ----------------------------------------------------------------------------
+// K1/K2, third form ("pair", round 3): TWO consecutive frames a, b of a row as ONE complex 2048-point FFT of
+// z = w (a + i b) per wave, 32 complex points per lane.  tools/fft_pair_model.py is the numpy model of exactly this data
+// movement (written first).  Against k_stft_mel_w: half the table reads and all of the per-frame loop overhead per frame,
+// no twiddle in the real-FFT split (|A|^2, |B|^2 from Z[k], Z[N - k] are 8 operations per bin pair), a radix-2 instead of
+// a radix-4 cross-lane stage, twice the independent work per wave between two LDS round trips, ~900 instead of ~1300 VALU
+// instructions per frame.
+//   load     lane l, dword j' (0 .. 15 + HJ): samples 128 j' + 2 l + e of the K0-padded PCM16 row (coalesced 256-byte
+//            rows; hop = 128 HJ, so frame b's dword j' is frame a's dword j' + HJ); e = 0, 1 are two 16-point sequences:
+//            lanes < 32 hold the even-j halves of columns 2 l + e, lanes >= 32 the odd-j halves of columns 2 (l - 32) + e
+//   stage 1  dft16 per sequence, v_permlane32_swap so that every lane has both halves of ONE column col(l) = 2 (l & 31) +
+//            (l >> 5), radix-2 combine -> Y[k1], k1 = 0..31; twiddle W_2048^(col k1)
+//   exchange T[k1][col] floats (real parts, then imaginary parts: the tile is 8.5 KB per wave, not 17);
+//            lane 2 k1' + h reads T[k1'][32 h .. 32 h + 31] as eight 16-byte reads per pass
+//   stage 2  radix-2 DIF across the lane pair (DPP), twiddle W_64^mm on h = 1, DFT32 in registers:
+//            X[k1' + 32 h + 64 k2'], k2' = 0..31
+//   split    lane' = k1' + 32 h owns bins lane' + 64 i (i < 16, in its registers); the partners N - k are the registers
+//            k2' >= 16 of lane' -> (64 - lane') & 63: only those go through LDS (17 x 80 floats per pass)
+//   power    4 |A|^2, 4 |B|^2 (the 1/4 is folded into the mel weights: exact) into two LDS rows; mel rows for both frames
+//            from one weight read
+// Only the hot configuration: PCM16 rows that K0 (or the pad kernel) has fix_length'd and centre padded, n_fft = 2048,
+// hop = 384; everything else takes k_stft_mel_w / k_stft_mel.
+// ----------------------------------------------------------------------------
+constexpr int kPairExS = 68;                        // exchange row stride in floats (= 4 mod 64: conflict-free 16-byte reads)
+constexpr int kPairScratch = 32 * kPairExS * 4;     // per-wave scratch: exchange tile, then partner tile, then the two power spectra
+constexpr int kPairPStride = kPairScratch / 8;      // floats between the two power spectra (1088 >= 1025 + tail)
+constexpr int kPairZS = 80;                         // partner tile row stride in floats (columns >= 32 shifted by 16 banks)
+constexpr int kPairWinBytes = 16 * 64 * 8, kPairTw2Bytes = 2 * 32 * 8, kPairTw1Bytes = 31 * 64 * 8;
+
+// Y[k + 16 p] = E[k] +- W32^k O[k]: e = DFT16 of the even inputs (X[k] at DFT16_POS(k)), o = of the odd ones, in place
+__device__ __forceinline__ void dft32_combine(float (&er)[16], float (&ei)[16], float (&orr)[16], float (&oi)[16]) {
+    constexpr float C[16] = {1.0f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f,
+                             0.70710678118654752440f, 0.55557023301960222474f, 0.38268343236508977173f, 0.19509032201612826785f,
+                             0.0f, -0.19509032201612826785f, -0.38268343236508977173f, -0.55557023301960222474f,
+                             -0.70710678118654752440f, -0.83146961230254523708f, -0.92387953251128675613f, -0.98078528040323044913f};
+    constexpr float S[16] = {0.0f, 0.19509032201612826785f, 0.38268343236508977173f, 0.55557023301960222474f,
+                             0.70710678118654752440f, 0.83146961230254523708f, 0.92387953251128675613f, 0.98078528040323044913f,
+                             1.0f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f,
+                             0.70710678118654752440f, 0.55557023301960222474f, 0.38268343236508977173f, 0.19509032201612826785f};
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        constexpr int dummy = 0; (void)dummy;
+        const int q = DFT16_POS(k);
+        float tr, ti;                               // W32^k o = (c - i s)(or + i oi)
+        if (k == 0) { tr = orr[q]; ti = oi[q]; }
+        else if (k == 8) { tr = oi[q]; ti = -orr[q]; }
+        else { tr = C[k] * orr[q] + S[k] * oi[q]; ti = C[k] * oi[q] - S[k] * orr[q]; }
+        const float ar = er[q], ai = ei[q];
+        er[q] = ar + tr; ei[q] = ai + ti;
+        orr[q] = ar - tr; oi[q] = ai - ti;
+    }
+}
+
+// TWL: the stage-1 twiddles (15.5 KB) live in LDS and are read where they are used; otherwise they are buffer loads issued a phase
+// ahead (62 registers in flight across the first DFTs: at three waves per SIMD the allocator spills)
+template <int NW, int HJ, bool TWL>
+__global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows) {
+    constexpr int kThreads = 64 * NW;
+    constexpr int ND = 16 + HJ;                         // dwords per lane and pair
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float2* win = reinterpret_cast<const float2*>(smem);                      // [16][64] (w[n], w[n + 1]) 2^-15
+    const float4* tw2 = reinterpret_cast<const float4*>(smem + kPairWinBytes);      // [2][16] twiddle pairs
+    const int meta_bytes = (p.n_mels * 12 + 15) & ~15;
+    const int melw_bytes = p.mel_w_floats * 4;
+    constexpr int kTab = kPairWinBytes + kPairTw2Bytes + (TWL ? kPairTw1Bytes : 0);
+    const float2* tw1_l = reinterpret_cast<const float2*>(smem + kPairWinBytes + kPairTw2Bytes) + lane;      // [31][64] (TWL)
+    int3* mel_meta = reinterpret_cast<int3*>(smem + kTab);
+    float* mel_w = reinterpret_cast<float*>(smem + kTab + meta_bytes);
+    char* wbase = smem + kTab + meta_bytes + melw_bytes + wave * kPairScratch;
+    float* T = reinterpret_cast<float*>(wbase);
+    float* Pa = T;
+    float* Pb = T + kPairPStride;
+    float* mp_row = reinterpret_cast<float*>(smem + kTab + meta_bytes + melw_bytes + NW * kPairScratch);
+    const bool fuse_db = p.db_out != nullptr;
+
+    // ---- once per workgroup: window pairs + stage-2 twiddles (one packed global array), mel rows (x 1/4: see above)
+    {
+        const float4* src = reinterpret_cast<const float4*>(p.pair_tables);
+        float4* dst = reinterpret_cast<float4*>(smem);
+        for (int i = tid; i < (kPairWinBytes + kPairTw2Bytes) / 16; i += kThreads) dst[i] = src[i];
+        if (TWL) {
+            const float4* s1 = reinterpret_cast<const float4*>(p.pair_tw1);
+            float4* d1 = reinterpret_cast<float4*>(smem + kPairWinBytes + kPairTw2Bytes);
+            for (int i = tid; i < kPairTw1Bytes / 16; i += kThreads) d1[i] = s1[i];
+        }
+        for (int m = tid; m < p.n_mels; m += kThreads) mel_meta[m] = make_int3(p.mel_start[m], p.mel_len[m], p.mel_wofs[m]);
+        const float4* wsrc = reinterpret_cast<const float4*>(p.mel_w);
+        float4* wdst = reinterpret_cast<float4*>(mel_w);
+        for (int i = tid; i < (p.mel_w_floats >> 2); i += kThreads) {
+            float4 v = wsrc[i];
+            v.x *= 0.25f; v.y *= 0.25f; v.z *= 0.25f; v.w *= 0.25f;
+            wdst[i] = v;
+        }
+    }
+    __syncthreads();
+
+    const int n_pairs = (p.n_frames + 1) >> 1;
+    const int col = 2 * (lane & 31) + (lane >> 5);          // stage-1 column of this lane
+    const int k1p = lane >> 1, h = lane & 1;                // stage-2 role
+    const int lanep = k1p + 32 * h;                         // bins lanep + 64 k2'
+    const int colp = (64 - lanep) & 63;                     // the lane' that holds the partners N - k
+    const int zw = lanep + ((lanep >> 5) << 4);             // partner tile column (write), bank-shifted
+    const int zr_ = colp + ((colp >> 5) << 4) + (lanep == 0 ? kPairZS : 0);   // (read; lane' 0: one row further, row 16 = Z[0])
+    const float sgn = h ? -1.0f : 1.0f;
+
+    // the next pair's raw dwords: requested before the mel rows of the current pair
+    uint32_t nx[ND];
+#pragma unroll
+    for (int j = 0; j < ND; ++j) nx[j] = 0;
+    // buffer loads (resource in SGPRs + a per-lane byte offset that never changes + a scalar offset): written as pointer arithmetic
+    // the 31 table rows and 19 sample rows each got their own 64-bit per-lane address, i.e. ~100 live VGPRs of addresses
+    const __amdgpu_buffer_rsrc_t rs_tw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(p.pair_tw1), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src.wave), 0, -1, 0x00020000);
+    const int lane4 = lane * 4, lane8 = lane * 8;
+    auto fetch = [&](int row_, int pr_) {
+        const int base = __builtin_amdgcn_readfirstlane((int)(((long long)row_ * p.src.row_stride) * 2 + (long long)pr_ * p.hop * 4));
+        const bool full = 2 * pr_ + 1 < p.n_frames;        // wave-uniform: the row's last pair may hold one frame only
+#pragma unroll
+        for (int j = 0; j < 16; ++j) nx[j] = __builtin_amdgcn_raw_buffer_load_b32(rs_x, lane4, base + 256 * j, 0);
+#pragma unroll
+        for (int j = 16; j < ND; ++j) nx[j] = full ? __builtin_amdgcn_raw_buffer_load_b32(rs_x, lane4, base + 256 * j, 0) : 0u;
+    };
+    if ((int)blockIdx.x < n_rows && wave < n_pairs) fetch(blockIdx.x, wave);
+
+    // The phases of a pair are fenced for the instruction scheduler (sched_barrier): left alone it builds ONE region of ~2 000
+    // instructions, runs out of registers and then serialises every table load behind its own wait (31 dependent L2 round
+    // trips for the stage-1 twiddles in the first build).  Inside a phase the loads are issued up front, by hand.
+#define AMPH_PHASE_FENCE() __builtin_amdgcn_sched_barrier(0)
+    for (int row = blockIdx.x; row < n_rows; row += gridDim.x) {
+        for (int pr = wave; pr < n_pairs; pr += NW) {
+            float xr[2][16], xi[2][16];
+            float2 tw[31];
+            // ---- stage-1 twiddles, first half: in flight under the decode and the first DFTs
+#pragma unroll
+            for (int k1 = 1; k1 < 16; ++k1) if (!TWL) tw[k1 - 1] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs_tw, lane8, (k1 - 1) * 512, 0));
+            AMPH_PHASE_FENCE();
+            // ---- decode + window: z = w (a + i b); sequence e = sample parity, m = j'
+            {
+                float2 wv[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) wv[j] = win[j * 64 + lane];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const uint32_t da = nx[j], db = nx[j + HJ];
+                    xr[0][j] = (float)(short)(da & 0xFFFFu) * wv[j].x;
+                    xr[1][j] = (float)((int)da >> 16) * wv[j].y;
+                    xi[0][j] = (float)(short)(db & 0xFFFFu) * wv[j].x;
+                    xi[1][j] = (float)((int)db >> 16) * wv[j].y;
+                }
+            }
+#pragma unroll
+            for (int k1 = 16; k1 < 32; ++k1) if (!TWL) tw[k1 - 1] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs_tw, lane8, (k1 - 1) * 512, 0));
+            AMPH_PHASE_FENCE();
+            // ---- stage 1: DFT32 down the lane's column
+            dft16(xr[0], xi[0]);
+            dft16(xr[1], xi[1]);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {                  // high lanes' sequence 0 <-> low lanes' sequence 1
+                const auto sr = __builtin_amdgcn_permlane32_swap(__float_as_uint(xr[0][q]), __float_as_uint(xr[1][q]), false, false);
+                const auto si = __builtin_amdgcn_permlane32_swap(__float_as_uint(xi[0][q]), __float_as_uint(xi[1][q]), false, false);
+                xr[0][q] = __uint_as_float(sr[0]); xr[1][q] = __uint_as_float(sr[1]);
+                xi[0][q] = __uint_as_float(si[0]); xi[1][q] = __uint_as_float(si[1]);
+            }
+            dft32_combine(xr[0], xi[0], xr[1], xi[1]);
+            AMPH_PHASE_FENCE();
+            if (TWL) {
+#pragma unroll
+                for (int k1 = 1; k1 < 16; ++k1) tw[k1 - 1] = tw1_l[(k1 - 1) * 64];
+            }
+#pragma unroll
+            for (int k1 = 1; k1 < 16; ++k1) {
+                const int q = DFT16_POS(k1 & 15);
+                AMPH_CMUL(xr[0][q], xi[0][q], tw[k1 - 1].x, tw[k1 - 1].y);
+            }
+            if (TWL) {
+                AMPH_PHASE_FENCE();
+#pragma unroll
+                for (int k1 = 16; k1 < 32; ++k1) tw[k1 - 1] = tw1_l[(k1 - 1) * 64];
+            }
+#pragma unroll
+            for (int k1 = 16; k1 < 32; ++k1) {
+                const int q = DFT16_POS(k1 & 15);
+                AMPH_CMUL(xr[1][q], xi[1][q], tw[k1 - 1].x, tw[k1 - 1].y);
+            }
+            // ---- exchange, real parts then imaginary parts.  LDS operations of a wave execute in order: the reads of the first
+            //      pass are queued behind its writes and in front of the second pass's writes, nothing waits in between
+            float ur[2][16], ui[2][16];
+#pragma unroll
+            for (int k1 = 0; k1 < 32; ++k1) T[k1 * kPairExS + col] = xr[k1 >> 4][DFT16_POS(k1 & 15)];
+            wave_lds_sync();
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float4 v = *reinterpret_cast<const float4*>(T + k1p * kPairExS + 32 * h + 4 * c);
+                ur[0][2 * c] = v.x; ur[1][2 * c] = v.y; ur[0][2 * c + 1] = v.z; ur[1][2 * c + 1] = v.w;
+            }
+            wave_lds_sync();
+#pragma unroll
+            for (int k1 = 0; k1 < 32; ++k1) T[k1 * kPairExS + col] = xi[k1 >> 4][DFT16_POS(k1 & 15)];
+            wave_lds_sync();
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float4 v = *reinterpret_cast<const float4*>(T + k1p * kPairExS + 32 * h + 4 * c);
+                ui[0][2 * c] = v.x; ui[1][2 * c] = v.y; ui[0][2 * c + 1] = v.z; ui[1][2 * c + 1] = v.w;
+            }
+            wave_lds_sync();
+            AMPH_PHASE_FENCE();
+            // ---- stage 2: radix-2 DIF across the lane pair, twiddle (h = 1: W_64^mm; requested eight pairs at a time: 32 registers),
+            //      DFT32
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                float4 t2[8];
+#pragma unroll
+                for (int m = 0; m < 8; ++m) t2[m] = tw2[h * 16 + 8 * half + m];
+#pragma unroll
+                for (int m8 = 0; m8 < 8; ++m8) {
+                    const int m = 8 * half + m8;
+#pragma unroll
+                    for (int pp = 0; pp < 2; ++pp) {
+                        float r = fmaf(ur[pp][m], sgn, dpp_xor1(ur[pp][m]));
+                        float i = fmaf(ui[pp][m], sgn, dpp_xor1(ui[pp][m]));
+                        if (m > 0 || pp > 0) {
+                            const float wr = pp ? t2[m8].z : t2[m8].x, wi = pp ? t2[m8].w : t2[m8].y;
+                            AMPH_CMUL(r, i, wr, wi);
+                        }
+                        ur[pp][m] = r; ui[pp][m] = i;
+                    }
+                }
+                AMPH_PHASE_FENCE();
+            }
+            dft16(ur[0], ui[0]);
+            dft16(ur[1], ui[1]);
+            dft32_combine(ur[0], ui[0], ur[1], ui[1]);
+            AMPH_PHASE_FENCE();
+            // ---- split: the partner values Z[N - k] come from the upper half (k2' >= 16) of lane' colp; both passes are queued
+            //      back to back like the exchange's
+            float pre[16], pim[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) T[r * kPairZS + zw] = ur[1][DFT16_POS(r)];
+            if (lanep == 0) T[16 * kPairZS] = ur[0][DFT16_POS(0)];
+            wave_lds_sync();
+#pragma unroll
+            for (int i = 0; i < 16; ++i) pre[i] = T[(15 - i) * kPairZS + zr_];
+            wave_lds_sync();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) T[r * kPairZS + zw] = ui[1][DFT16_POS(r)];
+            if (lanep == 0) T[16 * kPairZS] = ui[0][DFT16_POS(0)];
+            wave_lds_sync();
+#pragma unroll
+            for (int i = 0; i < 16; ++i) pim[i] = T[(15 - i) * kPairZS + zr_];
+            wave_lds_sync();
+            AMPH_PHASE_FENCE();
+            // ---- 4 |A[k]|^2, 4 |B[k]|^2: A = (Z[k] + conj Z[N-k]) / 2, B = (Z[k] - conj Z[N-k]) / 2i
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float zr = ur[0][DFT16_POS(i)], zi = ui[0][DFT16_POS(i)];
+                const float ar = zr + pre[i], ai = zi - pim[i], br = zi + pim[i], bi = pre[i] - zr;
+                Pa[lanep + 64 * i] = ar * ar + ai * ai;
+                Pb[lanep + 64 * i] = br * br + bi * bi;
+            }
+            if (lanep == 0) {                               // bin 1024 is its own partner
+                const float zr = ur[1][DFT16_POS(0)], zi = ui[1][DFT16_POS(0)];
+                Pa[1024] = 4.0f * zr * zr;
+                Pb[1024] = 4.0f * zi * zi;
+            }
+            for (int i = lane; i < p.p_tail; i += 64) { Pa[1025 + i] = 0.0f; Pb[1025 + i] = 0.0f; }   // the padded mel rows read there
+            wave_lds_sync();
+            AMPH_PHASE_FENCE();
+            // ---- this wave's next pair: its samples are requested now and land under the mel rows
+            {
+                int nrow = row, npr = pr + NW;
+                if (npr >= n_pairs) { nrow = row + gridDim.x; npr = wave; }
+                if (nrow < n_rows) fetch(nrow, npr);
+            }
+            AMPH_PHASE_FENCE();
+            // ---- mel rows of both frames: 4 lanes per filter, 4 bins per lane and step; one weight read serves both frames.
+            //      Four steps (twelve 16-byte reads) are requested at a time; even steps -> first accumulator, odd -> second,
+            //      as in k_stft_mel_w
+            {
+                const int q = lane & 3;
+                const int n_rounds = (p.n_mels + 15) >> 4;
+                const int fa = 2 * pr;
+                const bool has_b = fa + 1 < p.n_frames;     // wave-uniform
+                float* out_a = fuse_db ? mp_row + fa * p.n_mels : p.melpow + ((long long)row * p.n_frames + fa) * p.n_mels;
+                float* out_b = out_a + p.n_mels;
+                int3 mt = mel_meta[min(lane >> 2, p.n_mels - 1)];
+                for (int r = 0; r < n_rounds; ++r) {
+                    const int steps = __builtin_amdgcn_readfirstlane(mt.y);
+                    const float4* w = reinterpret_cast<const float4*>(mel_w + mt.z) + q;
+                    const float4* pa = reinterpret_cast<const float4*>(Pa + mt.x) + q;
+                    const float4* pb = reinterpret_cast<const float4*>(Pb + mt.x) + q;
+                    if (r + 1 < n_rounds) mt = mel_meta[min(16 * (r + 1) + (lane >> 2), p.n_mels - 1)];
+                    float a0 = 0.0f, a1 = 0.0f, b0 = 0.0f, b1 = 0.0f;
+#define AMPH_MEL_FMA(acc_, a_, b_)                                                         \
+    acc_ = fmaf(a_.x, b_.x, acc_); acc_ = fmaf(a_.y, b_.y, acc_); acc_ = fmaf(a_.z, b_.z, acc_); acc_ = fmaf(a_.w, b_.w, acc_);
+                    int i0 = 0;
+                    for (; i0 + 4 <= steps; i0 += 4) {
+                        float4 wq[4], xq[4], yq[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { wq[u] = w[4 * (i0 + u)]; xq[u] = pa[4 * (i0 + u)]; yq[u] = pb[4 * (i0 + u)]; }
+                        AMPH_MEL_FMA(a0, wq[0], xq[0]) AMPH_MEL_FMA(b0, wq[0], yq[0])
+                        AMPH_MEL_FMA(a1, wq[1], xq[1]) AMPH_MEL_FMA(b1, wq[1], yq[1])
+                        AMPH_MEL_FMA(a0, wq[2], xq[2]) AMPH_MEL_FMA(b0, wq[2], yq[2])
+                        AMPH_MEL_FMA(a1, wq[3], xq[3]) AMPH_MEL_FMA(b1, wq[3], yq[3])
+                    }
+                    if (i0 + 2 <= steps) {
+                        float4 wq[2], xq[2], yq[2];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) { wq[u] = w[4 * (i0 + u)]; xq[u] = pa[4 * (i0 + u)]; yq[u] = pb[4 * (i0 + u)]; }
+                        AMPH_MEL_FMA(a0, wq[0], xq[0]) AMPH_MEL_FMA(b0, wq[0], yq[0])
+                        AMPH_MEL_FMA(a1, wq[1], xq[1]) AMPH_MEL_FMA(b1, wq[1], yq[1])
+                        i0 += 2;
+                    }
+                    if (i0 < steps) {
+                        const float4 w0 = w[4 * i0], x0 = pa[4 * i0], y0 = pb[4 * i0];
+                        AMPH_MEL_FMA(a0, w0, x0) AMPH_MEL_FMA(b0, w0, y0)
+                    }
+#undef AMPH_MEL_FMA
+                    float sa = a0 + a1, sb = b0 + b1;
+                    sa += dpp_xor1(sa); sb += dpp_xor1(sb);
+                    sa += dpp_xor2(sa); sb += dpp_xor2(sb);
+                    const int m = 16 * r + (lane >> 2);
+                    if (q == 0 && m < p.n_mels) { out_a[m] = sa; if (has_b) out_b[m] = sb; }
+                }
+            }
+            wave_lds_sync();                                // the scratch is rewritten by the next pair
+            AMPH_PHASE_FENCE();
+        }
+#undef AMPH_PHASE_FENCE
+        // ---- fused dB stage on the row the workgroup holds (see k_stft_mel_w).  The LAST row (at batch 256: the only one) is
+        //      finished behind the loops: inlined here, the stage's per-thread index arithmetic is hoisted in front of the row loop
+        //      and sits in ~90 registers across the pair loop
+        if (fuse_db && row + (int)gridDim.x < n_rows) {
+            __syncthreads();
+            db_row_call<kThreads>(mp_row, p.n_frames, p.n_mels, p.db_target_frames, p.db_layout,
+                                  p.db_out + (long long)row * p.db_target_frames * p.n_mels,
+                                  reinterpret_cast<double*>(mp_row + ((p.n_frames * p.n_mels + 3) & ~3)));
+            __syncthreads();
+        }
+    }
+    if (fuse_db && (int)blockIdx.x < n_rows) {
+        const int last_row = blockIdx.x + (n_rows - 1 - (int)blockIdx.x) / (int)gridDim.x * (int)gridDim.x;
+        __syncthreads();
+        db_row_from_lds<kThreads>(mp_row, p.n_frames, p.n_mels, p.db_target_frames, p.db_layout,
+                                  p.db_out + (long long)last_row * p.db_target_frames * p.n_mels,
+                                  reinterpret_cast<double*>(mp_row + ((p.n_frames * p.n_mels + 3) & ~3)));
+    }
+}
+
+size_t stft_pair_lds_bytes(int n_frames, int n_mels, int mel_w_floats, int n_waves, bool fused) {
+    const size_t meta = ((size_t)n_mels * 12 + 15) & ~(size_t)15;
+    const size_t mp = fused ? (((size_t)n_frames * n_mels + 3) & ~(size_t)3) * 4 + 16 * 8 + 16 * 4 : 0;
+    return (size_t)kPairWinBytes + kPairTw2Bytes + meta + (size_t)mel_w_floats * 4 + (size_t)n_waves * kPairScratch + mp;
+}
+size_t stft_pair_tw1_lds_bytes() { return kPairTw1Bytes; }
+int stft_pair_table_bytes() { return kPairWinBytes + kPairTw2Bytes; }
+// the configurations the pair kernel covers (the caller also needs PCM16 rows padded by K0: src.lead == n_fft / 2)
+bool stft_pair_ok(int n_fft, int hop, int p_tail) { return n_fft == 2048 && hop == 384 && 1025 + p_tail <= kPairPStride; }
+
 static int table_bytes_for(int n_fft) { return n_fft == 2048 ? FftGeo<4>::TABLE_BYTES : FftGeo<2>::TABLE_BYTES; }
 
 int g_stft_indep = 1;    // 1: k_stft_mel_w (independent waves, no shared sample span); 0: the tile-synchronous kernel
@@ -1401,6 +1760,13 @@ hipError_t stft_mel_configure(int lds_bytes) {
         e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
     }
+    const void* pfns[6] = {reinterpret_cast<const void*>(&k_stft_pair<8, 3, false>), reinterpret_cast<const void*>(&k_stft_pair<10, 3, false>),
+                           reinterpret_cast<const void*>(&k_stft_pair<12, 3, false>), reinterpret_cast<const void*>(&k_stft_pair<8, 3, true>),
+                           reinterpret_cast<const void*>(&k_stft_pair<10, 3, true>), reinterpret_cast<const void*>(&k_stft_pair<12, 3, true>)};
+    for (const void* f : pfns) {
+        e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) return e;
+    }
     s_lds_max = lds_bytes;
     return hipSuccess;
 }
@@ -1437,6 +1803,24 @@ static void launch_stft_mel_nw(const StftParams& p, int n_tiles, int sample_is_p
 void launch_stft_mel(const StftParams& p, int n_rows, int sample_is_pcm16, int n_waves, hipStream_t s) {
     const int n_tiles = n_rows * p.tiles_per_row;
     if (n_tiles <= 0) return;
+    if (p.pair_tables && sample_is_pcm16 && p.src.lead == p.n_fft / 2 && stft_pair_ok(p.n_fft, p.hop, p.p_tail)) {
+        // one persistent workgroup per row (and CU): the row's pairs of frames go round-robin over its waves
+        const int nw = p.pair_waves;
+        size_t lds = stft_pair_lds_bytes(p.n_frames, p.n_mels, p.mel_w_floats, nw, p.db_out != nullptr);
+        const bool twl = p.pair_tw_lds && lds + kPairTw1Bytes <= 160 * 1024;      // stage-1 twiddles in LDS when they fit
+        if (twl) lds += kPairTw1Bytes;
+        const dim3 grid((unsigned)std::min(n_rows, g_stft_grid > 0 ? g_stft_grid : g_num_cus)), block(64 * nw);
+        if (twl) {
+            if (nw == 8) hipLaunchKernelGGL((k_stft_pair<8, 3, true>), grid, block, lds, s, p, n_rows);
+            else if (nw == 12) hipLaunchKernelGGL((k_stft_pair<12, 3, true>), grid, block, lds, s, p, n_rows);
+            else hipLaunchKernelGGL((k_stft_pair<10, 3, true>), grid, block, lds, s, p, n_rows);
+        } else {
+            if (nw == 8) hipLaunchKernelGGL((k_stft_pair<8, 3, false>), grid, block, lds, s, p, n_rows);
+            else if (nw == 12) hipLaunchKernelGGL((k_stft_pair<12, 3, false>), grid, block, lds, s, p, n_rows);
+            else hipLaunchKernelGGL((k_stft_pair<10, 3, false>), grid, block, lds, s, p, n_rows);
+        }
+        return;
+    }
     if (n_waves == 12) launch_stft_mel_nw<12>(p, n_tiles, sample_is_pcm16, s);
     else launch_stft_mel_nw<4>(p, n_tiles, sample_is_pcm16, s);
 }

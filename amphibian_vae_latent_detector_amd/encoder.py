@@ -204,6 +204,22 @@ class AmphSession:
             self._chk(N.lib.amph_mel_power_f32(self._ctx, _ptr(wave), B, wave.shape[1], _ptr(lens), _ptr(out), self._stream()))
         return out
 
+    def mel_pcm16(self, pcm, lengths=None, apply_rms: bool = False, layout: int = 0, want_power: bool = False):
+        """wav_to_mel for rows of decoded PCM16 samples (optionally through 00_normalize_dataset_rms.py's rms_normalize +
+        PCM16 write / read first) -> image [B, M, T] / [B, T, M]; want_power: also the raw mel power [B, T_raw, M]."""
+        pcm = self._dev(pcm, torch.int16)
+        if pcm.ndim == 1:
+            pcm = pcm[None]
+        B = pcm.shape[0]
+        lens = self._dev(lengths, torch.int32) if lengths is not None else None
+        shape = (B, self.cfg.n_mels, self.cfg.target_frames) if layout == 0 else (B, self.cfg.target_frames, self.cfg.n_mels)
+        out = torch.empty(shape, dtype=torch.float32, device=self.device)
+        pw = torch.empty((B, self.raw_frames, self.cfg.n_mels), dtype=torch.float32, device=self.device) if want_power else None
+        with torch.cuda.device(self.device):
+            self._chk(N.lib.amph_mel_pcm16(self._ctx, _ptr(pcm), B, pcm.shape[1], _ptr(lens), 1 if apply_rms else 0, layout,
+                                           _ptr(out), _ptr(pw), self._stream()))
+        return (out, pw) if want_power else out
+
     def encoder_forward(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         x = self._dev(x, torch.float32)
         if x.ndim != 4 or x.shape[1] != 1 or x.shape[2] != self.cfg.target_frames or x.shape[3] != self.cfg.n_mels:

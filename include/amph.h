@@ -192,6 +192,13 @@ int amph_mel_f32(amph_ctx* ctx, const float* d_wave, int n_rows, int n_in,
 int amph_mel_power_f32(amph_ctx* ctx, const float* d_wave, int n_rows, int n_in,
                        const int32_t* d_lengths, float* d_melpow_out, void* stream);
 
+/* The same from decoded PCM16 samples (what librosa.load reads from the files 00_normalize_dataset_rms.py writes, and the
+ * layout amph_encode_pcm16 takes): rows of n_in int16 samples; apply_rms != 0 runs rms_normalize + the PCM16 write / read of
+ * 00_normalize_dataset_rms.py:29-57 first.  d_mel_out (nullable) as amph_mel_f32; d_melpow_out (nullable) receives the raw mel
+ * power [B][T_raw][n_mels] (map_detector_core.py:219-228).  At least one of the two must be given. */
+int amph_mel_pcm16(amph_ctx* ctx, const int16_t* d_pcm, int n_rows, int n_in, const int32_t* d_lengths, int apply_rms,
+                   int layout, float* d_mel_out, float* d_melpow_out, void* stream);
+
 /* -------------------------------------------------------------------------
  * encoder(x) — map_detector_core.py:270 with x = [B,1,T,M] float32 (:268).
  * Writes mu[B][D] and (nullable) logvar[B][D].
