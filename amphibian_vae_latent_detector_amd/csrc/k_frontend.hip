@@ -161,8 +161,8 @@ __global__ __launch_bounds__(TH) void k_rms_scale(const T* __restrict__ in, long
     constexpr int kPassElems = kChunksPerPass * kNpChunk;
     constexpr int kVec = 16 / (int)sizeof(T);            // elements per 16-byte LDS read
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* heap = reinterpret_cast<float*>(smem);        // [kChunksPerPass][128]
-    char* img = smem + kChunksPerPass * 128 * 4;
+    float* heap = reinterpret_cast<float*>(smem);        // [kChunksPerPass][256]: nodes 1 .. 255 of a tree of depth <= 7
+    char* img = smem + kChunksPerPass * 256 * 4;
     const int row = blockIdx.x, tid = threadIdx.x;
     const T* x = in + (long long)row * row_stride;
     const int n = lengths ? min(lengths[row], n_in) : n_in;
@@ -203,14 +203,16 @@ __global__ __launch_bounds__(TH) void k_rms_scale(const T* __restrict__ in, long
             }
         }
         __syncthreads();
-        // ---- leaves: thread = (chunk of the pass, leaf slot); 8 accumulators in registers
-        if (tid < kChunksPerPass * 64) {
-            const int cl = tid >> 6, slot = tid & 63, chunk = c0 + cl;
+        // ---- leaves: thread = (chunk of the pass, leaf slot); 8 accumulators in registers.  A full chunk is 64 blocks of 128 at
+        //      depth 6; a partial chunk whose right-most path still holds more than 128 elements at depth 6 (441 of the 8 191
+        //      sizes, e.g. 7 922 -> ... -> 130 -> 64 + 66) has leaves at depth 7: 128 slots, heap nodes up to 255
+        if (tid < kChunksPerPass * 128) {
+            const int cl = tid >> 7, slot = tid & 127, chunk = c0 + cl;
             if (chunk < n_chunks) {
                 const int cn = min(kNpChunk, n - chunk * kNpChunk);
                 int off, size, lvl, rem = 0;
                 bool owner;
-                if (cn == kNpChunk) { off = slot * kNpBlock; size = kNpBlock; lvl = 6; owner = true; }
+                if (cn == kNpChunk) { off = (slot & 63) * kNpBlock; size = kNpBlock; lvl = 6; owner = slot < 64; }
                 else {
                     const int D = np_depth(cn);
                     owner = slot < (1 << D);
@@ -238,39 +240,39 @@ __global__ __launch_bounds__(TH) void k_rms_scale(const T* __restrict__ in, long
                         res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
                         for (int i = body; i < size; ++i) res = res + sq_of(*reinterpret_cast<const T*>(img + np_lds_off<T>(eb + i)));
                     }
-                    heap[cl * 128 + (1 << lvl) + (slot >> rem)] = res;
+                    heap[cl * 256 + (1 << lvl) + (slot >> rem)] = res;
                 }
             }
         }
         __syncthreads();
         // ---- internal nodes, deepest level first: value = left + right
-        for (int lvl = 5; lvl >= 0; --lvl) {
+        for (int lvl = 6; lvl >= 0; --lvl) {
             const int t = tid;
             if (t < (kChunksPerPass << lvl)) {
                 const int cl = t >> lvl, path = t & ((1 << lvl) - 1), chunk = c0 + cl;
                 if (chunk < n_chunks) {
                     const int cn = min(kNpChunk, n - chunk * kNpChunk);
-                    bool internal = cn == kNpChunk;
-                    if (!internal) {
+                    bool internal = cn == kNpChunk && lvl < 6;         // a full chunk's level 6 is its 64 leaves
+                    if (cn != kNpChunk) {
                         int off, size, reached;
                         np_walk(cn, path, lvl, off, size, reached);
                         internal = reached == lvl && size > kNpBlock;
                     }
                     if (internal) {
-                        const int idx = cl * 128 + (1 << lvl) + path;
-                        heap[idx] = heap[cl * 128 + 2 * ((1 << lvl) + path)] + heap[cl * 128 + 2 * ((1 << lvl) + path) + 1];
+                        const int idx = cl * 256 + (1 << lvl) + path;
+                        heap[idx] = heap[cl * 256 + 2 * ((1 << lvl) + path)] + heap[cl * 256 + 2 * ((1 << lvl) + path) + 1];
                     }
                 }
             }
             __syncthreads();
         }
         if (chunk_sums) {
-            if (tid < kChunksPerPass && c0 + tid < n_chunks) chunk_sums[(long long)row * chunk_stride + c0 + tid] = heap[tid * 128 + 1];
+            if (tid < kChunksPerPass && c0 + tid < n_chunks) chunk_sums[(long long)row * chunk_stride + c0 + tid] = heap[tid * 256 + 1];
             return;
         }
         if (tid == 0) {
             for (int cl = 0; cl < kChunksPerPass && c0 + cl < n_chunks; ++cl)
-                total = (c0 + cl == 0) ? heap[cl * 128 + 1] : total + heap[cl * 128 + 1];
+                total = (c0 + cl == 0) ? heap[cl * 256 + 1] : total + heap[cl * 256 + 1];
         }
         __syncthreads();
     }
@@ -391,7 +393,7 @@ __global__ __launch_bounds__(TH) void k_rms_scale(const T* __restrict__ in, long
 template <typename T, int CH = NpPass<T>::kChunks>
 static size_t rms_scale_lds() {
     constexpr int kChunksPerPass = CH;
-    return (size_t)kChunksPerPass * 128 * 4 + (size_t)kChunksPerPass * kNpChunk * sizeof(T) + (size_t)kChunksPerPass * 64 * 16;
+    return (size_t)kChunksPerPass * 256 * 4 + (size_t)kChunksPerPass * kNpChunk * sizeof(T) + (size_t)kChunksPerPass * 64 * 16;
 }
 
 // y = clip(x * scale, -1, 1) for scaled rows; gated rows (scale == 1 and not ok)

@@ -123,7 +123,9 @@ def test_rms_normalize_pcm16_bit_exact(env, fe):
     in numpy's own summation order.  Lengths straddle numpy's 8192-element buffer chunks
     and its 128-element pairwise blocks."""
     rng = np.random.default_rng(3)
-    for n in (env.cfg.n_samples, 8192, 8193, 16385, 129, 100, 7, 48000, 32769, 240000):     # > 32 768: K0's two-kernel path
+    # 7 922 / 8 191 / 16 114 / 40 457: a last numpy chunk whose pairwise tree is SEVEN levels deep (441 of the 8 191 partial sizes:
+    # the right-most path still holds 130 elements at depth 6) - K0 had 64 leaf slots per chunk until round 3
+    for n in (env.cfg.n_samples, 8192, 8193, 16385, 129, 100, 7, 48000, 32769, 240000, 7922, 8191, 16114, 40457):     # > 32 768: K0's two-kernel path
         idx = list(range(20)) + [49] if n == env.cfg.n_samples else [int(v) for v in rng.integers(0, 5000, 5)]
         pcm = env.synth(idx, n, env.cfg.sr)
         for numpy2, promotion in ((0, "numpy1"), (1, "numpy2")):       # each mode against its oracle twin
@@ -205,11 +207,13 @@ def test_mel_image_against_oracle_both_pad_modes(env, pad_mode):
     s2 = enc.session(cfg)
     lengths = np.array([cfg.n_samples, 15001, 700, 0, cfg.n_samples, 1, 4097, cfg.n_samples, 9000], dtype=np.int32)
     try:
+        s2.configure("stft_pair", 0)        # (k_stft_mel_w on both sides: the pair kernel, which only reads K0's rows, has its own test)
         for apply_rms in (True, False):
             a = s2.encode(pcm, lengths=lengths, apply_rms=apply_rms)[0]
             s2.configure("stft_prepad", 0)
             assert torch.equal(a, s2.encode(pcm, lengths=lengths, apply_rms=apply_rms)[0]), apply_rms
             s2.configure("stft_prepad", 1)
+        s2.configure("stft_pair", 1)
         want_z = []
         for r in range(9):
             yr, _ = env.ofe.normalize_pcm16_chunk(pcm[r, :lengths[r]], True) if lengths[r] else (np.zeros(0, np.float32), False)
@@ -218,6 +222,56 @@ def test_mel_image_against_oracle_both_pad_modes(env, pad_mode):
         _assert_latents(s2.encode(pcm, lengths=lengths, apply_rms=True)[0].cpu().numpy(), np.stack(want_z))
     finally:
         s2.configure("stft_prepad", 1)
+        s2.configure("stft_pair", 1)
+
+
+def test_pair_of_frames_stft_kernel_against_oracle_and_the_frame_per_wave_kernel(env, capsys):
+    """k_stft_pair (two frames per wave as one complex 2048-point FFT; the default for PCM16 rows at n_fft 2048 / hop 384) against
+    the CPU restatement of librosa's melspectrogram (map_detector_core.py:219-228) and against k_stft_mel_w on the same rows:
+    mel power within 1e-6 of the row's peak, images within 1e-4 of the oracle's, with and without the RMS stage, full and
+    ragged rows (a last pair with ONE frame is covered by the 3 s preset: 376 frames are 188 pairs, 626: 313), every
+    workgroup shape, stage-1 twiddles in LDS and from global memory, several rows per workgroup (in-loop dB stage), and the
+    fused dB stage equal to the separate kernel bit for bit."""
+    cfg = env.cfg
+    B = 12
+    sess = env.AmphSession(cfg, None, None, DEV, max_batch=B)
+    pcm = env.synth([0, 1, 2, 3, 4, 5, 6, 7, 8, 49, 10, 11], cfg.n_samples, cfg.sr)
+    lengths = np.array([cfg.n_samples, 16114, 700, 0, cfg.n_samples, 1, 4097, 7922, 9000, cfg.n_samples, 21999, 12345], dtype=np.int32)
+    worst_p = worst_i = 0.0
+    for apply_rms in (False, True):
+        for ln in (None, lengths):
+            want_p, want_i = [], []
+            for r in range(B):
+                q = pcm[r] if ln is None else pcm[r, :ln[r]]
+                yr = env.ofe.normalize_pcm16_chunk(q, apply_rms)[0] if q.size else np.zeros(0, np.float32)
+                yy = np.zeros(cfg.n_samples, np.float32)
+                yy[:yr.size] = yr
+                want_p.append(env.ofe.melspectrogram(yy, cfg.sr, cfg.n_fft, cfg.hop_length, cfg.n_mels, cfg.fmin, cfg.fmax).T)
+                want_i.append(env.ofe.wave_to_mel(yr, **cfg.mel_kwargs()).T)
+            want_p, want_i = np.stack(want_p), np.stack(want_i)
+            sess.configure("stft_pair", 0)
+            old_img, old_p = (t.cpu().numpy() for t in sess.mel_pcm16(pcm, lengths=ln, apply_rms=apply_rms, layout=1, want_power=True))
+            sess.configure("stft_pair", 1)
+            for waves, tw_lds, grid in ((10, 1, 0), (8, 1, 0), (12, 0, 0), (10, 0, 5), (8, 1, 3)):
+                sess.configure("stft_pair_waves", waves)
+                sess.configure("stft_pair_tw_lds", tw_lds)
+                sess.configure("stft_grid", grid)
+                img, pw = (t.cpu().numpy() for t in sess.mel_pcm16(pcm, lengths=ln, apply_rms=apply_rms, layout=1, want_power=True))
+                fused = sess.mel_pcm16(pcm, lengths=ln, apply_rms=apply_rms, layout=1).cpu().numpy()
+                assert np.array_equal(fused, img), (waves, tw_lds, grid)              # fused dB stage == separate kernel
+                peak = np.maximum(want_p.max(axis=(1, 2)), 1e-30)
+                ep = (np.abs(pw - want_p).max(axis=(1, 2)) / peak).max()
+                eo = (np.abs(pw - old_p).max(axis=(1, 2)) / peak).max()
+                assert ep <= 2e-6 and eo <= 1e-6, (apply_rms, waves, ep, eo)
+                assert np.abs(img - want_i).max() <= 1e-4 and np.abs(img - old_img).max() <= 5e-5
+                assert not pw[9].any()                                                # the silent row stays exactly zero
+                worst_p, worst_i = max(worst_p, ep), max(worst_i, float(np.abs(img - want_i).max()))
+            sess.configure("stft_grid", 0)
+            sess.configure("stft_pair_waves", 10)
+            sess.configure("stft_pair_tw_lds", 1)
+    with capsys.disabled():
+        print(f"\n[k_stft_pair] mel power vs oracle: {worst_p:.2e} of the row's peak; image vs oracle: {worst_i:.2e}")
+    sess.close()
 
 
 def test_fix_length_padding_truncation_and_ragged_lengths(env, fe):
@@ -669,7 +723,10 @@ def test_encode_edge_cases(env):
     y = env.ofe.pcm16_to_float(pcm)
     a, _, _ = sess.encode(pcm, apply_rms=True)
     b, _, _ = sess.encode(y, apply_rms=True)
-    assert torch.equal(a, b)
+    assert float((a - b).abs().max()) <= 1e-4            # PCM16 rows: k_stft_pair; float32 rows: k_stft_mel_w
+    sess.configure("stft_pair", 0)
+    assert torch.equal(sess.encode(pcm, apply_rms=True)[0], b)
+    sess.configure("stft_pair", 1)
     # odd row stride (rows not 4-byte aligned: per-sample paths of K0's normalised-row write and of the STFT fetch), and the
     # normalised rows written by K0 against the STFT kernel normalising on the fly: same bits
     odd = np.ascontiguousarray(pcm[:, : cfg.n_samples + 2999])
@@ -677,13 +734,18 @@ def test_encode_edge_cases(env):
     c, _, _ = sess.encode(odd, lengths=lengths_odd, apply_rms=True)
     assert torch.equal(c, sess.encode(pcm, lengths=lengths_odd, apply_rms=True)[0])
     try:
+        sess.configure("stft_pair", 0)                        # k_stft_mel_w on both sides (k_stft_pair only reads K0's padded rows)
+        c0 = sess.encode(odd, lengths=lengths_odd, apply_rms=True)[0]
+        a0 = sess.encode(pcm, apply_rms=True)[0]
+        assert float((c0 - c).abs().max()) <= 1e-4 and float((a0 - a).abs().max()) <= 1e-4
         for key in ("stft_prepad", "stft_prenorm"):           # K0 writes plain normalised rows / nothing: the STFT kernel pads
             sess.configure(key, 0)                            # (and normalises) itself
-            assert torch.equal(c, sess.encode(odd, lengths=lengths_odd, apply_rms=True)[0]), key
-            assert torch.equal(a, sess.encode(pcm, apply_rms=True)[0]), key
+            assert torch.equal(c0, sess.encode(odd, lengths=lengths_odd, apply_rms=True)[0]), key
+            assert torch.equal(a0, sess.encode(pcm, apply_rms=True)[0]), key
     finally:
         sess.configure("stft_prenorm", 1)
         sess.configure("stft_prepad", 1)
+        sess.configure("stft_pair", 1)
     # full-scale square wave: clipping + quantisation extremes
     sq = np.where(np.arange(cfg.n_samples) % 100 < 50, 32767, -32768).astype(np.int16)[None]
     mu, _, _ = sess.encode(sq, apply_rms=True)
