@@ -87,7 +87,8 @@ struct amph_ctx {
     float* d_pair_tables = nullptr;        // k_stft_pair: window pairs + stage-2 twiddles (packed LDS image); nullptr: configuration not covered
     float2* d_pair_tw1 = nullptr;          // k_stft_pair: stage-1 twiddles (global memory)
     bool stft_pair = true;                 // use k_stft_pair (two frames per wave as one complex FFT) where it applies
-    int stft_pair_waves = 10;              // its workgroup: 8, 10 or 12 waves (29 pairs of a 1 s row over 10 waves = 3 rounds)
+    int stft_pair_waves = 10;              // its workgroup: 8, 10, 11 or 12 waves; amph_create picks the largest whose LDS image, stage-1 twiddles
+                                           // included, fits (1 s rows with the fused dB stage: 11 - 29 pairs on 11 waves are 3 rounds, at most 8 pairs per SIMD)
     bool stft_pair_tw_lds = true;          // its stage-1 twiddles in LDS when the image still fits
     int mel_w_floats = 0, mel_p_tail = 0;
     int32_t *d_mel_start = nullptr, *d_mel_len = nullptr, *d_mel_wofs = nullptr;
@@ -350,6 +351,10 @@ int build_frontend(amph_ctx* c) {
                 const int k = st4 + e;
                 wv.push_back(k < F ? c->mel_basis[(size_t)m * F + k] : 0.0f);
             }
+            // the 16 filters of a round are read by 16 lane quads, 64 bytes per quad and step: with an even number of steps per
+            // filter the quads of one ds_read_b128 lane group (quads 0, 3, 5, 6 / 1, 2, 4, 7) start on the same banks (4-way
+            // conflict at 4 and 8 steps); one 64-byte pad makes the filter stride an odd number of 64-byte slots
+            if ((round_steps & 1) == 0) wv.insert(wv.end(), 16, 0.0f);
             p_tail = std::max(p_tail, st4 + 16 * round_steps - F);
         }
     }
@@ -1053,6 +1058,11 @@ int amph_create(const amph_frontend_config* cfg, const amph_encoder_spec* spec, 
             for (int nw : {4, 12})                  // the fused dB stage keeps a row's mel power in LDS too
                 if (stft_mel_can_fuse_db(c->cfg.n_fft, c->n_frames, c->cfg.n_mels, c->mel_w_floats, nw))
                     lds = std::max(lds, (int)stft_mel_fused_lds_bytes(c->cfg.n_fft, c->n_frames, c->cfg.n_mels, c->mel_w_floats, nw));
+            if (c->d_pair_tables) {
+                const bool fz = stft_mel_can_fuse_db(c->cfg.n_fft, c->n_frames, c->cfg.n_mels, c->mel_w_floats, c->stft_waves);
+                for (int nw : {8, 10, 11, 12})
+                    if (stft_pair_lds_bytes(c->n_frames, c->cfg.n_mels, c->mel_w_floats, nw, fz) + stft_pair_tw1_lds_bytes() <= 160 * 1024) c->stft_pair_waves = nw;
+            }
             if (c->d_pair_tables)
                 for (int fused = 0; fused < 2; ++fused) {
                     size_t lp = stft_pair_lds_bytes(c->n_frames, c->cfg.n_mels, c->mel_w_floats, c->stft_pair_waves, fused != 0);
@@ -1112,7 +1122,7 @@ int amph_configure(amph_ctx* c, const char* key, int value) {
     if (!std::strcmp(key, "stft_pair")) { c->stft_pair = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "stft_pair_tw_lds")) { c->stft_pair_tw_lds = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "stft_pair_waves")) {
-        if (value != 8 && value != 10 && value != 12) return fail(c, AMPH_ERR_INVALID_ARG, "stft_pair_waves must be 8, 10 or 12");
+        if (value != 8 && value != 10 && value != 11 && value != 12) return fail(c, AMPH_ERR_INVALID_ARG, "stft_pair_waves must be 8, 10, 11 or 12");
         if (c->d_pair_tables) {
             const size_t lds = stft_pair_lds_bytes(c->n_frames, c->cfg.n_mels, c->mel_w_floats, value, false);
             if (lds > 160 * 1024) return fail(c, AMPH_ERR_UNSUPPORTED, "stft_pair_waves=%d needs %zu bytes of LDS", value, lds);
@@ -1205,7 +1215,9 @@ int amph_configure(amph_ctx* c, const char* key, int value) {
         (void)hipMemcpy(h.data(), c->d_stamps, h.size() * 8, hipMemcpyDeviceToHost);
         double sum[16] = {0};
         for (int b = 0; b < value; ++b) for (int k = 1; k < 10; ++k) sum[k] += (double)(h[(size_t)b * 16 + k] - h[(size_t)b * 16 + k - 1]);
-        const char* nm[10] = {"", "staging+sync", "window+pack", "stageA+exwrite", "exread", "dft16B", "stageC+Zwrite", "Zread", "post+Pwrite", "mel"};
+        const char* nm_w[10] = {"", "staging+sync", "window+pack", "stageA+exwrite", "exread", "dft16B", "stageC+Zwrite", "Zread", "post+Pwrite", "mel"};
+        const char* nm_p[10] = {"", "decode+window", "stage-1 DFT32", "twiddle+exchange", "radix-2+twiddle", "stage-2 DFT32", "split passes", "power+Pwrite", "fetch issue", "mel"};
+        const char* const* nm = (c->stft_pair && c->d_pair_tables) ? nm_p : nm_w;      // (k_stft_pair: wave 0's first pair)
         for (int k = 1; k < 10; ++k) fprintf(stderr, "  stamp %-16s %9.0f cycles (mean over %d workgroups, first frame of wave 0)\n", nm[k], sum[k] / value, value);
         double w[6] = {0};
         for (int b = 0; b < value; ++b) for (int k = 0; k < 6; ++k) w[k] += (double)h[(size_t)b * 16 + 10 + k];

@@ -1384,7 +1384,7 @@ __global__ __launch_bounds__(64 * NW) void k_stft_mel_w(StftParams p, int n_tile
 constexpr int kPairExS = 68;                        // exchange row stride in floats (= 4 mod 64: conflict-free 16-byte reads)
 constexpr int kPairScratch = 32 * kPairExS * 4;     // per-wave scratch: exchange tile, then partner tile, then the two power spectra
 constexpr int kPairPStride = kPairScratch / 8;      // floats between the two power spectra (1088 >= 1025 + tail)
-constexpr int kPairZS = 80;                         // partner tile row stride in floats (columns >= 32 shifted by 16 banks)
+constexpr int kPairZS = 96;                         // partner tile row stride in floats (columns >= 32 shifted by 16 banks; lane' 0 reads one row further: same bank as column 0)
 constexpr int kPairWinBytes = 16 * 64 * 8, kPairTw2Bytes = 2 * 32 * 8, kPairTw1Bytes = 31 * 64 * 8;
 
 // Y[k + 16 p] = E[k] +- W32^k O[k]: e = DFT16 of the even inputs (X[k] at DFT16_POS(k)), o = of the odd ones, in place
@@ -1433,6 +1433,21 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
     float* Pb = T + kPairPStride;
     float* mp_row = reinterpret_cast<float*>(smem + kTab + meta_bytes + melw_bytes + NW * kPairScratch);
     const bool fuse_db = p.db_out != nullptr;
+#ifdef AMPH_STAMPS
+    unsigned long long pw_begin = 0;
+    const unsigned long long pw_rt0 = __builtin_amdgcn_s_memrealtime();
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pw_begin)::"memory");
+#define AMPH_PSTAMP(k_)                                                                     \
+    if (wave == 0 && pr == 0) {                                                             \
+        unsigned long long t_;                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+        if (lane == 0) p.stamps[(size_t)blockIdx.x * 16 + (k_)] = t_;                       \
+    }
+#else
+#define AMPH_PSTAMP(k_)
+#endif
 
     // ---- once per workgroup: window pairs + stage-2 twiddles (one packed global array), mel rows (x 1/4: see above)
     {
@@ -1491,10 +1506,7 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
         for (int pr = wave; pr < n_pairs; pr += NW) {
             float xr[2][16], xi[2][16];
             float2 tw[31];
-            // ---- stage-1 twiddles, first half: in flight under the decode and the first DFTs
-#pragma unroll
-            for (int k1 = 1; k1 < 16; ++k1) if (!TWL) tw[k1 - 1] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs_tw, lane8, (k1 - 1) * 512, 0));
-            AMPH_PHASE_FENCE();
+            AMPH_PSTAMP(0)
             // ---- decode + window: z = w (a + i b); sequence e = sample parity, m = j'
             {
                 float2 wv[16];
@@ -1509,11 +1521,18 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
                     xi[1][j] = (float)((int)db >> 16) * wv[j].y;
                 }
             }
+            AMPH_PSTAMP(1)
+            // ---- stage-1 twiddles from global memory (!TWL): the first half is requested here, the second behind the first DFT16 -
+            //      all 62 registers in flight from the top of the pair did not fit three waves per SIMD
 #pragma unroll
-            for (int k1 = 16; k1 < 32; ++k1) if (!TWL) tw[k1 - 1] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs_tw, lane8, (k1 - 1) * 512, 0));
+            for (int k1 = 1; k1 < 16; ++k1) if (!TWL) tw[k1 - 1] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs_tw, lane8, (k1 - 1) * 512, 0));
             AMPH_PHASE_FENCE();
             // ---- stage 1: DFT32 down the lane's column
             dft16(xr[0], xi[0]);
+            AMPH_PHASE_FENCE();
+#pragma unroll
+            for (int k1 = 16; k1 < 32; ++k1) if (!TWL) tw[k1 - 1] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs_tw, lane8, (k1 - 1) * 512, 0));
+            AMPH_PHASE_FENCE();
             dft16(xr[1], xi[1]);
 #pragma unroll
             for (int q = 0; q < 16; ++q) {                  // high lanes' sequence 0 <-> low lanes' sequence 1
@@ -1524,6 +1543,7 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
             }
             dft32_combine(xr[0], xi[0], xr[1], xi[1]);
             AMPH_PHASE_FENCE();
+            AMPH_PSTAMP(2)
             if (TWL) {
 #pragma unroll
                 for (int k1 = 1; k1 < 16; ++k1) tw[k1 - 1] = tw1_l[(k1 - 1) * 64];
@@ -1565,6 +1585,7 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
             }
             wave_lds_sync();
             AMPH_PHASE_FENCE();
+            AMPH_PSTAMP(3)
             // ---- stage 2: radix-2 DIF across the lane pair, twiddle (h = 1: W_64^mm; requested eight pairs at a time: 32 registers),
             //      DFT32
 #pragma unroll
@@ -1588,10 +1609,12 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
                 }
                 AMPH_PHASE_FENCE();
             }
+            AMPH_PSTAMP(4)
             dft16(ur[0], ui[0]);
             dft16(ur[1], ui[1]);
             dft32_combine(ur[0], ui[0], ur[1], ui[1]);
             AMPH_PHASE_FENCE();
+            AMPH_PSTAMP(5)
             // ---- split: the partner values Z[N - k] come from the upper half (k2' >= 16) of lane' colp; both passes are queued
             //      back to back like the exchange's
             float pre[16], pim[16];
@@ -1610,6 +1633,7 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
             for (int i = 0; i < 16; ++i) pim[i] = T[(15 - i) * kPairZS + zr_];
             wave_lds_sync();
             AMPH_PHASE_FENCE();
+            AMPH_PSTAMP(6)
             // ---- 4 |A[k]|^2, 4 |B[k]|^2: A = (Z[k] + conj Z[N-k]) / 2, B = (Z[k] - conj Z[N-k]) / 2i
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
@@ -1626,6 +1650,7 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
             for (int i = lane; i < p.p_tail; i += 64) { Pa[1025 + i] = 0.0f; Pb[1025 + i] = 0.0f; }   // the padded mel rows read there
             wave_lds_sync();
             AMPH_PHASE_FENCE();
+            AMPH_PSTAMP(7)
             // ---- this wave's next pair: its samples are requested now and land under the mel rows
             {
                 int nrow = row, npr = pr + NW;
@@ -1633,6 +1658,9 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
                 if (nrow < n_rows) fetch(nrow, npr);
             }
             AMPH_PHASE_FENCE();
+#ifdef AMPH_STAMPS
+            if (wave == 0 && pr == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); if (lane == 0) p.stamps[(size_t)blockIdx.x * 16 + 8] = t_; }
+#endif
             // ---- mel rows of both frames: 4 lanes per filter, 4 bins per lane and step; one weight read serves both frames.
             //      Four steps (twelve 16-byte reads) are requested at a time; even steps -> first accumulator, odd -> second,
             //      as in k_stft_mel_w
@@ -1685,6 +1713,7 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
             }
             wave_lds_sync();                                // the scratch is rewritten by the next pair
             AMPH_PHASE_FENCE();
+            AMPH_PSTAMP(9)
         }
 #undef AMPH_PHASE_FENCE
         // ---- fused dB stage on the row the workgroup holds (see k_stft_mel_w).  The LAST row (at batch 256: the only one) is
@@ -1698,6 +1727,16 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
             __syncthreads();
         }
     }
+#ifdef AMPH_STAMPS
+    if (tid == 0) {
+        unsigned long long pw_end;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pw_end)::"memory");
+        for (int k_ = 10; k_ < 16; ++k_) p.stamps[(size_t)blockIdx.x * 16 + k_] = 0;
+        p.stamps[(size_t)blockIdx.x * 16 + 13] = pw_end - pw_begin;        // frame loops of wave 0 (without the dB tail)
+        p.stamps[(size_t)blockIdx.x * 16 + 14] = __builtin_amdgcn_s_memrealtime() - pw_rt0;
+    }
+#endif
+#undef AMPH_PSTAMP
     if (fuse_db && (int)blockIdx.x < n_rows) {
         const int last_row = blockIdx.x + (n_rows - 1 - (int)blockIdx.x) / (int)gridDim.x * (int)gridDim.x;
         __syncthreads();
@@ -1762,9 +1801,10 @@ hipError_t stft_mel_configure(int lds_bytes) {
         e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
     }
-    const void* pfns[6] = {reinterpret_cast<const void*>(&k_stft_pair<8, 3, false>), reinterpret_cast<const void*>(&k_stft_pair<10, 3, false>),
-                           reinterpret_cast<const void*>(&k_stft_pair<12, 3, false>), reinterpret_cast<const void*>(&k_stft_pair<8, 3, true>),
-                           reinterpret_cast<const void*>(&k_stft_pair<10, 3, true>), reinterpret_cast<const void*>(&k_stft_pair<12, 3, true>)};
+    const void* pfns[8] = {reinterpret_cast<const void*>(&k_stft_pair<8, 3, false>), reinterpret_cast<const void*>(&k_stft_pair<10, 3, false>),
+                           reinterpret_cast<const void*>(&k_stft_pair<11, 3, false>), reinterpret_cast<const void*>(&k_stft_pair<12, 3, false>),
+                           reinterpret_cast<const void*>(&k_stft_pair<8, 3, true>), reinterpret_cast<const void*>(&k_stft_pair<10, 3, true>),
+                           reinterpret_cast<const void*>(&k_stft_pair<11, 3, true>), reinterpret_cast<const void*>(&k_stft_pair<12, 3, true>)};
     for (const void* f : pfns) {
         e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
@@ -1812,15 +1852,15 @@ void launch_stft_mel(const StftParams& p, int n_rows, int sample_is_pcm16, int n
         const bool twl = p.pair_tw_lds && lds + kPairTw1Bytes <= 160 * 1024;      // stage-1 twiddles in LDS when they fit
         if (twl) lds += kPairTw1Bytes;
         const dim3 grid((unsigned)std::min(n_rows, g_stft_grid > 0 ? g_stft_grid : g_num_cus)), block(64 * nw);
-        if (twl) {
-            if (nw == 8) hipLaunchKernelGGL((k_stft_pair<8, 3, true>), grid, block, lds, s, p, n_rows);
-            else if (nw == 12) hipLaunchKernelGGL((k_stft_pair<12, 3, true>), grid, block, lds, s, p, n_rows);
-            else hipLaunchKernelGGL((k_stft_pair<10, 3, true>), grid, block, lds, s, p, n_rows);
-        } else {
-            if (nw == 8) hipLaunchKernelGGL((k_stft_pair<8, 3, false>), grid, block, lds, s, p, n_rows);
-            else if (nw == 12) hipLaunchKernelGGL((k_stft_pair<12, 3, false>), grid, block, lds, s, p, n_rows);
-            else hipLaunchKernelGGL((k_stft_pair<10, 3, false>), grid, block, lds, s, p, n_rows);
-        }
+#define AMPH_PAIR_LAUNCH(NW_)                                                                              \
+    if (twl) hipLaunchKernelGGL((k_stft_pair<NW_, 3, true>), grid, dim3(64 * NW_), lds, s, p, n_rows);   \
+    else hipLaunchKernelGGL((k_stft_pair<NW_, 3, false>), grid, dim3(64 * NW_), lds, s, p, n_rows);
+        (void)block;
+        if (nw == 8) { AMPH_PAIR_LAUNCH(8) }
+        else if (nw == 11) { AMPH_PAIR_LAUNCH(11) }
+        else if (nw == 12) { AMPH_PAIR_LAUNCH(12) }
+        else { AMPH_PAIR_LAUNCH(10) }
+#undef AMPH_PAIR_LAUNCH
         return;
     }
     if (n_waves == 12) launch_stft_mel_nw<12>(p, n_tiles, sample_is_pcm16, s);
