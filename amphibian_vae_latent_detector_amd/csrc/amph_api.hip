@@ -681,7 +681,7 @@ int run_encoder(amph_ctx* c, Workspace& w, const float* d_x, int nb, float* d_mu
             p.x = w.act[0]; p.x_guard = w.act_guard[0]; p.M = nb * p.OH * p.OW; p.zeros = c->d_zeros; p.y = w.act[1];
             p.img = d_x; p.w1 = c->first.w; p.scale1 = c->first.scale; p.shift1 = c->first.shift;
             p.H0 = c->first.H; p.W0 = c->first.W; p.k1 = c->first.k; p.s1 = c->first.stride; p.p1 = c->first.pad;
-            if (c->patch_fused && c->bf16_pair && c->gemm[0].d_w_f4b && conv_gemm_f4s_ok(p)) {
+            if (c->patch_fused && c->bf16_pair && c->gemm[0].d_w_f4b && conv_gemm_f4b_ok(p)) {
                 // layers 1 + 2 in bf16 proper: image, weights and the layer-1 activation rounded to bf16, fp32 accumulate / BN
                 StageTimer t(c, ST_CONV0 + 1, s);
                 p.y_bf16 = 1;

@@ -197,6 +197,7 @@ void launch_conv_gemm_f4s(const ConvGemmParams& p, const void* wfrag, int wgs, h
 void conv_gemm_f4s_fragment_weights(const float* w, int n_pad, int K_pad, uint16_t* out);
 // ... and with one bf16 term per operand for the bf16 encoder (same shapes: conv_gemm_f4s_ok; bf16 NHWC output)
 void conv_gemm_f4b_fragment_weights(const float* w, int n_pad, int K_pad, uint16_t* out);
+bool conv_gemm_f4b_ok(const ConvGemmParams& p);
 void launch_conv_gemm_f4b(const ConvGemmParams& p, const void* wfrag, int wgs, hipStream_t s);
 // the 3x3 stride-2 layers behind the pair in the same form: weights in registers, the tile's input image(s) resident in LDS
 // (0: shape not covered; wfrag = conv_gemm_f4s_fragment_weights' output of the layer; wgs = workgroups, 0: one per CU)

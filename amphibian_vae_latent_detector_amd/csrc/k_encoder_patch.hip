@@ -779,7 +779,21 @@ void conv_gemm_f4b_fragment_weights(const float* w, int n_pad, int K_pad, uint16
                             rne(w[(size_t)(nt * 64 + ct * 32 + (lane & 31)) * K_pad + 16 * ks + 8 * (lane >> 5) + j]);
 }
 
-// same shapes as k_conv_gemm_f4s; wfrag = conv_gemm_f4b_fragment_weights' output; y is bf16 NHWC
+// the shapes k_conv_gemm_f4b covers: k_conv_gemm_f4s's (3x3 stride-2 pad-1 twice, 32 layer-1 channels, whole output rows per
+// 64-pixel tile: OW 16 or 32) with ITS LDS image - 80-byte instead of 208-byte patch pixels, one image plane instead of three, no
+// partial-sum inbox: OW = 32 (the 128-band geometry of BASELINE configs[3], 24 x 32 output pixels per image) fits in 60 KB where
+// the fp32-accurate kernel would need 172
+bool conv_gemm_f4b_ok(const ConvGemmParams& p) {
+    if (!(p.img && p.zeros && p.k == 3 && p.stride == 2 && p.pad == 1 && p.k1 == 3 && p.s1 == 2 && p.p1 == 1 && p.C_in == 32 &&
+          p.K == 288 && p.K_pad == 288 && p.splits == 1 && p.epilogue == 0 && (p.N % 4) == 0))
+        return false;
+    if ((p.OW != 16 && p.OW != 32) || (p.OH % (64 / p.OW)) || (p.M % 64) || p.M <= 0) return false;
+    if (p.H != (p.H0 + 2 - 3) / 2 + 1 || p.W != (p.W0 + 2 - 3) / 2 + 1 || p.OH != (p.H + 2 - 3) / 2 + 1 || p.OW != (p.W + 2 - 3) / 2 + 1) return false;
+    const PatchGeoB g = f4b_geo(p);
+    return g.n_img <= 256 * kPImgU && g.n_pix <= 12 * 32 && p.W == 2 * p.OW && p.H == 2 * p.OH && f4b_lds(g) <= 80 * 1024 && p.M < (1 << 22);
+}
+
+// wfrag = conv_gemm_f4b_fragment_weights' output; y is bf16 NHWC
 void launch_conv_gemm_f4b(const ConvGemmParams& p, const void* wfrag, int wgs, hipStream_t s) {
     static bool raised[64] = {false};
     int dev = 0;

@@ -822,8 +822,9 @@ def test_bf16_encoder_path(env, preset, name, capsys):
     # the first bf16 rounding is layer 2's OUTPUT; `tiny` (8 channels after layer 1) takes the unfused bf16 pair
     # thesis-shape at 64 mel bands (the bench geometry): layers 1 + 2 in bf16 proper (k_conv_gemm_f4b) - the image, both layers'
     # weights and the layer-1 activation are rounded to bf16 like every other layer's
-    fused12 = name == "thesis-shape" and cfg.n_mels != 64
-    true_bf16_pair = name == "thesis-shape" and cfg.n_mels == 64
+    # ... and at 128 bands too since round 3 (k_conv_gemm_f4b has its own shape gate: its LDS image fits where k_conv_gemm_f4s's does not)
+    fused12 = False
+    true_bf16_pair = name == "thesis-shape"
     with torch.no_grad():
         mu32, _ = tenc(x)
         h = bf(x) if true_bf16_pair else x
@@ -846,7 +847,7 @@ def test_bf16_encoder_path(env, preset, name, capsys):
     err_f32 = max(rel_l2(mu_b[r], mu32[r].numpy()) for r in range(11))
     with capsys.disabled():
         print(f"\n[bf16 encoder, {preset}/{name}] max rel L2 vs bf16-emulating torch: {err_emu:.2e}; vs fp32 oracle: {err_f32:.2e}")
-    assert err_emu <= 5e-3 and err_f32 <= 5e-2
+    assert err_emu <= 2e-3 and err_f32 <= 5e-2             # (measured 5e-7 ... 8.2e-4 / 4.4e-3 ... 6.0e-3)
     assert max(rel_l2(mu_f.cpu().numpy()[r], mu_b[r]) for r in range(11)) <= 5e-3   # HIP mel vs oracle mel in front
     _assert_latents(mu_fp32.cpu().numpy(), mu32.numpy(), 1e-5)       # switching back restores the fp32 path
 
