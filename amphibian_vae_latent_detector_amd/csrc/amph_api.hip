@@ -393,6 +393,26 @@ int build_frontend(amph_ctx* c) {
         HIP_TRY(c, upload(&c->d_pair_tables, pt));
         HIP_TRY(c, upload(&c->d_pair_tw1, tw1));
     }
+    // k_stft_pair2 (n_fft 1024, hop 256): lane' l (0..31) reads samples 64 j' + 2 l + e and owns column 2 (l & 15) + (l >> 4)
+    if (stft_pair2_ok(n_fft, f.hop_length, c->mel_p_tail)) {
+        std::vector<float> pt(stft_pair2_table_bytes() / 4, 0.0f);
+        for (int j = 0; j < 16; ++j)
+            for (int l = 0; l < 32; ++l)
+                for (int e = 0; e < 2; ++e) {
+                    const int n = 64 * j + 2 * l + e;
+                    const float w = (float)(0.5 - 0.5 * std::cos(2.0 * PI * (double)n / (double)n_fft));
+                    pt[(size_t)(j * 32 + l) * 2 + e] = w * (1.0f / 32768.0f);
+                }
+        std::vector<float2> tw1(31 * 32);
+        for (int k1 = 1; k1 < 32; ++k1)
+            for (int l = 0; l < 32; ++l) {
+                const int col = 2 * (l & 15) + (l >> 4);
+                const double a = -2.0 * PI * (double)((col * k1) % n_fft) / (double)n_fft;
+                tw1[(size_t)(k1 - 1) * 32 + l] = make_float2((float)std::cos(a), (float)std::sin(a));
+            }
+        HIP_TRY(c, upload(&c->d_pair_tables, pt));
+        HIP_TRY(c, upload(&c->d_pair_tw1, tw1));
+    }
     return AMPH_OK;
 }
 
@@ -851,9 +871,21 @@ int run_encoder(amph_ctx* c, Workspace& w, const float* d_x, int nb, float* d_mu
 }
 
 // can this context run the dB / z-score stage inside the STFT kernel (one workgroup per row, the row's mel power in LDS)?
-bool can_fuse_db(const amph_ctx* c) {
-    return c->stft_fuse_db && amph::g_stft_indep &&
-           stft_mel_can_fuse_db(c->cfg.n_fft, c->n_frames, c->cfg.n_mels, c->mel_w_floats, c->stft_waves);
+// LDS image of the pair kernel this context would use (k_stft_pair at n_fft 2048, k_stft_pair2 at 1024)
+size_t pair_lds(const amph_ctx* c, int nw, bool fused) {
+    return c->cfg.n_fft == 2048 ? stft_pair_lds_bytes(c->n_frames, c->cfg.n_mels, c->mel_w_floats, nw, fused)
+                                : stft_pair2_lds_bytes(c->n_frames, c->cfg.n_mels, c->mel_w_floats, nw, fused);
+}
+size_t pair_tw1_lds(const amph_ctx* c) { return c->cfg.n_fft == 2048 ? stft_pair_tw1_lds_bytes() : stft_pair2_tw1_lds_bytes(); }
+// do PCM16 rows that K0 / the pad kernel wrote go through a pair kernel?
+bool pair_path(const amph_ctx* c, bool pcm16) {
+    return pcm16 && c->stft_pair && c->d_pair_tables && c->stft_prenorm && c->stft_prepad && amph::g_stft_indep;
+}
+// pcm16_rows: the call's input is PCM16 (those rows take a pair kernel when the context has one)
+bool can_fuse_db(const amph_ctx* c, bool pcm16_rows = false) {
+    if (!c->stft_fuse_db || !amph::g_stft_indep) return false;
+    if (pair_path(c, pcm16_rows)) return pair_lds(c, c->stft_pair_waves, true) <= 160 * 1024;
+    return stft_mel_can_fuse_db(c->cfg.n_fft, c->n_frames, c->cfg.n_mels, c->mel_w_floats, c->stft_waves);
 }
 
 // db_out (nullable): the standardised image is written by the STFT kernel itself (fused dB stage), melpow is not
@@ -873,8 +905,7 @@ StftParams make_stft(amph_ctx* c, const WaveSrc& src, float* melpow, float* db_o
     p.n_mels = c->cfg.n_mels; p.mel_start = c->d_mel_start; p.mel_len = c->d_mel_len; p.mel_wofs = c->d_mel_wofs;
     p.mel_w = c->d_mel_w; p.melpow = melpow;
     // the pair kernel where it applies (launch_stft_mel checks the source rows); with the fused dB stage its LDS image must fit
-    if (c->stft_pair && c->d_pair_tables &&
-        stft_pair_lds_bytes(c->n_frames, c->cfg.n_mels, c->mel_w_floats, c->stft_pair_waves, db_out != nullptr) <= 160 * 1024) {
+    if (c->stft_pair && c->d_pair_tables && pair_lds(c, c->stft_pair_waves, db_out != nullptr) <= 160 * 1024) {
         p.pair_tables = c->d_pair_tables; p.pair_tw1 = c->d_pair_tw1; p.pair_waves = c->stft_pair_waves;
         p.pair_tw_lds = c->stft_pair_tw_lds ? 1 : 0;
     }
@@ -987,7 +1018,7 @@ int encode_common(amph_ctx* c, const void* d_wave, bool pcm16, int64_t n_rows, i
         hipStream_t ls = (bi % L == 0) ? s : w.stream;
         const char* wv = (const char*)d_wave + (size_t)off * n_in * esz;
         // a stage that fails (an allocation, a launch) stops the call: the later stages of the batch would read stale buffers
-        const bool fdb = can_fuse_db(c);               // dB / z-score / crop-pad inside the STFT kernel: no mel power in HBM
+        const bool fdb = can_fuse_db(c, pcm16);        // dB / z-score / crop-pad inside the STFT kernel: no mel power in HBM
         rc = run_frontend(c, w, wv, pcm16, nb, n_in, d_len ? d_len + off : nullptr, apply_rms, d_rms_ok ? d_rms_ok + off : nullptr,
                           w.melpow, ls, fdb ? w.image : nullptr, 1);
         if (rc == AMPH_OK && !fdb) rc = run_dbnorm(c, w.melpow, nb, 1, w.image, ls);
@@ -1059,16 +1090,26 @@ int amph_create(const amph_frontend_config* cfg, const amph_encoder_spec* spec, 
                 if (stft_mel_can_fuse_db(c->cfg.n_fft, c->n_frames, c->cfg.n_mels, c->mel_w_floats, nw))
                     lds = std::max(lds, (int)stft_mel_fused_lds_bytes(c->cfg.n_fft, c->n_frames, c->cfg.n_mels, c->mel_w_floats, nw));
             if (c->d_pair_tables) {
-                const bool fz = stft_mel_can_fuse_db(c->cfg.n_fft, c->n_frames, c->cfg.n_mels, c->mel_w_floats, c->stft_waves);
-                for (int nw : {8, 10, 11, 12})
-                    if (stft_pair_lds_bytes(c->n_frames, c->cfg.n_mels, c->mel_w_floats, nw, fz) + stft_pair_tw1_lds_bytes() <= 160 * 1024) c->stft_pair_waves = nw;
-            }
-            if (c->d_pair_tables)
+                // workgroup of the pair kernel: the largest whose LDS image fits WITH the fused dB stage and the stage-1 twiddles
+                // (1 s rows at n_fft 2048: 12 waves; the 128-band rows at n_fft 1024, 44.5 KB of mel power per row: 8), else the
+                // largest that fits without
+                const int* opts = c->cfg.n_fft == 2048 ? (const int[]){8, 10, 11, 12} : (const int[]){8, 12};
+                const int n_opts = c->cfg.n_fft == 2048 ? 4 : 2;
+                int pick = 0;
+                for (int fused = 1; fused >= 0 && !pick; --fused)
+                    for (int i = 0; i < n_opts; ++i)
+                        if (pair_lds(c, opts[i], fused != 0) + pair_tw1_lds(c) <= 160 * 1024) pick = opts[i];
+                if (pick) c->stft_pair_waves = pick;
+                else c->stft_pair_waves = opts[0];
+                // n_fft 1024, 128 bands: 12 waves + the separate dB kernel beat 8 waves with the stage fused (22 four-frame slots per row:
+                // 2 rounds against 3; 29.3 + 14.6 us against 41.0 us per 256 rows alone, 2.61 against 2.39 M chunks/s end to end in bf16 mode)
+                if (c->cfg.n_fft == 1024 && pair_lds(c, 12, false) + pair_tw1_lds(c) <= 160 * 1024) c->stft_pair_waves = 12;
                 for (int fused = 0; fused < 2; ++fused) {
-                    size_t lp = stft_pair_lds_bytes(c->n_frames, c->cfg.n_mels, c->mel_w_floats, c->stft_pair_waves, fused != 0);
-                    if (lp + stft_pair_tw1_lds_bytes() <= 160 * 1024) lp += stft_pair_tw1_lds_bytes();
+                    size_t lp = pair_lds(c, c->stft_pair_waves, fused != 0);
+                    if (lp + pair_tw1_lds(c) <= 160 * 1024) lp += pair_tw1_lds(c);
                     if (lp <= 160 * 1024) lds = std::max(lds, (int)lp);
                 }
+            }
             rc = amph::stft_mel_configure(lds) == hipSuccess ? AMPH_OK : fail(c, AMPH_ERR_HIP, "hipFuncSetAttribute failed");
         }
     }
@@ -1122,14 +1163,13 @@ int amph_configure(amph_ctx* c, const char* key, int value) {
     if (!std::strcmp(key, "stft_pair")) { c->stft_pair = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "stft_pair_tw_lds")) { c->stft_pair_tw_lds = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "stft_pair_waves")) {
-        if (value != 8 && value != 10 && value != 11 && value != 12) return fail(c, AMPH_ERR_INVALID_ARG, "stft_pair_waves must be 8, 10, 11 or 12");
+        const bool okv = c->cfg.n_fft == 2048 ? (value == 8 || value == 10 || value == 11 || value == 12) : (value == 8 || value == 12);
+        if (!okv) return fail(c, AMPH_ERR_INVALID_ARG, "stft_pair_waves must be 8, 10, 11 or 12 (n_fft 2048) / 8 or 12 (n_fft 1024)");
         if (c->d_pair_tables) {
-            const size_t lds = stft_pair_lds_bytes(c->n_frames, c->cfg.n_mels, c->mel_w_floats, value, false);
-            if (lds > 160 * 1024) return fail(c, AMPH_ERR_UNSUPPORTED, "stft_pair_waves=%d needs %zu bytes of LDS", value, lds);
-            size_t need = lds;
-            const size_t lf = stft_pair_lds_bytes(c->n_frames, c->cfg.n_mels, c->mel_w_floats, value, true);
-            if (lf <= 160 * 1024) need = lf;
-            if (need + stft_pair_tw1_lds_bytes() <= 160 * 1024) need += stft_pair_tw1_lds_bytes();
+            size_t need = pair_lds(c, value, false);
+            if (need > 160 * 1024) return fail(c, AMPH_ERR_UNSUPPORTED, "stft_pair_waves=%d needs %zu bytes of LDS", value, need);
+            if (pair_lds(c, value, true) <= 160 * 1024) need = pair_lds(c, value, true);
+            if (need + pair_tw1_lds(c) <= 160 * 1024) need += pair_tw1_lds(c);
             if (amph::stft_mel_configure((int)need) != hipSuccess) return fail(c, AMPH_ERR_HIP, "hipFuncSetAttribute failed");
         }
         c->stft_pair_waves = value;
@@ -1361,7 +1401,7 @@ int amph_mel_pcm16(amph_ctx* c, const int16_t* d_pcm, int n_rows, int n_in, cons
         const int nb = std::min(c->max_batch, n_rows - off);
         Workspace& w = c->lanes[0];
         // the mel power is wanted: it has to reach memory, so the dB stage runs as its own kernel
-        const bool fdb = !d_melpow_out && can_fuse_db(c);
+        const bool fdb = !d_melpow_out && can_fuse_db(c, true);
         float* mp = d_melpow_out ? d_melpow_out + (size_t)off * per_pow : w.melpow;
         int rc = run_frontend(c, w, d_pcm + (size_t)off * n_in, true, nb, n_in, d_lengths ? d_lengths + off : nullptr, apply_rms, nullptr, mp, s,
                               fdb ? d_mel_out + (size_t)off * per : nullptr, layout);

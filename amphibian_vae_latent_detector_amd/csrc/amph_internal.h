@@ -99,6 +99,11 @@ size_t stft_pair_lds_bytes(int n_frames, int n_mels, int mel_w_floats, int n_wav
 int stft_pair_table_bytes();
 size_t stft_pair_tw1_lds_bytes();
 bool stft_pair_ok(int n_fft, int hop, int p_tail);
+// ... and its n_fft 1024 / hop 256 form (k_stft_pair2: a pair per half wave, four frames per wave iteration; 8 or 12 waves)
+size_t stft_pair2_lds_bytes(int n_frames, int n_mels, int mel_w_floats, int n_waves, bool fused);
+int stft_pair2_table_bytes();
+size_t stft_pair2_tw1_lds_bytes();
+bool stft_pair2_ok(int n_fft, int hop, int p_tail);
 void launch_dbnorm(const DbNormParams& p, int n_rows, hipStream_t s);
 
 struct ResampleParams {      // resampy's resample_f for rows of equal length

@@ -945,13 +945,14 @@ __global__ __launch_bounds__(64 * NW) void k_stft_mel(StftParams p, int n_tiles)
 // mel power [n_frames][n_mels] the workgroup holds in LDS.  Same arithmetic as k_dbnorm (separately rounded dB terms, sums
 // in double, two-pass std); the mel power never reaches HBM (-3.7 MB written, -1.9 MB read and one launch less per 256 rows).
 __device__ __forceinline__ float to_db(float s, float ref_db);
-template <int NT>
+template <int NT, int C = 8>
 __device__ __forceinline__ void db_row_from_lds(const float* mp, int T, int M, int TT, int layout, float* out, double* red) {
     constexpr int NWV = NT / 64;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int n = T * M;
     float* redf = reinterpret_cast<float*>(red + 16);
-    constexpr int C = 8;                                 // values kept in registers per thread; beyond that recomputed per pass
+    // C values kept in registers per thread; beyond that recomputed per pass (8: a 58 x 64 row on 768 threads; the 87 x 128 rows of
+    // the 128-band preset on 512 threads take 24)
     float v[C];
     float mx = -INFINITY;
 #pragma unroll
@@ -1019,9 +1020,9 @@ __device__ __forceinline__ void db_row_from_lds(const float* mp, int T, int M, i
     }
 }
 
-template <int NT>
+template <int NT, int C = 8>
 __device__ __attribute__((noinline)) void db_row_call(const float* mp, int T, int M, int TT, int layout, float* out, double* red) {
-    db_row_from_lds<NT>(mp, T, M, TT, layout, out, red);
+    db_row_from_lds<NT, C>(mp, T, M, TT, layout, out, red);
 }
 
 // ----------------------------------------------------------------------------
@@ -1746,6 +1747,271 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
     }
 }
 
+// ----------------------------------------------------------------------------
+// The same for n_fft = 1024 / hop 256 ("pair2"; BASELINE configs[3]'s 128-band preset): a pair of frames is one complex 1024-point
+// FFT on a HALF wave (32 lanes x 32 points), a wave transforms two consecutive pairs = four consecutive frames per iteration
+// (tools/fft_pair_model.py, half_wave_pair_power).  Differences to k_stft_pair: lane' l = lane & 31 reads samples 64 j' + 2 l + e
+// (frame b = dword j' + 4), v_permlane16_swap pairs the column halves inside a half wave, the second stage needs NO cross-lane
+// step and no twiddle (lane k1' reads the whole exchange row T[k1'][0..31]), the partners N - k sit in lane' (32 - l) & 31, and
+// the mel rows of four frames share one weight read.
+// ----------------------------------------------------------------------------
+constexpr int kP2ExS = 36;                          // exchange row stride in floats (= 4 mod 64 over 16 rows: conflict-free 16-byte reads)
+constexpr int kP2Half = 32 * kP2ExS * 4;            // one half wave's tile: exchange (4 608 B), then partners (17 x 32 floats), then two power spectra
+constexpr int kP2Scratch = 2 * kP2Half;
+constexpr int kP2PStride = kP2Half / 8;             // floats between two power spectra (576 >= 513 + tail)
+constexpr int kP2WinBytes = 16 * 32 * 8, kP2Tw1Bytes = 31 * 32 * 8;
+
+template <int NW, bool TWL>
+__global__ __launch_bounds__(64 * NW) void k_stft_pair2(StftParams p, int n_rows) {
+    constexpr int kThreads = 64 * NW;
+    constexpr int HJ = 4, ND = 16 + HJ;
+    constexpr int kDbC = NW <= 8 ? 24 : 16;              // dB values a thread keeps in registers (87 x 128 on 512 threads: 22)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hw = lane >> 5, lp = lane & 31;
+    const float2* win = reinterpret_cast<const float2*>(smem) + lp;                      // [16][32] (w[n], w[n + 1]) 2^-15
+    constexpr int kTab = kP2WinBytes + (TWL ? kP2Tw1Bytes : 0);
+    const float2* tw1_l = reinterpret_cast<const float2*>(smem + kP2WinBytes) + lp;      // [31][32] (TWL)
+    const int meta_bytes = (p.n_mels * 12 + 15) & ~15;
+    const int melw_bytes = p.mel_w_floats * 4;
+    int3* mel_meta = reinterpret_cast<int3*>(smem + kTab);
+    float* mel_w = reinterpret_cast<float*>(smem + kTab + meta_bytes);
+    char* wbase = smem + kTab + meta_bytes + melw_bytes + wave * kP2Scratch;
+    float* Tw = reinterpret_cast<float*>(wbase);                                         // the wave's scratch (four power spectra)
+    float* T = reinterpret_cast<float*>(wbase + hw * kP2Half);                           // this half wave's tile
+    float* Pa = T;
+    float* Pb = T + kP2PStride;
+    float* mp_row = reinterpret_cast<float*>(smem + kTab + meta_bytes + melw_bytes + NW * kP2Scratch);
+    const bool fuse_db = p.db_out != nullptr;
+    {
+        const float4* src = reinterpret_cast<const float4*>(p.pair_tables);
+        float4* dst = reinterpret_cast<float4*>(smem);
+        for (int i = tid; i < kP2WinBytes / 16; i += kThreads) dst[i] = src[i];
+        if (TWL) {
+            const float4* s1 = reinterpret_cast<const float4*>(p.pair_tw1);
+            float4* d1 = reinterpret_cast<float4*>(smem + kP2WinBytes);
+            for (int i = tid; i < kP2Tw1Bytes / 16; i += kThreads) d1[i] = s1[i];
+        }
+        for (int m = tid; m < p.n_mels; m += kThreads) mel_meta[m] = make_int3(p.mel_start[m], p.mel_len[m], p.mel_wofs[m]);
+        const float4* wsrc = reinterpret_cast<const float4*>(p.mel_w);
+        float4* wdst = reinterpret_cast<float4*>(mel_w);
+        for (int i = tid; i < (p.mel_w_floats >> 2); i += kThreads) {
+            float4 v = wsrc[i];
+            v.x *= 0.25f; v.y *= 0.25f; v.z *= 0.25f; v.w *= 0.25f;
+            wdst[i] = v;
+        }
+    }
+    __syncthreads();
+
+    const int n_pairs = (p.n_frames + 1) >> 1, n_slots = (n_pairs + 1) >> 1;      // a slot = two pairs = four frames of one wave iteration
+    const int col = 2 * (lp & 15) + (lp >> 4);
+    const int zr_ = ((32 - lp) & 31) + (lp == 0 ? 32 : 0);
+    const __amdgpu_buffer_rsrc_t rs_tw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(p.pair_tw1), 0, -1, 0x00020000);
+    // (num_records = the rows' bytes: the frames of a pair past the row's last one read zeros behind the last row, finite samples of
+    // the next row elsewhere; their results are never stored)
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src.wave), 0, (int)((long long)n_rows * p.src.row_stride * 2), 0x00020000);
+    const int voff_x = lp * 4 + hw * p.hop * 4, lp8 = lp * 8;
+    uint32_t nx[ND];
+#pragma unroll
+    for (int j = 0; j < ND; ++j) nx[j] = 0;
+    auto fetch = [&](int row_, int q_) {
+        const int base = __builtin_amdgcn_readfirstlane((int)(((long long)row_ * p.src.row_stride) * 2 + (long long)q_ * p.hop * 8));
+#pragma unroll
+        for (int j = 0; j < ND; ++j) nx[j] = __builtin_amdgcn_raw_buffer_load_b32(rs_x, voff_x, base + 128 * j, 0);
+    };
+    if ((int)blockIdx.x < n_rows && wave < n_slots) fetch(blockIdx.x, wave);
+
+#define AMPH_PHASE_FENCE() __builtin_amdgcn_sched_barrier(0)
+    for (int row = blockIdx.x; row < n_rows; row += gridDim.x) {
+        for (int q = wave; q < n_slots; q += NW) {
+            float xr[2][16], xi[2][16];
+            float2 tw[31];
+            {
+                float2 wv[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) wv[j] = win[j * 32];
+                // a frame b past the row's last frame must be ZERO, not the next row's samples: the two frames of a pair leak into each
+                // other at the rounding level (1e-7 of the LOUDER one)
+                const bool has_b = 2 * (2 * q + hw) + 1 < p.n_frames;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const uint32_t da = nx[j], db = has_b ? nx[j + HJ] : 0u;
+                    xr[0][j] = (float)(short)(da & 0xFFFFu) * wv[j].x;
+                    xr[1][j] = (float)((int)da >> 16) * wv[j].y;
+                    xi[0][j] = (float)(short)(db & 0xFFFFu) * wv[j].x;
+                    xi[1][j] = (float)((int)db >> 16) * wv[j].y;
+                }
+            }
+#pragma unroll
+            for (int k1 = 1; k1 < 16; ++k1) if (!TWL) tw[k1 - 1] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs_tw, lp8, (k1 - 1) * 256, 0));
+            AMPH_PHASE_FENCE();
+            dft16(xr[0], xi[0]);
+            AMPH_PHASE_FENCE();
+#pragma unroll
+            for (int k1 = 16; k1 < 32; ++k1) if (!TWL) tw[k1 - 1] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs_tw, lp8, (k1 - 1) * 256, 0));
+            AMPH_PHASE_FENCE();
+            dft16(xr[1], xi[1]);
+#pragma unroll
+            for (int qq = 0; qq < 16; ++qq) {               // lanes' 16..31 sequence 0 <-> lanes' 0..15 sequence 1, in both half waves
+                const auto sr = __builtin_amdgcn_permlane16_swap(__float_as_uint(xr[0][qq]), __float_as_uint(xr[1][qq]), false, false);
+                const auto si = __builtin_amdgcn_permlane16_swap(__float_as_uint(xi[0][qq]), __float_as_uint(xi[1][qq]), false, false);
+                xr[0][qq] = __uint_as_float(sr[0]); xr[1][qq] = __uint_as_float(sr[1]);
+                xi[0][qq] = __uint_as_float(si[0]); xi[1][qq] = __uint_as_float(si[1]);
+            }
+            dft32_combine(xr[0], xi[0], xr[1], xi[1]);
+            AMPH_PHASE_FENCE();
+            if (TWL) {
+#pragma unroll
+                for (int k1 = 1; k1 < 16; ++k1) tw[k1 - 1] = tw1_l[(k1 - 1) * 32];
+            }
+#pragma unroll
+            for (int k1 = 1; k1 < 16; ++k1) {
+                const int qq = DFT16_POS(k1 & 15);
+                AMPH_CMUL(xr[0][qq], xi[0][qq], tw[k1 - 1].x, tw[k1 - 1].y);
+            }
+            if (TWL) {
+                AMPH_PHASE_FENCE();
+#pragma unroll
+                for (int k1 = 16; k1 < 32; ++k1) tw[k1 - 1] = tw1_l[(k1 - 1) * 32];
+            }
+#pragma unroll
+            for (int k1 = 16; k1 < 32; ++k1) {
+                const int qq = DFT16_POS(k1 & 15);
+                AMPH_CMUL(xr[1][qq], xi[1][qq], tw[k1 - 1].x, tw[k1 - 1].y);
+            }
+            // ---- exchange inside the half wave: lane k1' reads its whole row
+            float ur[2][16], ui[2][16];
+#pragma unroll
+            for (int k1 = 0; k1 < 32; ++k1) T[k1 * kP2ExS + col] = xr[k1 >> 4][DFT16_POS(k1 & 15)];
+            wave_lds_sync();
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float4 v = *reinterpret_cast<const float4*>(T + lp * kP2ExS + 4 * c);
+                ur[0][2 * c] = v.x; ur[1][2 * c] = v.y; ur[0][2 * c + 1] = v.z; ur[1][2 * c + 1] = v.w;
+            }
+            wave_lds_sync();
+#pragma unroll
+            for (int k1 = 0; k1 < 32; ++k1) T[k1 * kP2ExS + col] = xi[k1 >> 4][DFT16_POS(k1 & 15)];
+            wave_lds_sync();
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float4 v = *reinterpret_cast<const float4*>(T + lp * kP2ExS + 4 * c);
+                ui[0][2 * c] = v.x; ui[1][2 * c] = v.y; ui[0][2 * c + 1] = v.z; ui[1][2 * c + 1] = v.w;
+            }
+            wave_lds_sync();
+            AMPH_PHASE_FENCE();
+            // ---- stage 2: DFT32 of the row: X[k1' + 32 k2']
+            dft16(ur[0], ui[0]);
+            dft16(ur[1], ui[1]);
+            dft32_combine(ur[0], ui[0], ur[1], ui[1]);
+            AMPH_PHASE_FENCE();
+            // ---- split: partners N - k from the upper half (k2' >= 16) of lane' (32 - l) & 31
+            float pre[16], pim[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) T[r * 32 + lp] = ur[1][DFT16_POS(r)];
+            if (lp == 0) T[16 * 32] = ur[0][DFT16_POS(0)];
+            wave_lds_sync();
+#pragma unroll
+            for (int i = 0; i < 16; ++i) pre[i] = T[(15 - i) * 32 + zr_];
+            wave_lds_sync();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) T[r * 32 + lp] = ui[1][DFT16_POS(r)];
+            if (lp == 0) T[16 * 32] = ui[0][DFT16_POS(0)];
+            wave_lds_sync();
+#pragma unroll
+            for (int i = 0; i < 16; ++i) pim[i] = T[(15 - i) * 32 + zr_];
+            wave_lds_sync();
+            AMPH_PHASE_FENCE();
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float zr = ur[0][DFT16_POS(i)], zi = ui[0][DFT16_POS(i)];
+                const float ar = zr + pre[i], ai = zi - pim[i], br = zi + pim[i], bi = pre[i] - zr;
+                Pa[lp + 32 * i] = ar * ar + ai * ai;
+                Pb[lp + 32 * i] = br * br + bi * bi;
+            }
+            if (lp == 0) {                                  // bin 512 is its own partner
+                const float zr = ur[1][DFT16_POS(0)], zi = ui[1][DFT16_POS(0)];
+                Pa[512] = 4.0f * zr * zr;
+                Pb[512] = 4.0f * zi * zi;
+            }
+            for (int i = lp; i < p.p_tail; i += 32) { Pa[513 + i] = 0.0f; Pb[513 + i] = 0.0f; }
+            wave_lds_sync();
+            AMPH_PHASE_FENCE();
+            {
+                int nrow = row, nq = q + NW;
+                if (nq >= n_slots) { nrow = row + gridDim.x; nq = wave; }
+                if (nrow < n_rows) fetch(nrow, nq);
+            }
+            AMPH_PHASE_FENCE();
+            // ---- mel rows of the slot's four consecutive frames 4 q .. 4 q + 3: one weight read serves all four
+            {
+                const int qd = lane & 3;
+                const int n_rounds = (p.n_mels + 15) >> 4;
+                const int f0 = 4 * q;
+                const int nf = min(4, p.n_frames - f0);      // wave-uniform: frames of the slot that exist
+                float* out0 = fuse_db ? mp_row + f0 * p.n_mels : p.melpow + ((long long)row * p.n_frames + f0) * p.n_mels;
+                int3 mt = mel_meta[min(lane >> 2, p.n_mels - 1)];
+                for (int r = 0; r < n_rounds; ++r) {
+                    const int steps = __builtin_amdgcn_readfirstlane(mt.y);
+                    const float4* w = reinterpret_cast<const float4*>(mel_w + mt.z) + qd;
+                    const float4* pp = reinterpret_cast<const float4*>(Tw + mt.x) + qd;        // frame f of the slot: + f * kP2PStride floats
+                    if (r + 1 < n_rounds) mt = mel_meta[min(16 * (r + 1) + (lane >> 2), p.n_mels - 1)];
+                    float acc[4][2];
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) acc[f][0] = acc[f][1] = 0.0f;
+#define AMPH_MEL_FMA(acc_, a_, b_)                                                         \
+    acc_ = fmaf(a_.x, b_.x, acc_); acc_ = fmaf(a_.y, b_.y, acc_); acc_ = fmaf(a_.z, b_.z, acc_); acc_ = fmaf(a_.w, b_.w, acc_);
+                    int i0 = 0;
+                    for (; i0 + 2 <= steps; i0 += 2) {
+                        float4 wq[2], xq[2][4];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            wq[u] = w[4 * (i0 + u)];
+#pragma unroll
+                            for (int f = 0; f < 4; ++f) xq[u][f] = pp[4 * (i0 + u) + f * (kP2PStride / 4)];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 2; ++u)
+#pragma unroll
+                            for (int f = 0; f < 4; ++f) { AMPH_MEL_FMA(acc[f][u], wq[u], xq[u][f]) }
+                    }
+                    if (i0 < steps) {
+                        const float4 w0 = w[4 * i0];
+#pragma unroll
+                        for (int f = 0; f < 4; ++f) { const float4 x0 = pp[4 * i0 + f * (kP2PStride / 4)]; AMPH_MEL_FMA(acc[f][0], w0, x0) }
+                    }
+#undef AMPH_MEL_FMA
+                    const int m = 16 * r + (lane >> 2);
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) {
+                        float sa = acc[f][0] + acc[f][1];
+                        sa += dpp_xor1(sa);
+                        sa += dpp_xor2(sa);
+                        if (qd == 0 && m < p.n_mels && f < nf) out0[f * p.n_mels + m] = sa;
+                    }
+                }
+            }
+            wave_lds_sync();
+            AMPH_PHASE_FENCE();
+        }
+        if (fuse_db && row + (int)gridDim.x < n_rows) {
+            __syncthreads();
+            db_row_call<kThreads, kDbC>(mp_row, p.n_frames, p.n_mels, p.db_target_frames, p.db_layout,
+                                  p.db_out + (long long)row * p.db_target_frames * p.n_mels,
+                                  reinterpret_cast<double*>(mp_row + ((p.n_frames * p.n_mels + 3) & ~3)));
+            __syncthreads();
+        }
+    }
+#undef AMPH_PHASE_FENCE
+    if (fuse_db && (int)blockIdx.x < n_rows) {
+        const int last_row = blockIdx.x + (n_rows - 1 - (int)blockIdx.x) / (int)gridDim.x * (int)gridDim.x;
+        __syncthreads();
+        db_row_from_lds<kThreads, kDbC>(mp_row, p.n_frames, p.n_mels, p.db_target_frames, p.db_layout,
+                                  p.db_out + (long long)last_row * p.db_target_frames * p.n_mels,
+                                  reinterpret_cast<double*>(mp_row + ((p.n_frames * p.n_mels + 3) & ~3)));
+    }
+}
+
 size_t stft_pair_lds_bytes(int n_frames, int n_mels, int mel_w_floats, int n_waves, bool fused) {
     const size_t meta = ((size_t)n_mels * 12 + 15) & ~(size_t)15;
     const size_t mp = fused ? (((size_t)n_frames * n_mels + 3) & ~(size_t)3) * 4 + 16 * 8 + 16 * 4 : 0;
@@ -1753,6 +2019,14 @@ size_t stft_pair_lds_bytes(int n_frames, int n_mels, int mel_w_floats, int n_wav
 }
 size_t stft_pair_tw1_lds_bytes() { return kPairTw1Bytes; }
 int stft_pair_table_bytes() { return kPairWinBytes + kPairTw2Bytes; }
+size_t stft_pair2_lds_bytes(int n_frames, int n_mels, int mel_w_floats, int n_waves, bool fused) {
+    const size_t meta = ((size_t)n_mels * 12 + 15) & ~(size_t)15;
+    const size_t mp = fused ? (((size_t)n_frames * n_mels + 3) & ~(size_t)3) * 4 + 16 * 8 + 16 * 4 : 0;
+    return (size_t)kP2WinBytes + meta + (size_t)mel_w_floats * 4 + (size_t)n_waves * kP2Scratch + mp;
+}
+int stft_pair2_table_bytes() { return kP2WinBytes; }
+size_t stft_pair2_tw1_lds_bytes() { return kP2Tw1Bytes; }
+bool stft_pair2_ok(int n_fft, int hop, int p_tail) { return n_fft == 1024 && hop == 256 && 513 + p_tail <= kP2PStride; }
 // the configurations the pair kernel covers (the caller also needs PCM16 rows padded by K0: src.lead == n_fft / 2)
 bool stft_pair_ok(int n_fft, int hop, int p_tail) { return n_fft == 2048 && hop == 384 && 1025 + p_tail <= kPairPStride; }
 
@@ -1809,6 +2083,12 @@ hipError_t stft_mel_configure(int lds_bytes) {
         e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
     }
+    const void* p2fns[4] = {reinterpret_cast<const void*>(&k_stft_pair2<8, false>), reinterpret_cast<const void*>(&k_stft_pair2<8, true>),
+                            reinterpret_cast<const void*>(&k_stft_pair2<12, false>), reinterpret_cast<const void*>(&k_stft_pair2<12, true>)};
+    for (const void* f : p2fns) {
+        e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) return e;
+    }
     s_lds_max = lds_bytes;
     return hipSuccess;
 }
@@ -1861,6 +2141,21 @@ void launch_stft_mel(const StftParams& p, int n_rows, int sample_is_pcm16, int n
         else if (nw == 12) { AMPH_PAIR_LAUNCH(12) }
         else { AMPH_PAIR_LAUNCH(10) }
 #undef AMPH_PAIR_LAUNCH
+        return;
+    }
+    if (p.pair_tables && sample_is_pcm16 && p.src.lead == p.n_fft / 2 && stft_pair2_ok(p.n_fft, p.hop, p.p_tail)) {
+        const int nw = p.pair_waves == 8 ? 8 : 12;
+        size_t lds = stft_pair2_lds_bytes(p.n_frames, p.n_mels, p.mel_w_floats, nw, p.db_out != nullptr);
+        const bool twl = p.pair_tw_lds && lds + kP2Tw1Bytes <= 160 * 1024;
+        if (twl) lds += kP2Tw1Bytes;
+        const dim3 grid((unsigned)std::min(n_rows, g_stft_grid > 0 ? g_stft_grid : g_num_cus));
+        if (nw == 8) {
+            if (twl) hipLaunchKernelGGL((k_stft_pair2<8, true>), grid, dim3(512), lds, s, p, n_rows);
+            else hipLaunchKernelGGL((k_stft_pair2<8, false>), grid, dim3(512), lds, s, p, n_rows);
+        } else {
+            if (twl) hipLaunchKernelGGL((k_stft_pair2<12, true>), grid, dim3(768), lds, s, p, n_rows);
+            else hipLaunchKernelGGL((k_stft_pair2<12, false>), grid, dim3(768), lds, s, p, n_rows);
+        }
         return;
     }
     if (n_waves == 12) launch_stft_mel_nw<12>(p, n_tiles, sample_is_pcm16, s);

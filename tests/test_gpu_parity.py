@@ -225,14 +225,16 @@ def test_mel_image_against_oracle_both_pad_modes(env, pad_mode):
         s2.configure("stft_pair", 1)
 
 
-def test_pair_of_frames_stft_kernel_against_oracle_and_the_frame_per_wave_kernel(env, capsys):
+@pytest.mark.parametrize("preset", ["bench-1s", "bench-1s-128"])
+def test_pair_of_frames_stft_kernel_against_oracle_and_the_frame_per_wave_kernel(env, capsys, preset):
     """k_stft_pair (two frames per wave as one complex 2048-point FFT; the default for PCM16 rows at n_fft 2048 / hop 384) against
     the CPU restatement of librosa's melspectrogram (map_detector_core.py:219-228) and against k_stft_mel_w on the same rows:
     mel power within 1e-6 of the row's peak, images within 1e-4 of the oracle's, with and without the RMS stage, full and
     ragged rows (a last pair with ONE frame is covered by the 3 s preset: 376 frames are 188 pairs, 626: 313), every
     workgroup shape, stage-1 twiddles in LDS and from global memory, several rows per workgroup (in-loop dB stage), and the
-    fused dB stage equal to the separate kernel bit for bit."""
-    cfg = env.cfg
+    fused dB stage equal to the separate kernel bit for bit.  bench-1s-128: k_stft_pair2, the n_fft 1024 / hop 256 form (a pair per
+    half wave, four frames per wave iteration; 87 frames: the last slot holds three)."""
+    cfg = env.PRESETS[preset]
     B = 12
     sess = env.AmphSession(cfg, None, None, DEV, max_batch=B)
     pcm = env.synth([0, 1, 2, 3, 4, 5, 6, 7, 8, 49, 10, 11], cfg.n_samples, cfg.sr)
@@ -252,7 +254,8 @@ def test_pair_of_frames_stft_kernel_against_oracle_and_the_frame_per_wave_kernel
             sess.configure("stft_pair", 0)
             old_img, old_p = (t.cpu().numpy() for t in sess.mel_pcm16(pcm, lengths=ln, apply_rms=apply_rms, layout=1, want_power=True))
             sess.configure("stft_pair", 1)
-            for waves, tw_lds, grid in ((10, 1, 0), (8, 1, 0), (12, 0, 0), (10, 0, 5), (8, 1, 3)):
+            shapes = ((10, 1, 0), (8, 1, 0), (12, 0, 0), (10, 0, 5), (8, 1, 3)) if cfg.n_fft == 2048 else ((8, 1, 0), (12, 1, 0), (12, 0, 5), (8, 0, 3))
+            for waves, tw_lds, grid in shapes:
                 sess.configure("stft_pair_waves", waves)
                 sess.configure("stft_pair_tw_lds", tw_lds)
                 sess.configure("stft_grid", grid)
@@ -263,14 +266,15 @@ def test_pair_of_frames_stft_kernel_against_oracle_and_the_frame_per_wave_kernel
                 ep = (np.abs(pw - want_p).max(axis=(1, 2)) / peak).max()
                 eo = (np.abs(pw - old_p).max(axis=(1, 2)) / peak).max()
                 assert ep <= 2e-6 and eo <= 1e-6, (apply_rms, waves, ep, eo)
-                assert np.abs(img - want_i).max() <= 1e-4 and np.abs(img - old_img).max() <= 5e-5
+                e_or, e_old = float(np.abs(img - want_i).max()), float(np.abs(img - old_img).max())
+                assert e_or <= 1e-4 and e_old <= 1e-4, (apply_rms, waves, e_or, e_old)
                 assert not pw[9].any()                                                # the silent row stays exactly zero
                 worst_p, worst_i = max(worst_p, ep), max(worst_i, float(np.abs(img - want_i).max()))
             sess.configure("stft_grid", 0)
-            sess.configure("stft_pair_waves", 10)
+            sess.configure("stft_pair_waves", 10 if cfg.n_fft == 2048 else 8)
             sess.configure("stft_pair_tw_lds", 1)
     with capsys.disabled():
-        print(f"\n[k_stft_pair] mel power vs oracle: {worst_p:.2e} of the row's peak; image vs oracle: {worst_i:.2e}")
+        print(f"\n[k_stft_pair{'' if cfg.n_fft == 2048 else '2'}, {preset}] mel power vs oracle: {worst_p:.2e} of the row's peak; image vs oracle: {worst_i:.2e}")
     sess.close()
 
 

@@ -157,3 +157,84 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# n_fft = 1024 (k_stft_pair<..., LP = 32>): a pair of frames is one complex 1024-point FFT on a HALF wave (32 lanes x 32 points),
+# a wave transforms two pairs.  lane' l (0..31): samples 64 j' + 2 l + e; l < 16 even-j halves of columns 2 l + e, l >= 16 the odd-j
+# halves of columns 2 (l - 16) + e; v_permlane16_swap pairs them; col(l) = 2 (l & 15) + (l >> 4).  Stage 2 needs no cross-lane step:
+# lane k1' reads the whole exchange row T[k1'][0..31] and transforms it: X[k1' + 32 k2'].  Partners N - k: lane (32 - k1') & 31,
+# register 31 - i (k1' >= 1) / 32 - i (k1' = 0).
+def half_wave_pair_power(row, s0, hop=256):
+    n_ = 1024
+    w = 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(n_) / n_)
+    seq = np.zeros((32, 2, 16), complex)
+    for l in range(32):
+        for jp in range(16):
+            for e in range(2):
+                n = 64 * jp + 2 * l + e
+                seq[l, e, jp] = w[n] * (row[s0 + n] + 1j * row[s0 + hop + n])
+    d = np.zeros_like(seq)
+    for l in range(32):
+        for e in range(2):
+            d[l, e] = dft16_inplace(seq[l, e])
+    E, O = d[:, 0].copy(), d[:, 1].copy()
+    for i in range(16):                                   # v_permlane16_swap(vdst = seq0, src0 = seq1): vdst[16 + i] <-> src0[i]
+        E[16 + i], O[i] = d[i, 1].copy(), d[16 + i, 0].copy()
+    T = np.zeros((32, 32), complex)
+    for l in range(32):
+        c = 2 * (l & 15) + (l >> 4)
+        r0, r1 = np.empty(16, complex), np.empty(16, complex)
+        for k in range(16):
+            q = pos16(k)
+            t = np.exp(-2j * np.pi * k / 32) * O[l][q]
+            r0[q], r1[q] = E[l][q] + t, E[l][q] - t
+        for p, arr in enumerate((r0, r1)):
+            for k in range(16):
+                k1 = k + 16 * p
+                T[k1, c] = arr[pos16(k)] * np.exp(-2j * np.pi * ((c * k1) % n_) / n_)
+    out = np.zeros((32, 2, 16), complex)
+    for l in range(32):
+        u = T[l]
+        out[l, 0], out[l, 1] = dft32_arrays(u[0::2], u[1::2])
+    z = w * (row[s0:s0 + n_] + 1j * row[s0 + hop:s0 + hop + n_])
+    Z = np.fft.fft(z)
+    for l in range(32):
+        for p in range(2):
+            for k in range(16):
+                assert abs(out[l, p, pos16(k)] - Z[l + 32 * (k + 16 * p)]) < 1e-9 * (1 + abs(Z).max())
+    Zp = np.zeros((17, 32), complex)
+    for l in range(32):
+        for r in range(16):
+            Zp[r, l] = out[l, 1, pos16(r)]
+        if l == 0:
+            Zp[16, 0] = out[0, 0, pos16(0)]
+    Pa, Pb = np.zeros(n_ // 2 + 1), np.zeros(n_ // 2 + 1)
+    for l in range(32):
+        colp, rofs = (32 - l) & 31, (1 if l == 0 else 0)
+        for i in range(16):
+            zk, pk = out[l, 0, pos16(i)], Zp[15 - i + rofs, colp]
+            Pa[l + 32 * i] = (zk.real + pk.real) ** 2 + (zk.imag - pk.imag) ** 2
+            Pb[l + 32 * i] = (zk.imag + pk.imag) ** 2 + (pk.real - zk.real) ** 2
+        if l == 0:
+            zk = out[0, 1, pos16(0)]
+            Pa[512], Pb[512] = 4 * zk.real ** 2, 4 * zk.imag ** 2
+    return Pa, Pb
+
+
+def main2():
+    rng = np.random.default_rng(1)
+    row = rng.standard_normal(1024 + 8 * 256)
+    for s0 in (0, 512, 1280):
+        Pa, Pb = half_wave_pair_power(row, s0)
+        w = 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(1024) / 1024)
+        ra = np.abs(np.fft.rfft(w * row[s0:s0 + 1024])) ** 2
+        rb = np.abs(np.fft.rfft(w * row[s0 + 256:s0 + 256 + 1024])) ** 2
+        ea, eb = np.abs(Pa / 4 - ra).max() / ra.max(), np.abs(Pb / 4 - rb).max() / rb.max()
+        print(f"n_fft 1024, s0={s0}: {ea:.2e} (frame a), {eb:.2e} (frame b)")
+        assert ea < 1e-12 and eb < 1e-12
+    print("half-wave pair model OK")
+
+
+if __name__ == "__main__":
+    main2()

@@ -7,29 +7,18 @@ from amphibian_vae_latent_detector_amd import PRESETS
 from amphibian_vae_latent_detector_amd.encoder import AmphSession
 from amphibian_vae_latent_detector_amd.synth import synth_batch_pcm16
 from oracle import frontend as ofe
-cfg = PRESETS["bench-1s"]
-B = 40
+cfg = PRESETS[sys.argv[1] if len(sys.argv) > 1 else "bench-1s-128"]
+idx = [0, 1, 2, 3, 4, 5, 6, 7, 8, 49, 10, 11]
+B = len(idx)
 s = AmphSession(cfg, None, None, "cuda:0", max_batch=B)
-pcm_h = synth_batch_pcm16(list(range(B)), cfg.n_samples, cfg.sr)
+pcm_h = synth_batch_pcm16(idx, cfg.n_samples, cfg.sr)
 pcm = torch.from_numpy(pcm_h).to("cuda:0")
-lens_h = np.array([cfg.n_samples - 371 * r for r in range(B)], dtype=np.int32)
-lens = torch.from_numpy(lens_h).to("cuda:0")
-for v in (0, 1):
-    s.configure("stft_pair", v)
-    outs = []
-    for rep in range(3):
-        img, pw = s.mel_pcm16(pcm, lengths=lens, apply_rms=True, layout=1, want_power=True)
-        outs.append(pw.cpu().numpy())
-        nrm, ok = s.rms_normalize(pcm[:, :])
-    for a in outs[1:]:
-        d = np.abs(a - outs[0]).max(axis=(1, 2))
-        print("pair", v, "rows differing run to run:", np.nonzero(d > 0)[0].tolist(), d.max())
-    res = outs[-1]
-    bad = []
+for rms in (False, True):
+    want = np.stack([ofe.wave_to_mel(ofe.normalize_pcm16_chunk(q, rms)[0], **cfg.mel_kwargs()).T for q in pcm_h])
+    s.configure("stft_pair", 0)
+    i0, p0 = (t.cpu().numpy() for t in s.mel_pcm16(pcm, apply_rms=rms, layout=1, want_power=True))
+    s.configure("stft_pair", 1)
+    i1, p1 = (t.cpu().numpy() for t in s.mel_pcm16(pcm, apply_rms=rms, layout=1, want_power=True))
     for r in range(B):
-        yr, good = ofe.normalize_pcm16_chunk(pcm_h[r, :lens_h[r]], True)
-        yy = np.zeros(cfg.n_samples, np.float32); yy[:yr.size] = yr
-        want = ofe.melspectrogram(yy, cfg.sr, cfg.n_fft, cfg.hop_length, cfg.n_mels, cfg.fmin, cfg.fmax).T
-        e = np.abs(res[r] - want).max() / want.max()
-        if e > 1e-5: bad.append((r, float(e)))
-    print("pair", v, "rows off the oracle:", bad)
+        print(f"rms {int(rms)} row {r}: old vs oracle {np.abs(i0[r]-want[r]).max():.2e}  pair vs oracle {np.abs(i1[r]-want[r]).max():.2e}  pair vs old {np.abs(i1[r]-i0[r]).max():.2e}"
+              f"  power pair vs old / peak {np.abs(p1[r]-p0[r]).max()/max(p0[r].max(),1e-30):.2e}")
