@@ -145,12 +145,38 @@ def crop_or_pad_time(mel: np.ndarray, target_frames: int) -> np.ndarray:
     return np.pad(mel, ((0, 0), (left, -extra - left)), mode="constant")
 
 
-def _config(sr, duration, n_mels, fmin, fmax, hop_length, n_fft, target_frames, pad_mode=PAD_REFLECT) -> FrontendConfig:
+def _config(sr, duration, n_mels, fmin, fmax, hop_length, n_fft, target_frames, pad_mode=PAD_REFLECT,
+            whole_file_samples: Optional[int] = None) -> FrontendConfig:
+    """duration > 0: the fixed-length chunk of map_detector_core.py:212-217.  duration <= 0 (the reference then skips the
+    pad / truncate step and transforms the WHOLE file, :212): the caller passes the file's length and gets a configuration
+    whose n_samples is exactly that length - one front-end context per distinct length (cached like any other)."""
     if not duration > 0:
-        raise RuntimeError("duration must be > 0 on the HIP path (fixed-length chunks)")
-    return FrontendConfig(sr=int(sr), duration=float(duration), n_fft=int(n_fft), hop_length=int(hop_length),
-                          n_mels=int(n_mels), fmin=float(fmin), fmax=float(fmax), target_frames=int(target_frames),
-                          pad_mode=pad_mode)
+        if whole_file_samples is None:
+            raise RuntimeError("duration <= 0 means the whole file: its length is needed (whole_file_samples)")
+        n = int(whole_file_samples)
+        duration = (n + 0.5) / float(sr)                  # int(sr * duration) == n for every n (FrontendConfig.n_samples)
+    cfg = FrontendConfig(sr=int(sr), duration=float(duration), n_fft=int(n_fft), hop_length=int(hop_length),
+                         n_mels=int(n_mels), fmin=float(fmin), fmax=float(fmax), target_frames=int(target_frames),
+                         pad_mode=pad_mode)
+    if whole_file_samples is not None and cfg.n_samples != int(whole_file_samples):
+        raise RuntimeError(f"internal: n_samples {cfg.n_samples} != file length {whole_file_samples}")
+    return cfg
+
+
+def _whole_file(wav_path: Path, sr: int, device=None):
+    """The whole signal as librosa.load(path, sr=sr, mono=True) returns it (the duration <= 0 path): float32 [n]."""
+    wav_path = Path(wav_path)
+    if not wav_path.exists():
+        raise FileNotFoundError(f"No existe WAV: {wav_path}")
+    y, rate = wavio.load_audio(wav_path)
+    if rate != int(sr):
+        y = wavio.load_float_mono(wav_path, int(sr), session=_frontend_session(PRESETS_FOR_RESAMPLE(int(sr)), device))
+    return np.ascontiguousarray(y, dtype=np.float32)
+
+
+def PRESETS_FOR_RESAMPLE(sr: int) -> FrontendConfig:
+    """any valid configuration at this rate: the resampler (K8) only needs a context on the device"""
+    return FrontendConfig(sr=sr, duration=1.0, n_fft=2048, hop_length=384, n_mels=64, fmin=0.0, fmax=sr / 2.0, target_frames=64)
 
 
 _frontend_sessions: Dict[tuple, AmphSession] = {}
@@ -182,6 +208,10 @@ def _load_wave(wav_path: Path, cfg: FrontendConfig, device=None):
 def wav_to_mel(wav_path: Path, *, sr: int, duration: float, n_mels: int, fmin: float, fmax: float, hop_length: int,
                n_fft: int, target_frames: int, device: Optional[torch.device] = None) -> torch.Tensor:
     """float32 [n_mels, target_frames] on the host, computed by the HIP front end."""
+    if not duration > 0:                                  # whole file (ref :212: no pad / truncate step)
+        y = _whole_file(Path(wav_path), sr, device)
+        cfg = _config(sr, duration, n_mels, fmin, fmax, hop_length, n_fft, target_frames, whole_file_samples=y.shape[0])
+        return _frontend_session(cfg, device).mel(y[None], layout=0)[0].cpu()
     cfg = _config(sr, duration, n_mels, fmin, fmax, hop_length, n_fft, target_frames)
     sess = _frontend_session(cfg, device)
     y, n_valid = _load_wave(Path(wav_path), cfg, device)
@@ -221,8 +251,13 @@ def _adapt_output(out) -> np.ndarray:
 @torch.no_grad()
 def encode_wav_to_latent(encoder, wav_path: Path, device: torch.device, *, sr: int, duration: float, n_mels: int,
                          fmin: float, fmax: float, hop_length: int, n_fft: int, target_frames: int) -> np.ndarray:
-    cfg = _config(sr, duration, n_mels, fmin, fmax, hop_length, n_fft, target_frames)
-    y, n_valid = _load_wave(Path(wav_path), cfg, device)
+    if not duration > 0:                                  # whole file (ref :212): a context per file length
+        y = _whole_file(Path(wav_path), sr, device)
+        cfg = _config(sr, duration, n_mels, fmin, fmax, hop_length, n_fft, target_frames, whole_file_samples=y.shape[0])
+        n_valid = y.shape[0]
+    else:
+        cfg = _config(sr, duration, n_mels, fmin, fmax, hop_length, n_fft, target_frames)
+        y, n_valid = _load_wave(Path(wav_path), cfg, device)
     if isinstance(encoder, HipEncoder):
         sess = encoder.session(cfg)
         mu, _, _ = sess.encode(y[None], lengths=np.array([n_valid], dtype=np.int32), apply_rms=False)

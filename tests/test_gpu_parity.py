@@ -635,11 +635,14 @@ def test_config3_100k_chunks_as_8_virtual_shards_then_08_fit(env, capsys):
     rows400 = torch.from_numpy(np.array([pos[c] for sp in synth.SPECIES for c in plan400[sp]])).to(DEV)
     assert torch.equal(sess.encode(dev[rows400], apply_rms=True)[0], Z1[rows400])
     report = []
-    for tag, Zg_, Zc_ in (("max_per_class 0 (10 000-chunk subset)", Zg_sub, Zc_sub), ("max_per_class 400, seed 123", Zg_400, Zc_400)):
+    # every point of the reference's q_out grid (run_qout_grid.sh:13) on the 10 000-chunk subset; the sampled fit at its first point
+    cases = [(f"max_per_class 0 (10 000-chunk subset), q_out {q:.2f}", Zg_sub, Zc_sub, q) for q in (0.10, 0.15, 0.20, 0.25)]
+    cases.append(("max_per_class 400, seed 123, q_out 0.10", Zg_400, Zc_400, 0.10))
+    for tag, Zg_, Zc_, q_out in cases:
         for sp in synth.SPECIES:
             _assert_latents(Zg_[sp], Zc_[sp])
-        rg = prad.fit_radial_detector(Zg_, 0.95, 0.10, verbose=False)
-        rc = prad.fit_radial_detector(Zc_, 0.95, 0.10, verbose=False)
+        rg = prad.fit_radial_detector(Zg_, 0.95, q_out, verbose=False)
+        rc = prad.fit_radial_detector(Zc_, 0.95, q_out, verbose=False)
         worst = 0.0
         for sp in synth.SPECIES:
             rel = abs(rg["thresholds"][sp] - rc["thresholds"][sp]) / rc["thresholds"][sp]
@@ -1050,6 +1053,18 @@ def test_map_detector_core_surface(env, tmp_path):
     # a caller-supplied torch module goes through the HIP front end + the reference adapter
     z2 = core.encode_wav_to_latent(tenc.to("cuda"), wav, torch.device("cuda"), **kw)
     _assert_latents(z2[None], env.oenc.encode_mel_to_latent(tenc.cpu(), want_mel)[None])
+    # duration <= 0 (map_detector_core.py:212: no pad / truncate step): the WHOLE file - here 22 550 samples, 59 frames instead of
+    # 58 - through a front-end context of exactly that length; a second file of another length gets its own
+    kw0 = dict(kw, duration=0.0)
+    mel0 = core.wav_to_mel(wav, **kw0)
+    want0 = env.ofe.wav_to_mel(wav, **kw0)
+    assert tuple(mel0.shape) == (64, 64) and np.abs(mel0.numpy() - want0).max() <= 1e-4
+    assert np.abs(mel0.numpy() - mel.numpy()).max() > 1e-3                      # not the truncated chunk's image
+    z0 = core.encode_wav_to_latent(encoder, wav, torch.device("cuda"), **kw0)
+    _assert_latents(z0[None], env.oenc.encode_mel_to_latent(tenc, want0)[None])
+    wav_b = tmp_path / "other_length.wav"
+    synth.write_wav_pcm16(wav_b, synth.synth_chunk_pcm16(3, 30011, cfg.sr), cfg.sr)
+    assert np.abs(core.wav_to_mel(wav_b, **dict(kw0, duration=-1.0)).numpy() - env.ofe.wav_to_mel(wav_b, **kw0)).max() <= 1e-4
     # stereo file: channel mean on the float path
     st = np.stack([q, q], axis=1)
     synth.write_wav_pcm16(tmp_path / "st.wav", st, cfg.sr)

@@ -242,6 +242,34 @@ def test_cli_flags_are_the_reference_07_flags():
         parse_args([])                                             # --wav is required
 
 
+def test_07_output_adapter_variant_and_whole_file_configuration():
+    """07's own extract_vector (07_encode_wav_to_latent.py:264-297): the extra dict key "enc", ValueError, the empty time axis
+    guard, [B, D] tensor out; and the duration <= 0 configuration (map_detector_core.py:212: no pad / truncate step - the
+    whole file): n_samples equals the file length for every length."""
+    import torch
+    from amphibian_vae_latent_detector_amd.encode_wav_to_latent import extract_vector
+    from amphibian_vae_latent_detector_amd import map_detector_core as core
+    t = torch.arange(12, dtype=torch.float32).reshape(1, 3, 4)
+    assert torch.equal(extract_vector(t), t.mean(dim=1))                      # [B, T, C] -> mean over T
+    assert extract_vector(torch.zeros(2, 0, 5)).shape == (2, 0, 5)            # empty T axis: returned as it is, t[:, :0] (core's adapter would average it to NaN)
+    assert torch.equal(extract_vector({"enc": t[:, 0]}), t[:, 0])              # 07's extra key
+    assert torch.equal(extract_vector({"other": 1, "enc": t[:, 1], "mu": t[:, 2]}), t[:, 2])   # ... after the core's keys, in order
+    assert torch.equal(extract_vector({"x": "no", "y": t[:, 1]}), t[:, 1])     # else the first tensor value
+    assert torch.equal(extract_vector((None, t[:, 0], t[:, 1])), t[:, 0])
+    assert extract_vector(torch.zeros(2, 3, 4, 5)).shape == (2, 60)           # more than three axes: flattened, no mean
+    for bad in ([], {"a": 1}, 3.0):
+        with pytest.raises(ValueError):
+            extract_vector(bad)
+    kw = dict(n_mels=64, fmin=150.0, fmax=11025.0, hop_length=384, n_fft=2048, target_frames=64)
+    for sr in (22050, 48000, 44100):
+        for n in (1025, 22050, 22051, 65537, 240000, 999983):
+            assert core._config(sr, 0.0, whole_file_samples=n, **kw).n_samples == n
+            assert core._config(sr, -1.0, whole_file_samples=n, **kw).n_samples == n
+    with pytest.raises(RuntimeError):
+        core._config(22050, 0.0, **kw)                                        # whole file without its length
+    assert core._config(22050, 1.0, **kw).n_samples == 22050
+
+
 def _write_wav(path, data, rate, tag, bits, extensible=False):
     """Minimal RIFF writer for the loader tests (data: [n, ch] array already in the sample dtype)."""
     import struct
