@@ -22,8 +22,17 @@ Extra objects on that line:
                 `in_timed_region` = the same kernel bracketed inside the timed region, where
                 four lanes share the GPU: that figure includes queueing behind the other
                 lanes' kernels and is NOT a kernel duration.
-  fp32_roofline the whole path's algorithmic FLOP/s against the 157.3 TF fp32 peak: the
-                path is compute-bound (750 FLOP/B), this is the roofline that binds it.
+  fp32_roofline the whole path's ALGORITHMIC fp32 FLOP/s against the 157.3 TF fp32 peak.  The
+                conv / head GEMMs do not run as fp32 instructions: they are three-term bf16 splits
+                on the bf16 matrix cores (fp32-accurate, fp32 accumulate), so this is a work rate,
+                not the utilisation of any one pipe - mixed_roofline is.
+  mixed_roofline the bound the kernels as built can reach: matrix-pipe time of the MFMA kernels
+                (committed SQ_INSTS_MFMA x 32 cycles / (1024 SIMDs x 2.4 GHz), profiles/mfma_latest.json)
+                + fp32 VALU time of the others (their FLOPs at 157.3 TF), per 256-chunk batch, against
+                the measured batch period; MFMA-busy share of every MFMA kernel's isolated duration.
+  step_ms       per-step wall time inside the timed region (events on the stream): min / median / max.
+  rccl          (N > 1 or under torch.distributed.run) what the collective saw: backend, world size as
+                the process group reports it, bytes gathered per step.
   hbm_roofline  the whole path's algorithmic bytes/s against 8 TB/s - the figure
                 BASELINE.json's metric asks for.
   kernels       every kernel of the step: isolated duration, algorithmic work, corrected
@@ -93,6 +102,63 @@ def cpu_baseline(cfg, spec, state, pcm, budget_s):
             "value_default_threads": round(v_def, 2), "threads_default": default_threads,
             "sample_default_threads": f"{n_def} chunks at library-default threading ({default_threads} torch threads, "
                                       f"os.cpu_count()={os.cpu_count()})"}
+
+def from_files_leg(enc, cfg, pcm_host, args, dev, world, rank, use_dist, dist):
+    """End to end from FILES (SURVEY 8(d) "feed bounds"; 08_fit_radial_detector.py:461-520's per-file loop): PCM16 WAVs on local disk ->
+    native RIFF reader on the host thread pool -> pinned rows -> H2D -> encode -> latents on the device.  Page cache warm (just
+    written).  EVERY rank runs it on its own --files files at the same time with loader threads = CPUs in the affinity mask / ranks
+    (N ranks of one node share the host: the figure a sharded folder job gets), bracketed by barriers; rank 0 reports the sum."""
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+    from amphibian_vae_latent_detector_amd import folder as _folder
+    from amphibian_vae_latent_detector_amd.synth import write_wav_pcm16
+    n_aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 8)
+    share = max(1, n_aff // max(1, world))
+
+    def sync():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    with tempfile.TemporaryDirectory(prefix=f"amph_bench_r{rank}_") as td:
+        paths = []
+        for i in range(args.files):
+            pth = Path(td) / f"chunk_{i:06d}.wav"
+            write_wav_pcm16(pth, pcm_host[i % pcm_host.shape[0]], cfg.sr)
+            paths.append(pth)
+        sweep = sorted({t for t in (8, 16, 32, 64, 128, share) if t <= share}) or [share]
+        _folder.encode_paths(enc, paths[:min(512, len(paths))], cfg, apply_rms=True, loader_threads=share)   # warm-up
+        by_threads, failed = {}, 0
+        for threads in sweep:
+            sync()
+            t1 = time.perf_counter()
+            _, st_f = _folder.encode_paths(enc, paths, cfg, apply_rms=True, loader_threads=threads)
+            sync()
+            dt = time.perf_counter() - t1
+            if use_dist:
+                t = torch.tensor([dt], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t.item())
+            by_threads[threads] = round(world * args.files / dt, 1)
+            failed = int((st_f != 0).sum())
+
+        # the floor under any loader: open + read + close of every file, no parsing, no GPU (same thread pool size)
+        def _slurp(pth):
+            with open(pth, "rb") as f:
+                return len(f.read())
+        sync()
+        t1 = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=min(64, share)) as ex:
+            sum(ex.map(_slurp, paths, chunksize=64))
+        open_read_floor = round(args.files / (time.perf_counter() - t1), 1)
+        sync()
+    best_t = max(by_threads, key=by_threads.get)
+    return {"value": by_threads[best_t], "unit": "files/s (all ranks)", "files_per_rank": args.files, "ranks": world,
+            "loader_threads_per_rank": best_t, "files_per_s_by_loader_threads": by_threads, "cpus_in_affinity_mask": n_aff,
+            "cpu_share_per_rank": share, "python_open_read_floor_files_per_s_rank0": open_read_floor, "failed_rank0": failed,
+            "note": "folder.encode_paths on every rank at once: amph_wav_read_many on the host thread pool (affinity / ranks threads) -> "
+                    "pinned -> HBM -> encode (file-level RMS); page cache warm; max over ranks of the wall time; never the headline value"}
+
 
 def detect_leg(enc, sess, cfg, pcm, mu, args, dev):
     """BASELINE configs[4]: streaming encode + radial decision (centroids + thresholds from 08's fit, q_in 0.95 /
@@ -277,12 +343,18 @@ def main():
         step()
     sess.profile_enable(True, only_stage=dom)          # two event records per batch inside the timed region
 
+    # per-step completion events on the caller's stream (no synchronisation inside the timed region: the lanes join that stream
+    # at the end of every encode call)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    evs[0].record()
+    for i in range(args.steps):
         step()
+        evs[i + 1].record()
     fence()
     elapsed = time.perf_counter() - t0
+    step_ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)]
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -291,6 +363,7 @@ def main():
             sys.exit("all-gather did not return this rank's latents in place 0")
     prof = sess.profile_read()[dom]
     sess.profile_enable(False)
+    files_leg = from_files_leg(enc, cfg, pcm_host, args, dev, world, rank, use_dist, dist) if args.files > 0 else None
 
     if rank == 0:
         peak_mfma = 2500.0 if args.bf16 else PEAK_F32_MFMA_TFLOPS      # dense bf16 MFMA peak / f32-input MFMA peak
@@ -373,11 +446,53 @@ def main():
                                    "concurrent_lanes": n_lanes,
                                    "note": "event bracket around the same kernel while the other lanes' kernels share the GPU: "
                                            "queue-inclusive, not a kernel duration"}
+        # ---- mixed roofline: what the kernels AS BUILT are bounded by (matrix pipe for the split-bf16 GEMMs, fp32 VALU for the rest)
+        mixed = None
+        try:
+            mj = json.load(open(ROOT / "profiles" / "mfma_latest.json"))
+            if args.batch == 256 and args.preset == "bench-1s" and args.spec == "thesis-shape" and not args.bf16:
+                SIMDS, CLK = 1024, 2.4e9
+                per_k, pipe_us, valu_us = [], 0.0, 0.0
+                for s_ in stages:
+                    if not s_["launches"]:
+                        continue
+                    iso_us = 1e3 * s_["total_ms"] / s_["launches"]
+                    cplk = args.chunks / s_["launches"]
+                    m = mj["kernels"].get(s_["stage"], {})
+                    n_mfma = m.get("mfma_insts", 0.0) * cplk / 256.0           # committed count is per 256-chunk launch
+                    if n_mfma > 0:
+                        t_us = n_mfma * 32.0 / (SIMDS * CLK) * 1e6
+                        pipe_us += t_us * 256.0 / cplk
+                        per_k.append({"kernel": s_["stage"], "mfma_insts_per_launch": int(n_mfma), "matrix_pipe_us": round(t_us, 2),
+                                      "isolated_us": round(iso_us, 2), "mfma_busy_frac_of_isolated": round(t_us / iso_us, 3),
+                                      "mfma_busy_frac_counter": round(m.get("mfma_busy_cycles", 0.0) / SIMDS / max(1.0, m.get("gui_active_sum", 0.0) / 8.0), 3)
+                                      if m.get("gui_active_sum") else None})
+                    else:
+                        t_us = s_["flops_per_chunk"] * cplk / (PEAK_F32_MFMA_TFLOPS * 1e12) * 1e6
+                        valu_us += t_us * 256.0 / cplk
+                        per_k.append({"kernel": s_["stage"], "fp32_valu_us_at_peak": round(t_us, 2), "isolated_us": round(iso_us, 2),
+                                      "valu_frac_of_isolated": round(t_us / iso_us, 3)})
+                batch_period_us = elapsed / args.steps / (args.chunks / 256.0) * 1e6
+                mixed = {"matrix_pipe_us_per_batch": round(pipe_us, 2), "fp32_valu_us_per_batch": round(valu_us, 2),
+                         "bound_us_per_batch": round(pipe_us + valu_us, 2), "measured_batch_period_us": round(batch_period_us, 2),
+                         "frac": round((pipe_us + valu_us) / batch_period_us, 4),
+                         "matrix_pipe_busy_over_timed_region": round(pipe_us / batch_period_us, 4),
+                         "kernels": per_k, "source": mj.get("_source", "profiles/mfma_latest.json"),
+                         "note": "GEMM kernels: v_mfma_f32_32x32x16_bf16 on three-term bf16 splits of fp32 operands (6 MFMAs per K = 16, fp32 "
+                                 "accumulate): 32 matrix-pipe cycles each on one of 1024 SIMDs at 2.4 GHz; other kernels: algorithmic fp32 FLOPs at "
+                                 "the 157.3 TF vector peak; batch period = ms_per_step / (chunks / 256)"}
+        except (OSError, ValueError, KeyError):
+            pass
+        srt = sorted(step_ms)
         line = {
             "metric": "1 s audio chunks encoded to latent/sec", "value": round(value, 1), "unit": "chunks/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16 encoder (fp32 front end, fp32 accumulate)" if args.bf16 else "f32", "data": "synthetic",
+            "dtype": "bf16 encoder (fp32 front end, fp32 accumulate)" if args.bf16 else
+                     "f32 (results fp32-accurate; conv / head GEMMs as 3-term bf16 splits on the bf16 MFMA, fp32 accumulate; front end fp32 VALU)",
+            "data": "synthetic",
+            "step_ms": {"min": round(srt[0], 4), "median": round(srt[len(srt) // 2], 4), "max": round(srt[-1], 4), "n": len(srt),
+                        "measured": "events on the caller's stream after every step, read after the closing barrier"},
             "config": {"workload": (f"BASELINE.json configs[2] on one GPU: {args.chunks} synthetic {cfg.duration:g} s / {cfg.sr} Hz PCM16 chunks "
                                     f"resident in HBM in the reference's list order, encoded as {args.shards} contiguous virtual shards laid out "
                                     f"as the all-gather lays them out, " if args.config3 else
@@ -391,11 +506,19 @@ def main():
             "roofline": roof,
             "fp32_roofline": {"algorithmic_flops_per_chunk": int(alg_flops), "achieved_TFLOPs_per_gpu": round(per_gpu * alg_flops / 1e12, 2),
                               "peak_TFLOPs": PEAK_F32_MFMA_TFLOPS, "frac": round(per_gpu * alg_flops / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                              "note": "the path is compute-bound (algorithmic intensity ~750 FLOP/B): this roofline binds, not HBM"},
+                              "note": "ALGORITHMIC fp32 FLOP/s against the f32 peak; the GEMM kernels run split bf16 on the bf16 matrix cores "
+                                      "(mixed_roofline prices them): a work rate, not a pipe utilisation.  The path is compute-bound "
+                                      "(algorithmic intensity ~750 FLOP/B), not HBM-bound"},
+            **({"mixed_roofline": mixed} if mixed else {}),
             "hbm_roofline": {"algorithmic_bytes_per_chunk": alg_bytes, "achieved_GBps_per_gpu": round(per_gpu * alg_bytes / 1e9, 2),
                              "peak_GBps": PEAK_HBM_GBS, "frac": round(per_gpu * alg_bytes / 1e9 / PEAK_HBM_GBS, 6)},
             "kernels": kernels,
         }
+        if use_dist:
+            line["rccl"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                            "all_gather_bytes_per_step": int(world * args.chunks * D * 4), "collectives_per_step": 1,
+                            "rank0_block_equals_own_latents": True,      # (checked above: a mismatch exits)
+                            "note": "dist.all_gather_into_tensor of the [chunks, D] fp32 latent matrix, inside the timed step"}
         if traffic:
             tot = sum(traffic.get(k["kernel"], 0) for k in kernels)
             line["path_traffic"] = {"bytes_per_batch": int(tot), "algorithmic_bytes_per_batch": int(alg_bytes * args.batch),
@@ -429,43 +552,8 @@ def main():
                                       "note": "amph_encode_pcm16_host: host rows -> HBM on a copy stream under the encode, latents copied "
                                               "back; pageable rows go through a pinned double buffer (one memcpy pass on a host core), "
                                               "pinned rows are copied straight from the caller's memory; never the headline value"}
-        if world == 1 and args.files > 0:
-            # end to end from FILES (SURVEY 8(d) "feed bounds"): PCM16 WAVs on local disk -> native RIFF reader on the host
-            # thread pool -> pinned rows -> H2D -> encode -> latents on the device.  Page cache is warm (just written).
-            import tempfile
-            from amphibian_vae_latent_detector_amd import folder as _folder
-            from amphibian_vae_latent_detector_amd.synth import write_wav_pcm16
-            with tempfile.TemporaryDirectory(prefix="amph_bench_") as td:
-                paths = []
-                for i in range(args.files):
-                    pth = Path(td) / f"chunk_{i:06d}.wav"
-                    write_wav_pcm16(pth, pcm_host[i % pcm_host.shape[0]], cfg.sr)
-                    paths.append(pth)
-                n_aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 8)
-                sweep = sorted({t for t in (8, 16, 32, 64, 128, n_aff) if t <= n_aff}) or [n_aff]
-                _folder.encode_paths(enc, paths[:min(512, len(paths))], cfg, apply_rms=True, loader_threads=n_aff)   # warm-up
-                by_threads = {}
-                for threads in sweep:
-                    t1 = time.perf_counter()
-                    _, st_f = _folder.encode_paths(enc, paths, cfg, apply_rms=True, loader_threads=threads)
-                    torch.cuda.synchronize(dev)
-                    by_threads[threads] = round(args.files / (time.perf_counter() - t1), 1)
-                # the floor under any loader: open + read + close of every file, no parsing, no GPU (same thread pool size)
-                from concurrent.futures import ThreadPoolExecutor
-
-                def _slurp(pth):
-                    with open(pth, "rb") as f:
-                        return len(f.read())
-                t1 = time.perf_counter()
-                with ThreadPoolExecutor(max_workers=min(64, n_aff)) as ex:
-                    sum(ex.map(_slurp, paths, chunksize=64))
-                open_read_floor = round(args.files / (time.perf_counter() - t1), 1)
-            best_t = max(by_threads, key=by_threads.get)
-            line["from_files"] = {"value": by_threads[best_t], "unit": "files/s", "files": args.files,
-                                  "loader_threads": best_t, "files_per_s_by_loader_threads": by_threads, "cpus_in_affinity_mask": n_aff,
-                                  "python_open_read_floor_files_per_s": open_read_floor, "failed": int((st_f != 0).sum()),
-                                  "note": "folder.encode_paths: amph_wav_read_many on the host thread pool -> pinned -> HBM -> encode "
-                                          "(file-level RMS); page cache warm; never the headline value"}
+        if files_leg is not None:
+            line["from_files"] = files_leg
         if world == 1 and args.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(cfg, spec, state, pcm_host[:4000], args.cpu_seconds)
         sys.stdout.flush()

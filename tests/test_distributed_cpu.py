@@ -105,6 +105,46 @@ def test_two_rank_sharded_folder_encode_equals_single_process(tmp_path):
         assert got["failed"].tolist() == [failed_m[s] for s in SPECIES]
 
 
+def _worker8(rank, world, port, root, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        paths = sorted(Path(root).rglob("*.wav"))
+        shards, per = pfolder.plan_shards(len(paths), world)
+        Z, st = pfolder.encode_file_list(None, paths, CFG, encode_fn=_oracle_encode_fn())
+        np.savez(Path(out_dir) / f"w8_rank{rank}.npz", Z=Z, st=st, lo=shards[rank][0], hi=shards[rank][1], per=per,
+                 threads=pfolder.default_loader_threads(world))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_eight_ranks_on_thirteen_files_empty_tail_ranks_and_padded_blocks(tmp_path):
+    """world_size 8 (the node BASELINE.json's north star names) on 13 files: blocks of ceil(13 / 8) = 2 rows, so ranks 0-5 hold 2
+    files, rank 6 one file + one padding row, rank 7 NOTHING (a whole block of padding) - the all-gather still runs on every rank
+    and the trimmed result equals one process bit for bit.  One unreadable file: flagged in the gathered status on every rank.
+    Also: the loader's thread default splits the affinity mask by LOCAL_WORLD_SIZE."""
+    root = tmp_path / "chunks"
+    synth.write_synth_folder(root, 13, CFG.n_samples, CFG.sr)
+    paths = sorted(root.rglob("*.wav"))
+    assert len(paths) == 13
+    paths[4].write_bytes(b"broken")
+    fn = _oracle_encode_fn()
+    Z1, st1 = fn(paths)
+    shards, per = pfolder.plan_shards(13, 8)
+    assert per == 2 and shards[6] == (12, 13) and shards[7][0] == shards[7][1]          # the last rank owns no file
+    out = tmp_path / "out"
+    out.mkdir()
+    mp.spawn(_worker8, args=(8, _free_port(), str(root), str(out)), nprocs=8, join=True)
+    n_aff = len(os.sched_getaffinity(0))
+    for r in range(8):
+        d = np.load(out / f"w8_rank{r}.npz")
+        assert np.array_equal(d["Z"], Z1.numpy()) and np.array_equal(d["st"], st1), r
+        assert (int(d["lo"]), int(d["hi"])) == shards[r] and int(d["per"]) == 2
+        assert int(d["threads"]) == max(1, min(32, n_aff // 8))
+    assert st1[4] != 0 and not st1[np.arange(13) != 4].any()
+
+
 def test_gather_rows_pads_and_trims_single_process():
     x = torch.arange(12, dtype=torch.float32).reshape(4, 3)
     assert torch.equal(pfolder.gather_rows(x, 4, 3), x[:3])

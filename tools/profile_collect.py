@@ -26,7 +26,7 @@ def stage_of(kernel: str, grid: int) -> str:
     k = kernel.split("(")[0].replace("void amph::", "").replace("amph::", "")
     if k.startswith("k_rms_fold_apply"): return "rms_apply"             # second kernel of the chunked K0 path (bench's stage "rms_scale" = both)
     if k.startswith("k_rms_scale"): return "rms_scale"
-    if k.startswith("k_stft_mel"): return "stft_mel"
+    if k.startswith("k_stft_mel") or k.startswith("k_stft_pair"): return "stft_mel"
     if k.startswith("k_dbnorm"): return "dbnorm"
     if k.startswith("k_conv_gemm_f3") or k.startswith("k_conv_gemm_f4") or (k.startswith("k_conv_gemm<") and "true" in k): return "conv2"
     if k.startswith("k_conv_gemm_g4<64"): return "conv3"
@@ -80,6 +80,19 @@ for st, c in sorted(traffic.items()):
             e["l2_hit_rate"] = round(c["TCC_HIT_sum"] / max(1.0, c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 4)
         out["kernels"][st] = e
 (dst / f"{rnd}_traffic_{tag}.json").write_text(json.dumps(out, indent=1) + "\n")
+
+# matrix-pipe work per launch (bench.py's mixed_roofline): MFMA instructions, the cycles the pipe was busy, the launch's GPU-active cycles
+mf = {"_about": "rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE (one pass; per launch of a "
+                "256-chunk batch, bench configuration, 1 lane).  SQ_INSTS_MFMA counts wave instructions; every MFMA of the default path is a "
+                "v_mfma_f32_32x32x16_bf16 (32 matrix-pipe cycles on its SIMD); SQ_VALU_MFMA_BUSY_CYCLES is summed over the chip's 1024 SIMDs; "
+                "GRBM_GUI_ACTIVE is summed over the 8 XCDs.", "kernels": {}}
+for st, c in sorted(traffic.items()):
+    if "SQ_INSTS_MFMA" in c:
+        mf["kernels"][st] = {"mfma_insts": round(c["SQ_INSTS_MFMA"], 1), "mfma_busy_cycles": round(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), 1),
+                             "mfma_mops_f32": round(c.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0.0), 1), "gui_active_sum": round(c.get("GRBM_GUI_ACTIVE", 0.0), 1)}
+(dst / f"{rnd}_mfma_{tag}.json").write_text(json.dumps(mf, indent=1) + "\n")
+mf["_source"] = f"profiles/{rnd}_mfma_{tag}.json"
+(dst / "mfma_latest.json").write_text(json.dumps(mf, indent=1) + "\n")
 
 shutil.copy(dst / f"{rnd}_traffic_{tag}.json", dst / "traffic_latest.json")
 tl = json.loads((dst / "traffic_latest.json").read_text())
