@@ -47,7 +47,6 @@ struct Workspace {
     std::vector<void*> act_raw;            // the allocations
     std::vector<int> act_guard;
     float* partial = nullptr;
-    int* fold_counters = nullptr;          // head: one per output tile of the split-K GEMM (k_conv_gemm_s3's fold), zero between launches
     int16_t* norm16 = nullptr;             // RMS-normalised PCM16 rows of the batch (what 00_normalize writes to disk), input of the STFT
     size_t norm16_cap = 0;                 // samples
     float* chunk_sums = nullptr;           // K0 on long rows: per-row sums of the numpy chunks (8192 samples each)
@@ -87,6 +86,9 @@ struct amph_ctx {
     std::vector<unsigned char> radial_key; // the detector (K, D, centroids, thresholds, ranks) last uploaded for K6
     float* d_pair_tables = nullptr;        // k_stft_pair: window pairs + stage-2 twiddles (packed LDS image); nullptr: configuration not covered
     float2* d_pair_tw1 = nullptr;          // k_stft_pair: stage-1 twiddles (global memory)
+    bool stft_indep = true;                // k_stft_mel_w (independent waves) rather than the tile-synchronous k_stft_mel
+    int stft_grid = 0;                     // persistent STFT workgroups (0 = fill the chip)
+    int rms_chunk_path_over = 2;           // PCM16 rows of more numpy chunks than this: (row, chunk) + (row, tile) kernel pair
     bool stft_pair = true;                 // use k_stft_pair (two frames per wave as one complex FFT) where it applies
     int stft_pair_waves = 10;              // its workgroup: 8, 10, 11 or 12 waves; amph_create picks the largest whose LDS image, stage-1 twiddles
                                            // included, fits (1 s rows with the fused dB stage: 11 - 29 pairs on 11 waves are 3 rounds, at most 8 pairs per SIMD)
@@ -129,8 +131,6 @@ struct amph_ctx {
     bool stft_prepad = true;               // ... fix_length'd and centre padded (independent-wave STFT kernel only)
     bool stft_fuse_db = true;              // dB / z-score / crop-pad inside the STFT kernel when a row's mel power fits its LDS
     bool split_fused = true;               // ... the fused conv1 + conv2 kernel too (k_conv_gemm_f3s)
-    bool head_fold = false;                // head: the last split-K workgroup of a tile sums the partials (no k_head_reduce launch); measured SLOWER:
-                                           // the agent-scope release / acquire around the counter write back and invalidate L2 (include/amph.h)
     int patch_gemm = 1;                    // bit 0 / 1: conv3 / conv4 of the thesis shape with weights in registers and the input resident in LDS (k_conv_gemm_g4);
                                            // conv4 in that form is 2 us faster alone and 1 % slower end to end (two images = 127 KB of LDS per workgroup): off
     int patch_gemm_bf16 = 3;               // the same for the bf16 encoder (bf16 operands: patches of 42 / 44 KB)
@@ -622,11 +622,6 @@ int alloc_lane(amph_ctx* c, Workspace& w, bool own_stream) {
             w.act.push_back(reinterpret_cast<float*>(raw + guard));
         }
         HIP_TRY(c, hipMalloc((void**)&w.partial, (size_t)c->head_splits * MB * 2 * c->latent * sizeof(float)));
-        {
-            const size_t n_cnt = (size_t)((MB + 63) / 64) * ((2 * c->latent + 63) / 64);
-            HIP_TRY(c, hipMalloc((void**)&w.fold_counters, n_cnt * sizeof(int)));
-            HIP_TRY(c, hipMemset(w.fold_counters, 0, n_cnt * sizeof(int)));
-        }
     }
     return AMPH_OK;
 }
@@ -635,7 +630,7 @@ void free_lane(Workspace& w) {
     auto fr = [](void* p) { if (p) (void)hipFree(p); };
     fr(w.scale); fr(w.ok); fr(w.melpow); fr(w.image); fr(w.chunk_sums);
     for (auto p : w.act_raw) fr(p);
-    fr(w.partial); fr(w.fold_counters);
+    fr(w.partial);
     fr(w.norm16);
     if (w.done) (void)hipEventDestroy(w.done);
     if (w.stream) (void)hipStreamDestroy(w.stream);
@@ -812,7 +807,6 @@ int run_encoder(amph_ctx* c, Workspace& w, const float* d_x, int nb, float* d_mu
         p.y = w.act[0];
         launch_conv_first(p, nb, s);
     }
-    bool head_folded = false;
     for (int gi = 0; gi < n_gemm; ++gi) {
         const bool head = gi == n_gemm - 1;
 #ifdef AMPH_STAMPS
@@ -851,17 +845,12 @@ int run_encoder(amph_ctx* c, Workspace& w, const float* d_x, int nb, float* d_mu
         if (c->split_gemm && !fused_here && c->gemm[gi].d_w_s3 && conv_gemm_s3_ok(prm[gi])) {
             ConvGemmParams ps = prm[gi];
             ps.w = reinterpret_cast<const float*>(c->gemm[gi].d_w_s3);
-            if (head && c->head_fold && w.fold_counters) {
-                ps.fold_counters = w.fold_counters; ps.fold_bias = c->d_head_bias; ps.fold_D = c->latent;
-                ps.fold_mu = d_mu; ps.fold_logvar = d_logvar;
-                head_folded = true;
-            }
             launch_conv_gemm_s3(ps, s);
             continue;
         }
         launch_conv_gemm(prm[gi], bms[gi], fused_here, s);
     }
-    if (!head_folded) {
+    {
         StageTimer t(c, stage_head_reduce(c), s);
         HeadReduceParams p;
         p.partial = w.partial; p.bias = c->d_head_bias; p.splits = c->head_splits; p.D = c->latent;
@@ -880,11 +869,11 @@ size_t pair_lds(const amph_ctx* c, int nw, bool fused) {
 size_t pair_tw1_lds(const amph_ctx* c) { return c->cfg.n_fft == 2048 ? stft_pair_tw1_lds_bytes() : stft_pair2_tw1_lds_bytes(); }
 // do PCM16 rows that K0 / the pad kernel wrote go through a pair kernel?
 bool pair_path(const amph_ctx* c, bool pcm16) {
-    return pcm16 && c->stft_pair && c->d_pair_tables && c->stft_prenorm && c->stft_prepad && amph::g_stft_indep;
+    return pcm16 && c->stft_pair && c->d_pair_tables && c->stft_prenorm && c->stft_prepad && c->stft_indep;
 }
 // pcm16_rows: the call's input is PCM16 (those rows take a pair kernel when the context has one)
 bool can_fuse_db(const amph_ctx* c, bool pcm16_rows = false) {
-    if (!c->stft_fuse_db || !amph::g_stft_indep) return false;
+    if (!c->stft_fuse_db || !c->stft_indep) return false;
     if (pair_path(c, pcm16_rows)) return pair_lds(c, c->stft_pair_waves, true) <= 160 * 1024;
     return stft_mel_can_fuse_db(c->cfg.n_fft, c->n_frames, c->cfg.n_mels, c->mel_w_floats, c->stft_waves);
 }
@@ -897,6 +886,7 @@ StftParams make_stft(amph_ctx* c, const WaveSrc& src, float* melpow, float* db_o
     p.pad_mode = c->cfg.pad_mode; p.frames_per_block = c->frames_per_block;
     p.tiles_per_row = (c->n_frames + c->frames_per_block - 1) / c->frames_per_block;
     p.db_out = db_out; p.db_layout = db_layout; p.db_target_frames = c->cfg.target_frames;
+    p.indep = c->stft_indep ? 1 : 0; p.grid_wgs = c->stft_grid;
     if (db_out) {                                  // one tile = one whole row: its frames go round-robin over the waves
         const int round = c->stft_waves * (c->cfg.n_fft == 2048 ? 1 : 2);
         p.frames_per_block = (c->n_frames + round - 1) / round * round;
@@ -936,7 +926,7 @@ int run_frontend(amph_ctx* c, Workspace& w, const void* d_wave, bool pcm16, int 
         if (pcm16 && c->stft_prenorm) {
             // with the independent-wave STFT kernel the rows are written as that kernel wants to read them: fix_length'd and
             // centre padded, so that no frame needs index reflection
-            if (amph::g_stft_indep && c->stft_prepad) {
+            if (c->stft_indep && c->stft_prepad) {
                 pad.lead = c->cfg.n_fft / 2; pad.n_fix = c->cfg.n_samples; pad.mode = c->cfg.pad_mode;
                 pad.out_stride = ((long long)pad.n_fix + 2 * pad.lead + 1) & ~1ll;
             }
@@ -947,7 +937,7 @@ int run_frontend(amph_ctx* c, Workspace& w, const void* d_wave, bool pcm16, int 
         if (pcm16) {
             const int rcs = ensure_chunk_sums(c, w, n_in, s);
             if (rcs != AMPH_OK) return rcs;
-            launch_rms_scale_pcm16((const int16_t*)d_wave, n_in, d_len, n_in, nb, w.scale, okp, c->rms_f64_scale, norm, pad, w.chunk_sums, s);
+            launch_rms_scale_pcm16((const int16_t*)d_wave, n_in, d_len, n_in, nb, w.scale, okp, c->rms_f64_scale, norm, pad, w.chunk_sums, c->rms_chunk_path_over, s);
         }
         else launch_rms_scale_f32((const float*)d_wave, n_in, d_len, n_in, nb, w.scale, okp, c->rms_f64_scale, s);
         src.scale = w.scale;
@@ -959,7 +949,7 @@ int run_frontend(amph_ctx* c, Workspace& w, const void* d_wave, bool pcm16, int 
     } else {
         if (d_rms_ok) (void)hipMemsetAsync(d_rms_ok, 0, (size_t)nb * sizeof(int32_t), s);
         // PCM16 rows used as they are: the same fix_length'd, centre-padded copy, by a copy kernel (timed with the RMS stage)
-        if (pcm16 && c->stft_prenorm && c->stft_prepad && amph::g_stft_indep) {
+        if (pcm16 && c->stft_prenorm && c->stft_prepad && c->stft_indep) {
             StageTimer t(c, ST_RMS, s);
             NormPad pad{};
             pad.lead = c->cfg.n_fft / 2; pad.n_fix = c->cfg.n_samples; pad.mode = c->cfg.pad_mode;
@@ -1094,7 +1084,8 @@ int amph_create(const amph_frontend_config* cfg, const amph_encoder_spec* spec, 
                 // workgroup of the pair kernel: the largest whose LDS image fits WITH the fused dB stage and the stage-1 twiddles
                 // (1 s rows at n_fft 2048: 12 waves; the 128-band rows at n_fft 1024, 44.5 KB of mel power per row: 8), else the
                 // largest that fits without
-                const int* opts = c->cfg.n_fft == 2048 ? (const int[]){8, 10, 11, 12} : (const int[]){8, 12};
+                static const int opts2048[4] = {8, 10, 11, 12}, opts1024[2] = {8, 12};
+                const int* opts = c->cfg.n_fft == 2048 ? opts2048 : opts1024;
                 const int n_opts = c->cfg.n_fft == 2048 ? 4 : 2;
                 int pick = 0;
                 for (int fused = 1; fused >= 0 && !pick; --fused)
@@ -1178,11 +1169,10 @@ int amph_configure(amph_ctx* c, const char* key, int value) {
     }
     if (!std::strcmp(key, "split_gemm")) { c->split_gemm = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "split_fused")) { c->split_fused = value != 0; return AMPH_OK; }
-    if (!std::strcmp(key, "head_fold")) { c->head_fold = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "patch_gemm")) { c->patch_gemm = value & 3; return AMPH_OK; }
     if (!std::strcmp(key, "patch_gemm_bf16")) { c->patch_gemm_bf16 = value & 3; return AMPH_OK; }
     if (!std::strcmp(key, "patch_gemm_wgs")) { if (value < 0) return AMPH_ERR_INVALID_ARG; c->patch_gemm_wgs = value; return AMPH_OK; }
-    if (!std::strcmp(key, "rms_chunk_path_over")) { if (value < 1) return AMPH_ERR_INVALID_ARG; amph::g_rms_chunk_path_over = value; return AMPH_OK; }
+    if (!std::strcmp(key, "rms_chunk_path_over")) { if (value < 1) return AMPH_ERR_INVALID_ARG; c->rms_chunk_path_over = value; return AMPH_OK; }
     if (!std::strcmp(key, "bf16_pair")) { c->bf16_pair = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "patch_fused")) { c->patch_fused = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "patch_wgs")) { if (value < 0) return AMPH_ERR_INVALID_ARG; c->patch_wgs = value; return AMPH_OK; }
@@ -1279,16 +1269,10 @@ int amph_configure(amph_ctx* c, const char* key, int value) {
     }
     if (!std::strcmp(key, "stft_grid")) {
         if (value < 0 || value > 65536) return fail(c, AMPH_ERR_INVALID_ARG, "stft_grid must be in 0..65536 (0 = fill the chip)");
-        amph::g_stft_grid = value;
+        c->stft_grid = value;
         return AMPH_OK;
     }
-    if (!std::strcmp(key, "stft_indep")) { amph::g_stft_indep = value != 0; return AMPH_OK; }
-    if (!std::strcmp(key, "gemm_flags")) { amph::g_gemm_flags = value; return AMPH_OK; }
-    if (!std::strcmp(key, "gemm_min_lds")) {
-        if (value < 0 || value > 64 * 1024) return fail(c, AMPH_ERR_INVALID_ARG, "gemm_min_lds must be in 0..65536");
-        amph::g_gemm_min_lds = value;
-        return AMPH_OK;
-    }
+    if (!std::strcmp(key, "stft_indep")) { c->stft_indep = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "stft_waves")) {
         if (value != 4 && value != 12) return fail(c, AMPH_ERR_INVALID_ARG, "stft_waves must be 4 or 12");
         const int lds = (int)stft_mel_lds_bytes(c->cfg.n_fft, c->cfg.hop_length, c->frames_per_block, c->cfg.n_mels, c->mel_w_floats, value);
@@ -1346,10 +1330,10 @@ int amph_rms_normalize_pcm16(amph_ctx* c, const int16_t* d_in, int n_rows, int n
         if (rcs != AMPH_OK) return rcs;
         // (rows longer than one LDS pass: the two-kernel path writes the normalised rows itself)
         if (rms_scale_chunks(n) > 4) {
-            launch_rms_scale_pcm16(d_in + (size_t)off * n, n, nullptr, n, nb, w.scale, okp, c->rms_f64_scale, d_out + (size_t)off * n, NormPad{}, w.chunk_sums, s);
+            launch_rms_scale_pcm16(d_in + (size_t)off * n, n, nullptr, n, nb, w.scale, okp, c->rms_f64_scale, d_out + (size_t)off * n, NormPad{}, w.chunk_sums, c->rms_chunk_path_over, s);
             continue;
         }
-        launch_rms_scale_pcm16(d_in + (size_t)off * n, n, nullptr, n, nb, w.scale, okp, c->rms_f64_scale, nullptr, NormPad{}, nullptr, s);
+        launch_rms_scale_pcm16(d_in + (size_t)off * n, n, nullptr, n, nb, w.scale, okp, c->rms_f64_scale, nullptr, NormPad{}, nullptr, c->rms_chunk_path_over, s);
         launch_rms_apply_pcm16(d_in + (size_t)off * n, nb, n, w.scale, okp, d_out + (size_t)off * n, s);
     }
     return check_launch(c, "rms_normalize_pcm16");

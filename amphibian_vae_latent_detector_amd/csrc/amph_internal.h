@@ -56,6 +56,9 @@ struct StftParams {
     const float2* pair_tw1;    // [31][64] W_2048^(col(lane) k1), k1 = 1..31 (read from global memory)
     int pair_waves;            // waves per workgroup of that kernel (8, 10 or 12)
     int pair_tw_lds;           // keep pair_tw1 in LDS when the image still fits 160 KB
+    // per-context launch choices (were process-wide globals until round 3)
+    int indep;                 // 1: k_stft_mel_w (independent waves), 0: the tile-synchronous k_stft_mel
+    int grid_wgs;              // persistent workgroups; 0 = fill the chip
 #ifdef AMPH_STAMPS
     unsigned long long* stamps;   // diagnostic build: [grid][16] s_memtime stamps
 #endif
@@ -73,9 +76,10 @@ struct DbNormParams {
 // chunk_sums (nullable): workspace of n_rows * rms_scale_chunks(n_in) floats; with it, rows longer than one LDS pass take the
 // two-kernel path (chunk sums by (row, pass) workgroups, then fold + normalise + pad by (row, tile) workgroups)
 int rms_scale_chunks(int n_in);
+// chunk_path_over: rows of more numpy chunks than this take the two-kernel path (when chunk_sums is given)
 void launch_rms_scale_pcm16(const int16_t* in, long long row_stride, const int32_t* lengths, int n_in,
                             int n_rows, float* scale, int32_t* ok, int scale_f64, int16_t* norm_out, const NormPad& pad, float* chunk_sums,
-                            hipStream_t s);
+                            int chunk_path_over, hipStream_t s);
 void launch_pad_rows_pcm16(const int16_t* in, long long row_stride, const int32_t* lengths, int n_in, int n_rows, int16_t* out,
                            const NormPad& pad, hipStream_t s);
 void launch_rms_scale_f32(const float* in, long long row_stride, const int32_t* lengths, int n_in,
@@ -152,16 +156,8 @@ struct ConvGemmParams {      // implicit GEMM: M = B*OH*OW, N = C_out, K = k*k*C
     int H0, W0, k1, s1, p1;
     const float* zeros;      // >= 16 bytes of zeros (16-byte aligned): source of masked loads in the fused kernel
     int x_guard;             // bytes of ZEROS in front of x (same allocation): padded taps of k_conv_gemm_p3 read there
-    // k_conv_gemm_s3 with epilogue 1 only (nullptr: partials are left for k_head_reduce): the split-K partials of an output tile
-    // are summed - split 0 first, then the bias: k_head_reduce's order, same bits - by whichever of the tile's workgroups
-    // finishes last (agent-scope counter per tile, reset by that workgroup)
-    int* fold_counters;      // [m tiles][n tiles], zero between launches
-    const float* fold_bias;  // [N]
-    float* fold_mu;          // [M][fold_D]
-    float* fold_logvar;      // nullable [M][fold_D]
-    int fold_D;              // N == 2 fold_D
     int y_bf16;              // k_conv_gemm_f3s only: write the output as bf16 NHWC (the bf16 encoder's layer 3 reads it)
-    int flags;               // bit 1: use the first-generation kernel; bit 0: static issue priority from the wave's slot on its SIMD (see k_conv_gemm)
+    int flags;               // (first-generation kernel only; bit 0: static issue priority from the wave's slot on its SIMD - always 0 since round 3)
 #ifdef AMPH_STAMPS
     unsigned long long* stamps;   // diagnostic build: [workgroup][role][4]
 #endif
@@ -176,12 +172,7 @@ struct HeadReduceParams {    // mu/logvar = sum_s partial[s] + bias
 };
 
 void launch_conv_first(const ConvFirstParams& p, int n_rows, hipStream_t s);
-extern int g_gemm_min_lds;
-extern int g_gemm_flags;
-extern int g_num_cus;
-extern int g_stft_grid;
-extern int g_stft_indep;
-extern int g_rms_chunk_path_over;
+extern int g_num_cus;      // compute units of the device (a property of the hardware, not a knob)
 bool conv_gemm_can_fuse(const ConvGemmParams& p, int bm);
 size_t conv_gemm_x_guard(int k, int W, int C_in);          // zero guard k_conv_gemm_p3 needs in front of its input
 bool conv_gemm_f3_ok(const ConvGemmParams& p, int bm);   // second-generation fused kernel (64-row tiles, 32 first-layer channels)

@@ -1175,22 +1175,18 @@ bool conv_gemm_can_fuse(const ConvGemmParams& p, int bm) {
 }
 
 int g_num_cus = 256;      // compute units of the device (amph_create sets it)
-int g_gemm_flags = 0;     // experiment knob: ConvGemmParams::flags of every launch
-int g_gemm_min_lds = 0;   // experiment knob: request at least this much LDS (limits workgroups per CU)
 
 void launch_conv_gemm(const ConvGemmParams& p_in, int bm, bool fuse, hipStream_t s) {
     ConvGemmParams p = p_in;
-    p.flags = g_gemm_flags;
+    p.flags = 0;
     const dim3 grid((unsigned)((p.M + bm - 1) / bm), (unsigned)((p.N + kBN - 1) / kBN), (unsigned)p.splits);
-    const size_t lds = std::max(conv_gemm_lds(p, bm, fuse), (size_t)g_gemm_min_lds);
-    if (!fuse && (g_gemm_flags & 2) == 0 && conv_gemm_p3_ok(p, bm)) {
-        const size_t lds3 = std::max((size_t)3 * (bm + kBN) * kLdsRow * sizeof(float), (size_t)g_gemm_min_lds);
-        // gemm_flags bit 5: odd k-steps into a second accumulator (experiment: -0.7 us on conv3 / conv4, different rounding)
-        if (g_gemm_flags & 32) hipLaunchKernelGGL((k_conv_gemm_p3<64, true>), grid, dim3(256), lds3, s, p);
-        else hipLaunchKernelGGL((k_conv_gemm_p3<64, false>), grid, dim3(256), lds3, s, p);
+    const size_t lds = conv_gemm_lds(p, bm, fuse);
+    if (!fuse && conv_gemm_p3_ok(p, bm)) {
+        const size_t lds3 = (size_t)3 * (bm + kBN) * kLdsRow * sizeof(float);
+        hipLaunchKernelGGL((k_conv_gemm_p3<64, false>), grid, dim3(256), lds3, s, p);
         return;
     }
-    if (fuse && (g_gemm_flags & 4) == 0 && conv_gemm_f3_ok(p, bm)) {
+    if (fuse && conv_gemm_f3_ok(p, bm)) {
         static bool raised3[64] = {false};
         int dev = 0;
         (void)hipGetDevice(&dev);
@@ -1199,7 +1195,7 @@ void launch_conv_gemm(const ConvGemmParams& p_in, int bm, bool fuse, hipStream_t
             raised3[dev] = true;
         }
         const dim3 pgrid(std::min(grid.x, (unsigned)(2 * g_num_cus)), grid.y, 1);      // persistent: one resident round
-        hipLaunchKernelGGL((k_conv_gemm_f3<64>), pgrid, dim3(256), std::max(conv_gemm_f3_lds(p, bm), (size_t)g_gemm_min_lds), s, p);
+        hipLaunchKernelGGL((k_conv_gemm_f3<64>), pgrid, dim3(256), conv_gemm_f3_lds(p, bm), s, p);
         return;
     }
     if (fuse) {

@@ -361,47 +361,6 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm_s3(ConvGemmParams p) {
 #undef AMPH_S3_OUT
         }
     }
-    if (p.epilogue == 1 && p.fold_counters) {
-        // release this workgroup's partial tile, count it in; the workgroup whose count completes the tile acquires and reduces it
-        __shared__ int s_last;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __syncthreads();
-        if (tid == 0) {
-            int* cnt = p.fold_counters + blockIdx.x * gridDim.y + blockIdx.y;
-            const int prev = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-            s_last = prev == (int)gridDim.z - 1;
-            if (s_last) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // every other workgroup of the tile has added
-        }
-        __syncthreads();
-        if (s_last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            const long long step = (long long)p.M * p.N;
-            for (int e = tid; e < 64 * 16; e += 256) {                  // 64 rows x 16 float4 columns
-                const int m = m_blk + (e >> 4), n0 = n_blk + 4 * (e & 15);
-                if (m >= p.M || n0 >= p.N) continue;
-                const float* src = p.y + (long long)m * p.N + n0;
-                float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                for (int s0 = 0; s0 < (int)gridDim.z; s0 += 16) {
-                    float4 v[16];
-#pragma unroll
-                    for (int u = 0; u < 16; ++u)
-                        v[u] = s0 + u < (int)gridDim.z ? *reinterpret_cast<const float4*>(src + (long long)(s0 + u) * step) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                    for (int u = 0; u < 16; ++u)
-                        if (s0 + u < (int)gridDim.z) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
-                }
-                const float r[4] = {acc.x, acc.y, acc.z, acc.w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int n = n0 + j;
-                    if (n >= p.N) break;
-                    const float o = r[j] + p.fold_bias[n];
-                    if (n < p.fold_D) p.fold_mu[(long long)m * p.fold_D + n] = o;
-                    else if (p.fold_logvar) p.fold_logvar[(long long)m * p.fold_D + (n - p.fold_D)] = o;
-                }
-            }
-        }
-    }
 #ifdef AMPH_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     AMPH_S3_T(q_t3)

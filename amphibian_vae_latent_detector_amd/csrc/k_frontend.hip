@@ -145,7 +145,7 @@ __device__ __forceinline__ float sq_of(float y) {
 // 1024 threads: the reduction tree of a pass is written for 256 and leaves the rest idle, but staging and the
 // normalised-row write pass - latency- and issue-bound at one wave per SIMD - run on four times the waves
 // (rms stage 18.4 -> 16.1 us with 512, 14.8 us with 1024 threads; same bits)
-constexpr int kRmsThreads = 1024, kRmsTree = 256;
+constexpr int kRmsThreads = 1024;
 
 // TH threads per workgroup, CH numpy chunks staged per pass: <T, 1024, 4 | 2> for whole rows (one workgroup per row), <int16_t, 256, 1>
 // for the chunk-sums mode on long rows (one workgroup per chunk: 8 x the workgroups, each a fraction of the latency chain)
@@ -2032,7 +2032,6 @@ bool stft_pair_ok(int n_fft, int hop, int p_tail) { return n_fft == 2048 && hop 
 
 static int table_bytes_for(int n_fft) { return n_fft == 2048 ? FftGeo<4>::TABLE_BYTES : FftGeo<2>::TABLE_BYTES; }
 
-int g_stft_indep = 1;    // 1: k_stft_mel_w (independent waves, no shared sample span); 0: the tile-synchronous kernel
 
 size_t stft_mel_lds_bytes(int n_fft, int hop, int frames_per_block, int n_mels, int mel_w_floats, int n_waves) {
     // (sized for the tile-synchronous kernel, which also needs the span: either kernel may be launched)
@@ -2093,15 +2092,14 @@ hipError_t stft_mel_configure(int lds_bytes) {
     return hipSuccess;
 }
 
-int g_stft_grid = 0;     // persistent workgroups; 0 = fill the chip (2 per CU with 4 waves, 1 per CU with 12)
 
 template <int NW>
 static void launch_stft_mel_nw(const StftParams& p, int n_tiles, int sample_is_pcm16, hipStream_t s) {
     const size_t lds = p.db_out ? stft_mel_fused_lds_bytes(p.n_fft, p.n_frames, p.n_mels, p.mel_w_floats, NW)
                                 : stft_mel_lds_bytes(p.n_fft, p.hop, p.frames_per_block, p.n_mels, p.mel_w_floats, NW);
     const int fill = NW == 4 ? 512 : 256;
-    const dim3 grid((unsigned)std::min(n_tiles, g_stft_grid > 0 ? g_stft_grid : fill)), block(64 * NW);
-    if (g_stft_indep) {
+    const dim3 grid((unsigned)std::min(n_tiles, p.grid_wgs > 0 ? p.grid_wgs : fill)), block(64 * NW);      // 0: fill the chip (2 per CU with 4 waves, 1 with 12)
+    if (p.indep) {
         if (p.n_fft == 2048) {
             if (sample_is_pcm16) hipLaunchKernelGGL((k_stft_mel_w<true, 4, NW>), grid, block, lds, s, p, n_tiles);
             else hipLaunchKernelGGL((k_stft_mel_w<false, 4, NW>), grid, block, lds, s, p, n_tiles);
@@ -2131,7 +2129,7 @@ void launch_stft_mel(const StftParams& p, int n_rows, int sample_is_pcm16, int n
         size_t lds = stft_pair_lds_bytes(p.n_frames, p.n_mels, p.mel_w_floats, nw, p.db_out != nullptr);
         const bool twl = p.pair_tw_lds && lds + kPairTw1Bytes <= 160 * 1024;      // stage-1 twiddles in LDS when they fit
         if (twl) lds += kPairTw1Bytes;
-        const dim3 grid((unsigned)std::min(n_rows, g_stft_grid > 0 ? g_stft_grid : g_num_cus)), block(64 * nw);
+        const dim3 grid((unsigned)std::min(n_rows, p.grid_wgs > 0 ? p.grid_wgs : g_num_cus)), block(64 * nw);
 #define AMPH_PAIR_LAUNCH(NW_)                                                                              \
     if (twl) hipLaunchKernelGGL((k_stft_pair<NW_, 3, true>), grid, dim3(64 * NW_), lds, s, p, n_rows);   \
     else hipLaunchKernelGGL((k_stft_pair<NW_, 3, false>), grid, dim3(64 * NW_), lds, s, p, n_rows);
@@ -2148,7 +2146,7 @@ void launch_stft_mel(const StftParams& p, int n_rows, int sample_is_pcm16, int n
         size_t lds = stft_pair2_lds_bytes(p.n_frames, p.n_mels, p.mel_w_floats, nw, p.db_out != nullptr);
         const bool twl = p.pair_tw_lds && lds + kP2Tw1Bytes <= 160 * 1024;
         if (twl) lds += kP2Tw1Bytes;
-        const dim3 grid((unsigned)std::min(n_rows, g_stft_grid > 0 ? g_stft_grid : g_num_cus));
+        const dim3 grid((unsigned)std::min(n_rows, p.grid_wgs > 0 ? p.grid_wgs : g_num_cus));
         if (nw == 8) {
             if (twl) hipLaunchKernelGGL((k_stft_pair2<8, true>), grid, dim3(512), lds, s, p, n_rows);
             else hipLaunchKernelGGL((k_stft_pair2<8, false>), grid, dim3(512), lds, s, p, n_rows);
@@ -2267,12 +2265,12 @@ int rms_scale_chunks(int n_in) { return (n_in + kNpChunk - 1) / kNpChunk; }
 // up to 4 chunks, and alone on the GPU that form is faster (15 vs 20 us per 256 one-second rows), but its 1024-thread, 70 KB workgroups wait
 // for a free CU behind the other lanes' persistent kernels (49 us in the four-lane trace), the 256-thread ones of the two-kernel form
 // fit beside them: +0.8 % end to end at 3 chunks per row (profiles/r02_rms_chunk_path_sweep.txt)
-int g_rms_chunk_path_over = 2;
-
+// (the threshold is a per-context setting, "rms_chunk_path_over", default 2)
 void launch_rms_scale_pcm16(const int16_t* in, long long row_stride, const int32_t* lengths, int n_in, int n_rows,
-                            float* scale, int32_t* ok, int scale_f64, int16_t* norm_out, const NormPad& pad, float* chunk_sums, hipStream_t s) {
+                            float* scale, int32_t* ok, int scale_f64, int16_t* norm_out, const NormPad& pad, float* chunk_sums,
+                            int chunk_path_over, hipStream_t s) {
     const int n_chunks = rms_scale_chunks(n_in);
-    if (chunk_sums && n_chunks > g_rms_chunk_path_over) {
+    if (chunk_sums && n_chunks > chunk_path_over) {
         // rows longer than one LDS pass: (row, chunk) workgroups sum the chunks, (row, tile) workgroups fold + normalise + pad
         hipLaunchKernelGGL((k_rms_scale<int16_t, 256, 1>), dim3(n_rows, n_chunks), dim3(256), (rms_scale_lds<int16_t, 1>()), s, in, row_stride, lengths, n_in,
                            scale, ok, static_cast<int16_t*>(nullptr), NormPad{}, scale_f64, chunk_sums, n_chunks);

@@ -105,14 +105,8 @@ const char* amph_last_error(const amph_ctx* ctx);   /* ctx may be NULL: create-t
  *                            accumulation - as close to the torch-CPU fp32 result as the f32-MFMA kernels (1e-6), which 0
  *                            selects; results differ from those in the last bits (default 1)
  *   "split_fused"      0/1   ... the fused conv1 + conv2 kernel too (default 1)
- *   "head_fold"        0/1   head (fc_mu | fc_logvar as one split-K GEMM): 1 = the partial sums of an output tile are added - in split
- *                            order, then the bias: the reduce kernel's order, same bits - by the tile's last workgroup instead of by
- *                            a separate k_head_reduce launch.  Default 0: the agent-scope release / acquire fences the hand-off
- *                            needs (L2 write-back and invalidate on a multi-XCD part) cost more than the launch they save, and the
- *                            invalidate hits the other lanes' kernels too: head 10.5 + 6.3 -> 22.2 us, end to end -7 %
- *                            (profiles/r02_head_fold_sweep.txt)
  *   "rms_chunk_path_over" 1.. PCM16 rows of more than this many numpy chunks (8 192 samples) are normalised by the (row, chunk) + (row, tile)
- *                            kernel pair instead of one workgroup per row (default 2; same bits; PROCESS-wide)
+ *                            kernel pair instead of one workgroup per row (default 2; same bits)
  *   "patch_fused"      0/1   ... in its patch-resident form where the shape allows (3x3 stride-2 pad-1 twice, 32 layer-1 channels,
  *                            conv2 output 16 wide): the layer-1 activation of a 64-pixel tile is built once in LDS (layer 1 itself
  *                            on the matrix cores, split operands) and the conv2 weights stay in registers (default 1; 0 = the
@@ -136,19 +130,25 @@ const char* amph_last_error(const amph_ctx* ctx);   /* ctx may be NULL: create-t
  *                            per SIMD; the default when its LDS image fits 160 KB), 4 = two 256-thread ones
  *   "frames_per_block" 4..32 STFT frames per workgroup tile (multiple of 4; default 12 with 12 waves
  *                            at n_fft = 2048, 24 at n_fft = 1024, 8 with 4 waves)
- *   "stft_indep"       0/1   STFT kernel with independent waves (default 1: every wave fetches its own frame, no
+ *   "stft_indep"       0/1   frame-per-wave STFT kernel with independent waves (default 1: every wave fetches its own frame, no
  *                            workgroup barrier per tile) or the tile-synchronous one with a shared sample span in LDS
- *                            (0); PROCESS-wide; the two agree to the last bit or two (8e-8 relative)
+ *                            (0); the two agree to the last bit or two (8e-8 relative)
+ *   "stft_pair"        0/1   PCM16 rows padded by K0 / the pad kernel ("stft_prenorm" + "stft_prepad") at n_fft 2048 / hop 384 or
+ *                            n_fft 1024 / hop 256 go through the pair kernels (default 1): two consecutive frames as ONE complex FFT -
+ *                            k_stft_pair (a pair per wave, 32 points per lane) / k_stft_pair2 (a pair per half wave).  Mel power
+ *                            within 5e-7 of the row's peak of the frame-per-wave kernels' (0 selects those)
+ *   "stft_pair_waves"  8..12 waves per workgroup of that kernel (8, 10, 11, 12 at n_fft 2048; 8 or 12 at 1024); amph_create picks
+ *                            the largest whose LDS image fits; results do not depend on it
+ *   "stft_pair_tw_lds" 0/1   its stage-1 twiddles in LDS when the image still fits 160 KB (default 1), else buffer loads
  *   "stft_prenorm"     0/1   PCM16 input with apply_rms: the RMS kernel also writes the normalised, re-quantised PCM16
  *                            rows (what 00_normalize_dataset_rms.py puts on disk) and the STFT kernel reads those
  *                            (default 1) instead of normalising every sample of every frame itself (0); same bits
  *   "stft_prepad"      0/1   ... and writes them as the independent-wave STFT kernel reads them: truncated / zero padded to
  *                            n_samples and centre padded (n_fft / 2 reflected samples, or zeros, on both sides), so that no
  *                            frame needs index reflection (default 1; same bits)
- *   "stft_grid"        0..   persistent STFT workgroups (0 = fill the chip); PROCESS-wide, like the diagnostic
- *                            knobs "gemm_flags" / "gemm_min_lds" (A/B switches of tools/sweep.py; "gemm_min_wg128" is per context:
- *                            bit 0 wave-slot priority, bit 1 first-generation plain GEMM, bit 2 first-generation fused GEMM,
- *                            bit 5 second accumulator for odd k-steps in the plain GEMM)
+ *   "stft_grid"        0..   persistent STFT workgroups (0 = fill the chip; results do not depend on it)
+ * Every knob is a property of its context (round 3: "stft_indep", "stft_grid" and "rms_chunk_path_over" used to be process-wide;
+ * "head_fold", "gemm_flags" and "gemm_min_lds" are gone with the measured dead ends they selected).
  *   "bf16_encoder"     0/1   encoder in bf16 (weights, activations, v_mfma_f32_32x32x16_bf16) with fp32
  *                            accumulation, BN/ReLU and latents (default 0 = fp32, the path the 1e-4 parity
  *                            bar applies to); the front end is always fp32

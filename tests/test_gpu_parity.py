@@ -451,45 +451,6 @@ def test_register_resident_weight_conv_layers_match_oracle_and_staged_kernel(env
               % (e[0], e[1], e[2], e[3]))
 
 
-def test_head_fold_equals_reduce_kernel_bitwise(env):
-    """The split-K head GEMM's partial sums can be added by the last workgroup of each output tile ("head_fold" 1; default 0, it
-    measured slower: an agent-scope counter per tile, release / acquire fences around it) instead of by a separate reduce kernel.  Same order of
-    additions (split 0 first, then the bias), so the latents must be bit-identical to the two-kernel form - on every one of many
-    repeated runs (which workgroup comes last changes from run to run), ragged batches, and with all lanes busy."""
-    cfg = env.PRESETS["bench-1s"]
-    enc, tenc, spec = _encoders(env, "thesis-shape", cfg=cfg, max_batch=64)
-    sess = enc.session(cfg)
-    rng = np.random.default_rng(5)
-    x = torch.from_numpy(rng.standard_normal((150, 1, cfg.target_frames, cfg.n_mels)).astype(np.float32))
-    try:
-        sess.configure("head_fold", 0)
-        mu0, lv0 = sess.encoder_forward(x)
-        sess.configure("head_fold", 1)
-        for rep in range(40):
-            mu1, lv1 = sess.encoder_forward(x)
-            assert torch.equal(mu1, mu0) and torch.equal(lv1, lv0), f"run {rep}"
-        for nb in (1, 63, 65, 128):
-            mu1, lv1 = sess.encoder_forward(x[:nb])
-            assert torch.equal(mu1, mu0[:nb]) and torch.equal(lv1, lv0[:nb]), nb
-    finally:
-        sess.configure("head_fold", 0)
-    with torch.no_grad():
-        _assert_latents(mu0.cpu().numpy(), tenc(x)[0].numpy(), 1e-5)
-    # end to end, four lanes, 40 batches per call
-    pcm = torch.from_numpy(np.tile(env.synth(list(range(250)), cfg.n_samples, cfg.sr), (10, 1))).to(DEV)
-    big = env.HipEncoder(spec, env.random_init_state(spec, seed=0), DEV, max_batch=64).session(cfg)
-    try:
-        big.configure("head_fold", 0)
-        ref_mu, _, _ = big.encode(pcm, apply_rms=True)
-        ref_mu = ref_mu.clone()
-        big.configure("head_fold", 1)
-        for rep in range(5):
-            mu, _, _ = big.encode(pcm, apply_rms=True)
-            assert torch.equal(mu, ref_mu), f"end to end, run {rep}"
-    finally:
-        big.configure("head_fold", 0)
-
-
 def test_encoder_odd_shapes_generic_path(env):
     """Non power-of-two geometry: 5x5 stride-1 first layer, C_out not a multiple of 64, K padded to 32."""
     from amphibian_vae_latent_detector_amd import EncoderSpec
@@ -884,7 +845,7 @@ def test_unsupported_and_invalid_configurations_raise(env):
         sess.configure("stft_waves", waves)
         assert torch.equal(sess.mel_power(y), ref), (waves, ft)
     # the tile-synchronous kernel (shared sample span, two barriers per tile) against the default one with independent
-    # waves: the same arithmetic up to the compiler's FMA contractions (process-wide knob: restored)
+    # waves: the same arithmetic up to the compiler's FMA contractions
     try:
         sess.configure("stft_indep", 0)
         for waves, ft in ((12, 12), (4, 8)):
@@ -895,6 +856,29 @@ def test_unsupported_and_invalid_configurations_raise(env):
             assert not got[3].any()                            # the silent row stays exactly zero
     finally:
         sess.configure("stft_indep", 1)
+    # every knob is a property of ITS context (round 3: "stft_indep", "stft_grid", "rms_chunk_path_over" were process-wide): two
+    # contexts with different settings in one process each keep their own kernels and results, in either call order
+    a_ctx = env.AmphSession(env.cfg, None, None, DEV, max_batch=8)
+    b_ctx = env.AmphSession(env.cfg, None, None, DEV, max_batch=8)
+    pcm = env.synth([0, 1, 2, 3, 4, 5, 6], env.cfg.n_samples, env.cfg.sr)
+    try:
+        b_ctx.configure("stft_indep", 0)
+        b_ctx.configure("stft_grid", 3)
+        b_ctx.configure("stft_pair", 0)
+        b_ctx.configure("rms_chunk_path_over", 8)
+        ref_a = a_ctx.mel_pcm16(pcm, apply_rms=True, layout=1, want_power=True)[1]
+        ref_b = b_ctx.mel_pcm16(pcm, apply_rms=True, layout=1, want_power=True)[1]
+        assert not torch.equal(ref_a, ref_b)                               # different kernels: last-bit differences
+        assert float((ref_a - ref_b).abs().max()) <= 1e-6 * float(ref_a.max())
+        for _ in range(2):                                                 # interleaved: neither disturbs the other
+            assert torch.equal(b_ctx.mel_pcm16(pcm, apply_rms=True, layout=1, want_power=True)[1], ref_b)
+            assert torch.equal(a_ctx.mel_pcm16(pcm, apply_rms=True, layout=1, want_power=True)[1], ref_a)
+        for key in ("gemm_flags", "gemm_min_lds", "head_fold"):            # removed with the forms they selected
+            with pytest.raises(env.N.AmphError):
+                a_ctx.configure(key, 0)
+    finally:
+        a_ctx.close()
+        b_ctx.close()
 
 
 # ----------------------------------------------------------------------------- K6: radial decision

@@ -18,7 +18,7 @@ cfg = PRESETS["bench-1s"]
 spec = SPECS["thesis-shape"](64, 64)
 s = HipEncoder(spec, random_init_state(spec, 0), "cuda:0", max_batch=256).session(cfg)
 s.configure("lanes", 1)
-for a in sys.argv[1:]:                                   # key=value knobs, e.g. patch_fused=0 patch_wgs=128 gemm_flags=1
+for a in sys.argv[1:]:                                   # key=value knobs, e.g. patch_fused=0 patch_wgs=128
     k, v = a.split("=")
     s.configure(k, int(v))
 x = torch.randn(256, 1, 64, 64, device="cuda:0")
