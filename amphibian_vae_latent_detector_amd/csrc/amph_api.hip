@@ -39,10 +39,6 @@ struct Stage {
 struct Workspace {
     hipStream_t stream = nullptr;          // lane 0 uses the caller's stream
     hipEvent_t done = nullptr;
-    // "cu_partition" experiment: CU-masked streams of this lane (front end / encoder; the same stream when the lanes are split by
-    // CU set rather than by role) and the events that order them
-    hipStream_t cu_fe = nullptr, cu_enc = nullptr;
-    hipEvent_t cu_fe_done = nullptr, cu_enc_done = nullptr;
     float* scale = nullptr;
     int32_t* ok = nullptr;
     float* melpow = nullptr;
@@ -90,8 +86,6 @@ struct amph_ctx {
     std::vector<unsigned char> radial_key; // the detector (K, D, centroids, thresholds, ranks) last uploaded for K6
     float* d_pair_tables = nullptr;        // k_stft_pair: window pairs + stage-2 twiddles (packed LDS image); nullptr: configuration not covered
     float2* d_pair_tw1 = nullptr;          // k_stft_pair: stage-1 twiddles (global memory)
-    int cu_partition = 0;                  // experiment: 0 lanes share the chip through the hardware queues (default); -2 / -4 each lane's stream masked
-                                           // to a half / quarter of the CUs; X > 0: every lane's front end on a stream masked to X CUs, its encoder on the rest
     bool stft_indep = true;                // k_stft_mel_w (independent waves) rather than the tile-synchronous k_stft_mel
     int stft_grid = 0;                     // persistent STFT workgroups (0 = fill the chip)
     int rms_chunk_path_over = 2;           // PCM16 rows of more numpy chunks than this: (row, chunk) + (row, tile) kernel pair
@@ -639,10 +633,6 @@ void free_lane(Workspace& w) {
     fr(w.partial);
     fr(w.norm16);
     if (w.done) (void)hipEventDestroy(w.done);
-    if (w.cu_fe) (void)hipStreamDestroy(w.cu_fe);
-    if (w.cu_enc && w.cu_enc != w.cu_fe) (void)hipStreamDestroy(w.cu_enc);
-    if (w.cu_fe_done) (void)hipEventDestroy(w.cu_fe_done);
-    if (w.cu_enc_done) (void)hipEventDestroy(w.cu_enc_done);
     if (w.stream) (void)hipStreamDestroy(w.stream);
     w = Workspace();
 }
@@ -1020,22 +1010,12 @@ int encode_common(amph_ctx* c, const void* d_wave, bool pcm16, int64_t n_rows, i
         const char* wv = (const char*)d_wave + (size_t)off * n_in * esz;
         // a stage that fails (an allocation, a launch) stops the call: the later stages of the batch would read stale buffers
         const bool fdb = can_fuse_db(c, pcm16);        // dB / z-score / crop-pad inside the STFT kernel: no mel power in HBM
-        hipStream_t fs = ls, es = ls;
-        if (c->cu_partition != 0 && w.cu_fe) {         // experiment: CU-masked streams, forked from the lane's ordinary stream
-            fs = w.cu_fe; es = w.cu_enc;
-            HIP_TRY(c, hipEventRecord(w.done, ls));    // (w.done is re-recorded by the join below)
-            HIP_TRY(c, hipStreamWaitEvent(fs, w.done, 0));
-            if (es != fs) HIP_TRY(c, hipStreamWaitEvent(fs, w.cu_enc_done, 0));     // the previous batch's encoder still reads this lane's image
-        }
+        // (lanes on CU-masked streams - halves, quarters, a front-end / encoder split of the CUs - were measured in round 3 and run
+        // 5-7x slower than this: profiles/r03_cu_partition_sweep.txt)
         rc = run_frontend(c, w, wv, pcm16, nb, n_in, d_len ? d_len + off : nullptr, apply_rms, d_rms_ok ? d_rms_ok + off : nullptr,
-                          w.melpow, fs, fdb ? w.image : nullptr, 1);
-        if (rc == AMPH_OK && !fdb) rc = run_dbnorm(c, w.melpow, nb, 1, w.image, fs);
-        if (es != fs) { HIP_TRY(c, hipEventRecord(w.cu_fe_done, fs)); HIP_TRY(c, hipStreamWaitEvent(es, w.cu_fe_done, 0)); }
-        if (rc == AMPH_OK) rc = run_encoder(c, w, w.image, nb, d_mu + off * D, d_logvar ? d_logvar + off * D : nullptr, es);
-        if (es != ls) {                                // back onto the lane's ordinary stream (which the join below waits for)
-            HIP_TRY(c, hipEventRecord(w.cu_enc_done, es));
-            HIP_TRY(c, hipStreamWaitEvent(ls, w.cu_enc_done, 0));
-        }
+                          w.melpow, ls, fdb ? w.image : nullptr, 1);
+        if (rc == AMPH_OK && !fdb) rc = run_dbnorm(c, w.melpow, nb, 1, w.image, ls);
+        if (rc == AMPH_OK) rc = run_encoder(c, w, w.image, nb, d_mu + off * D, d_logvar ? d_logvar + off * D : nullptr, ls);
         if (rc == AMPH_OK) rc = check_launch(c, "encode");
     }
     for (int l = 1; l < L; ++l) {           // join (on failure too: the caller's stream must not run ahead of the lanes)
@@ -1170,36 +1150,6 @@ int amph_configure(amph_ctx* c, const char* key, int value) {
     if (!c || !key) return AMPH_ERR_INVALID_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     if (!std::strcmp(key, "lanes")) return set_lanes(c, value);
-    if (!std::strcmp(key, "cu_partition")) {
-        const int ncu = amph::g_num_cus;
-        if (!(value == 0 || value == -2 || value == -4 || (value > 0 && value < ncu))) return fail(c, AMPH_ERR_INVALID_ARG, "cu_partition: 0, -2, -4 or 1..CUs-1");
-        (void)hipDeviceSynchronize();
-        for (auto& w : c->lanes) {
-            if (w.cu_fe) (void)hipStreamDestroy(w.cu_fe);
-            if (w.cu_enc && w.cu_enc != w.cu_fe) (void)hipStreamDestroy(w.cu_enc);
-            w.cu_fe = w.cu_enc = nullptr;
-            if (!w.cu_fe_done) { HIP_TRY(c, hipEventCreateWithFlags(&w.cu_fe_done, hipEventDisableTiming)); HIP_TRY(c, hipEventCreateWithFlags(&w.cu_enc_done, hipEventDisableTiming)); }
-        }
-        c->cu_partition = value;
-        if (value == 0) return AMPH_OK;
-        const int words = (ncu + 31) / 32;
-        auto mask_of = [&](int lo, int hi) { std::vector<uint32_t> m((size_t)words, 0u); for (int i = lo; i < hi; ++i) m[(size_t)i >> 5] |= 1u << (i & 31); return m; };
-        const int L = (int)c->lanes.size();
-        for (int l = 0; l < L; ++l) {
-            Workspace& w = c->lanes[(size_t)l];
-            if (value < 0) {                               // lanes split the CUs among them
-                const int parts = -value, part = l % parts, lo = part * ncu / parts, hi = (part + 1) * ncu / parts;
-                auto m = mask_of(lo, hi);
-                HIP_TRY(c, hipExtStreamCreateWithCUMask(&w.cu_fe, (uint32_t)words, m.data()));
-                w.cu_enc = w.cu_fe;
-            } else {                                       // roles split the CUs: front end on [0, X), encoder on [X, CUs)
-                auto ma = mask_of(0, value), mb = mask_of(value, ncu);
-                HIP_TRY(c, hipExtStreamCreateWithCUMask(&w.cu_fe, (uint32_t)words, ma.data()));
-                HIP_TRY(c, hipExtStreamCreateWithCUMask(&w.cu_enc, (uint32_t)words, mb.data()));
-            }
-        }
-        return AMPH_OK;
-    }
     if (!std::strcmp(key, "fuse_conv12")) { c->fuse_conv12 = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "stft_prenorm")) { c->stft_prenorm = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "stft_prepad")) { c->stft_prepad = value != 0; return AMPH_OK; }
