@@ -378,18 +378,27 @@ int build_frontend(amph_ctx* c) {
                     const float w = (float)(0.5 - 0.5 * std::cos(2.0 * PI * (double)n / (double)n_fft));
                     pt[(size_t)(j * 64 + l) * 2 + e] = w * (1.0f / 32768.0f);      // x / 32768 * w == x * (w / 32768): exact scaling
                 }
+        // stage-2 twiddles as the kernel multiplies them: per (h, m) the PAIR of mm = 2 m, 2 m + 1: (cos, cos, sin, sin); h = 0: (1, 1, 0, 0)
         float* tw2 = pt.data() + 16 * 64 * 2;
-        for (int mm = 0; mm < 32; ++mm) {
-            const double a = -2.0 * PI * (double)mm / 64.0;
-            tw2[2 * mm] = 1.0f; tw2[2 * mm + 1] = 0.0f;
-            tw2[2 * (32 + mm)] = (float)std::cos(a); tw2[2 * (32 + mm) + 1] = (float)std::sin(a);
+        for (int m = 0; m < 16; ++m) {
+            float* e0 = tw2 + 4 * m;
+            float* e1 = tw2 + 4 * (16 + m);
+            e0[0] = e0[1] = 1.0f; e0[2] = e0[3] = 0.0f;
+            for (int u = 0; u < 2; ++u) {
+                const double a = -2.0 * PI * (double)(2 * m + u) / 64.0;
+                e1[u] = (float)std::cos(a); e1[2 + u] = (float)std::sin(a);
+            }
         }
-        std::vector<float2> tw1(31 * 64);
-        for (int k1 = 1; k1 < 32; ++k1)
+        // stage-1 twiddles: per (k, lane) the pair k1 = k, k + 16: (wr_k, wr_k+16, wi_k, wi_k+16), k = 0..15 (k1 = 0: (1, 0))
+        std::vector<float2> tw1(2 * 16 * 64);
+        for (int k = 0; k < 16; ++k)
             for (int l = 0; l < 64; ++l) {
                 const int col = 2 * (l & 31) + (l >> 5);
-                const double a = -2.0 * PI * (double)((col * k1) % n_fft) / (double)n_fft;
-                tw1[(size_t)(k1 - 1) * 64 + l] = make_float2((float)std::cos(a), (float)std::sin(a));
+                float* e = reinterpret_cast<float*>(tw1.data()) + ((size_t)k * 64 + l) * 4;
+                for (int u = 0; u < 2; ++u) {
+                    const double a = -2.0 * PI * (double)((col * (k + 16 * u)) % n_fft) / (double)n_fft;
+                    e[u] = (float)std::cos(a); e[2 + u] = (float)std::sin(a);
+                }
             }
         HIP_TRY(c, upload(&c->d_pair_tables, pt));
         HIP_TRY(c, upload(&c->d_pair_tw1, tw1));

@@ -552,6 +552,79 @@ __device__ __forceinline__ void dft16(float (&re)[16], float (&im)[16]) {
                    re[4 * ka + 3], im[4 * ka + 3]);
 }
 
+// The same 16-point DFT on PACKED PAIRS (round 3): T = float2 holding element j of TWO sequences a lane transforms side by side
+// (the pair kernels: sequences e = 0 / 1 of stage 1, p = 0 / 1 of stage 2).  Every operation of the scalar form becomes one
+// v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 with the constants broadcast from SGPRs - half the instructions.  What bounds the STFT
+// kernels is the instruction stream of ONE wave (tools/probe/valu_rate.hip: a wave issues a vector instruction every ~5 cycles
+// whether it is alone on its SIMD or one of four; v_pk_fma_f32 5.5), so instructions per frame are time.
+typedef float amph_f2 __attribute__((ext_vector_type(2)));
+#define AMPH_BFLY4_T(r0, i0, r1, i1, r2, i2, r3, i3)                   \
+    {                                                                  \
+        const auto ar = r0 + r2, ai = i0 + i2;                         \
+        const auto br = r0 - r2, bi = i0 - i2;                         \
+        const auto cr = r1 + r3, ci = i1 + i3;                         \
+        const auto dr = i1 - i3, di = r3 - r1;                         \
+        r0 = ar + cr; i0 = ai + ci;                                    \
+        r1 = br + dr; i1 = bi + di;                                    \
+        r2 = ar - cr; i2 = ai - ci;                                    \
+        r3 = br - dr; i3 = bi - di;                                    \
+    }
+#define AMPH_CMUL_T(r, i, wr, wi)                                      \
+    {                                                                  \
+        const auto tr_ = r * (wr) - i * (wi);                          \
+        i = r * (wi) + i * (wr);                                       \
+        r = tr_;                                                       \
+    }
+__device__ __forceinline__ void dft16_pk(amph_f2 (&re)[16], amph_f2 (&im)[16]) {
+    constexpr float C1 = 0.92387953251128675613f;   // cos(pi/8)
+    constexpr float S1 = 0.38268343236508977173f;   // sin(pi/8)
+    constexpr float R2 = 0.70710678118654752440f;   // sqrt(1/2)
+#pragma unroll
+    for (int j0 = 0; j0 < 4; ++j0)
+        AMPH_BFLY4_T(re[j0], im[j0], re[j0 + 4], im[j0 + 4], re[j0 + 8], im[j0 + 8], re[j0 + 12], im[j0 + 12]);
+    AMPH_CMUL_T(re[1 + 4], im[1 + 4], C1, -S1);
+    AMPH_CMUL_T(re[2 + 4], im[2 + 4], R2, -R2);
+    AMPH_CMUL_T(re[3 + 4], im[3 + 4], S1, -C1);
+    AMPH_CMUL_T(re[1 + 8], im[1 + 8], R2, -R2);
+    { const amph_f2 t = re[2 + 8]; re[2 + 8] = im[2 + 8]; im[2 + 8] = -t; }
+    AMPH_CMUL_T(re[3 + 8], im[3 + 8], -R2, -R2);
+    AMPH_CMUL_T(re[1 + 12], im[1 + 12], S1, -C1);
+    AMPH_CMUL_T(re[2 + 12], im[2 + 12], -R2, -R2);
+    AMPH_CMUL_T(re[3 + 12], im[3 + 12], -C1, S1);
+#pragma unroll
+    for (int ka = 0; ka < 4; ++ka)
+        AMPH_BFLY4_T(re[4 * ka], im[4 * ka], re[4 * ka + 1], im[4 * ka + 1], re[4 * ka + 2], im[4 * ka + 2], re[4 * ka + 3], im[4 * ka + 3]);
+}
+// Y[k + 16 p] = E[k] +- W32^k O[k] with E = the .x and O = the .y sequence of every pair, in place (.x <- Y[k], .y <- Y[k + 16])
+__device__ __forceinline__ void dft32_combine_pk(amph_f2 (&re)[16], amph_f2 (&im)[16]) {
+    constexpr float C[16] = {1.0f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f,
+                             0.70710678118654752440f, 0.55557023301960222474f, 0.38268343236508977173f, 0.19509032201612826785f,
+                             0.0f, -0.19509032201612826785f, -0.38268343236508977173f, -0.55557023301960222474f,
+                             -0.70710678118654752440f, -0.83146961230254523708f, -0.92387953251128675613f, -0.98078528040323044913f};
+    constexpr float S[16] = {0.0f, 0.19509032201612826785f, 0.38268343236508977173f, 0.55557023301960222474f,
+                             0.70710678118654752440f, 0.83146961230254523708f, 0.92387953251128675613f, 0.98078528040323044913f,
+                             1.0f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f,
+                             0.70710678118654752440f, 0.55557023301960222474f, 0.38268343236508977173f, 0.19509032201612826785f};
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int q = DFT16_POS(k);
+        const float orr = re[q].y, oi = im[q].y, ar = re[q].x, ai = im[q].x;
+        float tr, ti;
+        if (k == 0) { tr = orr; ti = oi; }
+        else if (k == 8) { tr = oi; ti = -orr; }
+        else { tr = C[k] * orr + S[k] * oi; ti = C[k] * oi - S[k] * orr; }
+        re[q].x = ar + tr; re[q].y = ar - tr;
+        im[q].x = ai + ti; im[q].y = ai - ti;
+    }
+}
+// LDS stores with ONE base register and a 16-bit byte offset.  Left to the compiler, neighbouring float stores are paired into
+// ds_write2_b32, whose 8-bit offsets reach 1 KB: the 32 rows of an exchange tile then need sixteen loop-invariant base registers
+// (~35 over the pair kernel), which at three waves per SIMD are spilled and reloaded in front of every store.  `base` is the
+// LDS byte address (low 32 bits of the generic pointer).  The "memory" clobber keeps the compiler's own LDS accesses on their side
+// of the store; its s_waitcnt counts only over-wait for these (LDS operations of a wave complete in order).
+#define AMPH_DS_ST32(base_, off_, val_) asm volatile("ds_write_b32 %0, %1 offset:%2" : : "v"(base_), "v"(val_), "n"(off_) : "memory")
+#define AMPH_DS_ST64(base_, off_, val_) asm volatile("ds_write_b64 %0, %1 offset:%2" : : "v"(base_), "v"(val_), "n"(off_) : "memory")
+
 // sample s of a row as float32 before normalisation (0 beyond the valid length: the zero
 // pad of fix_length, map_detector_core.py:214-215)
 template <bool PCM16>
@@ -1386,7 +1459,7 @@ constexpr int kPairExS = 68;                        // exchange row stride in fl
 constexpr int kPairScratch = 32 * kPairExS * 4;     // per-wave scratch: exchange tile, then partner tile, then the two power spectra
 constexpr int kPairPStride = kPairScratch / 8;      // floats between the two power spectra (1088 >= 1025 + tail)
 constexpr int kPairZS = 96;                         // partner tile row stride in floats (columns >= 32 shifted by 16 banks; lane' 0 reads one row further: same bank as column 0)
-constexpr int kPairWinBytes = 16 * 64 * 8, kPairTw2Bytes = 2 * 32 * 8, kPairTw1Bytes = 31 * 64 * 8;
+constexpr int kPairWinBytes = 16 * 64 * 8, kPairTw2Bytes = 2 * 32 * 8, kPairTw1Bytes = 16 * 64 * 16;
 
 // Y[k + 16 p] = E[k] +- W32^k O[k]: e = DFT16 of the even inputs (X[k] at DFT16_POS(k)), o = of the odd ones, in place
 __device__ __forceinline__ void dft32_combine(float (&er)[16], float (&ei)[16], float (&orr)[16], float (&oi)[16]) {
@@ -1425,13 +1498,12 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
     const int meta_bytes = (p.n_mels * 12 + 15) & ~15;
     const int melw_bytes = p.mel_w_floats * 4;
     constexpr int kTab = kPairWinBytes + kPairTw2Bytes + (TWL ? kPairTw1Bytes : 0);
-    const float2* tw1_l = reinterpret_cast<const float2*>(smem + kPairWinBytes + kPairTw2Bytes) + lane;      // [31][64] (TWL)
+    const float4* tw1_l = reinterpret_cast<const float4*>(smem + kPairWinBytes + kPairTw2Bytes) + lane;      // [16][64] (wr_k, wr_k+16, wi_k, wi_k+16) (TWL)
     int3* mel_meta = reinterpret_cast<int3*>(smem + kTab);
     float* mel_w = reinterpret_cast<float*>(smem + kTab + meta_bytes);
     char* wbase = smem + kTab + meta_bytes + melw_bytes + wave * kPairScratch;
     float* T = reinterpret_cast<float*>(wbase);
-    float* Pa = T;
-    float* Pb = T + kPairPStride;
+    amph_f2* P2 = reinterpret_cast<amph_f2*>(wbase);        // the pair's power spectra, interleaved: P2[k] = (4 |A[k]|^2, 4 |B[k]|^2)
     float* mp_row = reinterpret_cast<float*>(smem + kTab + meta_bytes + melw_bytes + NW * kPairScratch);
     const bool fuse_db = p.db_out != nullptr;
 #ifdef AMPH_STAMPS
@@ -1479,6 +1551,9 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
     const int zw = lanep + ((lanep >> 5) << 4);             // partner tile column (write), bank-shifted
     const int zr_ = colp + ((colp >> 5) << 4) + (lanep == 0 ? kPairZS : 0);   // (read; lane' 0: one row further, row 16 = Z[0])
     const float sgn = h ? -1.0f : 1.0f;
+    // LDS byte addresses of this lane's stores (AMPH_DS_ST32 / 64): exchange column, partner column, power bin
+    const uint32_t lds_w = (uint32_t)(uintptr_t)wbase;
+    const uint32_t st_col = lds_w + 4u * (uint32_t)col, st_zw = lds_w + 4u * (uint32_t)zw, st_p2 = lds_w + 8u * (uint32_t)lanep;
 
     // the next pair's raw dwords: requested before the mel rows of the current pair
     uint32_t nx[ND];
@@ -1488,7 +1563,7 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
     // the 31 table rows and 19 sample rows each got their own 64-bit per-lane address, i.e. ~100 live VGPRs of addresses
     const __amdgpu_buffer_rsrc_t rs_tw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(p.pair_tw1), 0, -1, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src.wave), 0, -1, 0x00020000);
-    const int lane4 = lane * 4, lane8 = lane * 8;
+    const int lane4 = lane * 4, lane16 = lane * 16;
     auto fetch = [&](int row_, int pr_) {
         const int base = __builtin_amdgcn_readfirstlane((int)(((long long)row_ * p.src.row_stride) * 2 + (long long)pr_ * p.hop * 4));
         const bool full = 2 * pr_ + 1 < p.n_frames;        // wave-uniform: the row's last pair may hold one frame only
@@ -1505,150 +1580,149 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
 #define AMPH_PHASE_FENCE() __builtin_amdgcn_sched_barrier(0)
     for (int row = blockIdx.x; row < n_rows; row += gridDim.x) {
         for (int pr = wave; pr < n_pairs; pr += NW) {
-            float xr[2][16], xi[2][16];
-            float2 tw[31];
+            // packed pairs: element j of the lane's TWO sequences (sample parity 0 / 1) side by side - dft16_pk
+            amph_f2 XR[16], XI[16];
+            float4 tw[16];
             AMPH_PSTAMP(0)
-            // ---- decode + window: z = w (a + i b); sequence e = sample parity, m = j'
-            {
-                float2 wv[16];
+            // ---- decode + window: z = w (a + i b); the pair is the two int16 of one dword times the window pair (w[n], w[n + 1])
 #pragma unroll
-                for (int j = 0; j < 16; ++j) wv[j] = win[j * 64 + lane];
+            for (int g = 0; g < 2; ++g) {
+                float2 wv[8];
 #pragma unroll
-                for (int j = 0; j < 16; ++j) {
+                for (int j = 0; j < 8; ++j) wv[j] = win[(8 * g + j) * 64 + lane];
+#pragma unroll
+                for (int j8 = 0; j8 < 8; ++j8) {
+                    const int j = 8 * g + j8;
                     const uint32_t da = nx[j], db = nx[j + HJ];
-                    xr[0][j] = (float)(short)(da & 0xFFFFu) * wv[j].x;
-                    xr[1][j] = (float)((int)da >> 16) * wv[j].y;
-                    xi[0][j] = (float)(short)(db & 0xFFFFu) * wv[j].x;
-                    xi[1][j] = (float)((int)db >> 16) * wv[j].y;
+                    const amph_f2 w2 = {wv[j8].x, wv[j8].y};
+                    XR[j] = amph_f2{(float)(short)(da & 0xFFFFu), (float)((int)da >> 16)} * w2;
+                    XI[j] = amph_f2{(float)(short)(db & 0xFFFFu), (float)((int)db >> 16)} * w2;
                 }
+                if (g == 0) AMPH_PHASE_FENCE();
             }
             AMPH_PSTAMP(1)
-            // ---- stage-1 twiddles from global memory (!TWL): the first half is requested here, the second behind the first DFT16 -
-            //      all 62 registers in flight from the top of the pair did not fit three waves per SIMD
+            // ---- stage-1 twiddles from global memory (!TWL): the first half is requested here, the second behind the DFT16
 #pragma unroll
-            for (int k1 = 1; k1 < 16; ++k1) if (!TWL) tw[k1 - 1] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs_tw, lane8, (k1 - 1) * 512, 0));
+            for (int k8 = 0; k8 < 8; ++k8) if (!TWL) tw[k8] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_tw, lane16, k8 * 1024, 0));
             AMPH_PHASE_FENCE();
-            // ---- stage 1: DFT32 down the lane's column
-            dft16(xr[0], xi[0]);
+            // ---- stage 1: DFT32 down the lane's column: both 16-point halves at once, the swap that brings the halves of ONE column
+            //      together (high lanes' sequence 0 <-> low lanes' sequence 1), the radix-2 combine
+            dft16_pk(XR, XI);
             AMPH_PHASE_FENCE();
 #pragma unroll
-            for (int k1 = 16; k1 < 32; ++k1) if (!TWL) tw[k1 - 1] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs_tw, lane8, (k1 - 1) * 512, 0));
-            AMPH_PHASE_FENCE();
-            dft16(xr[1], xi[1]);
+            for (int k8 = 8; k8 < 16; ++k8) if (!TWL) tw[k8] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_tw, lane16, k8 * 1024, 0));
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {                  // high lanes' sequence 0 <-> low lanes' sequence 1
-                const auto sr = __builtin_amdgcn_permlane32_swap(__float_as_uint(xr[0][q]), __float_as_uint(xr[1][q]), false, false);
-                const auto si = __builtin_amdgcn_permlane32_swap(__float_as_uint(xi[0][q]), __float_as_uint(xi[1][q]), false, false);
-                xr[0][q] = __uint_as_float(sr[0]); xr[1][q] = __uint_as_float(sr[1]);
-                xi[0][q] = __uint_as_float(si[0]); xi[1][q] = __uint_as_float(si[1]);
+            for (int q = 0; q < 16; ++q) {
+                const auto sr = __builtin_amdgcn_permlane32_swap(__float_as_uint(XR[q].x), __float_as_uint(XR[q].y), false, false);
+                const auto si = __builtin_amdgcn_permlane32_swap(__float_as_uint(XI[q].x), __float_as_uint(XI[q].y), false, false);
+                XR[q] = amph_f2{__uint_as_float(sr[0]), __uint_as_float(sr[1])};
+                XI[q] = amph_f2{__uint_as_float(si[0]), __uint_as_float(si[1])};
             }
-            dft32_combine(xr[0], xi[0], xr[1], xi[1]);
+            dft32_combine_pk(XR, XI);
             AMPH_PHASE_FENCE();
             AMPH_PSTAMP(2)
-            if (TWL) {
+            // ---- twiddle W_2048^(col k1): the pair (Y[k], Y[k + 16]) times the pair of its twiddles (LDS-resident table: four
+            //      pairs at a time - 16 registers, not 64)
 #pragma unroll
-                for (int k1 = 1; k1 < 16; ++k1) tw[k1 - 1] = tw1_l[(k1 - 1) * 64];
-            }
+            for (int g = 0; g < 4; ++g) {
+                if (TWL) {
 #pragma unroll
-            for (int k1 = 1; k1 < 16; ++k1) {
-                const int q = DFT16_POS(k1 & 15);
-                AMPH_CMUL(xr[0][q], xi[0][q], tw[k1 - 1].x, tw[k1 - 1].y);
-            }
-            if (TWL) {
-                AMPH_PHASE_FENCE();
+                    for (int k4 = 0; k4 < 4; ++k4) tw[4 * g + k4] = tw1_l[(4 * g + k4) * 64];
+                }
 #pragma unroll
-                for (int k1 = 16; k1 < 32; ++k1) tw[k1 - 1] = tw1_l[(k1 - 1) * 64];
-            }
-#pragma unroll
-            for (int k1 = 16; k1 < 32; ++k1) {
-                const int q = DFT16_POS(k1 & 15);
-                AMPH_CMUL(xr[1][q], xi[1][q], tw[k1 - 1].x, tw[k1 - 1].y);
+                for (int k4 = 0; k4 < 4; ++k4) {
+                    const int kk = 4 * g + k4, q = DFT16_POS(kk);
+                    const amph_f2 wr = {tw[kk].x, tw[kk].y}, wi = {tw[kk].z, tw[kk].w};
+                    AMPH_CMUL_T(XR[q], XI[q], wr, wi);
+                }
+                if (TWL && g < 3) AMPH_PHASE_FENCE();
             }
             // ---- exchange, real parts then imaginary parts.  LDS operations of a wave execute in order: the reads of the first
-            //      pass are queued behind its writes and in front of the second pass's writes, nothing waits in between
-            float ur[2][16], ui[2][16];
+            //      pass are queued behind its writes and in front of the second pass's writes, nothing waits in between.  A 16-byte
+            //      read returns mm = 4 c .. 4 c + 3 = the pairs (p = 0, 1) of m = 2 c and 2 c + 1: no register shuffling
+            amph_f2 UR[16], UI[16];
 #pragma unroll
-            for (int k1 = 0; k1 < 32; ++k1) T[k1 * kPairExS + col] = xr[k1 >> 4][DFT16_POS(k1 & 15)];
-            wave_lds_sync();
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const float4 v = *reinterpret_cast<const float4*>(T + k1p * kPairExS + 32 * h + 4 * c);
-                ur[0][2 * c] = v.x; ur[1][2 * c] = v.y; ur[0][2 * c + 1] = v.z; ur[1][2 * c + 1] = v.w;
+            for (int kk = 0; kk < 16; ++kk) {
+                AMPH_DS_ST32(st_col, kk * kPairExS * 4, XR[DFT16_POS(kk)].x);
+                AMPH_DS_ST32(st_col, (kk + 16) * kPairExS * 4, XR[DFT16_POS(kk)].y);
             }
             wave_lds_sync();
 #pragma unroll
-            for (int k1 = 0; k1 < 32; ++k1) T[k1 * kPairExS + col] = xi[k1 >> 4][DFT16_POS(k1 & 15)];
+            for (int c = 0; c < 8; ++c) {
+                const float4 v = *reinterpret_cast<const float4*>(T + k1p * kPairExS + 32 * h + 4 * c);
+                UR[2 * c] = amph_f2{v.x, v.y}; UR[2 * c + 1] = amph_f2{v.z, v.w};
+            }
+            wave_lds_sync();
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                AMPH_DS_ST32(st_col, kk * kPairExS * 4, XI[DFT16_POS(kk)].x);
+                AMPH_DS_ST32(st_col, (kk + 16) * kPairExS * 4, XI[DFT16_POS(kk)].y);
+            }
             wave_lds_sync();
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 const float4 v = *reinterpret_cast<const float4*>(T + k1p * kPairExS + 32 * h + 4 * c);
-                ui[0][2 * c] = v.x; ui[1][2 * c] = v.y; ui[0][2 * c + 1] = v.z; ui[1][2 * c + 1] = v.w;
+                UI[2 * c] = amph_f2{v.x, v.y}; UI[2 * c + 1] = amph_f2{v.z, v.w};
             }
             wave_lds_sync();
             AMPH_PHASE_FENCE();
             AMPH_PSTAMP(3)
-            // ---- stage 2: radix-2 DIF across the lane pair, twiddle (h = 1: W_64^mm; requested eight pairs at a time: 32 registers),
-            //      DFT32
+            // ---- stage 2: radix-2 DIF across the lane pair (DPP), twiddle (h = 1: W_64^mm; (1, 0) on h = 0), DFT32
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                float4 t2[8];
+            for (int g = 0; g < 4; ++g) {
+                float4 t2[4];
 #pragma unroll
-                for (int m = 0; m < 8; ++m) t2[m] = tw2[h * 16 + 8 * half + m];
+                for (int m = 0; m < 4; ++m) t2[m] = tw2[h * 16 + 4 * g + m];
 #pragma unroll
-                for (int m8 = 0; m8 < 8; ++m8) {
-                    const int m = 8 * half + m8;
-#pragma unroll
-                    for (int pp = 0; pp < 2; ++pp) {
-                        float r = fmaf(ur[pp][m], sgn, dpp_xor1(ur[pp][m]));
-                        float i = fmaf(ui[pp][m], sgn, dpp_xor1(ui[pp][m]));
-                        if (m > 0 || pp > 0) {
-                            const float wr = pp ? t2[m8].z : t2[m8].x, wi = pp ? t2[m8].w : t2[m8].y;
-                            AMPH_CMUL(r, i, wr, wi);
-                        }
-                        ur[pp][m] = r; ui[pp][m] = i;
-                    }
+                for (int m4 = 0; m4 < 4; ++m4) {
+                    const int m = 4 * g + m4;
+                    amph_f2 r = UR[m] * sgn + amph_f2{dpp_xor1(UR[m].x), dpp_xor1(UR[m].y)};
+                    amph_f2 i = UI[m] * sgn + amph_f2{dpp_xor1(UI[m].x), dpp_xor1(UI[m].y)};
+                    const amph_f2 wr = {t2[m4].x, t2[m4].y}, wi = {t2[m4].z, t2[m4].w};
+                    AMPH_CMUL_T(r, i, wr, wi);
+                    UR[m] = r; UI[m] = i;
                 }
                 AMPH_PHASE_FENCE();
             }
             AMPH_PSTAMP(4)
-            dft16(ur[0], ui[0]);
-            dft16(ur[1], ui[1]);
-            dft32_combine(ur[0], ui[0], ur[1], ui[1]);
+            dft16_pk(UR, UI);
+            dft32_combine_pk(UR, UI);          // .x: X[lane' + 64 k] (own bins), .y: X[lane' + 64 (k + 16)] (partners of another lane)
             AMPH_PHASE_FENCE();
             AMPH_PSTAMP(5)
             // ---- split: the partner values Z[N - k] come from the upper half (k2' >= 16) of lane' colp; both passes are queued
             //      back to back like the exchange's
             float pre[16], pim[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) T[r * kPairZS + zw] = ur[1][DFT16_POS(r)];
-            if (lanep == 0) T[16 * kPairZS] = ur[0][DFT16_POS(0)];
+            for (int r = 0; r < 16; ++r) AMPH_DS_ST32(st_zw, r * kPairZS * 4, UR[DFT16_POS(r)].y);
+            if (lanep == 0) T[16 * kPairZS] = UR[DFT16_POS(0)].x;
             wave_lds_sync();
 #pragma unroll
             for (int i = 0; i < 16; ++i) pre[i] = T[(15 - i) * kPairZS + zr_];
             wave_lds_sync();
 #pragma unroll
-            for (int r = 0; r < 16; ++r) T[r * kPairZS + zw] = ui[1][DFT16_POS(r)];
-            if (lanep == 0) T[16 * kPairZS] = ui[0][DFT16_POS(0)];
+            for (int r = 0; r < 16; ++r) AMPH_DS_ST32(st_zw, r * kPairZS * 4, UI[DFT16_POS(r)].y);
+            if (lanep == 0) T[16 * kPairZS] = UI[DFT16_POS(0)].x;
             wave_lds_sync();
 #pragma unroll
             for (int i = 0; i < 16; ++i) pim[i] = T[(15 - i) * kPairZS + zr_];
             wave_lds_sync();
             AMPH_PHASE_FENCE();
             AMPH_PSTAMP(6)
-            // ---- 4 |A[k]|^2, 4 |B[k]|^2: A = (Z[k] + conj Z[N-k]) / 2, B = (Z[k] - conj Z[N-k]) / 2i
+            // ---- (4 |A[k]|^2, 4 |B[k]|^2) as one pair: A = (Z[k] + conj Z[N-k]) / 2, B = (Z[k] - conj Z[N-k]) / 2i:
+            //      (ar, bi) = (pr + zr, pr - zr), (ai, br) = (zi - pi, zi + pi)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const float zr = ur[0][DFT16_POS(i)], zi = ui[0][DFT16_POS(i)];
-                const float ar = zr + pre[i], ai = zi - pim[i], br = zi + pim[i], bi = pre[i] - zr;
-                Pa[lanep + 64 * i] = ar * ar + ai * ai;
-                Pb[lanep + 64 * i] = br * br + bi * bi;
+                const float zr = UR[DFT16_POS(i)].x, zi = UI[DFT16_POS(i)].x;
+                const amph_f2 u = amph_f2{pre[i], pre[i]} + amph_f2{zr, -zr};
+                const amph_f2 v = amph_f2{zi, zi} + amph_f2{-pim[i], pim[i]};
+                const amph_f2 pw = u * u + v * v;
+                AMPH_DS_ST64(st_p2, 512 * i, pw);
             }
             if (lanep == 0) {                               // bin 1024 is its own partner
-                const float zr = ur[1][DFT16_POS(0)], zi = ui[1][DFT16_POS(0)];
-                Pa[1024] = 4.0f * zr * zr;
-                Pb[1024] = 4.0f * zi * zi;
+                const float zr = UR[DFT16_POS(0)].y, zi = UI[DFT16_POS(0)].y;
+                P2[1024] = amph_f2{4.0f * zr * zr, 4.0f * zi * zi};
             }
-            for (int i = lane; i < p.p_tail; i += 64) { Pa[1025 + i] = 0.0f; Pb[1025 + i] = 0.0f; }   // the padded mel rows read there
+            for (int i = lane; i < p.p_tail; i += 64) P2[1025 + i] = amph_f2{0.0f, 0.0f};     // the padded mel rows read there
             wave_lds_sync();
             AMPH_PHASE_FENCE();
             AMPH_PSTAMP(7)
@@ -1662,9 +1736,9 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
 #ifdef AMPH_STAMPS
             if (wave == 0 && pr == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); if (lane == 0) p.stamps[(size_t)blockIdx.x * 16 + 8] = t_; }
 #endif
-            // ---- mel rows of both frames: 4 lanes per filter, 4 bins per lane and step; one weight read serves both frames.
-            //      Four steps (twelve 16-byte reads) are requested at a time; even steps -> first accumulator, odd -> second,
-            //      as in k_stft_mel_w
+            // ---- mel rows of both frames at once: 4 lanes per filter, 4 bins per lane and step; the accumulators are (frame a, frame b)
+            //      pairs, a bin's two powers one 8-byte LDS element.  Four steps are requested at a time; even steps -> first
+            //      accumulator, odd -> second, as in k_stft_mel_w
             {
                 const int q = lane & 3;
                 const int n_rounds = (p.n_mels + 15) >> 4;
@@ -1676,40 +1750,39 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
                 for (int r = 0; r < n_rounds; ++r) {
                     const int steps = __builtin_amdgcn_readfirstlane(mt.y);
                     const float4* w = reinterpret_cast<const float4*>(mel_w + mt.z) + q;
-                    const float4* pa = reinterpret_cast<const float4*>(Pa + mt.x) + q;
-                    const float4* pb = reinterpret_cast<const float4*>(Pb + mt.x) + q;
+                    const float4* pp = reinterpret_cast<const float4*>(P2 + mt.x) + 2 * q;     // bins 4 q, 4 q + 1 | 4 q + 2, 4 q + 3 of a step
                     if (r + 1 < n_rounds) mt = mel_meta[min(16 * (r + 1) + (lane >> 2), p.n_mels - 1)];
-                    float a0 = 0.0f, a1 = 0.0f, b0 = 0.0f, b1 = 0.0f;
-#define AMPH_MEL_FMA(acc_, a_, b_)                                                         \
-    acc_ = fmaf(a_.x, b_.x, acc_); acc_ = fmaf(a_.y, b_.y, acc_); acc_ = fmaf(a_.z, b_.z, acc_); acc_ = fmaf(a_.w, b_.w, acc_);
+                    amph_f2 a0 = {0.0f, 0.0f}, a1 = {0.0f, 0.0f};
+#define AMPH_MEL_FMA2(acc_, w_, x_, y_)                                                    \
+    acc_ += w_.x * amph_f2{x_.x, x_.y}; acc_ += w_.y * amph_f2{x_.z, x_.w}; acc_ += w_.z * amph_f2{y_.x, y_.y}; acc_ += w_.w * amph_f2{y_.z, y_.w};
                     int i0 = 0;
                     for (; i0 + 4 <= steps; i0 += 4) {
                         float4 wq[4], xq[4], yq[4];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) { wq[u] = w[4 * (i0 + u)]; xq[u] = pa[4 * (i0 + u)]; yq[u] = pb[4 * (i0 + u)]; }
-                        AMPH_MEL_FMA(a0, wq[0], xq[0]) AMPH_MEL_FMA(b0, wq[0], yq[0])
-                        AMPH_MEL_FMA(a1, wq[1], xq[1]) AMPH_MEL_FMA(b1, wq[1], yq[1])
-                        AMPH_MEL_FMA(a0, wq[2], xq[2]) AMPH_MEL_FMA(b0, wq[2], yq[2])
-                        AMPH_MEL_FMA(a1, wq[3], xq[3]) AMPH_MEL_FMA(b1, wq[3], yq[3])
+                        for (int u = 0; u < 4; ++u) { wq[u] = w[4 * (i0 + u)]; xq[u] = pp[8 * (i0 + u)]; yq[u] = pp[8 * (i0 + u) + 1]; }
+                        AMPH_MEL_FMA2(a0, wq[0], xq[0], yq[0])
+                        AMPH_MEL_FMA2(a1, wq[1], xq[1], yq[1])
+                        AMPH_MEL_FMA2(a0, wq[2], xq[2], yq[2])
+                        AMPH_MEL_FMA2(a1, wq[3], xq[3], yq[3])
                     }
                     if (i0 + 2 <= steps) {
                         float4 wq[2], xq[2], yq[2];
 #pragma unroll
-                        for (int u = 0; u < 2; ++u) { wq[u] = w[4 * (i0 + u)]; xq[u] = pa[4 * (i0 + u)]; yq[u] = pb[4 * (i0 + u)]; }
-                        AMPH_MEL_FMA(a0, wq[0], xq[0]) AMPH_MEL_FMA(b0, wq[0], yq[0])
-                        AMPH_MEL_FMA(a1, wq[1], xq[1]) AMPH_MEL_FMA(b1, wq[1], yq[1])
+                        for (int u = 0; u < 2; ++u) { wq[u] = w[4 * (i0 + u)]; xq[u] = pp[8 * (i0 + u)]; yq[u] = pp[8 * (i0 + u) + 1]; }
+                        AMPH_MEL_FMA2(a0, wq[0], xq[0], yq[0])
+                        AMPH_MEL_FMA2(a1, wq[1], xq[1], yq[1])
                         i0 += 2;
                     }
                     if (i0 < steps) {
-                        const float4 w0 = w[4 * i0], x0 = pa[4 * i0], y0 = pb[4 * i0];
-                        AMPH_MEL_FMA(a0, w0, x0) AMPH_MEL_FMA(b0, w0, y0)
+                        const float4 w0 = w[4 * i0], x0 = pp[8 * i0], y0 = pp[8 * i0 + 1];
+                        AMPH_MEL_FMA2(a0, w0, x0, y0)
                     }
-#undef AMPH_MEL_FMA
-                    float sa = a0 + a1, sb = b0 + b1;
-                    sa += dpp_xor1(sa); sb += dpp_xor1(sb);
-                    sa += dpp_xor2(sa); sb += dpp_xor2(sb);
+#undef AMPH_MEL_FMA2
+                    amph_f2 sa = a0 + a1;
+                    sa += amph_f2{dpp_xor1(sa.x), dpp_xor1(sa.y)};
+                    sa += amph_f2{dpp_xor2(sa.x), dpp_xor2(sa.y)};
                     const int m = 16 * r + (lane >> 2);
-                    if (q == 0 && m < p.n_mels) { out_a[m] = sa; if (has_b) out_b[m] = sb; }
+                    if (q == 0 && m < p.n_mels) { out_a[m] = sa.x; if (has_b) out_b[m] = sa.y; }
                 }
             }
             wave_lds_sync();                                // the scratch is rewritten by the next pair
