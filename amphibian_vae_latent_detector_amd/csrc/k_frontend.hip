@@ -1727,10 +1727,12 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
             AMPH_PHASE_FENCE();
             AMPH_PSTAMP(7)
             // ---- this wave's next pair: its samples are requested now and land under the mel rows
+            //      (UNCONDITIONALLY - behind the last pair the row index is clamped and the samples are never used: a conditional
+            //      fetch makes the old dwords the value of the not-taken path, i.e. 19 registers live through every phase of the pair)
             {
                 int nrow = row, npr = pr + NW;
                 if (npr >= n_pairs) { nrow = row + gridDim.x; npr = wave; }
-                if (nrow < n_rows) fetch(nrow, npr);
+                fetch(min(nrow, n_rows - 1), npr);
             }
             AMPH_PHASE_FENCE();
 #ifdef AMPH_STAMPS
@@ -2010,10 +2012,10 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair2(StftParams p, int n_rows
             for (int i = lp; i < p.p_tail; i += 32) { Pa[513 + i] = 0.0f; Pb[513 + i] = 0.0f; }
             wave_lds_sync();
             AMPH_PHASE_FENCE();
-            {
+            {                                               // (unconditionally: see k_stft_pair)
                 int nrow = row, nq = q + NW;
                 if (nq >= n_slots) { nrow = row + gridDim.x; nq = wave; }
-                if (nrow < n_rows) fetch(nrow, nq);
+                fetch(min(nrow, n_rows - 1), nq);
             }
             AMPH_PHASE_FENCE();
             // ---- mel rows of the slot's four consecutive frames 4 q .. 4 q + 3: one weight read serves all four
