@@ -755,7 +755,7 @@ int run_encoder(amph_ctx* c, Workspace& w, const float* d_x, int nb, float* d_mu
             {
                 StageTimer t(c, head ? stage_head_gemm(c) : ST_CONV0 + 1 + gi, s);
                 const int kind = (!head && c->gemm[gi].d_w_f4b) ? conv_gemm_g4_kind(c->gemm[gi].prm_m(p.M)) : 0;
-                if ((kind == 3 && (c->patch_gemm_bf16 & 1)) || (kind == 4 && (c->patch_gemm_bf16 & 2))) {
+                if (((kind == 3 || kind == 5 || kind == 6) && (c->patch_gemm_bf16 & 1)) || (kind == 4 && (c->patch_gemm_bf16 & 2))) {
                     ConvGemmParams pg = c->gemm[gi].prm;              // (fp32 element counts: K, K_pad as the layer has them)
                     pg.x = w.act[gi]; pg.y = w.act[gi + 1]; pg.M = p.M; pg.y_bf16 = 1;
                     launch_conv_gemm_g4(pg, c->gemm[gi].d_w_f4b, c->patch_gemm_wgs, 1, s);
@@ -843,7 +843,7 @@ int run_encoder(amph_ctx* c, Workspace& w, const float* d_x, int nb, float* d_mu
         // GEMM layers on the bf16 matrix cores with three-term split operands (fp32-accurate): k_encoder_split.hip
         if (c->split_gemm && !fused_here && !head && c->gemm[gi].d_w_f4) {
             const int kind = conv_gemm_g4_kind(prm[gi]);
-            if ((kind == 3 && (c->patch_gemm & 1)) || (kind == 4 && (c->patch_gemm & 2))) {
+            if (((kind == 3 || kind == 5 || kind == 6) && (c->patch_gemm & 1)) || (kind == 4 && (c->patch_gemm & 2))) {
 #ifdef AMPH_STAMPS
                 c->gstamp_wgs[gi] = c->patch_gemm_wgs > 0 ? c->patch_gemm_wgs : 128;
 #endif

@@ -1098,12 +1098,241 @@ found:
     return g;
 }
 
+// ----------------------------------------------------------------------------
+// k_conv_gemm_g4's conv3 form for images that are NOT 16 x 16 ("g5", round 3): the tile is TH = 64 / OW whole output rows of an
+// image (OW = 8: 8 rows, OW = 16: 4 rows), several tiles per image, and the patch holds the 2 TH + 1 input rows the tile's taps
+// touch: a HALO row on top (the image's zero padding for its first tile, the previous tile's last input row otherwise) and the
+// left zero column.  Everything else is g4's kind 3: 64 input channels, 64 output channels per workgroup, wave = (channel tile,
+// K quarter) with its 9 k-steps x TERMS of the weights in registers, fragments read straight from the patch, K quarters added
+// through LDS in part order.  Covers the 128-band geometry of BASELINE configs[3] (24 x 32 x 64 -> 12 x 16 x 128: three tiles of
+// 9 x 33 pixels per image) and the reference's default (48 x 16 x 64 -> 24 x 8 x 128: three tiles of 17 x 17).
+// ----------------------------------------------------------------------------
+struct G5Geo { int PXB, PL, RS, patch_bytes, n_tiles, tpi, H; };
+
+template <int OWL, int TERMS>
+__global__ __launch_bounds__(512, 2) void k_conv_gemm_g5(ConvGemmParams p, G5Geo g, const uint4* __restrict__ wfrag) {
+    constexpr int C_IN = 64, KW = 4, RT = 2;
+    constexpr int OW = 1 << OWL, TH = 64 >> OWL, WW = 2 * OW, PR = 2 * TH + 1;
+    constexpr int KSTEPS = 9 * C_IN / 16, KPW = KSTEPS / KW, SPT = C_IN / 16, TERM_B = 2 * C_IN;
+    constexpr int CQ = TERMS == 3 ? C_IN / 4 : C_IN / 8;                 // 16-byte units per input pixel
+    constexpr int NE = PR * WW * CQ, NV = (NE + 511) / 512;              // units of a tile's input (halo row included), per thread
+    constexpr int UB = TERMS == 3 ? 8 : 16;                              // patch bytes per unit and term
+    constexpr int RPO = 16 / KW;
+    static_assert(KPW == 9 && RPO == 4 && TH * OW == 64, "shape");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const patch = smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ct = wave & 1, kq = wave >> 1;
+    const int px = lane & 31, kh2 = lane >> 5;
+    uint4 breg[9 * TERMS];
+    {
+        const uint4* wf = wfrag + (((size_t)blockIdx.y * 2 + ct) * KSTEPS + KPW * kq) * (TERMS * 64) + lane;
+#pragma unroll
+        for (int f = 0; f < 9 * TERMS; ++f) breg[f] = wf[f * 64];
+    }
+    int aoff[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int s = KPW * kq + i, tap = s / SPT, kh = tap / 3, kw = tap - 3 * kh;
+        aoff[i] = kh * g.RS + (kw & 1) * g.PL + (kw >> 1) * g.PXB + 32 * (s % SPT);
+    }
+    const int oh0 = px >> OWL, ow0 = px & (OW - 1);
+    const int a_base = oh0 * 2 * g.RS + ow0 * g.PXB + 16 * kh2;
+    const int rt1_off = (32 >> OWL) * 2 * g.RS;
+    const int n_base = blockIdx.y * 64 + ct * 32;
+    const int n_own = n_base + 8 * ((RPO * kq) >> 2) + 4 * kh2 + ((RPO * kq) & 3);
+    float e_sc[RPO], e_sh[RPO];
+#pragma unroll
+    for (int r = 0; r < RPO; ++r) { e_sc[r] = n_own < p.N ? p.scale[n_own + r] : 0.0f; e_sh[r] = n_own < p.N ? p.shift[n_own + r] : 0.0f; }
+    // this thread's input units (the same for every tile): unit tid + 512 u = (patch row y incl. the halo row 0, column x, channel group)
+    int in_dst[NV];
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        const int i = min(tid + 512 * u, NE - 1), c4 = i % CQ, pix = i / CQ, y = pix / WW, x = pix % WW;
+        in_dst[u] = y * g.RS + ((x + 1) & 1) * g.PL + ((x + 1) >> 1) * g.PXB + UB * c4;
+    }
+    float4 v[NV];
+    // a tile's input rows 2 TH ti - 1 .. 2 TH ti + 2 TH - 1 are contiguous in the NHWC tensor; row -1 of an image's first tile is padding
+#define AMPH_G5_FETCH(tile_)                                                               \
+    {                                                                                      \
+        const int img_ = (tile_) / g.tpi, ti_ = (tile_) - img_ * g.tpi;                    \
+        const long long base_ = ((long long)img_ * g.H + 2 * TH * ti_ - 1) * (WW * CQ);    \
+        const float4* src_ = reinterpret_cast<const float4*>(p.x);                         \
+        _Pragma("unroll") for (int u = 0; u < NV; ++u) {                                   \
+            const int i_ = tid + 512 * u;                                                  \
+            const bool ok_ = i_ < NE && (ti_ > 0 || i_ >= WW * CQ);                        \
+            v[u] = ok_ ? src_[base_ + i_] : make_float4(0.f, 0.f, 0.f, 0.f);               \
+        }                                                                                  \
+    }
+    int tile = blockIdx.x;
+    if (tile < g.n_tiles) AMPH_G5_FETCH(tile)
+    // the left zero column (column 0 of every patch row): written once, restored behind the inbox
+#define AMPH_G5_ZERO_COL()                                                                 \
+    {                                                                                      \
+        constexpr int CH = TERMS * TERM_B / 16;                                            \
+        for (int i = tid; i < PR * CH; i += 512) {                                         \
+            const int row = i / CH, ch = i - row * CH;                                     \
+            *reinterpret_cast<uint4*>(patch + row * g.RS + 16 * ch) = make_uint4(0u, 0u, 0u, 0u); \
+        }                                                                                  \
+    }
+    AMPH_G5_ZERO_COL()
+    float4* const inbox = reinterpret_cast<float4*>(patch);
+    for (; tile < g.n_tiles; tile += gridDim.x) {
+        // ---- (1) the tile's input into the patch (fp32: split in three bf16 terms; bf16: copied)
+        if (TERMS == 1) {
+#pragma unroll
+            for (int u = 0; u < NV; ++u) if (tid + 512 * u < NE) *reinterpret_cast<float4*>(patch + in_dst[u]) = v[u];
+        } else {
+#pragma unroll
+            for (int u = 0; u < NV; ++u) {
+                uint32_t h0, m0, l0, h1, m1, l1;
+                s3_split2_o(v[u].x, v[u].y, h0, m0, l0);
+                s3_split2_o(v[u].z, v[u].w, h1, m1, l1);
+                if (tid + 512 * u < NE) {
+                    char* dst = patch + in_dst[u];
+                    *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+                    *reinterpret_cast<uint2*>(dst + TERM_B) = make_uint2(m0, m1);
+                    *reinterpret_cast<uint2*>(dst + 2 * TERM_B) = make_uint2(l0, l1);
+                }
+            }
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < g.n_tiles) AMPH_G5_FETCH(tile + gridDim.x)      // lands under the multiply
+        // ---- (2) multiply: 9 k-steps, fragments of the next one read while this one is multiplied
+        f32x16 acc[RT];
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+#define AMPH_G5_FR(ptr_) __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ptr_))
+        bf16x8 fc[RT][TERMS], fn[RT][TERMS];
+        {
+            const char* pa = patch + a_base + aoff[0];
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+#pragma unroll
+                for (int q = 0; q < TERMS; ++q) fc[t][q] = AMPH_G5_FR(pa + t * rt1_off + q * TERM_B);
+        }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            if (i < 8) {
+                const char* pa = patch + a_base + aoff[i + 1];
+#pragma unroll
+                for (int t = 0; t < RT; ++t)
+#pragma unroll
+                    for (int q = 0; q < TERMS; ++q) fn[t][q] = AMPH_G5_FR(pa + t * rt1_off + q * TERM_B);
+            }
+            const bf16x8 wh = __builtin_bit_cast(bf16x8, breg[TERMS * i]), wm = __builtin_bit_cast(bf16x8, breg[TERMS * i + (TERMS == 3 ? 1 : 0)]),
+                         wl = __builtin_bit_cast(bf16x8, breg[TERMS * i + (TERMS == 3 ? 2 : 0)]);
+#define AMPH_G5_M(w_, q_)                                                                  \
+            _Pragma("unroll") for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_, fc[t][q_], acc[t], 0, 0, 0);
+            if (TERMS == 3) { AMPH_G5_M(wl, 0) AMPH_G5_M(wh, TERMS - 1) AMPH_G5_M(wm, TERMS / 2) AMPH_G5_M(wm, 0) AMPH_G5_M(wh, TERMS / 2) }
+            AMPH_G5_M(wh, 0)
+#undef AMPH_G5_M
+            if (i < 8) {
+#pragma unroll
+                for (int t = 0; t < RT; ++t)
+#pragma unroll
+                    for (int q = 0; q < TERMS; ++q) fc[t][q] = fn[t][q];
+            }
+        }
+#undef AMPH_G5_FR
+        __syncthreads();                                                 // every wave is done with the patch: it becomes the inbox
+        // ---- (3) K quarters -> their owners (k_conv_gemm_g4's exchange: part 0 first, a fixed order)
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+            for (int o = 0; o < KW; ++o) {
+                if (o == kq) continue;
+                const int ow_ = 2 * o + ct;
+                float* dst = reinterpret_cast<float*>(inbox) + ((((size_t)ow_ * RT + t) * KW + kq) * 64 + lane) * RPO;
+                *reinterpret_cast<float4*>(dst) = make_float4(acc[t][RPO * o], acc[t][RPO * o + 1], acc[t][RPO * o + 2], acc[t][RPO * o + 3]);
+            }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            float sum[RPO];
+#pragma unroll
+            for (int r = 0; r < RPO; ++r) sum[r] = 0.0f;
+#pragma unroll
+            for (int sdr = 0; sdr < KW; ++sdr) {
+                if (sdr == kq) {
+#pragma unroll
+                    for (int r = 0; r < RPO; ++r) sum[r] += acc[t][RPO * kq + r];
+                } else {
+                    const float4 q4 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(inbox) + ((((size_t)wave * RT + t) * KW + sdr) * 64 + lane) * RPO);
+                    sum[0] += q4.x; sum[1] += q4.y; sum[2] += q4.z; sum[3] += q4.w;
+                }
+            }
+            const int m = tile * 64 + 32 * t + px;                       // a tile = 64 consecutive output pixels (TH whole rows)
+            if (n_own < p.N && m < p.M) {
+#pragma unroll
+                for (int r = 0; r < RPO; ++r) sum[r] = fmaxf(fmaf(sum[r], e_sc[r], e_sh[r]), 0.0f);
+                if (TERMS == 1) {
+                    uint16_t* yo = reinterpret_cast<uint16_t*>(p.y) + (long long)m * p.N + n_own;
+                    const amph_bf16x2 lo_ = {(__bf16)sum[0], (__bf16)sum[1]}, hi_ = {(__bf16)sum[2], (__bf16)sum[3]};
+                    *reinterpret_cast<uint2*>(yo) = make_uint2(__builtin_bit_cast(uint32_t, lo_), __builtin_bit_cast(uint32_t, hi_));
+                } else *reinterpret_cast<float4*>(p.y + (long long)m * p.N + n_own) = make_float4(sum[0], sum[1], sum[2], sum[3]);
+            }
+        }
+        __syncthreads();                                                 // the inbox is read: the next tile's patch may be written
+        AMPH_G5_ZERO_COL()                                               // (overwritten by the inbox)
+    }
+#undef AMPH_G5_FETCH
+#undef AMPH_G5_ZERO_COL
+}
+
+template <int OWL, int TERMS>
+static G5Geo g5_geo(const ConvGemmParams& p) {
+    constexpr int OW = 1 << OWL, TH = 64 >> OWL, PR = 2 * TH + 1;
+    G5Geo g{};
+    g.PXB = TERMS * 128 + 16;
+    g.PL = (OW + 1) * g.PXB;
+    // row stride: the 16 lanes of every ds_read_b128 group (lane -> output row, column of its 32-pixel row tile) on 16 different 16-byte
+    // slots - searched as in g4_geo
+    static const int groups[2][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27}, {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31}};
+    const int rs0 = (2 * OW + 1) * g.PXB;
+    g.RS = rs0;
+    for (int rs = rs0; rs < rs0 + 512; rs += 16) {
+        bool ok = true;
+        for (int gi = 0; gi < 2 && ok; ++gi) {
+            unsigned used = 0;
+            for (int k = 0; k < 16; ++k) {
+                const int px = groups[gi][k], oh = px >> OWL, ow = px & (OW - 1);
+                const int slot = ((oh * 2 * rs + ow * g.PXB) >> 4) & 15;
+                if (used & (1u << slot)) { ok = false; break; }
+                used |= 1u << slot;
+            }
+        }
+        if (ok) { g.RS = rs; break; }
+    }
+    g.patch_bytes = PR * g.RS;
+    g.n_tiles = p.M / 64;
+    g.tpi = p.OH / TH;
+    g.H = p.H;
+    return g;
+}
+
+// 0: not covered; 3 / 4: k_conv_gemm_g4's two shapes; 5 / 6: k_conv_gemm_g5 with 8- / 16-wide output rows (64 input channels, whole
+// rows per 64-pixel tile, several tiles per image)
+static int conv_gemm_g5_owl(const ConvGemmParams& p) {
+    if (!(p.k == 3 && p.stride == 2 && p.pad == 1 && p.C_in == 64 && p.K == 576 && p.K_pad == 576 && p.splits == 1 && p.epilogue == 0 && !p.img && p.M > 0))
+        return 0;
+    if (p.W != 2 * p.OW || p.H != 2 * p.OH || (p.N % 64) || (p.M % 64)) return 0;
+    if (p.OW == 8 && (p.OH % 8) == 0) return 3;
+    if (p.OW == 16 && (p.OH % 4) == 0) return 4;
+    return 0;
+}
+
 // 0: not covered; 3: conv3's shape (16 x 16 x 64 -> 8 x 8 x 128k); 4: conv4's (8 x 8 x 128 -> 4 x 4 x 64k)
 int conv_gemm_g4_kind(const ConvGemmParams& p) {
     if (!(p.k == 3 && p.stride == 2 && p.pad == 1 && p.K == 9 * p.C_in && p.K_pad == p.K && p.splits == 1 && p.epilogue == 0 && !p.img && p.M > 0))
         return 0;
     if (p.C_in == 64 && p.OW == 8 && p.OH == 8 && p.W == 16 && p.H == 16 && (p.N % 64) == 0 && (p.M % 64) == 0) return 3;
     if (p.C_in == 128 && p.OW == 4 && p.OH == 4 && p.W == 8 && p.H == 8 && (p.N % 64) == 0 && (p.M % 16) == 0) return 4;
+    const int owl = conv_gemm_g5_owl(p);
+    if (owl) return owl + 2;                                             // 5: OW 8, 6: OW 16 (k_conv_gemm_g5)
     return 0;
 }
 
@@ -1135,6 +1364,21 @@ static void launch_g4_t(const ConvGemmParams& p, const void* wfrag, int wgs, hip
         const int per = std::max(1, wgs / ny);
         hipLaunchKernelGGL((k_conv_gemm_g4<128, 8, 1, 1, 2, 2, TERMS>), dim3((unsigned)std::min(g.n_tiles, per), (unsigned)ny), dim3(512), (size_t)std::max(g.patch_bytes, 32 * 1024), s, p, g,
                            reinterpret_cast<const uint4*>(wfrag));
+    } else if (kind == 5 || kind == 6) {
+        static bool raised5[64] = {false};
+        if (dev >= 0 && dev < 64 && !raised5[dev]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_gemm_g5<3, TERMS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_gemm_g5<4, TERMS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            raised5[dev] = true;
+        }
+        const int ny = p.N / 64;
+        const G5Geo g = kind == 5 ? g5_geo<3, TERMS>(p) : g5_geo<4, TERMS>(p);
+        if (wgs <= 0) wgs = std::min(g_num_cus, (g.n_tiles * ny + 3) / 4);
+        const int per = std::max(1, wgs / ny);
+        const dim3 grid((unsigned)std::min(g.n_tiles, per), (unsigned)ny);
+        const size_t lds = (size_t)std::max(g.patch_bytes, 64 * 1024);
+        if (kind == 5) hipLaunchKernelGGL((k_conv_gemm_g5<3, TERMS>), grid, dim3(512), lds, s, p, g, reinterpret_cast<const uint4*>(wfrag));
+        else hipLaunchKernelGGL((k_conv_gemm_g5<4, TERMS>), grid, dim3(512), lds, s, p, g, reinterpret_cast<const uint4*>(wfrag));
     }
 }
 void launch_conv_gemm_g4(const ConvGemmParams& p, const void* wfrag, int wgs, int terms, hipStream_t s) {
