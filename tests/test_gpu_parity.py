@@ -451,6 +451,57 @@ def test_register_resident_weight_conv_layers_match_oracle_and_staged_kernel(env
               % (e[0], e[1], e[2], e[3]))
 
 
+@pytest.mark.parametrize("preset", ["bench-1s-128", "ref-default"])
+def test_row_tiled_register_resident_conv3_on_other_geometries(env, capsys, preset):
+    """k_conv_gemm_g5 (round 3): conv3 with the weights in registers for images that are not 16 x 16 - tiles of whole output rows
+    with a halo row: the 128-band geometry of BASELINE configs[3] (conv3 24 x 32 x 64 -> 12 x 16 x 128, three 4-row tiles per image)
+    and the reference's default (10_benchmark_folder_detection.py:123-134: 192 x 64 image, conv3 48 x 16 x 64 -> 24 x 8 x 128, three
+    8-row tiles).  Against the torch-CPU fp32 encoder <= 1e-5 like every other form, within fp32 rounding of the staged kernel,
+    independent of batch, position and workgroup count (bitwise); the first / middle / last tile of an image take the zero row /
+    the halo of the tile above (a wrong halo shows at once: random images).  The bf16 form against its rounding emulation."""
+    cfg = env.PRESETS[preset]
+    enc, tenc, spec = _encoders(env, "thesis-shape", cfg=cfg, max_batch=16)
+    sess = enc.session(cfg)
+    x = torch.from_numpy(np.random.default_rng(23).standard_normal((13, 1, cfg.target_frames, cfg.n_mels)).astype(np.float32))
+    x[4] = 0.0
+    with torch.no_grad():
+        mu_o, lv_o = tenc(x)
+    res = {}
+    try:
+        for bits in (0, 1):
+            sess.configure("patch_gemm", bits)
+            mu, lv = sess.encoder_forward(x)
+            res[bits] = (mu.cpu().numpy(), lv.cpu().numpy())
+            for wgs in (1, 7, 4096):
+                sess.configure("patch_gemm_wgs", wgs)
+                mu_w, lv_w = sess.encoder_forward(x)
+                assert torch.equal(mu_w, mu) and torch.equal(lv_w, lv), (bits, wgs)
+            sess.configure("patch_gemm_wgs", 0)
+            for lo, hi in ((0, 1), (3, 6), (12, 13)):
+                assert torch.equal(sess.encoder_forward(x[lo:hi])[0], mu[lo:hi]), (bits, lo, hi)
+        # bf16 encoder: conv3 through the same kernel with one bf16 term, against the staged bf16 GEMM (same rounding points)
+        sess.configure("bf16_encoder", 1)
+        sess.configure("patch_gemm_bf16", 3)
+        mu_b = sess.encoder_forward(x)[0].cpu().numpy()
+        sess.configure("patch_gemm_bf16", 0)
+        mu_b0 = sess.encoder_forward(x)[0].cpu().numpy()
+    finally:
+        sess.configure("bf16_encoder", 0)
+        sess.configure("patch_gemm_bf16", 3)
+        sess.configure("patch_gemm", 1)
+        sess.configure("patch_gemm_wgs", 0)
+    for bits in (0, 1):
+        _assert_latents(res[bits][0], mu_o.numpy(), 1e-5)
+        _assert_latents(res[bits][1], lv_o.numpy(), 1e-5)
+    _assert_latents(res[1][0], res[0][0], 5e-6)
+    assert not np.array_equal(res[1][0], res[0][0])                          # (another kernel: last bits differ)
+    eb = max(rel_l2(mu_b[r], mu_b0[r]) for r in range(13))
+    assert eb <= 2e-3                                                        # bf16: same rounding points, another summation order
+    e = {bits: max(rel_l2(res[bits][0][r], mu_o.numpy()[r]) for r in range(13)) for bits in res}
+    with capsys.disabled():
+        print(f"\n[k_conv_gemm_g5, {preset}] max rel L2 of mu vs torch-CPU fp32: staged {e[0]:.2e}, row-tiled conv3 {e[1]:.2e}; bf16 form vs staged bf16 GEMM {eb:.2e}")
+
+
 def test_encoder_odd_shapes_generic_path(env):
     """Non power-of-two geometry: 5x5 stride-1 first layer, C_out not a multiple of 64, K padded to 32."""
     from amphibian_vae_latent_detector_amd import EncoderSpec
