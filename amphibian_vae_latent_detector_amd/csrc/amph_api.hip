@@ -21,6 +21,14 @@
 
 using namespace amph;
 
+#ifdef AMPH_ABL_SKIP
+// timing-only diagnostic build (make ablation_skip; tools/sweep.py --lib=... abl_skip=...): stages left out of the batch pipeline, bit 0 K0,
+// 1 STFT, 2.. the GEMM layers in order, 6 the head's reduction - what a stage's removal is worth end to end bounds what any faster form of it
+// can be worth.  Results are wrong by construction; never shipped.
+static int g_abl_skip = 0;
+extern "C" void amph_abl_skip(int mask) { g_abl_skip = mask; }
+#endif
+
 namespace {
 
 thread_local std::string g_create_error;
@@ -134,6 +142,10 @@ struct amph_ctx {
     int patch_gemm = 1;                    // bit 0 / 1: conv3 / conv4 of the thesis shape with weights in registers and the input resident in LDS (k_conv_gemm_g4);
                                            // conv4 in that form is 2 us faster alone and 1 % slower end to end (two images = 127 KB of LDS per workgroup): off
     int patch_gemm_bf16 = 3;               // the same for the bf16 encoder (bf16 operands: patches of 42 / 44 KB)
+    int wide_gemm = -1;                    // staged GEMM layers on 128 x 128 tiles (k_conv_gemm_s3w: a quarter of the workgroups, each ~1.6x as long; same results).
+                                           // -1: when the call's batches run on several lanes (a batch then costs the sum of its kernels' CU-time, not of their
+                                           // durations: profiles/r03_stage_skip_sweep.txt) and the grid still has a workgroup for a quarter of the CUs; 0 / 1: never / always
+    int active_lanes = 1;                  // lanes the running call spreads its batches over (set by the batch loop)
     int patch_gemm_wgs = 0;                // workgroups of that kernel (0: four tiles each, at most half the CUs)
     bool bf16_pair = true;                 // bf16 encoder: layers 1 + 2 in bf16 proper (k_conv_gemm_f4b) instead of fp32-accurate with a bf16 epilogue
     bool patch_fused = true;               // ... in its patch-resident form where the shape allows (k_conv_gemm_f4s)
@@ -818,6 +830,9 @@ int run_encoder(amph_ctx* c, Workspace& w, const float* d_x, int nb, float* d_mu
     }
     for (int gi = 0; gi < n_gemm; ++gi) {
         const bool head = gi == n_gemm - 1;
+#ifdef AMPH_ABL_SKIP
+        if (g_abl_skip & (4 << gi)) continue;
+#endif
 #ifdef AMPH_STAMPS
         if (!c->d_gstamps) (void)hipMalloc((void**)&c->d_gstamps, (size_t)n_gemm * 8192 * 8 * 8);
         prm[gi].stamps = c->d_gstamps + (size_t)gi * 8192 * 8;
@@ -854,11 +869,16 @@ int run_encoder(amph_ctx* c, Workspace& w, const float* d_x, int nb, float* d_mu
         if (c->split_gemm && !fused_here && c->gemm[gi].d_w_s3 && conv_gemm_s3_ok(prm[gi])) {
             ConvGemmParams ps = prm[gi];
             ps.w = reinterpret_cast<const float*>(c->gemm[gi].d_w_s3);
-            launch_conv_gemm_s3(ps, s);
+            const bool wide = c->wide_gemm > 0 || (c->wide_gemm < 0 && c->active_lanes > 1 && (long long)((ps.M + 127) / 128) * (ps.N / 128) * 4 >= amph::g_num_cus);
+            if (wide && !head && conv_gemm_s3w_ok(ps)) launch_conv_gemm_s3w(ps, s);
+            else launch_conv_gemm_s3(ps, s);
             continue;
         }
         launch_conv_gemm(prm[gi], bms[gi], fused_here, s);
     }
+#ifdef AMPH_ABL_SKIP
+    if (g_abl_skip & 64) return AMPH_OK;
+#endif
     {
         StageTimer t(c, stage_head_reduce(c), s);
         HeadReduceParams p;
@@ -946,6 +966,9 @@ int run_frontend(amph_ctx* c, Workspace& w, const void* d_wave, bool pcm16, int 
         if (pcm16) {
             const int rcs = ensure_chunk_sums(c, w, n_in, s);
             if (rcs != AMPH_OK) return rcs;
+#ifdef AMPH_ABL_SKIP
+            if (!(g_abl_skip & 1))
+#endif
             launch_rms_scale_pcm16((const int16_t*)d_wave, n_in, d_len, n_in, nb, w.scale, okp, c->rms_f64_scale, norm, pad, w.chunk_sums, c->rms_chunk_path_over, s);
         }
         else launch_rms_scale_f32((const float*)d_wave, n_in, d_len, n_in, nb, w.scale, okp, c->rms_f64_scale, s);
@@ -971,6 +994,9 @@ int run_frontend(amph_ctx* c, Workspace& w, const void* d_wave, bool pcm16, int 
     }
     {
         StageTimer t(c, ST_STFT, s);
+#ifdef AMPH_ABL_SKIP
+        if (!(g_abl_skip & 2))
+#endif
         launch_stft_mel(make_stft(c, src, melpow, db_out, db_layout), nb, pcm16 ? 1 : 0, c->stft_waves, s);
     }
     return AMPH_OK;
@@ -1002,6 +1028,7 @@ int encode_common(amph_ctx* c, const void* d_wave, bool pcm16, int64_t n_rows, i
     // fork: batches go round-robin over the lanes; lane 0 runs on the caller's stream
     const int64_t n_batches = (n_rows + c->max_batch - 1) / c->max_batch;
     const int L = (int)std::min<int64_t>((int64_t)c->lanes.size(), std::max<int64_t>(n_batches, 1));
+    c->active_lanes = L;
     if (L > 1) {
         HIP_TRY(c, hipEventRecord(c->ev_fork, s));
         for (int l = 1; l < L; ++l) HIP_TRY(c, hipStreamWaitEvent(c->lanes[l].stream, c->ev_fork, 0));
@@ -1181,6 +1208,7 @@ int amph_configure(amph_ctx* c, const char* key, int value) {
     if (!std::strcmp(key, "split_gemm")) { c->split_gemm = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "split_fused")) { c->split_fused = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "patch_gemm")) { c->patch_gemm = value & 3; return AMPH_OK; }
+    if (!std::strcmp(key, "wide_gemm")) { c->wide_gemm = value < 0 ? -1 : (value ? 1 : 0); return AMPH_OK; }
     if (!std::strcmp(key, "patch_gemm_bf16")) { c->patch_gemm_bf16 = value & 3; return AMPH_OK; }
     if (!std::strcmp(key, "patch_gemm_wgs")) { if (value < 0) return AMPH_ERR_INVALID_ARG; c->patch_gemm_wgs = value; return AMPH_OK; }
     if (!std::strcmp(key, "rms_chunk_path_over")) { if (value < 1) return AMPH_ERR_INVALID_ARG; c->rms_chunk_path_over = value; return AMPH_OK; }
@@ -1415,6 +1443,7 @@ int amph_encoder_forward(amph_ctx* c, const float* d_x, int n_rows, float* d_mu,
     hipStream_t s = (hipStream_t)stream;
     const size_t per = (size_t)c->cfg.target_frames * c->cfg.n_mels;
     const int D = c->latent;
+    c->active_lanes = 1;
     for (int off = 0; off < n_rows; off += c->max_batch) {
         const int nb = std::min(c->max_batch, n_rows - off);
         const int rc = run_encoder(c, c->lanes[0], d_x + (size_t)off * per, nb, d_mu + (size_t)off * D, d_logvar ? d_logvar + (size_t)off * D : nullptr, s);

@@ -182,6 +182,8 @@ void launch_head_reduce(const HeadReduceParams& p, int n_rows, hipStream_t s);
 // fp32-accurate GEMM layers on the bf16 matrix cores (k_encoder_split.hip): p.w = split weights [n_pad / 64][K_pad / 32][64][3][32] bf16
 bool conv_gemm_s3_ok(const ConvGemmParams& p);
 void launch_conv_gemm_s3(const ConvGemmParams& p, hipStream_t s);
+bool conv_gemm_s3w_ok(const ConvGemmParams& p);           // 128 x 128 tiles, 512 threads (same weights, bit-identical results)
+void launch_conv_gemm_s3w(const ConvGemmParams& p, hipStream_t s);
 void conv_gemm_s3_split_weights(const float* w, int n_pad, int K_pad, uint16_t* out);
 // ... and the fused first-layer pair in the same arithmetic (p.img etc. as for k_conv_gemm_f3, p.w = split weights)
 bool conv_gemm_f3s_ok(const ConvGemmParams& p);

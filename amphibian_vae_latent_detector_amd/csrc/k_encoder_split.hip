@@ -374,6 +374,220 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm_s3(ConvGemmParams p) {
 }
 
 // ----------------------------------------------------------------------------
+// k_conv_gemm_s3 on 128 x 128 tiles ("s3w", round 3): 512 threads, wave = (64-row half, 32-channel tile) with TWO accumulators.
+//
+// Why: with four free-running lanes a batch costs the SUM of what its kernels cost in CU-time (profiles/r03_stage_skip_sweep.txt:
+// leaving a stage out shortens the batch period by its duration x the share of the CUs it holds), so a GEMM layer is worth what
+// it does per CU and second, not how soon it ends alone.  The 64 x 64 tile of s3 stages 20 KB and issues ~170 instructions per
+// wave for twelve MFMAs; here the same per-thread staging work (two A float4 + their split, three B uint4) feeds 24 MFMAs per wave,
+// a fragment set serves two row tiles, and the two waves of a SIMD overlap each other's staging: conv4 at a 256-chunk batch is 64
+// workgroups (a quarter of the CUs) instead of 256.  Per accumulator the MFMA order is s3's (slice, k-step, term pair), so the
+// results are bit-identical to s3's.  Weights: s3's split matrix; threads 0-255 stage 64-channel block 2 by, 256-511 block 2 by + 1.
+// ----------------------------------------------------------------------------
+constexpr int kWBuf = 128 * kSRow;       // bytes per operand per slice buffer (128 rows)
+constexpr size_t kS3wLds = (size_t)6 * kWBuf + 1024;   // 148 480 B: slice buffers + the tile's BN constants
+
+__global__ __launch_bounds__(512, 1) void k_conv_gemm_s3w(ConvGemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* As = smem;                                   // [3][128][192]
+    char* Bs = smem + 3 * kWBuf;                       // [3][128][192]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c4 = tid & 7, r0 = tid >> 3;             // A staging: rows r0, r0 + 64; k = 4 c4 .. 4 c4 + 3 of the slice
+    const int bh = wave >> 2, bt = tid & 255;          // B staging: 64-channel block 2 by + bh, 16-byte piece bt + 256 i of its 12 KB
+    const int m_blk = blockIdx.x * 128, n_blk = blockIdx.y * 128;
+    const int n_slices = p.K_pad / kSBK;
+
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(p.x) - p.x_guard), 0, -1, 0x00020000);
+    float4 sa[4][2];                                   // register stages (indices are literals everywhere: registers, never scratch)
+    uint4 sb[4][3];
+    int w_soff = __builtin_amdgcn_readfirstlane(((2 * (int)blockIdx.y + bh) * n_slices) * (64 * kSWRow));
+    const unsigned woff = 16u * (unsigned)bt;
+#define AMPH_W_LOADB(q)                                                                    \
+    {                                                                                      \
+        sb[q][0] = __builtin_bit_cast(uint4, AMPH_S3_BUFLOAD(rs_w, woff, w_soff));          \
+        sb[q][1] = __builtin_bit_cast(uint4, AMPH_S3_BUFLOAD(rs_w, woff + 4096u, w_soff));  \
+        sb[q][2] = __builtin_bit_cast(uint4, AMPH_S3_BUFLOAD(rs_w, woff + 8192u, w_soff));  \
+    }
+    {
+        const int blk = 64 * kSWRow;
+        const int o1 = n_slices > 1 ? blk : 0, o2 = n_slices > 2 ? 2 * blk : o1, o3 = n_slices > 3 ? 3 * blk : o2;
+        AMPH_W_LOADB(0)
+        w_soff += o1; AMPH_W_LOADB(1)
+        w_soff += o2 - o1; AMPH_W_LOADB(2)
+        w_soff += o3 - o2; AMPH_W_LOADB(3)
+        w_soff -= o3;
+    }
+    const int ohw = p.OH * p.OW;
+    const float rcp_ohw = 1.0f / (float)ohw, rcp_ow = 1.0f / (float)p.OW;
+    constexpr int kEl = 4;
+    unsigned aoff[2], vmask[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m_blk + r0 + 64 * i;
+        const bool mv = m < p.M;
+        const int mm = mv ? m : 0;
+        const int b = s3_div_small(mm, ohw, rcp_ohw), rem = mm - b * ohw;
+        const int oh = s3_div_small(rem, p.OW, rcp_ow), ow = rem - oh * p.OW;
+        const int ih0 = oh * p.stride - p.pad, iw0 = ow * p.stride - p.pad;
+        aoff[i] = (unsigned)p.x_guard + (unsigned)kEl * (unsigned)(((b * p.H + ih0) * p.W + iw0) * p.C_in) + 16u * (unsigned)c4;
+        unsigned vm = 0;
+        if (p.k == 3) {
+            const unsigned hb = ((unsigned)iw0 < (unsigned)p.W ? 0x049u : 0u) | ((unsigned)(iw0 + 1) < (unsigned)p.W ? 0x092u : 0u) |
+                                ((unsigned)(iw0 + 2) < (unsigned)p.W ? 0x124u : 0u);
+            const unsigned rb_ = ((unsigned)ih0 < (unsigned)p.H ? 0x007u : 0u) | ((unsigned)(ih0 + 1) < (unsigned)p.H ? 0x038u : 0u) |
+                                 ((unsigned)(ih0 + 2) < (unsigned)p.H ? 0x1c0u : 0u);
+            vm = hb & rb_;
+        } else {
+            for (int kh = 0; kh < p.k; ++kh)
+                for (int kw = 0; kw < p.k; ++kw)
+                    if ((unsigned)(ih0 + kh) < (unsigned)p.H && (unsigned)(iw0 + kw) < (unsigned)p.W) vm |= 1u << (kh * p.k + kw);
+        }
+        vmask[i] = mv ? vm : 0u;
+    }
+    int l_left = n_slices;
+    int l_ci0 = 0, l_kw = 0, x_soff = 0;
+    unsigned l_bit = 1u;
+    const int row_skip = kEl * (p.W - p.k) * p.C_in;
+#define AMPH_W_LOADA(q)                                                                    \
+    {                                                                                      \
+        sa[q][0] = __builtin_bit_cast(float4, AMPH_S3_BUFLOAD(rs_x, (vmask[0] & l_bit) ? aoff[0] : 0u, x_soff)); \
+        sa[q][1] = __builtin_bit_cast(float4, AMPH_S3_BUFLOAD(rs_x, (vmask[1] & l_bit) ? aoff[1] : 0u, x_soff)); \
+    }
+#define AMPH_W_LOAD(q) { AMPH_W_LOADB(q) AMPH_W_LOADA(q) AMPH_S3_ADV() }
+#define AMPH_W_LOADA_ADV(q) { AMPH_W_LOADA(q) AMPH_S3_ADV() }
+    const int st_a = r0 * kSRow + 16 * ((c4 >> 1) ^ ((r0 >> 2) & 3)) + 8 * (c4 & 1);     // (row r0 + 64 has the same swizzle)
+    int st_b[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int o = 16 * bt + 4096 * i, row = o / kSWRow, col = o % kSWRow;
+        st_b[i] = (64 * bh + row) * kSRow + 16 * ((col >> 4) ^ ((row >> 2) & 3));
+    }
+#define AMPH_W_ST_B(q, buf_)                                                               \
+    {                                                                                      \
+        char* b_ = Bs + (buf_) * kWBuf;                                                    \
+        *reinterpret_cast<uint4*>(b_ + st_b[0]) = sb[q][0];                                \
+        *reinterpret_cast<uint4*>(b_ + st_b[1]) = sb[q][1];                                \
+        *reinterpret_cast<uint4*>(b_ + st_b[2]) = sb[q][2];                                \
+    }
+#define AMPH_W_ST_A(q, buf_, i_) { char* a_ = As + (buf_) * kWBuf + st_a + (i_) * 64 * kSRow; AMPH_S3_SPLIT_ROW(sa[q][i_], a_) }
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    const int rg = wave >> 2, ct = wave & 3;
+    // BN constants of the tile's 128 channels wait in LDS for the epilogue (32 registers through the loop otherwise)
+    float* const bn = reinterpret_cast<float*>(smem + 6 * kWBuf);       // [2][128]
+    if (tid < 256) bn[tid] = (tid < 128 ? p.scale : p.shift)[n_blk + (tid & 127)];
+    // fragment addresses (s3's): lane l holds row (l & 31), k = 16 kstep + 8 (l >> 5) + j of each term
+    const int swl = ((lane & 31) >> 2) & 3;
+    const char* a_rd[2] = {As + (rg * 64 + (lane & 31)) * kSRow + 16 * ((lane >> 5) ^ swl), As + (rg * 64 + (lane & 31)) * kSRow + 16 * ((2 + (lane >> 5)) ^ swl)};
+    const char* b_rd[2] = {Bs + (ct * 32 + (lane & 31)) * kSRow + 16 * ((lane >> 5) ^ swl), Bs + (ct * 32 + (lane & 31)) * kSRow + 16 * ((2 + (lane >> 5)) ^ swl)};
+    struct Frag { bf16x8 x[2][3], w[3]; };               // [row tile][term], [term]
+#define AMPH_W_FR(ptr_) __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ptr_))
+#define AMPH_W_READ9(f_, buf_, ks_)                                                        \
+    {                                                                                      \
+        _Pragma("unroll") for (int q_ = 0; q_ < 3; ++q_) {                                 \
+            f_.x[0][q_] = AMPH_W_FR(a_rd[ks_] + (buf_) * kWBuf + 64 * q_);                 \
+            f_.x[1][q_] = AMPH_W_FR(a_rd[ks_] + (buf_) * kWBuf + 32 * kSRow + 64 * q_);    \
+            f_.w[q_] = AMPH_W_FR(b_rd[ks_] + (buf_) * kWBuf + 64 * q_);                    \
+        }                                                                                  \
+    }
+    // term pair (w term, x term) on both row tiles; weights first: transposed accumulator (lane = output row, registers = channels)
+#define AMPH_W_M(f_, wq_, xq_)                                                             \
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f_.w[wq_], f_.x[0][xq_], acc[0], 0, 0, 0); \
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f_.w[wq_], f_.x[1][xq_], acc[1], 0, 0, 0);
+    // one slice from LDS buffer R (s3's step with two row tiles): stage QL receives slice s + 4, stage QS (slice s + 2) goes to buffer
+    // (R + 2) % 3 in the MFMA gaps of k-step 0, the k-step-1 fragments are read under those, the next slice's k-step-0 fragments under k-step 1
+#define AMPH_W_STEP(R, QL, QS)                                                             \
+    {                                                                                      \
+        Frag f1;                                                                           \
+        AMPH_W_LOAD(QL)                                                                    \
+        AMPH_W_READ9(f1, R, 1)                                                             \
+        AMPH_S3_SB();                                                                      \
+        AMPH_W_M(f0, 2, 0)                                                                 \
+        AMPH_S3_SB();                                                                      \
+        AMPH_W_ST_B(QS, (R + 2) % 3)                                                       \
+        AMPH_S3_SB();                                                                      \
+        AMPH_W_M(f0, 0, 2)                                                                 \
+        AMPH_W_M(f0, 1, 1)                                                                 \
+        AMPH_S3_SB();                                                                      \
+        AMPH_W_ST_A(QS, (R + 2) % 3, 0)                                                    \
+        AMPH_S3_SB();                                                                      \
+        AMPH_W_M(f0, 1, 0)                                                                 \
+        AMPH_W_M(f0, 0, 1)                                                                 \
+        AMPH_S3_SB();                                                                      \
+        AMPH_W_ST_A(QS, (R + 2) % 3, 1)                                                    \
+        AMPH_S3_SB();                                                                      \
+        AMPH_W_M(f0, 0, 0)                                                                 \
+        AMPH_S3_SB();                                                                      \
+        AMPH_W_READ9(f0, (R + 1) % 3, 0)                                                   \
+        AMPH_S3_SB();                                                                      \
+        AMPH_W_M(f1, 2, 0)                                                                 \
+        AMPH_W_M(f1, 0, 2)                                                                 \
+        AMPH_W_M(f1, 1, 1)                                                                 \
+        AMPH_W_M(f1, 1, 0)                                                                 \
+        AMPH_W_M(f1, 0, 1)                                                                 \
+        AMPH_W_M(f1, 0, 0)                                                                 \
+        AMPH_S3_SB();                                                                      \
+        __syncthreads();                                                                   \
+    }
+    // prologue: slices 0 .. 3 into the register stages, 0 and 1 on to LDS
+    AMPH_W_LOADA_ADV(0)
+    AMPH_W_LOADA_ADV(1)
+    AMPH_W_LOADA_ADV(2)
+    AMPH_W_LOADA_ADV(3)
+    AMPH_W_ST_B(0, 0) AMPH_W_ST_A(0, 0, 0) AMPH_W_ST_A(0, 0, 1)
+    AMPH_W_ST_B(1, 1) AMPH_W_ST_A(1, 1, 0) AMPH_W_ST_A(1, 1, 1)
+    __syncthreads();
+    Frag f0;                                           // (the next slice's k-step-0 fragments are read into the same registers once its last MFMA has issued)
+    AMPH_W_READ9(f0, 0, 0)
+    int ks = 0;
+    for (; ks + 12 <= n_slices; ks += 12) {
+#define AMPH_S3_X(i, R, QL, QS) AMPH_W_STEP(R, QL, QS)
+        AMPH_S3_STEPS_0_11(AMPH_S3_X)
+#undef AMPH_S3_X
+    }
+    {
+        const int rem = n_slices - ks;
+#define AMPH_S3_X(i, R, QL, QS) if (rem > i) AMPH_W_STEP(R, QL, QS)
+        AMPH_S3_STEPS_0_11(AMPH_S3_X)
+#undef AMPH_S3_X
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int m = m_blk + rg * 64 + t * 32 + (lane & 31);
+        if (m < p.M) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n0 = n_blk + ct * 32 + 8 * g + 4 * (lane >> 5);
+                if (n0 < p.N) {
+                    const float4 e_sc = *reinterpret_cast<const float4*>(bn + n0 - n_blk), e_sh = *reinterpret_cast<const float4*>(bn + 128 + n0 - n_blk);
+                    float4 v = make_float4(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
+                    v.x = fmaxf(fmaf(v.x, e_sc.x, e_sh.x), 0.0f); v.y = fmaxf(fmaf(v.y, e_sc.y, e_sh.y), 0.0f);
+                    v.z = fmaxf(fmaf(v.z, e_sc.z, e_sh.z), 0.0f); v.w = fmaxf(fmaf(v.w, e_sc.w, e_sh.w), 0.0f);
+                    *reinterpret_cast<float4*>(p.y + (long long)m * p.N + n0) = v;
+                }
+            }
+        }
+    }
+#undef AMPH_W_LOADB
+#undef AMPH_W_LOADA
+#undef AMPH_W_LOAD
+#undef AMPH_W_LOADA_ADV
+#undef AMPH_W_ST_B
+#undef AMPH_W_ST_A
+#undef AMPH_W_FR
+#undef AMPH_W_READ9
+#undef AMPH_W_M
+#undef AMPH_W_STEP
+}
+
+// ----------------------------------------------------------------------------
 // Fused conv1 -> conv2 on the bf16 matrix cores ("f3s"): k_conv_gemm_f3's structure - persistent over the M tiles, layer 1
 // (C_in == 1 direct 3x3 conv + BN + ReLU, k_conv_first's FMA order in fp32) recomputed from an image patch in LDS for the
 // 2 x 4 A-tile values a thread stages per slice, continuous slice stream across tiles, cyclic B pointer - with the
@@ -781,6 +995,22 @@ void launch_conv_gemm_s3(const ConvGemmParams& p, hipStream_t s) {
     }
     const dim3 grid((unsigned)((p.M + 63) / 64), (unsigned)((p.N + 63) / 64), (unsigned)p.splits);
     hipLaunchKernelGGL(k_conv_gemm_s3, grid, dim3(256), kS3Lds, s, p);
+}
+
+// the 128 x 128 tile form: BN + ReLU layers whose channel count is a multiple of 128 (both 64-channel weight blocks of a tile exist)
+bool conv_gemm_s3w_ok(const ConvGemmParams& p) {
+    return conv_gemm_s3_ok(p) && p.splits == 1 && p.epilogue == 0 && (p.N % 128) == 0 && p.scale && p.shift;
+}
+void launch_conv_gemm_s3w(const ConvGemmParams& p, hipStream_t s) {
+    static bool raised[64] = {false};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !raised[dev]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_gemm_s3w), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kS3wLds);
+        raised[dev] = true;
+    }
+    const dim3 grid((unsigned)((p.M + 127) / 128), (unsigned)(p.N / 128), 1);
+    hipLaunchKernelGGL(k_conv_gemm_s3w, grid, dim3(512), kS3wLds, s, p);
 }
 
 // host: x -> (h, m, l) exactly as s3_split2 does on the device (RNE; every subtraction exact)

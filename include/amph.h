@@ -121,6 +121,8 @@ const char* amph_last_error(const amph_ctx* ctx);   /* ctx may be NULL: create-t
  *   "bf16_pair"        0/1   bf16 encoder: conv1 + conv2 in bf16 proper (k_conv_gemm_f4b: image, weights and the layer-1 activation
  *                            rounded to bf16, fp32 accumulate / BN; default 1) instead of the fp32-accurate pair with a bf16 epilogue
  *   "patch_gemm_wgs"   0..   workgroups of that kernel (0 = four tiles each, at most half the CUs; results do not depend on it)
+ *   "wide_gemm"        -1/0/1  staged split GEMM layers on 128 x 128 tiles (a quarter of the workgroups, each longer: less CU-time per batch, more
+ *                      latency alone; bit-identical results).  -1 (default) = when the call's batches run on several lanes; 0 / 1 = never / always
  *   "patch_wgs"        0..   persistent workgroups of the "patch_fused" kernel (0 = eight tiles each, at most half the CUs; results do
  *                            not depend on it)
  *   "stft_fuse_db"     0/1   power_to_db + z-score + crop / pad inside the STFT kernel (one workgroup per row, the row's mel

@@ -451,6 +451,36 @@ def test_register_resident_weight_conv_layers_match_oracle_and_staged_kernel(env
               % (e[0], e[1], e[2], e[3]))
 
 
+@pytest.mark.parametrize("preset", ["bench-1s", "ref-default", "bench-1s-128"])
+def test_wide_tile_staged_gemm_is_bit_identical_to_the_64_row_tile(env, capsys, preset):
+    """The staged split GEMM on 128 x 128 tiles ("wide_gemm"; csrc/k_encoder_split.hip, k_conv_gemm_s3w: what multi-lane calls use
+    for conv4 - and conv3 where the register-resident kernel does not apply) keeps k_conv_gemm_s3's order of operations per output
+    element, so forcing it on (1) or off (0) must not change a bit, at any batch (1 image: a tile with 16 of its 128 rows; odd
+    counts: a partial last tile), with conv3 on either kernel family; and it must meet the 1e-5 bar against the torch-CPU oracle."""
+    cfg = env.PRESETS[preset]
+    enc, tenc, spec = _encoders(env, "thesis-shape", cfg=cfg, max_batch=48)
+    sess = enc.session(cfg)
+    x = torch.from_numpy(np.random.default_rng(23).standard_normal((45, 1, cfg.target_frames, cfg.n_mels)).astype(np.float32))
+    x[9] = 0.0
+    with torch.no_grad():
+        mu_o, lv_o = tenc(x)
+    try:
+        for pg in (1, 0):
+            sess.configure("patch_gemm", pg)
+            sess.configure("wide_gemm", 0)
+            mu0, lv0 = sess.encoder_forward(x)
+            sess.configure("wide_gemm", 1)
+            mu1, lv1 = sess.encoder_forward(x)
+            assert torch.equal(mu1, mu0) and torch.equal(lv1, lv0), f"patch_gemm {pg}: the 128 x 128 tile changed the result"
+            for lo, hi in ((0, 1), (2, 5), (7, 20), (44, 45)):
+                assert torch.equal(sess.encoder_forward(x[lo:hi])[0], mu0[lo:hi]), f"patch_gemm {pg}: result depends on the batch"
+            _assert_latents(mu1.cpu().numpy(), mu_o.numpy(), 1e-5)
+            _assert_latents(lv1.cpu().numpy(), lv_o.numpy(), 1e-5)
+    finally:
+        sess.configure("patch_gemm", 1)
+        sess.configure("wide_gemm", -1)
+
+
 @pytest.mark.parametrize("preset", ["bench-1s-128", "ref-default"])
 def test_row_tiled_register_resident_conv3_on_other_geometries(env, capsys, preset):
     """k_conv_gemm_g5 (round 3): conv3 with the weights in registers for images that are not 16 x 16 - tiles of whole output rows

@@ -27,6 +27,15 @@ def main():
     rms = bool(int(opts.get("rms", 1)))            # --rms=0: rows used as they are (already normalised files)
     cfg = PRESETS[opts.get("preset", "bench-1s")]
     spec = SPECS["thesis-shape"](cfg.target_frames, cfg.n_mels)
+    if "lib" in opts:                                # a diagnostic build (e.g. build_ab/libamph_skip.so) instead of the shipped library
+        import ctypes as C
+        from amphibian_vae_latent_detector_amd import _native as N
+        lib = C.CDLL(str(Path(opts["lib"]).resolve()))
+        for name in N.EXPORTED_SYMBOLS:
+            if hasattr(lib, name):
+                fn, ref_ = getattr(lib, name), getattr(N.lib, name)
+                fn.restype, fn.argtypes = ref_.restype, ref_.argtypes
+        N.lib = lib
     enc = HipEncoder(spec, random_init_state(spec, 0), "cuda:0", max_batch=batch)
     sess = enc.session(cfg)
     pool = synth_batch_pcm16(list(range(1000)), cfg.n_samples, cfg.sr)
@@ -40,7 +49,10 @@ def main():
     for r in range(rounds):
         for c in combos:
             for k, v in zip(keys, c):
-                sess.configure(k, v)
+                if k == "abl_skip":
+                    N.lib.amph_abl_skip(int(v))
+                else:
+                    sess.configure(k, v)
             sess.encode(pcm, apply_rms=rms, out_mu=mu)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
