@@ -930,7 +930,7 @@ StftParams make_stft(amph_ctx* c, const WaveSrc& src, float* melpow, float* db_o
         p.pair_tw_lds = c->stft_pair_tw_lds ? 1 : 0;
     }
 #ifdef AMPH_STAMPS
-    if (!c->d_stamps) (void)hipMalloc((void**)&c->d_stamps, (size_t)c->max_batch * 64 * 16 * 8);
+    if (!c->d_stamps) (void)hipMalloc((void**)&c->d_stamps, (size_t)(c->max_batch * 64 + 6 * 4096) * 16 * 8);   // + the pair kernel's timeline region
     p.stamps = c->d_stamps;
 #endif
     return p;
@@ -1277,6 +1277,42 @@ int amph_configure(amph_ctx* c, const char* key, int value) {
                 fprintf(stderr, "\n");
             }
         }
+        return AMPH_OK;
+    }
+    if (!std::strcmp(key, "dump_timeline")) {    // k_stft_pair's workgroup timeline; value = workgroups of the last launch
+        (void)hipDeviceSynchronize();
+        std::vector<unsigned long long> h((size_t)value * 16);
+        (void)hipMemcpy(h.data(), c->d_stamps + 16 * 4096, h.size() * 8, hipMemcpyDeviceToHost);
+        double d[8] = {0}, ticks = 0;
+        int n = 0;
+        for (int b = 0; b < value; ++b) {
+            const unsigned long long* t = h.data() + (size_t)b * 16;
+            if (!t[7]) continue;
+            ++n;
+            d[0] += (double)(t[1] - t[0]);
+            unsigned long long prev = t[1];
+            for (int r = 0; r < 4; ++r) if (t[2 + r]) { d[1 + r] += (double)(t[2 + r] - prev); prev = t[2 + r]; }
+            d[5] += (double)(t[6] - prev); d[6] += (double)(t[7] - t[6]); d[7] += (double)(t[7] - t[0]); ticks += (double)t[8];
+        }
+        {
+            std::vector<unsigned long long> w((size_t)value * 16 * 8);
+            (void)hipMemcpy(w.data(), c->d_stamps + 32 * 4096, w.size() * 8, hipMemcpyDeviceToHost);
+            for (int wv = 0; wv < 12; ++wv) {
+                double st[3] = {0}, du[3] = {0};
+                int cn[3] = {0};
+                for (int b = 0; b < value; ++b) {
+                    const unsigned long long* t = w.data() + ((size_t)b * 16 + wv) * 8;
+                    const unsigned long long t1 = h[(size_t)b * 16 + 1];
+                    for (int r = 0; r < 3; ++r) if (t[2 * r] && t[2 * r + 1] > t[2 * r]) { st[r] += (double)(t[2 * r] - t1); du[r] += (double)(t[2 * r + 1] - t[2 * r]); ++cn[r]; }
+                }
+                fprintf(stderr, "    wave %2d: pair rounds start (after tables) / duration:", wv);
+                for (int r = 0; r < 3; ++r) if (cn[r]) fprintf(stderr, "  %6.0f / %6.0f", st[r] / cn[r], du[r] / cn[r]);
+                fprintf(stderr, "\n");
+            }
+        }
+        if (n) fprintf(stderr, "  k_stft_pair timeline, mean cycles over %d workgroups: tables staged %.0f | pair rounds (last wave) %.0f %.0f %.0f %.0f | to the barrier %.0f | dB stage %.0f | "
+                               "total %.0f cycles = %.0f ticks of 10 ns (%.2f GHz)\n", n, d[0] / n, d[1] / n, d[2] / n, d[3] / n, d[4] / n, d[5] / n, d[6] / n, d[7] / n, ticks / n,
+                       ticks > 0 ? d[7] / ticks / 10.0 : 0.0);
         return AMPH_OK;
     }
     if (!std::strcmp(key, "dump_stamps")) {      // value = number of workgroups of the last stft launch

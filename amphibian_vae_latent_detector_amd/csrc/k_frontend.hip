@@ -595,27 +595,56 @@ __device__ __forceinline__ void dft16_pk(amph_f2 (&re)[16], amph_f2 (&im)[16]) {
     for (int ka = 0; ka < 4; ++ka)
         AMPH_BFLY4_T(re[4 * ka], im[4 * ka], re[4 * ka + 1], im[4 * ka + 1], re[4 * ka + 2], im[4 * ka + 2], re[4 * ka + 3], im[4 * ka + 3]);
 }
-// Y[k + 16 p] = E[k] +- W32^k O[k] with E = the .x and O = the .y sequence of every pair, in place (.x <- Y[k], .y <- Y[k + 16])
-__device__ __forceinline__ void dft32_combine_pk(amph_f2 (&re)[16], amph_f2 (&im)[16]) {
-    constexpr float C[16] = {1.0f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f,
-                             0.70710678118654752440f, 0.55557023301960222474f, 0.38268343236508977173f, 0.19509032201612826785f,
-                             0.0f, -0.19509032201612826785f, -0.38268343236508977173f, -0.55557023301960222474f,
-                             -0.70710678118654752440f, -0.83146961230254523708f, -0.92387953251128675613f, -0.98078528040323044913f};
-    constexpr float S[16] = {0.0f, 0.19509032201612826785f, 0.38268343236508977173f, 0.55557023301960222474f,
-                             0.70710678118654752440f, 0.83146961230254523708f, 0.92387953251128675613f, 0.98078528040323044913f,
-                             1.0f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f,
-                             0.70710678118654752440f, 0.55557023301960222474f, 0.38268343236508977173f, 0.19509032201612826785f};
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int q = DFT16_POS(k);
-        const float orr = re[q].y, oi = im[q].y, ar = re[q].x, ai = im[q].x;
-        float tr, ti;
-        if (k == 0) { tr = orr; ti = oi; }
-        else if (k == 8) { tr = oi; ti = -orr; }
-        else { tr = C[k] * orr + S[k] * oi; ti = C[k] * oi - S[k] * orr; }
-        re[q].x = ar + tr; re[q].y = ar - tr;
-        im[q].x = ai + ti; im[q].y = ai - ti;
+// Y[k + 16 p] = E[k] +- W32^k O[k] with E = the .x and O = the .y sequence of every pair, in place (.x <- Y[k], .y <- Y[k + 16]).
+// The operands of one butterfly sit in the two HALVES of a register pair, so plain packed arithmetic cannot reach them; the VOP3P
+// operand-half selectors can (op_sel / op_sel_hi: which half of each source feeds the low / the high result; neg_lo / neg_hi):
+//   tmp = (or c, -or s)                v_pk_mul_f32  re[.y, .y] * P[c | s]
+//   T   = (oi s + or c, oi c - or s)   v_pk_fma_f32  im[.y, .y] * P[s | c] + tmp         T = W32^k O = (tr, ti)
+//   re  = (er + tr, er - tr)           v_pk_add_f32  re[.x, .x] + T[.x, -.x]
+//   im  = (ei + ti, ei - ti)           v_pk_add_f32  im[.x, .x] + T[.y, -.y]
+// four instructions per k instead of eight scalar ones (the kernel is bound by its vector instruction count: every one holds the
+// SIMD for four cycles, packed or not - 86 % VALU-busy inside the pair loop, profiles/r03_stft_pair_timeline.txt).  The constant
+// pair P = (cos, sin)(pi j / 16), j = 1..4, serves all k through the selectors: c, s = P.x, P.y (k = j), P.y, P.x (k = 8 - j),
+// -P.y, P.x (k = 8 + j), -P.x, P.y (k = 16 - j) - four SGPR pairs.  tools/probe/pk_opsel.hip checks the selector semantics.
+template <int K>
+__device__ __forceinline__ void dft32_comb_k(amph_f2& re, amph_f2& im) {
+    amph_f2 r2, i2;
+    if constexpr (K == 0) {                              // T = O
+        asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_lo:[0,0] neg_hi:[0,1]" : "=v"(r2) : "v"(re));
+        asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_lo:[0,0] neg_hi:[0,1]" : "=v"(i2) : "v"(im));
+    } else if constexpr (K == 8) {                       // T = -i O = (oi, -or)
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,1] neg_lo:[0,0] neg_hi:[0,1]" : "=v"(r2) : "v"(re), "v"(im));
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,0]" : "=v"(i2) : "v"(im), "v"(re));
+    } else {
+        constexpr int J = K < 5 ? K : K < 8 ? 8 - K : K < 13 ? K - 8 : 16 - K;
+        constexpr bool SWAP = (K >= 5 && K <= 7) || (K >= 9 && K <= 12), CNEG = K > 8;
+        constexpr float CJ[5] = {1.0f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f, 0.70710678118654752440f};
+        constexpr float SJ[5] = {0.0f, 0.19509032201612826785f, 0.38268343236508977173f, 0.55557023301960222474f, 0.70710678118654752440f};
+        const amph_f2 P = {CJ[J], SJ[J]};
+        amph_f2 tmp, T;
+        if constexpr (!SWAP && !CNEG) {
+            asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[0,0] neg_hi:[0,1]" : "=v"(tmp) : "v"(re), "s"(P));
+            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,0,0] neg_hi:[0,0,0]" : "=v"(T) : "v"(im), "s"(P), "v"(tmp));
+        } else if constexpr (SWAP && !CNEG) {
+            asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,0] neg_hi:[0,1]" : "=v"(tmp) : "v"(re), "s"(P));
+            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[0,0,0] neg_hi:[0,0,0]" : "=v"(T) : "v"(im), "s"(P), "v"(tmp));
+        } else if constexpr (SWAP && CNEG) {
+            asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(tmp) : "v"(re), "s"(P));
+            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[0,0,0] neg_hi:[0,1,0]" : "=v"(T) : "v"(im), "s"(P), "v"(tmp));
+        } else {
+            asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(tmp) : "v"(re), "s"(P));
+            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,0,0] neg_hi:[0,1,0]" : "=v"(T) : "v"(im), "s"(P), "v"(tmp));
+        }
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,0] neg_lo:[0,0] neg_hi:[0,1]" : "=v"(r2) : "v"(re), "v"(T));
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,1] neg_lo:[0,0] neg_hi:[0,1]" : "=v"(i2) : "v"(im), "v"(T));
     }
+    re = r2; im = i2;
+}
+__device__ __forceinline__ void dft32_combine_pk(amph_f2 (&re)[16], amph_f2 (&im)[16]) {
+#define AMPH_COMB(k_) dft32_comb_k<k_>(re[DFT16_POS(k_)], im[DFT16_POS(k_)]);
+    AMPH_COMB(0) AMPH_COMB(1) AMPH_COMB(2) AMPH_COMB(3) AMPH_COMB(4) AMPH_COMB(5) AMPH_COMB(6) AMPH_COMB(7)
+    AMPH_COMB(8) AMPH_COMB(9) AMPH_COMB(10) AMPH_COMB(11) AMPH_COMB(12) AMPH_COMB(13) AMPH_COMB(14) AMPH_COMB(15)
+#undef AMPH_COMB
 }
 // LDS stores with ONE base register and a 16-bit byte offset.  Left to the compiler, neighbouring float stores are paired into
 // ds_write2_b32, whose 8-bit offsets reach 1 KB: the 32 rows of an exchange tile then need sixteen loop-invariant base registers
@@ -1504,12 +1533,14 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
     char* wbase = smem + kTab + meta_bytes + melw_bytes + wave * kPairScratch;
     float* T = reinterpret_cast<float*>(wbase);
     amph_f2* P2 = reinterpret_cast<amph_f2*>(wbase);        // the pair's power spectra, interleaved: P2[k] = (4 |A[k]|^2, 4 |B[k]|^2)
-    float* mp_row = reinterpret_cast<float*>(smem + kTab + meta_bytes + melw_bytes + NW * kPairScratch);
+    int* const next_pair = reinterpret_cast<int*>(smem + kTab + meta_bytes + melw_bytes + NW * kPairScratch);      // the row's next unassigned pair
+    float* mp_row = reinterpret_cast<float*>(smem + kTab + meta_bytes + melw_bytes + NW * kPairScratch + 16);
     const bool fuse_db = p.db_out != nullptr;
 #ifdef AMPH_STAMPS
     unsigned long long pw_begin = 0;
     const unsigned long long pw_rt0 = __builtin_amdgcn_s_memrealtime();
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pw_begin)::"memory");
+#ifdef AMPH_STAMPS_PHASES
 #define AMPH_PSTAMP(k_)                                                                     \
     if (wave == 0 && pr == 0) {                                                             \
         unsigned long long t_;                                                              \
@@ -1521,39 +1552,9 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
 #else
 #define AMPH_PSTAMP(k_)
 #endif
-
-    // ---- once per workgroup: window pairs + stage-2 twiddles (one packed global array), mel rows (x 1/4: see above)
-    {
-        const float4* src = reinterpret_cast<const float4*>(p.pair_tables);
-        float4* dst = reinterpret_cast<float4*>(smem);
-        for (int i = tid; i < (kPairWinBytes + kPairTw2Bytes) / 16; i += kThreads) dst[i] = src[i];
-        if (TWL) {
-            const float4* s1 = reinterpret_cast<const float4*>(p.pair_tw1);
-            float4* d1 = reinterpret_cast<float4*>(smem + kPairWinBytes + kPairTw2Bytes);
-            for (int i = tid; i < kPairTw1Bytes / 16; i += kThreads) d1[i] = s1[i];
-        }
-        for (int m = tid; m < p.n_mels; m += kThreads) mel_meta[m] = make_int3(p.mel_start[m], p.mel_len[m], p.mel_wofs[m]);
-        const float4* wsrc = reinterpret_cast<const float4*>(p.mel_w);
-        float4* wdst = reinterpret_cast<float4*>(mel_w);
-        for (int i = tid; i < (p.mel_w_floats >> 2); i += kThreads) {
-            float4 v = wsrc[i];
-            v.x *= 0.25f; v.y *= 0.25f; v.z *= 0.25f; v.w *= 0.25f;
-            wdst[i] = v;
-        }
-    }
-    __syncthreads();
-
-    const int n_pairs = (p.n_frames + 1) >> 1;
-    const int col = 2 * (lane & 31) + (lane >> 5);          // stage-1 column of this lane
-    const int k1p = lane >> 1, h = lane & 1;                // stage-2 role
-    const int lanep = k1p + 32 * h;                         // bins lanep + 64 k2'
-    const int colp = (64 - lanep) & 63;                     // the lane' that holds the partners N - k
-    const int zw = lanep + ((lanep >> 5) << 4);             // partner tile column (write), bank-shifted
-    const int zr_ = colp + ((colp >> 5) << 4) + (lanep == 0 ? kPairZS : 0);   // (read; lane' 0: one row further, row 16 = Z[0])
-    const float sgn = h ? -1.0f : 1.0f;
-    // LDS byte addresses of this lane's stores (AMPH_DS_ST32 / 64): exchange column, partner column, power bin
-    const uint32_t lds_w = (uint32_t)(uintptr_t)wbase;
-    const uint32_t st_col = lds_w + 4u * (uint32_t)col, st_zw = lds_w + 4u * (uint32_t)zw, st_p2 = lds_w + 8u * (uint32_t)lanep;
+#else
+#define AMPH_PSTAMP(k_)
+#endif
 
     // the next pair's raw dwords: requested before the mel rows of the current pair
     uint32_t nx[ND];
@@ -1572,17 +1573,91 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
 #pragma unroll
         for (int j = 16; j < ND; ++j) nx[j] = full ? __builtin_amdgcn_raw_buffer_load_b32(rs_x, lane4, base + 256 * j, 0) : 0u;
     };
-    if ((int)blockIdx.x < n_rows && wave < n_pairs) fetch(blockIdx.x, wave);
+    // (the first pair's samples come from HBM: requested BEFORE the tables are staged, the two latencies overlap)
+    if ((int)blockIdx.x < n_rows && wave < ((p.n_frames + 1) >> 1)) fetch(blockIdx.x, wave);
+
+    // ---- once per workgroup: window pairs + stage-2 twiddles (one packed array), stage-1 twiddles (TWL), mel rows (x 1/4: see above).  Every load is requested before the
+    //      first store: one global round trip (beside the sample fetch above), not one per table
+    {
+        const float4* src = reinterpret_cast<const float4*>(p.pair_tables);
+        const float4* s1 = reinterpret_cast<const float4*>(p.pair_tw1);
+        float4* dst = reinterpret_cast<float4*>(smem);
+        float4* d1 = reinterpret_cast<float4*>(smem + kPairWinBytes + kPairTw2Bytes);
+        constexpr int NWIN = (kPairWinBytes + kPairTw2Bytes) / 16, NT1 = TWL ? kPairTw1Bytes / 16 : 0;
+        constexpr int UW = (NWIN + kThreads - 1) / kThreads, UT = (NT1 + kThreads - 1) / kThreads;
+        float4 vw[UW], vt[UT ? UT : 1];
+#pragma unroll
+        for (int u = 0; u < UW; ++u) { const int i = tid + kThreads * u; vw[u] = i < NWIN ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f); }
+#pragma unroll
+        for (int u = 0; u < UT; ++u) { const int i = tid + kThreads * u; vt[u] = i < NT1 ? s1[i] : make_float4(0.f, 0.f, 0.f, 0.f); }
+        int3 mm_ = make_int3(0, 0, 0);
+        if (tid < p.n_mels) mm_ = make_int3(p.mel_start[tid], p.mel_len[tid], p.mel_wofs[tid]);
+        const float4* wsrc = reinterpret_cast<const float4*>(p.mel_w);
+        float4* wdst = reinterpret_cast<float4*>(mel_w);
+        const int n4 = p.mel_w_floats >> 2;
+        for (int base = 0; base < n4; base += 2 * kThreads) {
+            const int i0 = base + tid, i1 = i0 + kThreads;
+            float4 v0 = i0 < n4 ? wsrc[i0] : make_float4(0.f, 0.f, 0.f, 0.f), v1 = i1 < n4 ? wsrc[i1] : make_float4(0.f, 0.f, 0.f, 0.f);
+            v0.x *= 0.25f; v0.y *= 0.25f; v0.z *= 0.25f; v0.w *= 0.25f;
+            v1.x *= 0.25f; v1.y *= 0.25f; v1.z *= 0.25f; v1.w *= 0.25f;
+            if (i0 < n4) wdst[i0] = v0;
+            if (i1 < n4) wdst[i1] = v1;
+        }
+        for (int m = tid + kThreads; m < p.n_mels; m += kThreads) mel_meta[m] = make_int3(p.mel_start[m], p.mel_len[m], p.mel_wofs[m]);
+        if (tid < p.n_mels) mel_meta[tid] = mm_;
+        if (tid == 0) *next_pair = NW;                   // pairs 0 .. NW - 1 are the waves' first ones
+#pragma unroll
+        for (int u = 0; u < UW; ++u) { const int i = tid + kThreads * u; if (i < NWIN) dst[i] = vw[u]; }
+#pragma unroll
+        for (int u = 0; u < UT; ++u) { const int i = tid + kThreads * u; if (i < NT1) d1[i] = vt[u]; }
+    }
+    __syncthreads();
+#ifdef AMPH_STAMPS
+    // workgroup timeline (tools/stft_stamps.py timeline): [0] start, [1] tables staged, [2 + i] the LAST wave's end of pair round i,
+    // [6] every wave out of the pair loop, [7] dB stage done; second region of the stamp buffer
+    unsigned long long* const tl = p.stamps + 16 * 4096 + (size_t)blockIdx.x * 16;
+    int tl_round = 0;
+    if (tid == 0) {
+        unsigned long long t_;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");
+        tl[0] = pw_begin; tl[1] = t_;
+        for (int k_ = 2; k_ < 16; ++k_) tl[k_] = 0;
+    }
+    __syncthreads();
+#endif
+
+    const int n_pairs = (p.n_frames + 1) >> 1;
+    const int col = 2 * (lane & 31) + (lane >> 5);          // stage-1 column of this lane
+    const int k1p = lane >> 1, h = lane & 1;                // stage-2 role
+    const int lanep = k1p + 32 * h;                         // bins lanep + 64 k2'
+    const int colp = (64 - lanep) & 63;                     // the lane' that holds the partners N - k
+    const int zw = lanep + ((lanep >> 5) << 4);             // partner tile column (write), bank-shifted
+    const int zr_ = colp + ((colp >> 5) << 4) + (lanep == 0 ? kPairZS : 0);   // (read; lane' 0: one row further, row 16 = Z[0])
+    const float sgn = h ? -1.0f : 1.0f;
+    // LDS byte addresses of this lane's stores (AMPH_DS_ST32 / 64): exchange column, partner column, power bin
+    const uint32_t lds_w = (uint32_t)(uintptr_t)wbase;
+    const uint32_t st_col = lds_w + 4u * (uint32_t)col, st_zw = lds_w + 4u * (uint32_t)zw, st_p2 = lds_w + 8u * (uint32_t)lanep;
+
 
     // The phases of a pair are fenced for the instruction scheduler (sched_barrier): left alone it builds ONE region of ~2 000
     // instructions, runs out of registers and then serialises every table load behind its own wait (31 dependent L2 round
     // trips for the stage-1 twiddles in the first build).  Inside a phase the loads are issued up front, by hand.
 #define AMPH_PHASE_FENCE() __builtin_amdgcn_sched_barrier(0)
+    // Pairs are handed out DYNAMICALLY (an LDS counter per row; wave w starts with pair w): the SIMD issues oldest-wave-first, so its
+    // first wave runs a pair in ~12.6 k cycles, its second in ~20 k, its third in ~35 k (profiles/r03_stft_pair_timeline.txt) - with
+    // a fixed pr = wave + 12 i the first waves idle at the end while the SIMD that drew the row's 29th pair still works
     for (int row = blockIdx.x; row < n_rows; row += gridDim.x) {
-        for (int pr = wave; pr < n_pairs; pr += NW) {
+        for (int pr = wave, pr_next = 0; pr < n_pairs; pr = pr_next) {
             // packed pairs: element j of the lane's TWO sequences (sample parity 0 / 1) side by side - dft16_pk
             amph_f2 XR[16], XI[16];
             float4 tw[16];
+#ifdef AMPH_STAMPS
+            if (tl_round < 4) {                 // per wave and round: start (here) and end, third region of the stamp buffer
+                unsigned long long t_;
+                asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");
+                if (lane == 0) p.stamps[32 * 4096 + ((size_t)blockIdx.x * 16 + wave) * 8 + 2 * tl_round] = t_;
+            }
+#endif
             AMPH_PSTAMP(0)
             // ---- decode + window: z = w (a + i b); the pair is the two int16 of one dword times the window pair (w[n], w[n + 1])
 #pragma unroll
@@ -1641,6 +1716,10 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
             //      pass are queued behind its writes and in front of the second pass's writes, nothing waits in between.  A 16-byte
             //      read returns mm = 4 c .. 4 c + 3 = the pairs (p = 0, 1) of m = 2 c and 2 c + 1: no register shuffling
             amph_f2 UR[16], UI[16];
+#ifdef AMPH_ABL_PAIR_NOEX                  /* timing-only ablation: no exchange through LDS at all (64 stores + 16 reads less), same arithmetic */
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) { UR[kk] = XR[kk]; UI[kk] = XI[kk]; }
+#else
 #pragma unroll
             for (int kk = 0; kk < 16; ++kk) {
                 AMPH_DS_ST32(st_col, kk * kPairExS * 4, XR[DFT16_POS(kk)].x);
@@ -1653,11 +1732,18 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
                 UR[2 * c] = amph_f2{v.x, v.y}; UR[2 * c + 1] = amph_f2{v.z, v.w};
             }
             wave_lds_sync();
+#ifndef AMPH_ABL_PAIR_NOIMAG               /* timing-only ablation: 32 LDS stores less per pair, same arithmetic */
 #pragma unroll
             for (int kk = 0; kk < 16; ++kk) {
                 AMPH_DS_ST32(st_col, kk * kPairExS * 4, XI[DFT16_POS(kk)].x);
                 AMPH_DS_ST32(st_col, (kk + 16) * kPairExS * 4, XI[DFT16_POS(kk)].y);
             }
+#else
+            asm volatile("" :: "v"(XI[0].x), "v"(XI[1].x), "v"(XI[2].x), "v"(XI[3].x), "v"(XI[4].x), "v"(XI[5].x), "v"(XI[6].x), "v"(XI[7].x));
+            asm volatile("" :: "v"(XI[8].x), "v"(XI[9].x), "v"(XI[10].x), "v"(XI[11].x), "v"(XI[12].x), "v"(XI[13].x), "v"(XI[14].x), "v"(XI[15].x));
+            asm volatile("" :: "v"(XI[0].y), "v"(XI[1].y), "v"(XI[2].y), "v"(XI[3].y), "v"(XI[4].y), "v"(XI[5].y), "v"(XI[6].y), "v"(XI[7].y));
+            asm volatile("" :: "v"(XI[8].y), "v"(XI[9].y), "v"(XI[10].y), "v"(XI[11].y), "v"(XI[12].y), "v"(XI[13].y), "v"(XI[14].y), "v"(XI[15].y));
+#endif
             wave_lds_sync();
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
@@ -1665,6 +1751,7 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
                 UI[2 * c] = amph_f2{v.x, v.y}; UI[2 * c + 1] = amph_f2{v.z, v.w};
             }
             wave_lds_sync();
+#endif
             AMPH_PHASE_FENCE();
             AMPH_PSTAMP(3)
             // ---- stage 2: radix-2 DIF across the lane pair (DPP), twiddle (h = 1: W_64^mm; (1, 0) on h = 0), DFT32
@@ -1730,9 +1817,12 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
             //      (UNCONDITIONALLY - behind the last pair the row index is clamped and the samples are never used: a conditional
             //      fetch makes the old dwords the value of the not-taken path, i.e. 19 registers live through every phase of the pair)
             {
-                int nrow = row, npr = pr + NW;
-                if (npr >= n_pairs) { nrow = row + gridDim.x; npr = wave; }
-                fetch(min(nrow, n_rows - 1), npr);
+                int got = 0;
+                if (lane == 0) got = atomicAdd(next_pair, 1);
+                pr_next = __builtin_amdgcn_readfirstlane(got);
+                int nrow = row, npr = pr_next;
+                if (npr >= n_pairs) { nrow = row + gridDim.x; npr = wave; }     // nothing left in this row: the wave's first pair of its next row
+                fetch(min(nrow, n_rows - 1), min(npr, n_pairs - 1));
             }
             AMPH_PHASE_FENCE();
 #ifdef AMPH_STAMPS
@@ -1790,13 +1880,27 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
             wave_lds_sync();                                // the scratch is rewritten by the next pair
             AMPH_PHASE_FENCE();
             AMPH_PSTAMP(9)
+#ifdef AMPH_STAMPS
+            {
+                unsigned long long t_;
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");
+                if (lane == 0 && tl_round < 4) { atomicMax(&tl[2 + tl_round], t_); p.stamps[32 * 4096 + ((size_t)blockIdx.x * 16 + wave) * 8 + 2 * tl_round + 1] = t_; }
+                ++tl_round;
+            }
+#endif
         }
 #undef AMPH_PHASE_FENCE
         // ---- fused dB stage on the row the workgroup holds (see k_stft_mel_w).  The LAST row (at batch 256: the only one) is
         //      finished behind the loops: inlined here, the stage's per-thread index arithmetic is hoisted in front of the row loop
         //      and sits in ~90 registers across the pair loop
+        if (!fuse_db && row + (int)gridDim.x < n_rows) {  // (every wave has drawn its last index of this row before the counter starts over)
+            __syncthreads();
+            if (tid == 0) *next_pair = NW;
+            __syncthreads();
+        }
         if (fuse_db && row + (int)gridDim.x < n_rows) {
             __syncthreads();
+            if (tid == 0) *next_pair = NW;
             db_row_call<kThreads>(mp_row, p.n_frames, p.n_mels, p.db_target_frames, p.db_layout,
                                   p.db_out + (long long)row * p.db_target_frames * p.n_mels,
                                   reinterpret_cast<double*>(mp_row + ((p.n_frames * p.n_mels + 3) & ~3)));
@@ -1816,9 +1920,16 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
     if (fuse_db && (int)blockIdx.x < n_rows) {
         const int last_row = blockIdx.x + (n_rows - 1 - (int)blockIdx.x) / (int)gridDim.x * (int)gridDim.x;
         __syncthreads();
+#ifdef AMPH_STAMPS
+        if (tid == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); tl[6] = t_; }
+#endif
         db_row_from_lds<kThreads>(mp_row, p.n_frames, p.n_mels, p.db_target_frames, p.db_layout,
                                   p.db_out + (long long)last_row * p.db_target_frames * p.n_mels,
                                   reinterpret_cast<double*>(mp_row + ((p.n_frames * p.n_mels + 3) & ~3)));
+#ifdef AMPH_STAMPS
+        __syncthreads();
+        if (tid == 0) { unsigned long long t_; asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); tl[7] = t_; tl[8] = __builtin_amdgcn_s_memrealtime() - pw_rt0; }
+#endif
     }
 }
 
@@ -2090,7 +2201,7 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair2(StftParams p, int n_rows
 size_t stft_pair_lds_bytes(int n_frames, int n_mels, int mel_w_floats, int n_waves, bool fused) {
     const size_t meta = ((size_t)n_mels * 12 + 15) & ~(size_t)15;
     const size_t mp = fused ? (((size_t)n_frames * n_mels + 3) & ~(size_t)3) * 4 + 16 * 8 + 16 * 4 : 0;
-    return (size_t)kPairWinBytes + kPairTw2Bytes + meta + (size_t)mel_w_floats * 4 + (size_t)n_waves * kPairScratch + mp;
+    return (size_t)kPairWinBytes + kPairTw2Bytes + meta + (size_t)mel_w_floats * 4 + (size_t)n_waves * kPairScratch + 16 + mp;      // (16: the pair counter)
 }
 size_t stft_pair_tw1_lds_bytes() { return kPairTw1Bytes; }
 int stft_pair_table_bytes() { return kPairWinBytes + kPairTw2Bytes; }

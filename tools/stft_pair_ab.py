@@ -31,5 +31,21 @@ for nw in (8, 10, 12):
                   f"{np.abs(i0 - i1).max():.2e}; image (fused dB) max |d| = {np.abs(f0 - f1).max():.2e}; fused vs separate (pair) {np.abs(f1 - i1).max():.2e}",
                   flush=True)
             worst = max(worst, dp.max())
+# several rows per workgroup (the pair counter starts over per row; the dB stage of a row runs between two rows' pairs)
+s.configure("stft_pair_waves", 12)
+for grid in (7, 3):
+    outs = []
+    for v in (0, 1):
+        s.configure("stft_pair", v)
+        s.configure("stft_grid", grid if v else 0)
+        img, pw = s.mel_pcm16(pcm, lengths=lens, apply_rms=True, layout=1, want_power=True)
+        fused = s.mel_pcm16(pcm, lengths=lens, apply_rms=True, layout=1)
+        outs.append((pw.cpu().numpy(), img.cpu().numpy(), fused.cpu().numpy()))
+    s.configure("stft_grid", 0)
+    (p0, i0, f0), (p1, i1, f1) = outs
+    dp = np.abs(p0 - p1).max(axis=(1, 2)) / np.maximum(p0.max(axis=(1, 2)), 1e-30)
+    print(f"{grid} workgroups for {B} rows: mel power max |d| / row max = {dp.max():.2e}; image (fused dB) max |d| = {np.abs(f0 - f1).max():.2e}; "
+          f"fused vs separate (pair) {np.abs(f1 - i1).max():.2e}", flush=True)
+    worst = max(worst, dp.max())
 print("worst mel power difference relative to the row's peak:", worst)
 assert worst < 1e-6

@@ -8,7 +8,8 @@ ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
 from amphibian_vae_latent_detector_amd import PRESETS
 from amphibian_vae_latent_detector_amd import _native as N
-lib = C.CDLL(str(ROOT / "build_ab" / "libamph_stamps.so"))
+import os
+lib = C.CDLL(str(ROOT / "build_ab" / os.environ.get("AMPH_STAMPS_LIB", "libamph_stamps.so")))   # (or an ablation built with -DAMPH_STAMPS)
 for name in N.EXPORTED_SYMBOLS:
     fn, ref = getattr(lib, name), getattr(N.lib, name)
     fn.restype, fn.argtypes = ref.restype, ref.argtypes
@@ -28,3 +29,7 @@ for _ in range(3):
     s.encode(pcm, apply_rms=True)                       # the PCM16 + RMS path of the benchmark
 torch.cuda.synchronize()
 s.configure("dump_stamps", int(sys.argv[1]) if len(sys.argv) > 1 else 256)   # workgroups of the launch (12-wave kernel: 256)
+try:
+    s.configure("dump_timeline", int(sys.argv[1]) if len(sys.argv) > 1 else 256)   # k_stft_pair: tables | pair rounds | dB stage
+except Exception as e:                                   # (older diagnostic builds)
+    print("no timeline:", e)
