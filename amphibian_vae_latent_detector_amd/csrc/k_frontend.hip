@@ -53,6 +53,45 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_down(v, o));
     return v;
 }
+// The same reductions on the DPP network - no LDS round trip per step (a __shfl_down is a ds_bpermute: six of them, twelve for a double,
+// ~100 cycles apiece behind one another): butterflies inside a quad, half-row and row mirrors (every lane of a row then holds the row's
+// value), then the row broadcasts.  The result is valid in LANE 63 only.  Fixed order, like the shuffle form (a different one).
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true)); }
+template <int CTRL, int ROWS>
+__device__ __forceinline__ float dpp_f_rows(float v, float other) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(other), __float_as_int(v), CTRL, ROWS, 0xF, false));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_mov_dpp((int)b, CTRL, 0xF, 0xF, true), hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), CTRL, 0xF, 0xF, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+template <int CTRL, int ROWS>
+__device__ __forceinline__ double dpp_d_rows(double v) {            // 0.0 in the rows outside ROWS
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, ROWS, 0xF, false), hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROWS, 0xF, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ float wave_max_dpp(float v) {
+    v = fmaxf(v, dpp_f<0xB1>(v));                        // quad_perm [1, 0, 3, 2]
+    v = fmaxf(v, dpp_f<0x4E>(v));                        // quad_perm [2, 3, 0, 1]
+    v = fmaxf(v, dpp_f<0x141>(v));                       // row_half_mirror
+    v = fmaxf(v, dpp_f<0x140>(v));                       // row_mirror
+    v = fmaxf(v, dpp_f_rows<0x142, 0xA>(v, v));          // row_bcast:15 into rows 1, 3
+    v = fmaxf(v, dpp_f_rows<0x143, 0xC>(v, v));          // row_bcast:31 into rows 2, 3
+    return v;
+}
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+    v += dpp_d<0xB1>(v);
+    v += dpp_d<0x4E>(v);
+    v += dpp_d<0x141>(v);
+    v += dpp_d<0x140>(v);
+    v += dpp_d_rows<0x142, 0xA>(v);
+    v += dpp_d_rows<0x143, 0xC>(v);
+    return v;
+}
 // Block-wide reductions for blocks of NW waves (4 or 16); result valid in every thread.
 template <int NW = 4>
 __device__ __forceinline__ double block_sum(double v, double* sh) {
@@ -1060,8 +1099,8 @@ __device__ __forceinline__ void db_row_from_lds(const float* mp, int T, int M, i
 #pragma unroll
     for (int j = 0; j < C; ++j) { const int i = tid + NT * j; v[j] = i < n ? mp[i] : -INFINITY; mx = fmaxf(mx, v[j]); }
     for (int i = tid + NT * C; i < n; i += NT) mx = fmaxf(mx, mp[i]);
-    mx = wave_max(mx);
-    if (lane == 0) redf[w] = mx;
+    mx = wave_max_dpp(mx);
+    if (lane == 63) redf[w] = mx;
     __syncthreads();
     mx = redf[0];
 #pragma unroll
@@ -1071,8 +1110,8 @@ __device__ __forceinline__ void db_row_from_lds(const float* mp, int T, int M, i
 #pragma unroll
     for (int j = 0; j < C; ++j) if (tid + NT * j < n) { v[j] = to_db(v[j], ref_db); acc += (double)v[j]; }
     for (int i = tid + NT * C; i < n; i += NT) acc += (double)to_db(mp[i], ref_db);
-    acc = wave_sum(acc);
-    if (lane == 0) red[w] = acc;
+    acc = wave_sum_dpp(acc);
+    if (lane == 63) red[w] = acc;
     __syncthreads();
     double tot = 0.0;
 #pragma unroll
@@ -1082,9 +1121,9 @@ __device__ __forceinline__ void db_row_from_lds(const float* mp, int T, int M, i
 #pragma unroll
     for (int j = 0; j < C; ++j) if (tid + NT * j < n) { const float dlt = v[j] - mean; acc += (double)(dlt * dlt); }
     for (int i = tid + NT * C; i < n; i += NT) { const float dlt = to_db(mp[i], ref_db) - mean; acc += (double)(dlt * dlt); }
-    acc = wave_sum(acc);
+    acc = wave_sum_dpp(acc);
     __syncthreads();                                     // every wave has read the first sums
-    if (lane == 0) red[w] = acc;
+    if (lane == 63) red[w] = acc;
     __syncthreads();
     tot = 0.0;
 #pragma unroll
