@@ -43,17 +43,7 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
-    return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_down(v, o));
-    return v;
-}
-// The same reductions on the DPP network - no LDS round trip per step (a __shfl_down is a ds_bpermute: six of them, twelve for a double,
+// Wave-wide reductions on the DPP network - no LDS round trip per step (a __shfl_down is a ds_bpermute: six of them, twelve for a double,
 // ~100 cycles apiece behind one another): butterflies inside a quad, half-row and row mirrors (every lane of a row then holds the row's
 // value), then the row broadcasts.  The result is valid in LANE 63 only.  Fixed order, like the shuffle form (a different one).
 template <int CTRL>
@@ -96,9 +86,9 @@ __device__ __forceinline__ double wave_sum_dpp(double v) {
 template <int NW = 4>
 __device__ __forceinline__ double block_sum(double v, double* sh) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    v = wave_sum(v);
+    v = wave_sum_dpp(v);
     __syncthreads();
-    if (lane == 0) sh[w] = v;
+    if (lane == 63) sh[w] = v;
     __syncthreads();
     if (NW == 4) return (sh[0] + sh[1]) + (sh[2] + sh[3]);
     double q[4];
@@ -109,9 +99,9 @@ __device__ __forceinline__ double block_sum(double v, double* sh) {
 template <int NW = 4>
 __device__ __forceinline__ float block_max(float v, float* sh) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    v = wave_max(v);
+    v = wave_max_dpp(v);
     __syncthreads();
-    if (lane == 0) sh[w] = v;
+    if (lane == 63) sh[w] = v;
     __syncthreads();
     float m = sh[0];
 #pragma unroll

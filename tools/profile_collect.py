@@ -31,6 +31,7 @@ def stage_of(kernel: str, grid: int) -> str:
     if k.startswith("k_conv_gemm_f3") or k.startswith("k_conv_gemm_f4") or (k.startswith("k_conv_gemm<") and "true" in k): return "conv2"
     if k.startswith("k_conv_gemm_g4<64"): return "conv3"
     if k.startswith("k_conv_gemm_g4<128"): return "conv4"
+    if k.startswith("k_conv_gemm_s3w"): return {32768: "conv4_wide"}.get(grid, f"gemm_wide_grid{grid}")   # 128 x 128 tiles (multi-lane calls)
     if k.startswith("k_conv_gemm_p3") or k.startswith("k_conv_gemm_s3") or k.startswith("k_conv_gemm<"):
         return {131072: "conv3", 65536: "conv4", 16384: "head_gemm"}.get(grid, f"gemm_grid{grid}")
     if k.startswith("k_head_reduce"): return "head_reduce"
@@ -49,8 +50,12 @@ def counters(d):
 
 
 lines, traffic = [], collections.defaultdict(dict)
-for name in ("pmc_fetch", "pmc_write", "pmc_l2", "pmc_sq", "pmc_mfma"):
+for name in ("pmc_fetch", "pmc_write", "pmc_l2", "pmc_sq", "pmc_mfma", "pmc_mfma_wide"):
     by = counters(src / name)
+    if name == "pmc_mfma_wide":                          # the same pass with --knob wide_gemm=1: only the kernel it adds
+        by = {kg: cs for kg, cs in by.items() if stage_of(*kg) == "conv4_wide"}
+        if not by:
+            continue
     lines.append(f"== {name}   (rocprofv3 --kernel-trace --pmc ..., python3 bench.py --steps 2 --warmup 1 --chunks 5120 --cpu-seconds 0 --lanes 1)")
     # full-size launches only: the largest grid of each stage (the last batch of 5120 chunks is a full 256 too)
     best = {}

@@ -22,6 +22,7 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write
 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$OUT/pmc_l2" -- $PM > /dev/null 2> "$OUT/pmc_l2.err" || exit 1
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS --output-format csv -d "$OUT/pmc_sq" -- $PM > /dev/null 2> "$OUT/pmc_sq.err" || exit 1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_mfma" -- $PM > /dev/null 2> "$OUT/pmc_mfma.err" || exit 1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_mfma_wide" -- $PM --knob wide_gemm=1 > /dev/null 2> "$OUT/pmc_mfma_wide.err" || exit 1
 echo "pmc passes done"
 python3 tools/pmc_summary.py "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_l2" "$OUT/pmc_sq" "$OUT/pmc_mfma" > "$OUT/pmc_summary.txt" 2>&1
 find "$OUT" -name "*kernel_stats.csv" | head
