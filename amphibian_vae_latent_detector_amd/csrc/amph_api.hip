@@ -26,7 +26,8 @@ using namespace amph;
 // 1 STFT, 2.. the GEMM layers in order, 6 the head's reduction - what a stage's removal is worth end to end bounds what any faster form of it
 // can be worth.  Results are wrong by construction; never shipped.
 static int g_abl_skip = 0;
-extern "C" void amph_abl_skip(int mask) { g_abl_skip = mask; }
+namespace amph { extern int g_abl_skip_k0; }
+extern "C" void amph_abl_skip(int mask) { g_abl_skip = mask; amph::g_abl_skip_k0 = (mask >> 7) & 3; }
 #endif
 
 namespace {
@@ -1309,6 +1310,19 @@ int amph_configure(amph_ctx* c, const char* key, int value) {
                 for (int r = 0; r < 3; ++r) if (cn[r]) fprintf(stderr, "  %6.0f / %6.0f", st[r] / cn[r], du[r] / cn[r]);
                 fprintf(stderr, "\n");
             }
+        }
+        {
+            double dd[6] = {0};
+            int nn = 0;
+            for (int b = 0; b < value; ++b) {
+                const unsigned long long* t = h.data() + (size_t)b * 16;
+                if (!t[7] || !t[9]) continue;
+                ++nn;
+                dd[0] += (double)(t[9] - t[6]); dd[1] += (double)(t[10] - t[9]); dd[2] += (double)(t[11] - t[10]); dd[3] += (double)(t[12] - t[11]);
+                dd[4] += (double)(t[13] - t[12]); dd[5] += (double)(t[7] - t[13]);
+            }
+            if (nn) fprintf(stderr, "    dB stage (thread 0): max + barrier %.0f | log10 + sums %.0f | reduce + barrier %.0f | mean, squares, reduce, barriers %.0f | std %.0f | z + stores %.0f\n",
+                            dd[0] / nn, dd[1] / nn, dd[2] / nn, dd[3] / nn, dd[4] / nn, dd[5] / nn);
         }
         if (n) fprintf(stderr, "  k_stft_pair timeline, mean cycles over %d workgroups: tables staged %.0f | pair rounds (last wave) %.0f %.0f %.0f %.0f | to the barrier %.0f | dB stage %.0f | "
                                "total %.0f cycles = %.0f ticks of 10 ns (%.2f GHz)\n", n, d[0] / n, d[1] / n, d[2] / n, d[3] / n, d[4] / n, d[5] / n, d[6] / n, d[7] / n, ticks / n,

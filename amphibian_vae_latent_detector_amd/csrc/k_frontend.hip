@@ -1077,7 +1077,12 @@ __global__ __launch_bounds__(64 * NW) void k_stft_mel(StftParams p, int n_tiles)
 // in double, two-pass std); the mel power never reaches HBM (-3.7 MB written, -1.9 MB read and one launch less per 256 rows).
 __device__ __forceinline__ float to_db(float s, float ref_db);
 template <int NT, int C = 8>
-__device__ __forceinline__ void db_row_from_lds(const float* mp, int T, int M, int TT, int layout, float* out, double* red) {
+__device__ __forceinline__ void db_row_from_lds(const float* mp, int T, int M, int TT, int layout, float* out, double* red, unsigned long long* dbg = nullptr) {
+#ifdef AMPH_STAMPS
+#define AMPH_DB_T(k_) if (dbg && threadIdx.x == 0) { unsigned long long t_; asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); dbg[k_] = t_; }
+#else
+#define AMPH_DB_T(k_)
+#endif
     constexpr int NWV = NT / 64;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int n = T * M;
@@ -1092,6 +1097,7 @@ __device__ __forceinline__ void db_row_from_lds(const float* mp, int T, int M, i
     mx = wave_max_dpp(mx);
     if (lane == 63) redf[w] = mx;
     __syncthreads();
+    AMPH_DB_T(0)
     mx = redf[0];
 #pragma unroll
     for (int g = 1; g < NWV; ++g) mx = fmaxf(mx, redf[g]);
@@ -1100,9 +1106,11 @@ __device__ __forceinline__ void db_row_from_lds(const float* mp, int T, int M, i
 #pragma unroll
     for (int j = 0; j < C; ++j) if (tid + NT * j < n) { v[j] = to_db(v[j], ref_db); acc += (double)v[j]; }
     for (int i = tid + NT * C; i < n; i += NT) acc += (double)to_db(mp[i], ref_db);
+    AMPH_DB_T(1)
     acc = wave_sum_dpp(acc);
     if (lane == 63) red[w] = acc;
     __syncthreads();
+    AMPH_DB_T(2)
     double tot = 0.0;
 #pragma unroll
     for (int g = 0; g < NWV; ++g) tot += red[g];
@@ -1115,19 +1123,22 @@ __device__ __forceinline__ void db_row_from_lds(const float* mp, int T, int M, i
     __syncthreads();                                     // every wave has read the first sums
     if (lane == 63) red[w] = acc;
     __syncthreads();
+    AMPH_DB_T(3)
     tot = 0.0;
 #pragma unroll
     for (int g = 0; g < NWV; ++g) tot += red[g];
     const float sd = sqrtf((float)(tot / (double)n));
     const float den = sd + 1e-8f;
+    AMPH_DB_T(4)
     // crop_or_pad_time (map_detector_core.py:185-195): destination frame = source frame - shift
     const int shift = (T >= TT) ? (T - TT) / 2 : -((TT - T) / 2);
+    const int m_sh = (M & (M - 1)) == 0 ? __builtin_ctz(M) : -1;        // band counts are powers of two in every preset: e / M as a shift
     // source-major, like k_dbnorm's cached form: the dB values of passes 2 and 3 are still in registers (no third log10)
 #pragma unroll
     for (int j = 0; j < C; ++j) {
         const int e = tid + NT * j;
         if (e < n) {
-            const int fr = e / M, m = e - fr * M, tt = fr - shift;
+            const int fr = m_sh >= 0 ? e >> m_sh : e / M, m = e - fr * M, tt = fr - shift;
             if (tt >= 0 && tt < TT) {
                 const float z = (v[j] - mean) / den;
                 if (layout == 1) out[tt * M + m] = z; else out[m * TT + tt] = z;
@@ -1954,7 +1965,11 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
 #endif
         db_row_from_lds<kThreads>(mp_row, p.n_frames, p.n_mels, p.db_target_frames, p.db_layout,
                                   p.db_out + (long long)last_row * p.db_target_frames * p.n_mels,
-                                  reinterpret_cast<double*>(mp_row + ((p.n_frames * p.n_mels + 3) & ~3)));
+                                  reinterpret_cast<double*>(mp_row + ((p.n_frames * p.n_mels + 3) & ~3))
+#ifdef AMPH_STAMPS
+                                  , tl + 9
+#endif
+                                  );
 #ifdef AMPH_STAMPS
         __syncthreads();
         if (tid == 0) { unsigned long long t_; asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); tl[7] = t_; tl[8] = __builtin_amdgcn_s_memrealtime() - pw_rt0; }
@@ -2475,6 +2490,9 @@ void launch_dbnorm(const DbNormParams& p, int n_rows, hipStream_t s) {
     else hipLaunchKernelGGL((k_dbnorm<0, 256>), dim3(n_rows), dim3(256), 0, s, p);                          // anything longer: recompute per pass
 }
 
+#ifdef AMPH_ABL_SKIP
+int g_abl_skip_k0 = 0;       // timing-only diagnostic build: bit 0 / 1 leave out K0's first / second kernel (amph_abl_skip bits 7 / 8)
+#endif
 int rms_scale_chunks(int n_in) { return (n_in + kNpChunk - 1) / kNpChunk; }
 // Rows of more numpy chunks (8 192 samples) than this take the (row, chunk) + (row, tile) kernels.  A one-pass row fits the single kernel
 // up to 4 chunks, and alone on the GPU that form is faster (15 vs 20 us per 256 one-second rows), but its 1024-thread, 70 KB workgroups wait
@@ -2487,10 +2505,16 @@ void launch_rms_scale_pcm16(const int16_t* in, long long row_stride, const int32
     const int n_chunks = rms_scale_chunks(n_in);
     if (chunk_sums && n_chunks > chunk_path_over) {
         // rows longer than one LDS pass: (row, chunk) workgroups sum the chunks, (row, tile) workgroups fold + normalise + pad
+#ifdef AMPH_ABL_SKIP
+        if (!(g_abl_skip_k0 & 1))
+#endif
         hipLaunchKernelGGL((k_rms_scale<int16_t, 256, 1>), dim3(n_rows, n_chunks), dim3(256), (rms_scale_lds<int16_t, 1>()), s, in, row_stride, lengths, n_in,
                            scale, ok, static_cast<int16_t*>(nullptr), NormPad{}, scale_f64, chunk_sums, n_chunks);
         const int total_out = (pad.lead > 0 ? pad.n_fix : n_in) + 2 * pad.lead;
         const int tiles = norm_out ? std::max(1, std::min(64, total_out / (2 * 256 * 16))) : 1;      // ~16 dwords per thread
+#ifdef AMPH_ABL_SKIP
+        if (!(g_abl_skip_k0 & 2))
+#endif
         hipLaunchKernelGGL(k_rms_fold_apply, dim3(n_rows, tiles), dim3(256), 0, s, in, row_stride, lengths, n_in, chunk_sums, n_chunks, scale_f64,
                            scale, ok, norm_out, pad);
         return;
