@@ -30,6 +30,7 @@ for nw in (8, 10, 12):
             print(f"waves {nw} rms {int(rms)} ragged {int(ln is not None)}: mel power max |d| / row max = {dp.max():.2e}; image (separate dB) max |d| = "
                   f"{np.abs(i0 - i1).max():.2e}; image (fused dB) max |d| = {np.abs(f0 - f1).max():.2e}; fused vs separate (pair) {np.abs(f1 - i1).max():.2e}",
                   flush=True)
+            assert np.isfinite(dp).all() and np.isfinite(f1).all() and np.isfinite(i1).all(), "non-finite output"
             worst = max(worst, dp.max())
 # several rows per workgroup (the pair counter starts over per row; the dB stage of a row runs between two rows' pairs)
 s.configure("stft_pair_waves", 12)
@@ -48,4 +49,4 @@ for grid in (7, 3):
           f"fused vs separate (pair) {np.abs(f1 - i1).max():.2e}", flush=True)
     worst = max(worst, dp.max())
 print("worst mel power difference relative to the row's peak:", worst)
-assert worst < 1e-6
+assert np.isfinite(worst) and 0.0 < worst < 1e-6, worst
