@@ -384,10 +384,12 @@ int build_frontend(amph_ctx* c) {
     // of the first stage (tools/fft_pair_model.py)
     if (stft_pair_ok(n_fft, f.hop_length, c->mel_p_tail)) {
         std::vector<float> pt(stft_pair_table_bytes() / 4, 0.0f);
+        // lane l reads dword dw(l) of every 64-dword sample row (k_stft_pair: lanes l, l + 16 share a column pair)
+        auto lane_dw = [](int l) { return (l & 15) + 16 * (l >> 5) + 32 * ((l >> 4) & 1); };
         for (int j = 0; j < 16; ++j)
             for (int l = 0; l < 64; ++l)
                 for (int e = 0; e < 2; ++e) {
-                    const int n = 128 * j + 2 * l + e;
+                    const int n = 128 * j + 2 * lane_dw(l) + e;
                     const float w = (float)(0.5 - 0.5 * std::cos(2.0 * PI * (double)n / (double)n_fft));
                     pt[(size_t)(j * 64 + l) * 2 + e] = w * (1.0f / 32768.0f);      // x / 32768 * w == x * (w / 32768): exact scaling
                 }
@@ -406,7 +408,7 @@ int build_frontend(amph_ctx* c) {
         std::vector<float2> tw1(2 * 16 * 64);
         for (int k = 0; k < 16; ++k)
             for (int l = 0; l < 64; ++l) {
-                const int col = 2 * (l & 31) + (l >> 5);
+                const int col = 2 * ((l & 15) + 16 * (l >> 5)) + ((l >> 4) & 1);
                 float* e = reinterpret_cast<float*>(tw1.data()) + ((size_t)k * 64 + l) * 4;
                 for (int u = 0; u < 2; ++u) {
                     const double a = -2.0 * PI * (double)((col * (k + 16 * u)) % n_fft) / (double)n_fft;

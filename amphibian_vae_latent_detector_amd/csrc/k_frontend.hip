@@ -1508,11 +1508,12 @@ __global__ __launch_bounds__(64 * NW) void k_stft_mel_w(StftParams p, int n_tile
 // no twiddle in the real-FFT split (|A|^2, |B|^2 from Z[k], Z[N - k] are 8 operations per bin pair), a radix-2 instead of
 // a radix-4 cross-lane stage, twice the independent work per wave between two LDS round trips, ~900 instead of ~1300 VALU
 // instructions per frame.
-//   load     lane l, dword j' (0 .. 15 + HJ): samples 128 j' + 2 l + e of the K0-padded PCM16 row (coalesced 256-byte
-//            rows; hop = 128 HJ, so frame b's dword j' is frame a's dword j' + HJ); e = 0, 1 are two 16-point sequences:
-//            lanes < 32 hold the even-j halves of columns 2 l + e, lanes >= 32 the odd-j halves of columns 2 (l - 32) + e
-//   stage 1  dft16 per sequence, v_permlane32_swap so that every lane has both halves of ONE column col(l) = 2 (l & 31) +
-//            (l >> 5), radix-2 combine -> Y[k1], k1 = 0..31; twiddle W_2048^(col k1)
+//   load     lane l, dword j' (0 .. 15 + HJ): samples 128 j' + 2 d + e, d = dw(l) = (l & 15) + 16 (l >> 5) + 32 ((l >> 4) & 1), of the
+//            K0-padded PCM16 row (whole 256-byte rows per wave load; hop = 128 HJ, so frame b's dword j' is frame a's dword j' + HJ);
+//            e = 0, 1 are two 16-point sequences: with p = (l & 15) + 16 (l >> 5), lanes with bit 4 clear hold the even-j halves of
+//            columns 2 p + e, their neighbours l + 16 the odd-j halves
+//   stage 1  dft16 per sequence, v_permlane16_swap so that every lane has both halves of ONE column col(l) = 2 p + ((l >> 4) & 1) -
+//            lanes 0..31 own columns 0..31: conflict-free exchange stores -, radix-2 combine -> Y[k1], k1 = 0..31; twiddle W_2048^(col k1)
 //   exchange T[k1][col] floats (real parts, then imaginary parts: the tile is 8.5 KB per wave, not 17);
 //            lane 2 k1' + h reads T[k1'][32 h .. 32 h + 31] as eight 16-byte reads per pass
 //   stage 2  radix-2 DIF across the lane pair (DPP), twiddle W_64^mm on h = 1, DFT32 in registers:
@@ -1604,7 +1605,11 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
     // the 31 table rows and 19 sample rows each got their own 64-bit per-lane address, i.e. ~100 live VGPRs of addresses
     const __amdgpu_buffer_rsrc_t rs_tw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(p.pair_tw1), 0, -1, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src.wave), 0, -1, 0x00020000);
-    const int lane4 = lane * 4, lane16 = lane * 16;
+    // lane -> dword of a 64-dword sample row: lanes l and l + 16 hold the even-j / odd-j halves of ONE column pair (dwords d, d + 32),
+    // so that v_permlane16_swap completes a column per lane and each 32-lane half ends up with 32 CONSECUTIVE columns - its exchange
+    // stores hit 32 different banks (with lanes l, l + 32 paired a half owned the even columns only: every store 2-way conflicted)
+    const int lane_dw = (lane & 15) + 16 * (lane >> 5) + 32 * ((lane >> 4) & 1);
+    const int lane4 = lane_dw * 4, lane16 = lane * 16;
     auto fetch = [&](int row_, int pr_) {
         const int base = __builtin_amdgcn_readfirstlane((int)(((long long)row_ * p.src.row_stride) * 2 + (long long)pr_ * p.hop * 4));
         const bool full = 2 * pr_ + 1 < p.n_frames;        // wave-uniform: the row's last pair may hold one frame only
@@ -1667,7 +1672,7 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
 #endif
 
     const int n_pairs = (p.n_frames + 1) >> 1;
-    const int col = 2 * (lane & 31) + (lane >> 5);          // stage-1 column of this lane
+    const int col = 2 * ((lane & 15) + 16 * (lane >> 5)) + ((lane >> 4) & 1);      // stage-1 column of this lane
     const int k1p = lane >> 1, h = lane & 1;                // stage-2 role
     const int lanep = k1p + 32 * h;                         // bins lanep + 64 k2'
     const int colp = (64 - lanep) & 63;                     // the lane' that holds the partners N - k
@@ -1728,8 +1733,8 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
             for (int k8 = 8; k8 < 16; ++k8) if (!TWL) tw[k8] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_tw, lane16, k8 * 1024, 0));
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                const auto sr = __builtin_amdgcn_permlane32_swap(__float_as_uint(XR[q].x), __float_as_uint(XR[q].y), false, false);
-                const auto si = __builtin_amdgcn_permlane32_swap(__float_as_uint(XI[q].x), __float_as_uint(XI[q].y), false, false);
+                const auto sr = __builtin_amdgcn_permlane16_swap(__float_as_uint(XR[q].x), __float_as_uint(XR[q].y), false, false);
+                const auto si = __builtin_amdgcn_permlane16_swap(__float_as_uint(XI[q].x), __float_as_uint(XI[q].y), false, false);
                 XR[q] = amph_f2{__uint_as_float(sr[0]), __uint_as_float(sr[1])};
                 XI[q] = amph_f2{__uint_as_float(si[0]), __uint_as_float(si[1])};
             }
