@@ -5,12 +5,13 @@ z = w (a + i b) on one 64-lane wave, 32 complex points per lane.  The model move
 (which lane, which register, which LDS word) and checks the result against numpy's rfft of both frames; it was written
 before the kernel.  Run: python tools/fft_pair_model.py
 
-Index maps (N = 2048, lane l, col(l) = 2 (l & 31) + (l >> 5)):
-  load     lane l, dword j' (0..15): samples n = 128 j' + 2 l + e, e = 0, 1        -> seq[e][m = j']
-           l < 32: n = 64 (2 j') + (2 l + e)        : the EVEN-j half of column 2 l + e
-           l >= 32: n = 64 (2 j' + 1) + (2 (l-32) + e): the ODD-j half of column 2 (l - 32) + e
-  dft16    per sequence; then v_permlane32_swap(seq[0] of the high lanes <-> seq[1] of the low lanes):
-           every lane holds E (seq 0) and O (seq 1) of ONE column col(l)
+Index maps (N = 2048, lane l, p(l) = (l & 15) + 16 (l >> 5), b4 = (l >> 4) & 1, dw(l) = p + 32 b4, col(l) = 2 p + b4):
+  load     lane l, dword j' (0..15): samples n = 128 j' + 2 dw(l) + e, e = 0, 1    -> seq[e][m = j']
+           b4 = 0: n = 64 (2 j') + (2 p + e)        : the EVEN-j half of column 2 p + e
+           b4 = 1: n = 64 (2 j' + 1) + (2 p + e)    : the ODD-j half of column 2 p + e
+  dft16    per sequence; then v_permlane16_swap(seq[0] of the odd 16-lane rows <-> seq[1] of the even rows):
+           every lane holds E (seq 0) and O (seq 1) of ONE column col(l); lanes 0..31 own columns 0..31 (conflict-free
+           exchange stores; the first version paired lanes l, l + 32: a half wave owned the even columns only)
   combine  Y[k + 16 p] = E[k] +- W32^k O[k]                                         -> arr[p][POS(k)]
   twiddle  Y'[k1] = Y[k1] W_2048^(col(l) k1)
   exchange T[k1][col]; lane 2 k1' + h reads T[k1'][32 h + mm], mm = 0..31 (b128 rows)
@@ -52,8 +53,12 @@ def dft32_arrays(a0, a1):
     return r0, r1
 
 
+def pair_of_lane(l):
+    return (l & 15) + 16 * (l >> 5)
+
+
 def col_of_lane(l):
-    return 2 * (l & 31) + (l >> 5)
+    return 2 * pair_of_lane(l) + ((l >> 4) & 1)
 
 
 def wave_pair_power(row, s0):
@@ -64,18 +69,19 @@ def wave_pair_power(row, s0):
     for l in range(64):
         for jp in range(16):
             for e in range(2):
-                n = 128 * jp + 2 * l + e
+                n = 128 * jp + 2 * (pair_of_lane(l) + 32 * ((l >> 4) & 1)) + e
                 seq[l, e, jp] = w[n] * (row[s0 + n] + 1j * row[s0 + HOP + n])
     # ---- dft16 per sequence
     d = np.zeros_like(seq)
     for l in range(64):
         for e in range(2):
             d[l, e] = dft16_inplace(seq[l, e])
-    # ---- permlane32_swap(vdst = seq0, src0 = seq1): vdst[32 + i] <-> src0[i]
+    # ---- permlane16_swap(vdst = seq0, src0 = seq1): vdst's odd rows of 16 lanes <-> src0's even rows
     E = d[:, 0].copy()
     O = d[:, 1].copy()
-    for i in range(32):
-        E[32 + i], O[i] = d[i, 1].copy(), d[32 + i, 0].copy()
+    for r in (0, 2):
+        for i in range(16):
+            E[16 * (r + 1) + i], O[16 * r + i] = d[16 * r + i, 1].copy(), d[16 * (r + 1) + i, 0].copy()
     # now lane l: E = even-j half, O = odd-j half of column col_of_lane(l)
     arr = np.zeros((64, 2, 16), complex)
     for l in range(64):
