@@ -631,8 +631,8 @@ __device__ __forceinline__ void dft16_pk(amph_f2 (&re)[16], amph_f2 (&im)[16]) {
 //   T   = (oi s + or c, oi c - or s)   v_pk_fma_f32  im[.y, .y] * P[s | c] + tmp         T = W32^k O = (tr, ti)
 //   re  = (er + tr, er - tr)           v_pk_add_f32  re[.x, .x] + T[.x, -.x]
 //   im  = (ei + ti, ei - ti)           v_pk_add_f32  im[.x, .x] + T[.y, -.y]
-// four instructions per k instead of eight scalar ones (the kernel is bound by its vector instruction count: every one holds the
-// SIMD for four cycles, packed or not - 86 % VALU-busy inside the pair loop, profiles/r03_stft_pair_timeline.txt).  The constant
+// four instructions per k instead of eight scalar ones (1 228 -> 1 031 vector instructions per pair; a SIMD's first wave runs its
+// pairs 4 % sooner, the aggregate is set by the LDS pipe: profiles/r03_stft_pair_timeline.txt).  The constant
 // pair P = (cos, sin)(pi j / 16), j = 1..4, serves all k through the selectors: c, s = P.x, P.y (k = j), P.y, P.x (k = 8 - j),
 // -P.y, P.x (k = 8 + j), -P.x, P.y (k = 16 - j) - four SGPR pairs.  tools/probe/pk_opsel.hip checks the selector semantics.
 template <int K>
