@@ -67,7 +67,8 @@ struct GemmLayer {
     ConvGemmParams prm_m(int M) const { ConvGemmParams q = prm; q.M = M; return q; }
     int bm = 128;
     float* d_w = nullptr;
-    uint16_t* d_w_s3 = nullptr;     // three-term bf16 split [n_pad / 64][K_pad / 32][64][3][32] for k_conv_gemm_s3 (nullptr: shape not covered)
+    uint16_t* d_w_s3 = nullptr;     // three-term bf16 split [n_pad / 64][K_pad / 32][64][3][32] for k_conv_gemm_f3s (nullptr: shape not covered)
+    uint16_t* d_w_h2 = nullptr;     // two-term fp16 split [n_pad / 64][K_pad / 32][64][2][32] for k_conv_gemm_s3 / _s3w
     uint16_t* d_w_f4 = nullptr;     // the same split in MFMA fragment order for k_conv_gemm_f4s (first GEMM layer) / k_conv_gemm_g4 (C_in 64 / 128)
     uint16_t* d_w_f4b = nullptr;    // bf16 weights in MFMA fragment order for k_conv_gemm_f4b (first GEMM layer, K_pad == 288 only)
     uint16_t* d_w_bf16 = nullptr;   // bf16 copy [n_pad][K_pad_b] for the bf16 encoder path
@@ -519,6 +520,11 @@ int build_encoder(amph_ctx* c, const float* hw, size_t n_floats) {
                 std::vector<uint16_t> w3((size_t)n_pad * K_pad * 3);
                 conv_gemm_s3_split_weights(wg.data(), n_pad, K_pad, w3.data());
                 HIP_TRY(c, upload(&gl.d_w_s3, w3));
+                {
+                    std::vector<uint16_t> w2((size_t)n_pad * K_pad * 2);
+                    conv_gemm_h2_split_weights(wg.data(), n_pad, K_pad, w2.data());
+                    HIP_TRY(c, upload(&gl.d_w_h2, w2));
+                }
                 if (i == 1 && K_pad == 288) {
                     std::vector<uint16_t> wb((size_t)n_pad * K_pad);
                     conv_gemm_f4b_fragment_weights(wg.data(), n_pad, K_pad, wb.data());
@@ -568,10 +574,10 @@ int build_encoder(amph_ctx* c, const float* hw, size_t n_floats) {
         }
         GemmLayer gl;
         HIP_TRY(c, upload(&gl.d_w, wg));
-        if (flat % 32 == 0) {
-            std::vector<uint16_t> w3((size_t)n_pad * K_pad * 3);
-            conv_gemm_s3_split_weights(wg.data(), n_pad, K_pad, w3.data());
-            HIP_TRY(c, upload(&gl.d_w_s3, w3));
+        if (flat % 32 == 0) {                            // the head only runs through k_conv_gemm_s3: the two-term fp16 weights
+            std::vector<uint16_t> w2((size_t)n_pad * K_pad * 2);
+            conv_gemm_h2_split_weights(wg.data(), n_pad, K_pad, w2.data());
+            HIP_TRY(c, upload(&gl.d_w_h2, w2));
         }
         gl.K_pad_b = (flat + 63) / 64 * 64;
         HIP_TRY(c, upload_bf16(&gl.d_w_bf16, wg, n_pad, K_pad, gl.K_pad_b));
@@ -869,9 +875,9 @@ int run_encoder(amph_ctx* c, Workspace& w, const float* d_x, int nb, float* d_mu
                 continue;
             }
         }
-        if (c->split_gemm && !fused_here && c->gemm[gi].d_w_s3 && conv_gemm_s3_ok(prm[gi])) {
+        if (c->split_gemm && !fused_here && c->gemm[gi].d_w_h2 && conv_gemm_s3_ok(prm[gi])) {
             ConvGemmParams ps = prm[gi];
-            ps.w = reinterpret_cast<const float*>(c->gemm[gi].d_w_s3);
+            ps.w = reinterpret_cast<const float*>(c->gemm[gi].d_w_h2);
             const bool wide = c->wide_gemm > 0 || (c->wide_gemm < 0 && c->active_lanes > 1 && (long long)((ps.M + 127) / 128) * (ps.N / 128) * 4 >= amph::g_num_cus);
             if (wide && !head && conv_gemm_s3w_ok(ps)) launch_conv_gemm_s3w(ps, s);
             else launch_conv_gemm_s3(ps, s);
@@ -1163,7 +1169,7 @@ void amph_destroy(amph_ctx* c) {
     fr(c->d_tables); fr(c->d_tw_a); fr(c->d_pair_tables); fr(c->d_pair_tw1);
     fr(c->d_mel_start); fr(c->d_mel_len); fr(c->d_mel_wofs); fr(c->d_mel_w);
     fr(c->d_first_w); fr(c->d_first_scale); fr(c->d_first_shift);
-    for (auto& g : c->gemm) { fr(g.d_w); fr(g.d_w_s3); fr(g.d_w_f4); fr(g.d_w_f4b); fr(g.d_w_bf16); fr(g.d_scale); fr(g.d_shift); }
+    for (auto& g : c->gemm) { fr(g.d_w); fr(g.d_w_s3); fr(g.d_w_h2); fr(g.d_w_f4); fr(g.d_w_f4b); fr(g.d_w_bf16); fr(g.d_scale); fr(g.d_shift); }
     fr(c->d_head_bias); fr(c->d_zeros);
     for (auto& w : c->lanes) free_lane(w);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);

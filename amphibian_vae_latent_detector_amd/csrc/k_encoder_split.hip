@@ -39,13 +39,32 @@ namespace amph {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 amph_h2 __attribute__((ext_vector_type(2)));
+constexpr float kH2Lo = 1.0f / 2048.0f;          // weight of the cross-term accumulator
+// x -> (h, l) pairs of two values: h = fp16(x) (RNE), l = fp16((x - h) 2^11) - x - h is exact in fp32
+__device__ __forceinline__ void h2_split2(float x0, float x1, uint32_t& h, uint32_t& l) {
+    const amph_h2 hp = {(_Float16)x0, (_Float16)x1};
+    h = __builtin_bit_cast(uint32_t, hp);
+    const float r0 = (x0 - (float)hp.x) * 2048.0f, r1 = (x1 - (float)hp.y) * 2048.0f;
+    const amph_h2 lp = {(_Float16)r0, (_Float16)r1};
+    l = __builtin_bit_cast(uint32_t, lp);
+}
 
 constexpr int kSBK = 32;                 // K elements per slice (one tap's 32-channel group)
 constexpr int kSRow = 192;               // LDS bytes per row: [h | m | l] x 32 bf16, packed; the 16-byte slot j of row r sits at
                                          // 16 (j ^ ((r >> 2) & 3)): conflict-free 16-byte fragment reads AND conflict-free stores (the padded
                                          // 208-byte rows of the first version showed 26 % of its LDS cycles as bank conflicts)
-constexpr int kSBuf = 64 * kSRow;        // bytes per operand per slice buffer
 constexpr int kSWRow = 192;              // bytes per (n, slice) in the split weight matrix
+// Two-term fp16 split (k_conv_gemm_s3 / _s3w since round 3): x = h + 2^-11 l with h = fp16(x), l = fp16((x - h) 2^11) - 22 significand
+// bits in TWO terms (bf16 needs three for 24), both products of 11-bit values exact in fp32.  x w = h h' + 2^-11 (h l' + l h') (+ 2^-22 l l':
+// dropped) is THREE v_mfma_f32_32x32x16_f16 per K = 16 instead of six: h h' goes to one accumulator, the cross terms to a second that is
+// scaled once in the epilogue.  Measured against the float64 product of the same operands: 1.8e-7 relative (bf16 x 3: 1.3e-8, a plain fp32
+// matmul 5.9e-7 - tools/split_schemes_model.py), i.e. still below the rounding noise of fp32 accumulation.  fp16's range holds the encoder's
+// operands with room (|x| < 65 504; below 6e-5 the split keeps an absolute 3e-11).
+constexpr int kHRow = 128;               // LDS bytes per row: [h | l] x 32 fp16; 16-byte slot j of row r at 16 (j ^ ((r >> 2) & 3))
+constexpr int kHBuf = 64 * kHRow;        // bytes per 64-row operand tile per slice buffer
+constexpr int kHWRow = 128;              // bytes per (n, slice) in the two-term weight matrix
 
 __device__ __forceinline__ int s3_div_small(int n, int d, float rcp) {
     int q = (int)((float)n * rcp);
@@ -75,8 +94,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm_s3(ConvGemmParams p) {
     const unsigned long long q_rt0 = __builtin_amdgcn_s_memrealtime();
     AMPH_S3_T(q_t0)
 #endif
-    char* As = smem;                                   // [3][64][192]
-    char* Bs = smem + 3 * kSBuf;                       // [3][64][192]
+    char* As = smem;                                   // [3][64][128]
+    char* Bs = smem + 3 * kHBuf;                       // [3][64][128]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c4 = tid & 7, r0 = tid >> 3;             // A staging: rows r0, r0 + 32; k = 4 c4 .. 4 c4 + 3 of the slice
@@ -98,19 +117,18 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm_s3(ConvGemmParams p) {
     // operand delivery from L2 (20 KB per workgroup and slice against 384 cycles of MFMA time per wave), i.e. by the bytes a
     // CU keeps in flight: with three stages (one slice in flight per workgroup) conv3 took 22.8 us against 6.6 us of MFMA time
     float4 sa0x, sa0y, sa1x, sa1y, sa2x, sa2y, sa3x, sa3y;             // rows r0, r0 + 32
-    uint4 sb0a, sb0b, sb0c, sb1a, sb1b, sb1c, sb2a, sb2b, sb2c, sb3a, sb3b, sb3c;
-    int w_soff = (blockIdx.y * n_slices + ks_begin) * (64 * kSWRow);
+    uint4 sb0a, sb0b, sb1a, sb1b, sb2a, sb2b, sb3a, sb3b;
+    int w_soff = (blockIdx.y * n_slices + ks_begin) * (64 * kHWRow);
     const unsigned woff = 16u * (unsigned)tid;
 #define AMPH_S3_LOADB(q)                                                                   \
     {                                                                                      \
         sb##q##a = __builtin_bit_cast(uint4, AMPH_S3_BUFLOAD(rs_w, woff, w_soff));          \
         sb##q##b = __builtin_bit_cast(uint4, AMPH_S3_BUFLOAD(rs_w, woff + 4096u, w_soff));  \
-        sb##q##c = __builtin_bit_cast(uint4, AMPH_S3_BUFLOAD(rs_w, woff + 8192u, w_soff));  \
     }
 
     // the B halves of the four prologue slices are requested before any setup arithmetic (slice min(s, sps - 1), as ADV clamps)
     {
-        const int blk = 64 * kSWRow;
+        const int blk = 64 * kHWRow;
         const int o1 = sps > 1 ? blk : 0, o2 = sps > 2 ? 2 * blk : o1, o3 = sps > 3 ? 3 * blk : o2;
         AMPH_S3_LOADB(0)
         w_soff += o1; AMPH_S3_LOADB(1)
@@ -170,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm_s3(ConvGemmParams p) {
     {                                                                                      \
         const int adv_ = l_left > 1 ? 1 : 0;                                               \
         l_left -= adv_;                                                                    \
-        w_soff = __builtin_amdgcn_readfirstlane(w_soff + 64 * kSWRow * adv_);              \
+        w_soff = __builtin_amdgcn_readfirstlane(w_soff + 64 * kHWRow * adv_);              \
         x_soff += kSBK * kEl * adv_;                                                       \
         l_ci0 += kSBK * adv_;                                                              \
         const int wrap_ = l_ci0 >= p.C_in ? 1 : 0;                                         \
@@ -185,37 +203,35 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm_s3(ConvGemmParams p) {
 #define AMPH_S3_LOADA_ADV(q) { AMPH_S3_LOADA(q) AMPH_S3_ADV() }
 
     // stage q -> LDS buffer buf_: B rows are the LDS image already; A rows are split here
-    const int st_a = r0 * kSRow + 16 * ((c4 >> 1) ^ ((r0 >> 2) & 3)) + 8 * (c4 & 1);     // (row r0 + 32 has the same swizzle)
-    int st_b0, st_b1, st_b2;                           // byte o of the block -> LDS row o / 192, swizzled slot of column o % 192
+    const int st_a = r0 * kHRow + 16 * ((c4 >> 1) ^ ((r0 >> 2) & 3)) + 8 * (c4 & 1);     // (row r0 + 32 has the same swizzle)
+    int st_b0, st_b1;                                  // byte o of the block -> LDS row o / 128, swizzled slot of column o % 128
     {
-        const int o0 = 16 * tid, o1 = o0 + 4096, o2 = o0 + 8192;
-#define AMPH_S3_SW(o_) (((o_) / kSWRow) * kSRow + 16 * ((((o_) % kSWRow) >> 4) ^ ((((o_) / kSWRow) >> 2) & 3)))
-        st_b0 = AMPH_S3_SW(o0); st_b1 = AMPH_S3_SW(o1); st_b2 = AMPH_S3_SW(o2);
+        const int o0 = 16 * tid, o1 = o0 + 4096;
+#define AMPH_S3_SW(o_) (((o_) / kHWRow) * kHRow + 16 * ((((o_) % kHWRow) >> 4) ^ ((((o_) / kHWRow) >> 2) & 3)))
+        st_b0 = AMPH_S3_SW(o0); st_b1 = AMPH_S3_SW(o1);
 #undef AMPH_S3_SW
     }
 #define AMPH_S3_SPLIT_ROW(v_, dst_)                                                        \
     {                                                                                      \
-        uint32_t h0, m0, l0, h1, m1, l1;                                                   \
-        s3_split2(v_.x, v_.y, h0, m0, l0);                                                 \
-        s3_split2(v_.z, v_.w, h1, m1, l1);                                                 \
+        uint32_t h0, l0, h1, l1;                                                           \
+        h2_split2(v_.x, v_.y, h0, l0);                                                     \
+        h2_split2(v_.z, v_.w, h1, l1);                                                     \
         *reinterpret_cast<uint2*>(dst_) = make_uint2(h0, h1);                              \
-        *reinterpret_cast<uint2*>(dst_ + 64) = make_uint2(m0, m1);                         \
-        *reinterpret_cast<uint2*>(dst_ + 128) = make_uint2(l0, l1);                        \
+        *reinterpret_cast<uint2*>(dst_ + 64) = make_uint2(l0, l1);                         \
     }
 #define AMPH_S3_STORE(q, buf_)                                                             \
     {                                                                                      \
-        char* a_ = As + (buf_) * kSBuf + st_a;                                             \
-        char* b_ = Bs + (buf_) * kSBuf;                                                    \
+        char* a_ = As + (buf_) * kHBuf + st_a;                                             \
+        char* b_ = Bs + (buf_) * kHBuf;                                                    \
         *reinterpret_cast<uint4*>(b_ + st_b0) = sb##q##a;                                  \
         *reinterpret_cast<uint4*>(b_ + st_b1) = sb##q##b;                                  \
-        *reinterpret_cast<uint4*>(b_ + st_b2) = sb##q##c;                                  \
         AMPH_S3_SPLIT_ROW(sa##q##x, a_)                                                    \
-        AMPH_S3_SPLIT_ROW(sa##q##y, (a_ + 32 * kSRow))                                     \
+        AMPH_S3_SPLIT_ROW(sa##q##y, (a_ + 32 * kHRow))                                     \
     }
 
-    f32x16 acc;
+    f32x16 acc, accl;                                  // h h' | h l' + l h' (x 2^-11 in the epilogue)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.0f; accl[r] = 0.0f; }
     const int row_tile = wave >> 1, col_tile = wave & 1;
     float4 e_sc0, e_sc1, e_sc2, e_sc3, e_sh0, e_sh1, e_sh2, e_sh3;
     {
@@ -229,40 +245,39 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm_s3(ConvGemmParams p) {
 #undef AMPH_S3_BN
     }
     // fragment addresses: lane l holds row (l & 31), k = 16 kstep + 8 (l >> 5) + j of each term
-    // (slot 4 t + 2 kstep + (l >> 5) of the row; the swizzle touches the low two bits only, so the terms stay 64 bytes apart)
+    // (slot 4 t + 2 kstep + (l >> 5) of the row; the swizzle touches the low two bits only, so the two terms stay 64 bytes apart)
     const int swl = ((lane & 31) >> 2) & 3;
-    const char* a_rd0 = As + (row_tile * 32 + (lane & 31)) * kSRow + 16 * ((lane >> 5) ^ swl);
-    const char* a_rd1 = As + (row_tile * 32 + (lane & 31)) * kSRow + 16 * ((2 + (lane >> 5)) ^ swl);
-    const char* b_rd0 = Bs + (col_tile * 32 + (lane & 31)) * kSRow + 16 * ((lane >> 5) ^ swl);
-    const char* b_rd1 = Bs + (col_tile * 32 + (lane & 31)) * kSRow + 16 * ((2 + (lane >> 5)) ^ swl);
-#define AMPH_S3_FRAG(base_, buf_, ks_, t_) __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>((base_##ks_) + (buf_) * kSBuf + 64 * (t_)))
+    const char* a_rd0 = As + (row_tile * 32 + (lane & 31)) * kHRow + 16 * ((lane >> 5) ^ swl);
+    const char* a_rd1 = As + (row_tile * 32 + (lane & 31)) * kHRow + 16 * ((2 + (lane >> 5)) ^ swl);
+    const char* b_rd0 = Bs + (col_tile * 32 + (lane & 31)) * kHRow + 16 * ((lane >> 5) ^ swl);
+    const char* b_rd1 = Bs + (col_tile * 32 + (lane & 31)) * kHRow + 16 * ((2 + (lane >> 5)) ^ swl);
+#define AMPH_S3_FRAG(base_, buf_, ks_, t_) __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>((base_##ks_) + (buf_) * kHBuf + 64 * (t_)))
     // weights as the FIRST operand: transposed accumulator (lane = output row m, registers 4g .. 4g + 3 = channels), see p3
-#define AMPH_S3_MFMA(w_, x_) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_, x_, acc, 0, 0, 0);
+#define AMPH_S3_MFMA(a_, w_, x_) a_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(w_, x_, a_, 0, 0, 0);
 #define AMPH_S3_READ6(pre_, buf_, ks_)                                                     \
-    pre_##xh = AMPH_S3_FRAG(a_rd, buf_, ks_, 0); pre_##xm = AMPH_S3_FRAG(a_rd, buf_, ks_, 1); pre_##xl = AMPH_S3_FRAG(a_rd, buf_, ks_, 2); \
-    pre_##wh = AMPH_S3_FRAG(b_rd, buf_, ks_, 0); pre_##wm = AMPH_S3_FRAG(b_rd, buf_, ks_, 1); pre_##wl = AMPH_S3_FRAG(b_rd, buf_, ks_, 2);
+    pre_##xh = AMPH_S3_FRAG(a_rd, buf_, ks_, 0); pre_##xl = AMPH_S3_FRAG(a_rd, buf_, ks_, 1); \
+    pre_##wh = AMPH_S3_FRAG(b_rd, buf_, ks_, 0); pre_##wl = AMPH_S3_FRAG(b_rd, buf_, ks_, 1);
     // pieces of the staging work of one slice (stage q -> LDS buffer buf_), one per MFMA gap
 #define AMPH_S3_ST_B(q, buf_)                                                              \
     {                                                                                      \
-        char* b_ = Bs + (buf_) * kSBuf;                                                    \
+        char* b_ = Bs + (buf_) * kHBuf;                                                    \
         *reinterpret_cast<uint4*>(b_ + st_b0) = sb##q##a;                                  \
         *reinterpret_cast<uint4*>(b_ + st_b1) = sb##q##b;                                  \
-        *reinterpret_cast<uint4*>(b_ + st_b2) = sb##q##c;                                  \
     }
-#define AMPH_S3_ST_AX(q, buf_) { char* a_ = As + (buf_) * kSBuf + st_a; AMPH_S3_SPLIT_ROW(sa##q##x, a_) }
-#define AMPH_S3_ST_AY(q, buf_) { char* a_ = As + (buf_) * kSBuf + st_a + 32 * kSRow; AMPH_S3_SPLIT_ROW(sa##q##y, a_) }
+#define AMPH_S3_ST_AX(q, buf_) { char* a_ = As + (buf_) * kHBuf + st_a; AMPH_S3_SPLIT_ROW(sa##q##x, a_) }
+#define AMPH_S3_ST_AY(q, buf_) { char* a_ = As + (buf_) * kHBuf + st_a + 32 * kHRow; AMPH_S3_SPLIT_ROW(sa##q##y, a_) }
 #if defined(AMPH_S3_ABL_NOLOAD)            /* timing-only ablations (make ablations_s3; never shipped) */
 #define AMPH_S3_LOOPLOAD(QL) AMPH_S3_ADV()
 #else
 #define AMPH_S3_LOOPLOAD(QL) AMPH_S3_LOAD(QL)
 #endif
 #if defined(AMPH_S3_ABL_NOMFMA)
-#define AMPH_S3_M(w_, x_) acc[0] += (float)w_[0] + (float)x_[1];
+#define AMPH_S3_M(a_, w_, x_) a_[0] += (float)w_[0] + (float)x_[1];
 #else
-#define AMPH_S3_M(w_, x_) AMPH_S3_MFMA(w_, x_)
+#define AMPH_S3_M(a_, w_, x_) AMPH_S3_MFMA(a_, w_, x_)
 #endif
 #if defined(AMPH_S3_ABL_NOSTORE)
-#define AMPH_S3_SB_(q, buf_) acc[1] += __uint_as_float(sb##q##a.x ^ sb##q##b.y ^ sb##q##c.z);
+#define AMPH_S3_SB_(q, buf_) acc[1] += __uint_as_float(sb##q##a.x ^ sb##q##b.y);
 #define AMPH_S3_SX_(q, buf_) acc[2] += sa##q##x.x;
 #define AMPH_S3_SY_(q, buf_) acc[3] += sa##q##y.y;
 #else
@@ -276,37 +291,30 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm_s3(ConvGemmParams p) {
     // barrier) under the last six: no MFMA waits for an LDS round trip it could not overlap.
 #define AMPH_S3_STEP(R, QL, QS)                                                            \
     {                                                                                      \
-        bf16x8 f1xh, f1xm, f1xl, f1wh, f1wm, f1wl, n0xh, n0xm, n0xl, n0wh, n0wm, n0wl;     \
+        f16x8 f1xh, f1xl, f1wh, f1wl, n0xh, n0xl, n0wh, n0wl;                              \
         AMPH_S3_LOOPLOAD(QL)                                                               \
         AMPH_S3_READ6(f1, R, 1)                                                            \
         AMPH_S3_SB();                                                                      \
-        AMPH_S3_M(f0wl, f0xh)                                                              \
+        AMPH_S3_M(accl, f0wl, f0xh)                                                        \
         AMPH_S3_SB();                                                                      \
         AMPH_S3_SB_(QS, (R + 2) % 3)                                                       \
         AMPH_S3_SB();                                                                      \
-        AMPH_S3_M(f0wh, f0xl)                                                              \
-        AMPH_S3_M(f0wm, f0xm)                                                              \
+        AMPH_S3_M(accl, f0wh, f0xl)                                                        \
         AMPH_S3_SB();                                                                      \
         AMPH_S3_SX_(QS, (R + 2) % 3)                                                       \
         AMPH_S3_SB();                                                                      \
-        AMPH_S3_M(f0wm, f0xh)                                                              \
-        AMPH_S3_M(f0wh, f0xm)                                                              \
+        AMPH_S3_M(acc, f0wh, f0xh)                                                         \
         AMPH_S3_SB();                                                                      \
         AMPH_S3_SY_(QS, (R + 2) % 3)                                                       \
         AMPH_S3_SB();                                                                      \
-        AMPH_S3_M(f0wh, f0xh)                                                              \
-        AMPH_S3_SB();                                                                      \
         AMPH_S3_READ6(n0, (R + 1) % 3, 0)                                                  \
         AMPH_S3_SB();                                                                      \
-        AMPH_S3_M(f1wl, f1xh)                                                              \
-        AMPH_S3_M(f1wh, f1xl)                                                              \
-        AMPH_S3_M(f1wm, f1xm)                                                              \
-        AMPH_S3_M(f1wm, f1xh)                                                              \
-        AMPH_S3_M(f1wh, f1xm)                                                              \
-        AMPH_S3_M(f1wh, f1xh)                                                              \
+        AMPH_S3_M(accl, f1wl, f1xh)                                                        \
+        AMPH_S3_M(accl, f1wh, f1xl)                                                        \
+        AMPH_S3_M(acc, f1wh, f1xh)                                                         \
         AMPH_S3_SB();                                                                      \
         __syncthreads();                                                                   \
-        f0xh = n0xh; f0xm = n0xm; f0xl = n0xl; f0wh = n0wh; f0wm = n0wm; f0wl = n0wl;      \
+        f0xh = n0xh; f0xl = n0xl; f0wh = n0wh; f0wl = n0wl;                                \
     }
 
     // prologue: slices 0 .. 3 into the register stages, 0 and 1 on to LDS
@@ -319,7 +327,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm_s3(ConvGemmParams p) {
     AMPH_S3_T(q_tb)
     AMPH_S3_STORE(1, 1)
     __syncthreads();
-    bf16x8 f0xh, f0xm, f0xl, f0wh, f0wm, f0wl;
+    f16x8 f0xh, f0xl, f0wh, f0wl;
     AMPH_S3_READ6(f0, 0, 0)
     AMPH_S3_T(q_t1)
     // step s uses LDS buffer s % 3 and register stages s % 4 (load) / (s + 2) % 4 (store): twelve steps per trip keep every
@@ -349,7 +357,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm_s3(ConvGemmParams p) {
             {                                                                              \
                 const int n0 = n_blk + col_tile * 32 + 8 * g + 4 * (lane >> 5);            \
                 if (n0 < p.N) {                                                            \
-                    float4 v = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]); \
+                    float4 v = make_float4(fmaf(accl[4 * g], kH2Lo, acc[4 * g]), fmaf(accl[4 * g + 1], kH2Lo, acc[4 * g + 1]),       \
+                                           fmaf(accl[4 * g + 2], kH2Lo, acc[4 * g + 2]), fmaf(accl[4 * g + 3], kH2Lo, acc[4 * g + 3])); \
                     if (p.epilogue == 0) {                                                 \
                         v.x = fmaxf(fmaf(v.x, e_sc##g.x, e_sh##g.x), 0.0f); v.y = fmaxf(fmaf(v.y, e_sc##g.y, e_sh##g.y), 0.0f); \
                         v.z = fmaxf(fmaf(v.z, e_sc##g.z, e_sh##g.z), 0.0f); v.w = fmaxf(fmaf(v.w, e_sc##g.w, e_sh##g.w), 0.0f); \
@@ -384,17 +393,17 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm_s3(ConvGemmParams p) {
 // workgroups (a quarter of the CUs) instead of 256.  Per accumulator the MFMA order is s3's (slice, k-step, term pair), so the
 // results are bit-identical to s3's.  Weights: s3's split matrix; threads 0-255 stage 64-channel block 2 by, 256-511 block 2 by + 1.
 // ----------------------------------------------------------------------------
-constexpr int kWBuf = 128 * kSRow;       // bytes per operand per slice buffer (128 rows)
-constexpr size_t kS3wLds = (size_t)6 * kWBuf + 1024;   // 148 480 B: slice buffers + the tile's BN constants
+constexpr int kWBuf = 128 * kHRow;       // bytes per operand per slice buffer (128 rows)
+constexpr size_t kS3wLds = (size_t)6 * kWBuf + 1024;   // 99 328 B: slice buffers + the tile's BN constants
 
 __global__ __launch_bounds__(512, 1) void k_conv_gemm_s3w(ConvGemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* As = smem;                                   // [3][128][192]
-    char* Bs = smem + 3 * kWBuf;                       // [3][128][192]
+    char* As = smem;                                   // [3][128][128]
+    char* Bs = smem + 3 * kWBuf;                       // [3][128][128]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c4 = tid & 7, r0 = tid >> 3;             // A staging: rows r0, r0 + 64; k = 4 c4 .. 4 c4 + 3 of the slice
-    const int bh = wave >> 2, bt = tid & 255;          // B staging: 64-channel block 2 by + bh, 16-byte piece bt + 256 i of its 12 KB
+    const int bh = wave >> 2, bt = tid & 255;          // B staging: 64-channel block 2 by + bh, 16-byte piece bt + 256 i of its 8 KB
     const int m_blk = blockIdx.x * 128, n_blk = blockIdx.y * 128;
     const int n_slices = p.K_pad / kSBK;
 
@@ -402,17 +411,16 @@ __global__ __launch_bounds__(512, 1) void k_conv_gemm_s3w(ConvGemmParams p) {
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(reinterpret_cast<const char*>(p.x) - p.x_guard), 0, -1, 0x00020000);
     float4 sa[4][2];                                   // register stages (indices are literals everywhere: registers, never scratch)
-    uint4 sb[4][3];
-    int w_soff = __builtin_amdgcn_readfirstlane(((2 * (int)blockIdx.y + bh) * n_slices) * (64 * kSWRow));
+    uint4 sb[4][2];
+    int w_soff = __builtin_amdgcn_readfirstlane(((2 * (int)blockIdx.y + bh) * n_slices) * (64 * kHWRow));
     const unsigned woff = 16u * (unsigned)bt;
 #define AMPH_W_LOADB(q)                                                                    \
     {                                                                                      \
         sb[q][0] = __builtin_bit_cast(uint4, AMPH_S3_BUFLOAD(rs_w, woff, w_soff));          \
         sb[q][1] = __builtin_bit_cast(uint4, AMPH_S3_BUFLOAD(rs_w, woff + 4096u, w_soff));  \
-        sb[q][2] = __builtin_bit_cast(uint4, AMPH_S3_BUFLOAD(rs_w, woff + 8192u, w_soff));  \
     }
     {
-        const int blk = 64 * kSWRow;
+        const int blk = 64 * kHWRow;
         const int o1 = n_slices > 1 ? blk : 0, o2 = n_slices > 2 ? 2 * blk : o1, o3 = n_slices > 3 ? 3 * blk : o2;
         AMPH_W_LOADB(0)
         w_soff += o1; AMPH_W_LOADB(1)
@@ -458,49 +466,48 @@ __global__ __launch_bounds__(512, 1) void k_conv_gemm_s3w(ConvGemmParams p) {
     }
 #define AMPH_W_LOAD(q) { AMPH_W_LOADB(q) AMPH_W_LOADA(q) AMPH_S3_ADV() }
 #define AMPH_W_LOADA_ADV(q) { AMPH_W_LOADA(q) AMPH_S3_ADV() }
-    const int st_a = r0 * kSRow + 16 * ((c4 >> 1) ^ ((r0 >> 2) & 3)) + 8 * (c4 & 1);     // (row r0 + 64 has the same swizzle)
-    int st_b[3];
+    const int st_a = r0 * kHRow + 16 * ((c4 >> 1) ^ ((r0 >> 2) & 3)) + 8 * (c4 & 1);     // (row r0 + 64 has the same swizzle)
+    int st_b[2];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int o = 16 * bt + 4096 * i, row = o / kSWRow, col = o % kSWRow;
-        st_b[i] = (64 * bh + row) * kSRow + 16 * ((col >> 4) ^ ((row >> 2) & 3));
+    for (int i = 0; i < 2; ++i) {
+        const int o = 16 * bt + 4096 * i, row = o / kHWRow, col = o % kHWRow;
+        st_b[i] = (64 * bh + row) * kHRow + 16 * ((col >> 4) ^ ((row >> 2) & 3));
     }
 #define AMPH_W_ST_B(q, buf_)                                                               \
     {                                                                                      \
         char* b_ = Bs + (buf_) * kWBuf;                                                    \
         *reinterpret_cast<uint4*>(b_ + st_b[0]) = sb[q][0];                                \
         *reinterpret_cast<uint4*>(b_ + st_b[1]) = sb[q][1];                                \
-        *reinterpret_cast<uint4*>(b_ + st_b[2]) = sb[q][2];                                \
     }
-#define AMPH_W_ST_A(q, buf_, i_) { char* a_ = As + (buf_) * kWBuf + st_a + (i_) * 64 * kSRow; AMPH_S3_SPLIT_ROW(sa[q][i_], a_) }
+#define AMPH_W_ST_A(q, buf_, i_) { char* a_ = As + (buf_) * kWBuf + st_a + (i_) * 64 * kHRow; AMPH_S3_SPLIT_ROW(sa[q][i_], a_) }
 
-    f32x16 acc[2];
+    f32x16 acc[2], accl[2];                            // per row tile: h h' | h l' + l h' (x 2^-11 in the epilogue)
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+        for (int r = 0; r < 16; ++r) { acc[t][r] = 0.0f; accl[t][r] = 0.0f; }
     const int rg = wave >> 2, ct = wave & 3;
     // BN constants of the tile's 128 channels wait in LDS for the epilogue (32 registers through the loop otherwise)
     float* const bn = reinterpret_cast<float*>(smem + 6 * kWBuf);       // [2][128]
     if (tid < 256) bn[tid] = (tid < 128 ? p.scale : p.shift)[n_blk + (tid & 127)];
     // fragment addresses (s3's): lane l holds row (l & 31), k = 16 kstep + 8 (l >> 5) + j of each term
     const int swl = ((lane & 31) >> 2) & 3;
-    const char* a_rd[2] = {As + (rg * 64 + (lane & 31)) * kSRow + 16 * ((lane >> 5) ^ swl), As + (rg * 64 + (lane & 31)) * kSRow + 16 * ((2 + (lane >> 5)) ^ swl)};
-    const char* b_rd[2] = {Bs + (ct * 32 + (lane & 31)) * kSRow + 16 * ((lane >> 5) ^ swl), Bs + (ct * 32 + (lane & 31)) * kSRow + 16 * ((2 + (lane >> 5)) ^ swl)};
-    struct Frag { bf16x8 x[2][3], w[3]; };               // [row tile][term], [term]
-#define AMPH_W_FR(ptr_) __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ptr_))
+    const char* a_rd[2] = {As + (rg * 64 + (lane & 31)) * kHRow + 16 * ((lane >> 5) ^ swl), As + (rg * 64 + (lane & 31)) * kHRow + 16 * ((2 + (lane >> 5)) ^ swl)};
+    const char* b_rd[2] = {Bs + (ct * 32 + (lane & 31)) * kHRow + 16 * ((lane >> 5) ^ swl), Bs + (ct * 32 + (lane & 31)) * kHRow + 16 * ((2 + (lane >> 5)) ^ swl)};
+    struct Frag { f16x8 x[2][2], w[2]; };                // [row tile][term], [term]
+#define AMPH_W_FR(ptr_) __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(ptr_))
 #define AMPH_W_READ9(f_, buf_, ks_)                                                        \
     {                                                                                      \
-        _Pragma("unroll") for (int q_ = 0; q_ < 3; ++q_) {                                 \
+        _Pragma("unroll") for (int q_ = 0; q_ < 2; ++q_) {                                 \
             f_.x[0][q_] = AMPH_W_FR(a_rd[ks_] + (buf_) * kWBuf + 64 * q_);                 \
-            f_.x[1][q_] = AMPH_W_FR(a_rd[ks_] + (buf_) * kWBuf + 32 * kSRow + 64 * q_);    \
+            f_.x[1][q_] = AMPH_W_FR(a_rd[ks_] + (buf_) * kWBuf + 32 * kHRow + 64 * q_);    \
             f_.w[q_] = AMPH_W_FR(b_rd[ks_] + (buf_) * kWBuf + 64 * q_);                    \
         }                                                                                  \
     }
     // term pair (w term, x term) on both row tiles; weights first: transposed accumulator (lane = output row, registers = channels)
-#define AMPH_W_M(f_, wq_, xq_)                                                             \
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f_.w[wq_], f_.x[0][xq_], acc[0], 0, 0, 0); \
-    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f_.w[wq_], f_.x[1][xq_], acc[1], 0, 0, 0);
+#define AMPH_W_M(a_, f_, wq_, xq_)                                                         \
+    a_[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f_.w[wq_], f_.x[0][xq_], a_[0], 0, 0, 0); \
+    a_[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f_.w[wq_], f_.x[1][xq_], a_[1], 0, 0, 0);
     // one slice from LDS buffer R (s3's step with two row tiles): stage QL receives slice s + 4, stage QS (slice s + 2) goes to buffer
     // (R + 2) % 3 in the MFMA gaps of k-step 0, the k-step-1 fragments are read under those, the next slice's k-step-0 fragments under k-step 1
 #define AMPH_W_STEP(R, QL, QS)                                                             \
@@ -509,30 +516,23 @@ __global__ __launch_bounds__(512, 1) void k_conv_gemm_s3w(ConvGemmParams p) {
         AMPH_W_LOAD(QL)                                                                    \
         AMPH_W_READ9(f1, R, 1)                                                             \
         AMPH_S3_SB();                                                                      \
-        AMPH_W_M(f0, 2, 0)                                                                 \
+        AMPH_W_M(accl, f0, 1, 0)                                                           \
         AMPH_S3_SB();                                                                      \
         AMPH_W_ST_B(QS, (R + 2) % 3)                                                       \
         AMPH_S3_SB();                                                                      \
-        AMPH_W_M(f0, 0, 2)                                                                 \
-        AMPH_W_M(f0, 1, 1)                                                                 \
+        AMPH_W_M(accl, f0, 0, 1)                                                           \
         AMPH_S3_SB();                                                                      \
         AMPH_W_ST_A(QS, (R + 2) % 3, 0)                                                    \
         AMPH_S3_SB();                                                                      \
-        AMPH_W_M(f0, 1, 0)                                                                 \
-        AMPH_W_M(f0, 0, 1)                                                                 \
+        AMPH_W_M(acc, f0, 0, 0)                                                            \
         AMPH_S3_SB();                                                                      \
         AMPH_W_ST_A(QS, (R + 2) % 3, 1)                                                    \
         AMPH_S3_SB();                                                                      \
-        AMPH_W_M(f0, 0, 0)                                                                 \
-        AMPH_S3_SB();                                                                      \
         AMPH_W_READ9(f0, (R + 1) % 3, 0)                                                   \
         AMPH_S3_SB();                                                                      \
-        AMPH_W_M(f1, 2, 0)                                                                 \
-        AMPH_W_M(f1, 0, 2)                                                                 \
-        AMPH_W_M(f1, 1, 1)                                                                 \
-        AMPH_W_M(f1, 1, 0)                                                                 \
-        AMPH_W_M(f1, 0, 1)                                                                 \
-        AMPH_W_M(f1, 0, 0)                                                                 \
+        AMPH_W_M(accl, f1, 1, 0)                                                           \
+        AMPH_W_M(accl, f1, 0, 1)                                                           \
+        AMPH_W_M(acc, f1, 0, 0)                                                            \
         AMPH_S3_SB();                                                                      \
         __syncthreads();                                                                   \
     }
@@ -567,7 +567,8 @@ __global__ __launch_bounds__(512, 1) void k_conv_gemm_s3w(ConvGemmParams p) {
                 const int n0 = n_blk + ct * 32 + 8 * g + 4 * (lane >> 5);
                 if (n0 < p.N) {
                     const float4 e_sc = *reinterpret_cast<const float4*>(bn + n0 - n_blk), e_sh = *reinterpret_cast<const float4*>(bn + 128 + n0 - n_blk);
-                    float4 v = make_float4(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
+                    float4 v = make_float4(fmaf(accl[t][4 * g], kH2Lo, acc[t][4 * g]), fmaf(accl[t][4 * g + 1], kH2Lo, acc[t][4 * g + 1]),
+                                           fmaf(accl[t][4 * g + 2], kH2Lo, acc[t][4 * g + 2]), fmaf(accl[t][4 * g + 3], kH2Lo, acc[t][4 * g + 3]));
                     v.x = fmaxf(fmaf(v.x, e_sc.x, e_sh.x), 0.0f); v.y = fmaxf(fmaf(v.y, e_sc.y, e_sh.y), 0.0f);
                     v.z = fmaxf(fmaf(v.z, e_sc.z, e_sh.z), 0.0f); v.w = fmaxf(fmaf(v.w, e_sc.w, e_sh.w), 0.0f);
                     *reinterpret_cast<float4*>(p.y + (long long)m * p.N + n0) = v;
@@ -966,25 +967,25 @@ void launch_conv_gemm_f3s(const ConvGemmParams& p, hipStream_t s) {
             int nb8 = -1, nb4 = -1, nbs = -1;
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb8, k_conv_gemm_f3s<8>, 256, conv_gemm_f3s_lds(p));
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb4, k_conv_gemm_f3s<4>, 256, conv_gemm_f3s_lds(p));
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbs, k_conv_gemm_s3, 256, (size_t)6 * kSBuf);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbs, k_conv_gemm_s3, 256, (size_t)6 * kHBuf);
             fprintf(stderr, "[amph] occupancy (workgroups per CU): f3s<8> %d, f3s<4> %d (lds %zu, n_patch %d), s3 %d (lds %zu)\n", nb8, nb4,
-                    conv_gemm_f3s_lds(p), n_patch, nbs, (size_t)6 * kSBuf);
+                    conv_gemm_f3s_lds(p), n_patch, nbs, (size_t)6 * kHBuf);
         }
     }
     if (n_patch <= 256 * 4) hipLaunchKernelGGL(k_conv_gemm_f3s<4>, grid, dim3(256), conv_gemm_f3s_lds(p), s, p);
     else hipLaunchKernelGGL(k_conv_gemm_f3s<8>, grid, dim3(256), conv_gemm_f3s_lds(p), s, p);
 }
 
-constexpr size_t kS3Lds = (size_t)6 * kSBuf;           // 73 728 B: two workgroups per CU
+constexpr size_t kS3Lds = (size_t)6 * kHBuf;           // 49 152 B: three workgroups per CU
 
 bool conv_gemm_s3_ok(const ConvGemmParams& p) {
     const unsigned long long span = (unsigned long long)p.M / (p.OH * p.OW) * p.H * p.W * p.C_in * 4ull + p.x_guard;     // 32-bit lane offsets
     return (p.C_in % kSBK) == 0 && p.K == p.K_pad && p.k * p.k <= 32 && (p.N % 4) == 0 && p.pad < p.k && p.zeros != nullptr &&
            (size_t)p.x_guard >= conv_gemm_x_guard(p.k, p.W, p.C_in) && span < (1ull << 32) &&
-           (unsigned long long)((p.N + 63) / 64 * 64) * (p.K_pad / kSBK) * kSWRow < (1ull << 31) && p.M < (1 << 22);
+           (unsigned long long)((p.N + 63) / 64 * 64) * (p.K_pad / kSBK) * kHWRow < (1ull << 31) && p.M < (1 << 22);
 }
 
-// p.w = the split weight matrix [n_pad / 64][K_pad / 32][64][3][32] bf16 (conv_gemm_s3_split_weights)
+// p.w = the two-term weight matrix [n_pad / 64][K_pad / 32][64][2][32] fp16 (conv_gemm_h2_split_weights)
 void launch_conv_gemm_s3(const ConvGemmParams& p, hipStream_t s) {
     static bool raised[64] = {false};
     int dev = 0;
@@ -1026,6 +1027,22 @@ static float s3_bf16_f32(uint16_t h) {
     float f;
     std::memcpy(&f, &u, 4);
     return f;
+}
+// host: x -> (h, l) as h2_split2 does on the device; [n_pad / 64][K_pad / 32][64][2][32] fp16
+void conv_gemm_h2_split_weights(const float* w, int n_pad, int K_pad, uint16_t* out) {
+    const int n_slices = K_pad / kSBK;
+    for (int n = 0; n < n_pad; ++n)
+        for (int sl = 0; sl < n_slices; ++sl)
+            for (int k = 0; k < kSBK; ++k) {
+                const float x = w[(size_t)n * K_pad + (size_t)sl * kSBK + k];
+                const _Float16 h = (_Float16)x;
+                const _Float16 l = (_Float16)((x - (float)h) * 2048.0f);
+                uint16_t hb, lb;
+                std::memcpy(&hb, &h, 2);
+                std::memcpy(&lb, &l, 2);
+                uint16_t* o = out + (((size_t)(n / 64) * n_slices + sl) * 64 + (size_t)(n % 64)) * 2 * kSBK;
+                o[k] = hb; o[kSBK + k] = lb;
+            }
 }
 void conv_gemm_s3_split_weights(const float* w, int n_pad, int K_pad, uint16_t* out) {
     const int n_slices = K_pad / kSBK;
