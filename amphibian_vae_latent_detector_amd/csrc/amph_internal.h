@@ -186,6 +186,7 @@ bool conv_gemm_s3w_ok(const ConvGemmParams& p);           // 128 x 128 tiles, 51
 void launch_conv_gemm_s3w(const ConvGemmParams& p, hipStream_t s);
 void conv_gemm_s3_split_weights(const float* w, int n_pad, int K_pad, uint16_t* out);
 void conv_gemm_h2_split_weights(const float* w, int n_pad, int K_pad, uint16_t* out);     // two-term fp16 split (k_conv_gemm_s3 / _s3w)
+void conv_gemm_h2_fragment_weights(const float* w, int n_pad, int K_pad, uint16_t* out);  // the same in MFMA fragment order (k_conv_gemm_g4 / _g5, fp32 layers)
 // ... and the fused first-layer pair in the same arithmetic (p.img etc. as for k_conv_gemm_f3, p.w = split weights)
 bool conv_gemm_f3s_ok(const ConvGemmParams& p);
 void launch_conv_gemm_f3s(const ConvGemmParams& p, hipStream_t s);

@@ -47,6 +47,21 @@ namespace amph {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 amph_h2v __attribute__((ext_vector_type(2)));
+// operand fragments of the register-resident-weight kernels: bf16 (TERMS 1: the bf16 encoder) or fp16 (TERMS 2: fp32 layers as the two-term
+// split x = h + 2^-11 l of k_encoder_split.hip - three MFMAs per K = 16, the cross terms in a second accumulator)
+template <int TERMS> struct G4Frag { typedef f16x8 type; };
+template <> struct G4Frag<1> { typedef bf16x8 type; };
+__device__ __forceinline__ f32x16 g4_mfma(const bf16x8& w, const bf16x8& x, const f32x16& c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, x, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 g4_mfma(const f16x8& w, const f16x8& x, const f32x16& c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(w, x, c, 0, 0, 0); }
+constexpr float kG4Lo = 1.0f / 2048.0f;
+__device__ __forceinline__ void g4_split2(float x0, float x1, uint32_t& h, uint32_t& l) {     // (h2_split2 of k_encoder_split.hip)
+    const amph_h2v hp = {(_Float16)x0, (_Float16)x1};
+    h = __builtin_bit_cast(uint32_t, hp);
+    const amph_h2v lp = {(_Float16)((x0 - (float)hp.x) * 2048.0f), (_Float16)((x1 - (float)hp.y) * 2048.0f)};
+    l = __builtin_bit_cast(uint32_t, lp);
+}
 
 constexpr int kPPix = 208;               // bytes per patch pixel: [h | m | l] x 32 bf16 + 16 B pad (13 slots: odd)
 constexpr int kPImgU = 6;                // staged image elements per producer lane (host check)
@@ -826,14 +841,14 @@ struct G4Geo {
 
 // C_IN input channels; KW K parts x CT channel tiles of 32 = 8 waves; RT row tiles of 32 output pixels per tile; IM images per tile;
 // OWL = log2(output width); the input is (2 OW) x (2 OW) x C_IN per image
-// TERMS = 3: fp32 NHWC input split in three bf16 terms, fp32 output; TERMS = 1 (bf16 encoder): bf16 NHWC input copied, bf16 weights, bf16 output
+// TERMS = 2: fp32 NHWC input split in two fp16 terms (x = h + 2^-11 l), fp32 output; TERMS = 1 (bf16 encoder): bf16 NHWC input copied, bf16 weights, bf16 output
 template <int C_IN, int KW, int CT, int RT, int IM, int OWL, int TERMS>
 __global__ __launch_bounds__(512, 2) void k_conv_gemm_g4(ConvGemmParams p, G4Geo g, const uint4* __restrict__ wfrag) {
     constexpr int OW = 1 << OWL, W = 2 * OW, PR = W + 1, PC = W + 1;
     constexpr int KSTEPS = 9 * C_IN / 16, KPW = KSTEPS / KW;            // k-steps of 16 in all, per wave (9)
     constexpr int SPT = C_IN / 16;                                       // k-steps per tap
     constexpr int TERM_B = 2 * C_IN;
-    constexpr int CQ = TERMS == 3 ? C_IN / 4 : C_IN / 8;                 // 16-byte units per input pixel: float4 (fp32) / 8 bf16
+    constexpr int CQ = TERMS != 1 ? C_IN / 4 : C_IN / 8;                 // 16-byte units per input pixel: float4 (fp32) / 8 bf16
     constexpr int NV = IM * W * W * CQ / 512;                            // units per thread and tile (8 / 4)
     constexpr int RPO = 16 / KW;                                         // accumulator registers per owner and row tile
     static_assert(KW * CT == 8 && KPW == 9 && RT * 32 == IM * OW * OW && NV * 512 == IM * W * W * CQ, "shape");
@@ -878,7 +893,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_g4(ConvGemmParams p, G4Geo
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
         const int i = tid + 512 * u, c4 = i % CQ, pix = i / CQ, im = pix / (W * W), y = (pix / W) % W, x = pix % W;
-        in_dst[u] = im * g.IMG_B + (y + 1) * g.RS + ((x + 1) & 1) * g.PL + ((x + 1) >> 1) * g.PXB + (TERMS == 3 ? 8 : 16) * c4;
+        in_dst[u] = im * g.IMG_B + (y + 1) * g.RS + ((x + 1) & 1) * g.PL + ((x + 1) >> 1) * g.PXB + (TERMS != 1 ? 8 : 16) * c4;
     }
     float4 v[NV];
     const int n_v_total = (p.M >> (2 * OWL)) * (W * W * CQ);             // float4 of all the batch's images (a last tile may be short of images)
@@ -913,37 +928,23 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_g4(ConvGemmParams p, G4Geo
 #pragma unroll
             for (int u = 0; u < NV; ++u) *reinterpret_cast<float4*>(patch + in_dst[u]) = v[u];
         } else {
+            // two fp16 terms, stage by stage over the 2 NV pairs (every instruction's inputs are 2 NV instructions old)
             float x_[4 * NV], r_[4 * NV];
-            uint32_t h_[2 * NV], m_[2 * NV], l_[2 * NV];
+            uint32_t h_[2 * NV], l_[2 * NV];
 #pragma unroll
             for (int u = 0; u < NV; ++u) { x_[4 * u] = v[u].x; x_[4 * u + 1] = v[u].y; x_[4 * u + 2] = v[u].z; x_[4 * u + 3] = v[u].w; }
+            amph_h2v hp_[2 * NV];
 #pragma unroll
-            for (int k = 0; k < 2 * NV; ++k) {
-                const amph_bf16x2 hp = {(__bf16)x_[2 * k], (__bf16)x_[2 * k + 1]};
-                h_[k] = __builtin_bit_cast(uint32_t, hp);
-                asm volatile("" : "+v"(h_[k]));
-            }
+            for (int k = 0; k < 2 * NV; ++k) { hp_[k] = amph_h2v{(_Float16)x_[2 * k], (_Float16)x_[2 * k + 1]}; h_[k] = __builtin_bit_cast(uint32_t, hp_[k]); }
 #pragma unroll
-            for (int k = 0; k < 2 * NV; ++k) { r_[2 * k] = x_[2 * k] - __uint_as_float(h_[k] << 16); r_[2 * k + 1] = x_[2 * k + 1] - __uint_as_float(h_[k] & 0xFFFF0000u); }
+            for (int k = 0; k < 2 * NV; ++k) { r_[2 * k] = (x_[2 * k] - (float)hp_[k].x) * 2048.0f; r_[2 * k + 1] = (x_[2 * k + 1] - (float)hp_[k].y) * 2048.0f; }
 #pragma unroll
-            for (int k = 0; k < 2 * NV; ++k) {
-                const amph_bf16x2 mp = {(__bf16)r_[2 * k], (__bf16)r_[2 * k + 1]};
-                m_[k] = __builtin_bit_cast(uint32_t, mp);
-                asm volatile("" : "+v"(m_[k]));
-            }
-#pragma unroll
-            for (int k = 0; k < 2 * NV; ++k) { r_[2 * k] = r_[2 * k] - __uint_as_float(m_[k] << 16); r_[2 * k + 1] = r_[2 * k + 1] - __uint_as_float(m_[k] & 0xFFFF0000u); }
-#pragma unroll
-            for (int k = 0; k < 2 * NV; ++k) {
-                const amph_bf16x2 lp = {(__bf16)r_[2 * k], (__bf16)r_[2 * k + 1]};
-                l_[k] = __builtin_bit_cast(uint32_t, lp);
-            }
+            for (int k = 0; k < 2 * NV; ++k) { const amph_h2v lp = {(_Float16)r_[2 * k], (_Float16)r_[2 * k + 1]}; l_[k] = __builtin_bit_cast(uint32_t, lp); }
 #pragma unroll
             for (int u = 0; u < NV; ++u) {
                 char* dst = patch + in_dst[u];
                 *reinterpret_cast<uint2*>(dst) = make_uint2(h_[2 * u], h_[2 * u + 1]);
-                *reinterpret_cast<uint2*>(dst + TERM_B) = make_uint2(m_[2 * u], m_[2 * u + 1]);
-                *reinterpret_cast<uint2*>(dst + 2 * TERM_B) = make_uint2(l_[2 * u], l_[2 * u + 1]);
+                *reinterpret_cast<uint2*>(dst + TERM_B) = make_uint2(l_[2 * u], l_[2 * u + 1]);
             }
         }
         AMPH_F4_T(q_b)
@@ -951,13 +952,14 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_g4(ConvGemmParams p, G4Geo
         AMPH_F4_T(q_c)
         if (tile + (int)gridDim.x < g.n_tiles) AMPH_G4_FETCH(tile + gridDim.x)      // lands under the multiply
         // ---- (2) multiply: 9 k-steps, fragments of the next one read while this one is multiplied
-        f32x16 acc[RT];
+        typedef typename G4Frag<TERMS>::type frag_t;
+        f32x16 acc[RT], accl[RT];                                        // (accl: the cross terms of the two-term split)
 #pragma unroll
         for (int t = 0; t < RT; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-#define AMPH_G4_FR(ptr_) __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ptr_))
-        bf16x8 fc[RT][TERMS], fn[RT][TERMS];
+            for (int r = 0; r < 16; ++r) { acc[t][r] = 0.0f; accl[t][r] = 0.0f; }
+#define AMPH_G4_FR(ptr_) __builtin_bit_cast(frag_t, *reinterpret_cast<const uint4*>(ptr_))
+        frag_t fc[RT][TERMS], fn[RT][TERMS];
         {
             const char* pa = patch + a_base + aoff[0];
 #pragma unroll
@@ -974,12 +976,11 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_g4(ConvGemmParams p, G4Geo
 #pragma unroll
                     for (int q = 0; q < TERMS; ++q) fn[t][q] = AMPH_G4_FR(pa + t * rt1_off + q * TERM_B);
             }
-            const bf16x8 wh = __builtin_bit_cast(bf16x8, breg[TERMS * i]), wm = __builtin_bit_cast(bf16x8, breg[TERMS * i + (TERMS == 3 ? 1 : 0)]),
-                         wl = __builtin_bit_cast(bf16x8, breg[TERMS * i + (TERMS == 3 ? 2 : 0)]);
-#define AMPH_G4_M(w_, q_)                                                                  \
-            _Pragma("unroll") for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_, fc[t][q_], acc[t], 0, 0, 0);
-            if (TERMS == 3) { AMPH_G4_M(wl, 0) AMPH_G4_M(wh, TERMS - 1) AMPH_G4_M(wm, TERMS / 2) AMPH_G4_M(wm, 0) AMPH_G4_M(wh, TERMS / 2) }
-            AMPH_G4_M(wh, 0)
+            const frag_t wh = __builtin_bit_cast(frag_t, breg[TERMS * i]), wl = __builtin_bit_cast(frag_t, breg[TERMS * i + TERMS - 1]);
+#define AMPH_G4_M(a_, w_, q_)                                                              \
+            _Pragma("unroll") for (int t = 0; t < RT; ++t) a_[t] = g4_mfma(w_, fc[t][q_], a_[t]);
+            if (TERMS == 2) { AMPH_G4_M(accl, wl, 0) AMPH_G4_M(accl, wh, TERMS - 1) }
+            AMPH_G4_M(acc, wh, 0)
 #undef AMPH_G4_M
             if (i < 8) {
 #pragma unroll
@@ -989,6 +990,12 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_g4(ConvGemmParams p, G4Geo
             }
         }
 #undef AMPH_G4_FR
+        if (TERMS == 2) {
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] = fmaf(accl[t][r], kG4Lo, acc[t][r]);
+        }
         AMPH_F4_T(q_d)
         __syncthreads();                                                 // every wave is done with the patch: it becomes the inbox
         AMPH_F4_T(q_e)
@@ -1114,9 +1121,9 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_g5(ConvGemmParams p, G5Geo
     constexpr int C_IN = 64, KW = 4, RT = 2;
     constexpr int OW = 1 << OWL, TH = 64 >> OWL, WW = 2 * OW, PR = 2 * TH + 1;
     constexpr int KSTEPS = 9 * C_IN / 16, KPW = KSTEPS / KW, SPT = C_IN / 16, TERM_B = 2 * C_IN;
-    constexpr int CQ = TERMS == 3 ? C_IN / 4 : C_IN / 8;                 // 16-byte units per input pixel
+    constexpr int CQ = TERMS != 1 ? C_IN / 4 : C_IN / 8;                 // 16-byte units per input pixel
     constexpr int NE = PR * WW * CQ, NV = (NE + 511) / 512;              // units of a tile's input (halo row included), per thread
-    constexpr int UB = TERMS == 3 ? 8 : 16;                              // patch bytes per unit and term
+    constexpr int UB = TERMS != 1 ? 8 : 16;                              // patch bytes per unit and term
     constexpr int RPO = 16 / KW;
     static_assert(KPW == 9 && RPO == 4 && TH * OW == 64, "shape");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1179,34 +1186,34 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_g5(ConvGemmParams p, G5Geo
     AMPH_G5_ZERO_COL()
     float4* const inbox = reinterpret_cast<float4*>(patch);
     for (; tile < g.n_tiles; tile += gridDim.x) {
-        // ---- (1) the tile's input into the patch (fp32: split in three bf16 terms; bf16: copied)
+        // ---- (1) the tile's input into the patch (fp32: split in two fp16 terms; bf16: copied)
         if (TERMS == 1) {
 #pragma unroll
             for (int u = 0; u < NV; ++u) if (tid + 512 * u < NE) *reinterpret_cast<float4*>(patch + in_dst[u]) = v[u];
         } else {
 #pragma unroll
             for (int u = 0; u < NV; ++u) {
-                uint32_t h0, m0, l0, h1, m1, l1;
-                s3_split2_o(v[u].x, v[u].y, h0, m0, l0);
-                s3_split2_o(v[u].z, v[u].w, h1, m1, l1);
+                uint32_t h0, l0, h1, l1;
+                g4_split2(v[u].x, v[u].y, h0, l0);
+                g4_split2(v[u].z, v[u].w, h1, l1);
                 if (tid + 512 * u < NE) {
                     char* dst = patch + in_dst[u];
                     *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
-                    *reinterpret_cast<uint2*>(dst + TERM_B) = make_uint2(m0, m1);
-                    *reinterpret_cast<uint2*>(dst + 2 * TERM_B) = make_uint2(l0, l1);
+                    *reinterpret_cast<uint2*>(dst + TERM_B) = make_uint2(l0, l1);
                 }
             }
         }
         __syncthreads();
         if (tile + (int)gridDim.x < g.n_tiles) AMPH_G5_FETCH(tile + gridDim.x)      // lands under the multiply
         // ---- (2) multiply: 9 k-steps, fragments of the next one read while this one is multiplied
-        f32x16 acc[RT];
+        typedef typename G4Frag<TERMS>::type frag_t;
+        f32x16 acc[RT], accl[RT];
 #pragma unroll
         for (int t = 0; t < RT; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-#define AMPH_G5_FR(ptr_) __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ptr_))
-        bf16x8 fc[RT][TERMS], fn[RT][TERMS];
+            for (int r = 0; r < 16; ++r) { acc[t][r] = 0.0f; accl[t][r] = 0.0f; }
+#define AMPH_G5_FR(ptr_) __builtin_bit_cast(frag_t, *reinterpret_cast<const uint4*>(ptr_))
+        frag_t fc[RT][TERMS], fn[RT][TERMS];
         {
             const char* pa = patch + a_base + aoff[0];
 #pragma unroll
@@ -1223,12 +1230,11 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_g5(ConvGemmParams p, G5Geo
 #pragma unroll
                     for (int q = 0; q < TERMS; ++q) fn[t][q] = AMPH_G5_FR(pa + t * rt1_off + q * TERM_B);
             }
-            const bf16x8 wh = __builtin_bit_cast(bf16x8, breg[TERMS * i]), wm = __builtin_bit_cast(bf16x8, breg[TERMS * i + (TERMS == 3 ? 1 : 0)]),
-                         wl = __builtin_bit_cast(bf16x8, breg[TERMS * i + (TERMS == 3 ? 2 : 0)]);
-#define AMPH_G5_M(w_, q_)                                                                  \
-            _Pragma("unroll") for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_, fc[t][q_], acc[t], 0, 0, 0);
-            if (TERMS == 3) { AMPH_G5_M(wl, 0) AMPH_G5_M(wh, TERMS - 1) AMPH_G5_M(wm, TERMS / 2) AMPH_G5_M(wm, 0) AMPH_G5_M(wh, TERMS / 2) }
-            AMPH_G5_M(wh, 0)
+            const frag_t wh = __builtin_bit_cast(frag_t, breg[TERMS * i]), wl = __builtin_bit_cast(frag_t, breg[TERMS * i + TERMS - 1]);
+#define AMPH_G5_M(a_, w_, q_)                                                              \
+            _Pragma("unroll") for (int t = 0; t < RT; ++t) a_[t] = g4_mfma(w_, fc[t][q_], a_[t]);
+            if (TERMS == 2) { AMPH_G5_M(accl, wl, 0) AMPH_G5_M(accl, wh, TERMS - 1) }
+            AMPH_G5_M(acc, wh, 0)
 #undef AMPH_G5_M
             if (i < 8) {
 #pragma unroll
@@ -1238,6 +1244,12 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_g5(ConvGemmParams p, G5Geo
             }
         }
 #undef AMPH_G5_FR
+        if (TERMS == 2) {
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] = fmaf(accl[t][r], kG4Lo, acc[t][r]);
+        }
         __syncthreads();                                                 // every wave is done with the patch: it becomes the inbox
         // ---- (3) K quarters -> their owners (k_conv_gemm_g4's exchange: part 0 first, a fixed order)
 #pragma unroll
@@ -1336,7 +1348,7 @@ int conv_gemm_g4_kind(const ConvGemmParams& p) {
     return 0;
 }
 
-// wfrag = conv_gemm_f4s_fragment_weights' (terms 3: fp32 in / out) or conv_gemm_f4b_fragment_weights' (terms 1: bf16 in / out) output of the layer
+// wfrag = conv_gemm_h2_fragment_weights' (TERMS 2: fp32 in / out) or conv_gemm_f4b_fragment_weights' (TERMS 1: bf16 in / out) output of the layer
 template <int TERMS>
 static void launch_g4_t(const ConvGemmParams& p, const void* wfrag, int wgs, hipStream_t s) {
     static bool raised[64] = {false};
@@ -1381,9 +1393,33 @@ static void launch_g4_t(const ConvGemmParams& p, const void* wfrag, int wgs, hip
         else hipLaunchKernelGGL((k_conv_gemm_g5<4, TERMS>), grid, dim3(512), lds, s, p, g, reinterpret_cast<const uint4*>(wfrag));
     }
 }
+// terms 1: bf16 encoder (wfrag = conv_gemm_f4b_fragment_weights' output); otherwise fp32 layers on the two-term fp16 split
+// (wfrag = conv_gemm_h2_fragment_weights' output)
 void launch_conv_gemm_g4(const ConvGemmParams& p, const void* wfrag, int wgs, int terms, hipStream_t s) {
     if (terms == 1) launch_g4_t<1>(p, wfrag, wgs, s);
-    else launch_g4_t<3>(p, wfrag, wgs, s);
+    else launch_g4_t<2>(p, wfrag, wgs, s);
+}
+
+// two-term fp16 weights in MFMA fragment order: [n tile][channel tile][k-step (K_pad / 16)][term][lane][8 fp16];
+// lane l holds row (l & 31), k = 16 kstep + 8 (l >> 5) + j
+void conv_gemm_h2_fragment_weights(const float* w, int n_pad, int K_pad, uint16_t* out) {
+    const int ksteps = K_pad / 16;
+    for (int nt = 0; nt < n_pad / 64; ++nt)
+        for (int ct = 0; ct < 2; ++ct)
+            for (int ks = 0; ks < ksteps; ++ks)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int n = nt * 64 + ct * 32 + (lane & 31), k = 16 * ks + 8 * (lane >> 5) + j;
+                        const float x = w[(size_t)n * K_pad + k];
+                        const _Float16 h = (_Float16)x;
+                        const _Float16 l = (_Float16)((x - (float)h) * 2048.0f);
+                        uint16_t hb, lb;
+                        std::memcpy(&hb, &h, 2);
+                        std::memcpy(&lb, &l, 2);
+                        const size_t base = (((size_t)(nt * 2 + ct) * ksteps + ks) * 2) * 64 * 8;
+                        out[base + (0 * 64 + lane) * 8 + j] = hb;
+                        out[base + (1 * 64 + lane) * 8 + j] = lb;
+                    }
 }
 
 }  // namespace amph
