@@ -535,11 +535,7 @@ int build_encoder(amph_ctx* c, const float* hw, size_t n_floats) {
                     conv_gemm_f4b_fragment_weights(wg.data(), n_pad, K_pad, wb.data());
                     HIP_TRY(c, upload(&gl.d_w_f4b, wb));
                 }
-                if (i == 1 && K_pad == 288) {                                                            // k_conv_gemm_f4s: three bf16 terms
-                    conv_gemm_f4s_fragment_weights(wg.data(), n_pad, K_pad, w3.data());
-                    HIP_TRY(c, upload(&gl.d_w_f4, w3));
-                }
-                if (i > 1 && (l.c_in == 64 || l.c_in == 128) && K_pad == 9 * l.c_in) {                  // k_conv_gemm_g4 / _g5: two fp16 terms
+                if ((i == 1 && K_pad == 288) || (i > 1 && (l.c_in == 64 || l.c_in == 128) && K_pad == 9 * l.c_in)) {   // k_conv_gemm_f4s / _g4 / _g5: two fp16 terms
                     std::vector<uint16_t> wf((size_t)n_pad * K_pad * 2);
                     conv_gemm_h2_fragment_weights(wg.data(), n_pad, K_pad, wf.data());
                     HIP_TRY(c, upload(&gl.d_w_f4, wf));

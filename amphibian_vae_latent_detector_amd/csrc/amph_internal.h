@@ -194,13 +194,11 @@ void launch_conv_gemm_f3s(const ConvGemmParams& p, hipStream_t s);
 // wfrag = split weights in MFMA fragment order [n_pad / 64][2][K_pad / 16][3][64 lanes][8] bf16, wgs = workgroups (0: one per CU)
 bool conv_gemm_f4s_ok(const ConvGemmParams& p);
 void launch_conv_gemm_f4s(const ConvGemmParams& p, const void* wfrag, int wgs, hipStream_t s);
-void conv_gemm_f4s_fragment_weights(const float* w, int n_pad, int K_pad, uint16_t* out);
 // ... and with one bf16 term per operand for the bf16 encoder (same shapes: conv_gemm_f4s_ok; bf16 NHWC output)
 void conv_gemm_f4b_fragment_weights(const float* w, int n_pad, int K_pad, uint16_t* out);
 bool conv_gemm_f4b_ok(const ConvGemmParams& p);
 void launch_conv_gemm_f4b(const ConvGemmParams& p, const void* wfrag, int wgs, hipStream_t s);
 // the 3x3 stride-2 layers behind the pair in the same form: weights in registers, the tile's input image(s) resident in LDS
-// (0: shape not covered; wfrag = conv_gemm_f4s_fragment_weights' output of the layer; wgs = workgroups, 0: one per CU)
 int conv_gemm_g4_kind(const ConvGemmParams& p);
 void launch_conv_gemm_g4(const ConvGemmParams& p, const void* wfrag, int wgs, int terms, hipStream_t s);   // terms 3: fp32 in / out; 1: bf16 in / out (wfrag: conv_gemm_f4b_fragment_weights)
 // bf16 encoder path (k_encoder_bf16.hip): x / w are bf16, y bf16 (epilogue 0) or fp32 partials (epilogue 1);

@@ -63,7 +63,7 @@ __device__ __forceinline__ void g4_split2(float x0, float x1, uint32_t& h, uint3
     l = __builtin_bit_cast(uint32_t, lp);
 }
 
-constexpr int kPPix = 208;               // bytes per patch pixel: [h | m | l] x 32 bf16 + 16 B pad (13 slots: odd)
+constexpr int kPPix = 144;               // bytes per patch pixel: [h | l] x 32 fp16 (the two-term split of k_encoder_split.hip) + 16 B pad (9 slots: odd)
 constexpr int kPImgU = 6;                // staged image elements per producer lane (host check)
 constexpr int kPGroupU = 3;              // 32-pixel groups of a tile's patch per producer wave (host check)
 
@@ -102,9 +102,9 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_f4s(ConvGemmParams p, Patc
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const patch0 = smem;                                                       // [2 parity][PR][RS]
     char* const patch1 = smem + 2 * g.plane;
-    uint16_t* const img_stage = reinterpret_cast<uint16_t*>(smem + 4 * g.plane);     // [2][3 terms][2 PR + 1][img_row] bf16
+    uint16_t* const img_stage = reinterpret_cast<uint16_t*>(smem + 4 * g.plane);     // [2][2 terms][2 PR + 1][img_row] fp16
     const int img_pl = (g.n_img + 8) & ~7;                                           // elements per term plane
-    char* const part = smem + 4 * g.plane + 2 * 3 * img_pl * 2;                      // [4 consumer waves][4][64] float4
+    char* const part = smem + 4 * g.plane + 2 * 2 * img_pl * 2;                      // [4 consumer waves][4][64] float4
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);                       // the role branch below is scalar
     const int n_blk = blockIdx.y * 64;
@@ -123,18 +123,17 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_f4s(ConvGemmParams p, Patc
         // bf16 terms (six MFMAs, as in layer 2).  k = 8 kh2 + j pairs with the dwords a lane reads from the staged image: lanes < 32
         // read columns (c0, c1) of the pixel's three window rows, lanes >= 32 (c2, c3): k 0..5 = taps (r, 0), (r, 1), k 8 / 10 / 12
         // = taps (r, 2); the slots that see c3 or nothing carry zero weights.
-        bf16x8 w1h, w1m, w1l;
+        f16x8 w1h, w1l;
         {
-            uint32_t hh[4], mm[4], ll[4];
+            uint32_t hh[4], ll[4];
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
                 const int tap0 = d < 3 ? (kh2 ? 3 * d + 2 : 3 * d) : -1, tap1 = (d < 3 && !kh2) ? 3 * d + 1 : -1;
                 const float v0 = tap0 >= 0 ? p.w1[tap0 * p.C_in + px] : 0.0f, v1 = tap1 >= 0 ? p.w1[tap1 * p.C_in + px] : 0.0f;
-                s3_split2_o(v0, v1, hh[d], mm[d], ll[d]);
+                g4_split2(v0, v1, hh[d], ll[d]);
             }
-            w1h = __builtin_bit_cast(bf16x8, make_uint4(hh[0], hh[1], hh[2], hh[3]));
-            w1m = __builtin_bit_cast(bf16x8, make_uint4(mm[0], mm[1], mm[2], mm[3]));
-            w1l = __builtin_bit_cast(bf16x8, make_uint4(ll[0], ll[1], ll[2], ll[3]));
+            w1h = __builtin_bit_cast(f16x8, make_uint4(hh[0], hh[1], hh[2], hh[3]));
+            w1l = __builtin_bit_cast(f16x8, make_uint4(ll[0], ll[1], ll[2], ll[3]));
         }
         float4 sc1[4], sh1[4];                                     // BN of this lane's accumulator channels 8 q + 4 kh2 + r
 #pragma unroll
@@ -198,41 +197,32 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_f4s(ConvGemmParams p, Patc
         }
         // the three-term split of n pairs, stage by stage over all the pairs: every instruction's inputs are n instructions old
         // (one after the other the eleven instructions of a pair form a dependent chain at ~8 cycles apiece)
-#define AMPH_F4_SPLIT_PAIRS(n_, x_, h_, m_, l_)                                            \
+#define AMPH_F4_SPLIT_PAIRS(n_, x_, h_, l_)                                                \
         {                                                                                  \
             float r_[2 * (n_)];                                                            \
+            amph_h2v hp_[n_];                                                              \
             _Pragma("unroll") for (int k = 0; k < (n_); ++k) {                             \
-                const amph_bf16x2 hp_ = {(__bf16)x_[2 * k], (__bf16)x_[2 * k + 1]};        \
-                h_[k] = __builtin_bit_cast(uint32_t, hp_);                                 \
-                asm volatile("" : "+v"(h_[k]));                                            \
+                hp_[k] = amph_h2v{(_Float16)x_[2 * k], (_Float16)x_[2 * k + 1]};           \
+                h_[k] = __builtin_bit_cast(uint32_t, hp_[k]);                              \
             }                                                                              \
             _Pragma("unroll") for (int k = 0; k < (n_); ++k) {                             \
-                r_[2 * k] = x_[2 * k] - __uint_as_float(h_[k] << 16);                      \
-                r_[2 * k + 1] = x_[2 * k + 1] - __uint_as_float(h_[k] & 0xFFFF0000u);      \
+                r_[2 * k] = (x_[2 * k] - (float)hp_[k].x) * 2048.0f;                       \
+                r_[2 * k + 1] = (x_[2 * k + 1] - (float)hp_[k].y) * 2048.0f;               \
             }                                                                              \
             _Pragma("unroll") for (int k = 0; k < (n_); ++k) {                             \
-                const amph_bf16x2 mp_ = {(__bf16)r_[2 * k], (__bf16)r_[2 * k + 1]};        \
-                m_[k] = __builtin_bit_cast(uint32_t, mp_);                                 \
-                asm volatile("" : "+v"(m_[k]));                                            \
-            }                                                                              \
-            _Pragma("unroll") for (int k = 0; k < (n_); ++k) {                             \
-                r_[2 * k] = r_[2 * k] - __uint_as_float(m_[k] << 16);                      \
-                r_[2 * k + 1] = r_[2 * k + 1] - __uint_as_float(m_[k] & 0xFFFF0000u);      \
-            }                                                                              \
-            _Pragma("unroll") for (int k = 0; k < (n_); ++k) {                             \
-                const amph_bf16x2 lp_ = {(__bf16)r_[2 * k], (__bf16)r_[2 * k + 1]};        \
+                const amph_h2v lp_ = {(_Float16)r_[2 * k], (_Float16)r_[2 * k + 1]};       \
                 l_[k] = __builtin_bit_cast(uint32_t, lp_);                                 \
             }                                                                              \
         }
 #define AMPH_F4_WRITE_IMG(dst_)                                                            \
         {                                                                                  \
-            uint32_t h_[kPImgU / 2], m_[kPImgU / 2], l_[kPImgU / 2];                       \
-            AMPH_F4_SPLIT_PAIRS(kPImgU / 2, pf, h_, m_, l_)                                \
+            uint32_t h_[kPImgU / 2], l_[kPImgU / 2];                                       \
+            AMPH_F4_SPLIT_PAIRS(kPImgU / 2, pf, h_, l_)                                    \
             _Pragma("unroll") for (int k = 0; k < kPImgU / 2; ++k) {                       \
                 uint16_t* d0_ = (dst_) + io_w[2 * k];                                      \
                 uint16_t* d1_ = (dst_) + io_w[2 * k + 1];                                  \
-                d0_[0] = (uint16_t)h_[k]; d0_[img_pl] = (uint16_t)m_[k]; d0_[2 * img_pl] = (uint16_t)l_[k]; \
-                d1_[0] = (uint16_t)(h_[k] >> 16); d1_[img_pl] = (uint16_t)(m_[k] >> 16); d1_[2 * img_pl] = (uint16_t)(l_[k] >> 16); \
+                d0_[0] = (uint16_t)h_[k]; d0_[img_pl] = (uint16_t)l_[k];                   \
+                d1_[0] = (uint16_t)(h_[k] >> 16); d1_[img_pl] = (uint16_t)(l_[k] >> 16);   \
             }                                                                              \
         }
         int tile = blockIdx.x;
@@ -247,18 +237,18 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_f4s(ConvGemmParams p, Patc
             unsigned long long q_f, q_g, q_g1, q_g2;
             AMPH_F4_T(q_f)
 #endif
-            const char* sbuf = reinterpret_cast<const char*>(img_stage + (i & 1) * 3 * img_pl);
+            const char* sbuf = reinterpret_cast<const char*>(img_stage + (i & 1) * 2 * img_pl);
             char* patch = (i & 1) ? patch1 : patch0;
             const int tr = tile - f4_div_small(tile, g.tiles_per_image, rcp_tpi) * g.tiles_per_image;
             const unsigned it_pad = it_pad_always | (tr == 0 ? it_pad_top : 0u);
             // (conv1 rows 2 oh0 - 1 + yl, yl < PR, and columns xi - 1, xi < PC, never pass the bottom / right edge: host check)
             // all the window reads of the three groups, then their MFMAs interleaved (three independent accumulation chains)
-            uint32_t xw[kPGroupU][3][3];                             // [group][term][window row]
+            uint32_t xw[kPGroupU][2][3];                             // [group][term][window row]
 #pragma unroll
             for (int u = 0; u < kPGroupU; ++u) {
                 const char* sp = sbuf + it_src[u];
 #pragma unroll
-                for (int t = 0; t < 3; ++t)
+                for (int t = 0; t < 2; ++t)
 #pragma unroll
                     for (int r = 0; r < 3; ++r) xw[u][t][r] = *reinterpret_cast<const uint32_t*>(sp + 2 * (t * img_pl + r * g.img_row));
             }
@@ -266,17 +256,17 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_f4s(ConvGemmParams p, Patc
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             AMPH_F4_T(q_g1)
 #endif
-            f32x16 acc[kPGroupU];
+            f32x16 acc[kPGroupU], accl[kPGroupU];                     // h h' | the cross terms (x 2^-11 below)
 #pragma unroll
             for (int u = 0; u < kPGroupU; ++u)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[u][r] = 0.0f;
-#define AMPH_F4_XT(u_, t_) __builtin_bit_cast(bf16x8, make_uint4(xw[u_][t_][0], xw[u_][t_][1], xw[u_][t_][2], 0u))
-#define AMPH_F4_M3(w_, t_)                                                                 \
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_, AMPH_F4_XT(0, t_), acc[0], 0, 0, 0); \
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_, AMPH_F4_XT(1, t_), acc[1], 0, 0, 0); \
-            acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_, AMPH_F4_XT(2, t_), acc[2], 0, 0, 0);
-            AMPH_F4_M3(w1l, 0) AMPH_F4_M3(w1h, 2) AMPH_F4_M3(w1m, 1) AMPH_F4_M3(w1m, 0) AMPH_F4_M3(w1h, 1) AMPH_F4_M3(w1h, 0)
+                for (int r = 0; r < 16; ++r) { acc[u][r] = 0.0f; accl[u][r] = 0.0f; }
+#define AMPH_F4_XT(u_, t_) __builtin_bit_cast(f16x8, make_uint4(xw[u_][t_][0], xw[u_][t_][1], xw[u_][t_][2], 0u))
+#define AMPH_F4_M3(a_, w_, t_)                                                             \
+            a_[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w_, AMPH_F4_XT(0, t_), a_[0], 0, 0, 0); \
+            a_[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w_, AMPH_F4_XT(1, t_), a_[1], 0, 0, 0); \
+            a_[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w_, AMPH_F4_XT(2, t_), a_[2], 0, 0, 0);
+            AMPH_F4_M3(accl, w1l, 0) AMPH_F4_M3(accl, w1h, 1) AMPH_F4_M3(acc, w1h, 0)
 #undef AMPH_F4_M3
 #undef AMPH_F4_XT
 #ifdef AMPH_STAMPS
@@ -289,20 +279,21 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_f4s(ConvGemmParams p, Patc
                 float a[16];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    a[4 * q] = fmaf(acc[u][4 * q], sc1[q].x, sh1[q].x); a[4 * q + 1] = fmaf(acc[u][4 * q + 1], sc1[q].y, sh1[q].y);
-                    a[4 * q + 2] = fmaf(acc[u][4 * q + 2], sc1[q].z, sh1[q].z); a[4 * q + 3] = fmaf(acc[u][4 * q + 3], sc1[q].w, sh1[q].w);
+                    a[4 * q] = fmaf(fmaf(accl[u][4 * q], kG4Lo, acc[u][4 * q]), sc1[q].x, sh1[q].x);
+                    a[4 * q + 1] = fmaf(fmaf(accl[u][4 * q + 1], kG4Lo, acc[u][4 * q + 1]), sc1[q].y, sh1[q].y);
+                    a[4 * q + 2] = fmaf(fmaf(accl[u][4 * q + 2], kG4Lo, acc[u][4 * q + 2]), sc1[q].z, sh1[q].z);
+                    a[4 * q + 3] = fmaf(fmaf(accl[u][4 * q + 3], kG4Lo, acc[u][4 * q + 3]), sc1[q].w, sh1[q].w);
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) a[r] = __builtin_amdgcn_fmed3f(a[r], 0.0f, cap);
-                uint32_t hh[8], mm[8], ll[8];
-                AMPH_F4_SPLIT_PAIRS(8, a, hh, mm, ll)
+                uint32_t hh[8], ll[8];
+                AMPH_F4_SPLIT_PAIRS(8, a, hh, ll)
                 if ((it_live >> u) & 1u) {
                     char* dst = patch + it_dst[u];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         *reinterpret_cast<uint2*>(dst + 16 * q) = make_uint2(hh[2 * q], hh[2 * q + 1]);
-                        *reinterpret_cast<uint2*>(dst + 16 * q + 64) = make_uint2(mm[2 * q], mm[2 * q + 1]);
-                        *reinterpret_cast<uint2*>(dst + 16 * q + 128) = make_uint2(ll[2 * q], ll[2 * q + 1]);
+                        *reinterpret_cast<uint2*>(dst + 16 * q + 64) = make_uint2(ll[2 * q], ll[2 * q + 1]);
                     }
                 }
             }
@@ -311,7 +302,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_f4s(ConvGemmParams p, Patc
             q_s2 += q_f - q_a; q_s3 += q_g - q_f;
             q_p0 += q_g1 - q_f; q_p1 += q_g2 - q_g1; q_p2 += q_g - q_g2;
 #endif
-            AMPH_F4_WRITE_IMG(img_stage + ((i + 1) & 1) * 3 * img_pl)   // that buffer's last read came before the previous X
+            AMPH_F4_WRITE_IMG(img_stage + ((i + 1) & 1) * 2 * img_pl)   // that buffer's last read came before the previous X
             AMPH_F4_T(q_b)
             __syncthreads();                                         // X: patch i complete (the consumers are done with patch i - 1)
             __syncthreads();                                         // Y
@@ -333,11 +324,11 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_f4s(ConvGemmParams p, Patc
 
     // ==================================================================== consumers
     const int ct = wave & 1, th = wave >> 1;                         // channel tile, K half (k-steps 9 th .. 9 th + 8); owner of row tile th
-    uint4 breg[27];                                                  // [k-step][term]: this wave's weights, for the whole kernel
+    uint4 breg[18];                                                  // [k-step][term]: this wave's weights, for the whole kernel
     {
-        const uint4* wf = wfrag + (((size_t)blockIdx.y * 2 + ct) * 18 + 9 * th) * (3 * 64) + lane;
+        const uint4* wf = wfrag + (((size_t)blockIdx.y * 2 + ct) * 18 + 9 * th) * (2 * 64) + lane;
 #pragma unroll
-        for (int f = 0; f < 27; ++f) breg[f] = wf[f * 64];
+        for (int f = 0; f < 18; ++f) breg[f] = wf[f * 64];
     }
     int aoff[9];                                                     // patch offset of k-step 9 th + i: tap (kh, kw), channel half
 #pragma unroll
@@ -382,40 +373,35 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_f4s(ConvGemmParams p, Patc
     for (int tile = blockIdx.x; tile < g.n_tiles; tile += gridDim.x, ++i) {
         const char* pb = ((i & 1) ? patch1 : patch0) + a_base;
         AMPH_F4_T(q_a)
-        f32x16 acc0, acc1;
+        f32x16 acc0, acc1, accl0, accl1;                             // per row tile: h h' | the cross terms
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
-#define AMPH_F4_FR(ptr_) __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ptr_))
-        bf16x8 c0h, c0m, c0l, c1h, c1m, c1l, n0h, n0m, n0l, n1h, n1m, n1l;
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; accl0[r] = 0.0f; accl1[r] = 0.0f; }
+#define AMPH_F4_FR(ptr_) __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(ptr_))
+        f16x8 c0h, c0l, c1h, c1l, n0h, n0l, n1h, n1l;
         {
             const char* pa = pb + aoff[0];
-            c0h = AMPH_F4_FR(pa); c0m = AMPH_F4_FR(pa + 64); c0l = AMPH_F4_FR(pa + 128);
-            c1h = AMPH_F4_FR(pa + g.rt1_off); c1m = AMPH_F4_FR(pa + g.rt1_off + 64); c1l = AMPH_F4_FR(pa + g.rt1_off + 128);
+            c0h = AMPH_F4_FR(pa); c0l = AMPH_F4_FR(pa + 64);
+            c1h = AMPH_F4_FR(pa + g.rt1_off); c1l = AMPH_F4_FR(pa + g.rt1_off + 64);
         }
 #pragma unroll
         for (int s = 0; s < 9; ++s) {
             if (s < 8) {
                 const char* pa = pb + aoff[s + 1];
-                n0h = AMPH_F4_FR(pa); n0m = AMPH_F4_FR(pa + 64); n0l = AMPH_F4_FR(pa + 128);
-                n1h = AMPH_F4_FR(pa + g.rt1_off); n1m = AMPH_F4_FR(pa + g.rt1_off + 64); n1l = AMPH_F4_FR(pa + g.rt1_off + 128);
+                n0h = AMPH_F4_FR(pa); n0l = AMPH_F4_FR(pa + 64);
+                n1h = AMPH_F4_FR(pa + g.rt1_off); n1l = AMPH_F4_FR(pa + g.rt1_off + 64);
             }
-            const bf16x8 wh = __builtin_bit_cast(bf16x8, breg[3 * s]), wm = __builtin_bit_cast(bf16x8, breg[3 * s + 1]),
-                         wl = __builtin_bit_cast(bf16x8, breg[3 * s + 2]);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, c0h, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, c1h, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, c0l, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, c1l, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, c0m, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, c1m, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, c0h, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, c1h, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, c0m, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, c1m, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, c0h, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, c1h, acc1, 0, 0, 0);
-            if (s < 8) { c0h = n0h; c0m = n0m; c0l = n0l; c1h = n1h; c1m = n1m; c1l = n1l; }
+            const f16x8 wh = __builtin_bit_cast(f16x8, breg[2 * s]), wl = __builtin_bit_cast(f16x8, breg[2 * s + 1]);
+            accl0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, c0h, accl0, 0, 0, 0);
+            accl1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, c1h, accl1, 0, 0, 0);
+            accl0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, c0l, accl0, 0, 0, 0);
+            accl1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, c1l, accl1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, c0h, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, c1h, acc1, 0, 0, 0);
+            if (s < 8) { c0h = n0h; c0l = n0l; c1h = n1h; c1l = n1l; }
         }
 #undef AMPH_F4_FR
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = fmaf(accl0[r], kG4Lo, acc0[r]); acc1[r] = fmaf(accl1[r], kG4Lo, acc1[r]); }
         // the partial sum of the row tile this wave does not own goes to the partner (same ct, other K half)
         AMPH_F4_T(q_b)
         f32x16 keep, send;
@@ -493,7 +479,7 @@ static PatchGeo f4s_geo(const ConvGemmParams& p) {
     g.rt1_off = (32 / p.OW) * 2 * g.RS;
     return g;
 }
-static size_t f4s_lds(const PatchGeo& g) { return (size_t)4 * g.plane + (size_t)2 * 3 * ((g.n_img + 8) & ~7) * sizeof(uint16_t) + 4 * 4096; }
+static size_t f4s_lds(const PatchGeo& g) { return (size_t)4 * g.plane + (size_t)2 * 2 * ((g.n_img + 8) & ~7) * sizeof(uint16_t) + 4 * 4096; }
 
 // the shapes it covers: 3x3 stride-2 pad-1 twice, 32 layer-1 channels, whole output rows per 64-pixel tile (OW 16 or 32)
 bool conv_gemm_f4s_ok(const ConvGemmParams& p) {
@@ -506,37 +492,7 @@ bool conv_gemm_f4s_ok(const ConvGemmParams& p) {
     return g.n_img <= 256 * kPImgU && g.n_pix <= 12 * 32 && (kPImgU % 2) == 0 && g.n_img <= 256 * kPImgU - 256 * (kPImgU & 1) && p.W == 2 * p.OW && p.H == 2 * p.OH && f4s_lds(g) <= 160 * 1024 && p.M < (1 << 22);
 }
 
-// split weights in MFMA fragment order: [n tile][channel tile][k-step (K_pad / 16)][term][lane][8 bf16];
-// lane l holds row (l & 31), k = 16 kstep + 8 (l >> 5) + j
-void conv_gemm_f4s_fragment_weights(const float* w, int n_pad, int K_pad, uint16_t* out) {
-    auto rne = [](float f) {
-        uint32_t u;
-        std::memcpy(&u, &f, 4);
-        if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
-        u += 0x7fffu + ((u >> 16) & 1u);
-        return (uint16_t)(u >> 16);
-    };
-    auto up = [](uint16_t h) { const uint32_t u = (uint32_t)h << 16; float f; std::memcpy(&f, &u, 4); return f; };
-    const int ksteps = K_pad / 16;
-    for (int nt = 0; nt < n_pad / 64; ++nt)
-        for (int ct = 0; ct < 2; ++ct)
-            for (int ks = 0; ks < ksteps; ++ks)
-                for (int lane = 0; lane < 64; ++lane)
-                    for (int j = 0; j < 8; ++j) {
-                        const int n = nt * 64 + ct * 32 + (lane & 31), k = 16 * ks + 8 * (lane >> 5) + j;
-                        const float x = w[(size_t)n * K_pad + k];
-                        const uint16_t h = rne(x);
-                        const float r = x - up(h);
-                        const uint16_t m = rne(r);
-                        const uint16_t l = rne(r - up(m));
-                        const size_t base = (((size_t)(nt * 2 + ct) * ksteps + ks) * 3) * 64 * 8;
-                        out[base + (0 * 64 + lane) * 8 + j] = h;
-                        out[base + (1 * 64 + lane) * 8 + j] = m;
-                        out[base + (2 * 64 + lane) * 8 + j] = l;
-                    }
-}
-
-// wfrag = conv_gemm_f4s_fragment_weights' output on the device; wgs = workgroups to launch (0: the rule below)
+// wfrag = conv_gemm_h2_fragment_weights' output on the device (two fp16 terms in MFMA fragment order); wgs = workgroups to launch (0: the rule below)
 void launch_conv_gemm_f4s(const ConvGemmParams& p, const void* wfrag, int wgs, hipStream_t s) {
     static bool raised[64] = {false};
     int dev = 0;

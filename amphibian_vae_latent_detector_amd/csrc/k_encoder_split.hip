@@ -52,9 +52,6 @@ __device__ __forceinline__ void h2_split2(float x0, float x1, uint32_t& h, uint3
 }
 
 constexpr int kSBK = 32;                 // K elements per slice (one tap's 32-channel group)
-constexpr int kSRow = 192;               // LDS bytes per row: [h | m | l] x 32 bf16, packed; the 16-byte slot j of row r sits at
-                                         // 16 (j ^ ((r >> 2) & 3)): conflict-free 16-byte fragment reads AND conflict-free stores (the padded
-                                         // 208-byte rows of the first version showed 26 % of its LDS cycles as bank conflicts)
 constexpr int kSWRow = 192;              // bytes per (n, slice) in the split weight matrix
 // Two-term fp16 split (k_conv_gemm_s3 / _s3w since round 3): x = h + 2^-11 l with h = fp16(x), l = fp16((x - h) 2^11) - 22 significand
 // bits in TWO terms (bf16 needs three for 24), both products of 11-bit values exact in fp32.  x w = h h' + 2^-11 (h l' + l h') (+ 2^-22 l l':
