@@ -23,8 +23,9 @@ Extra objects on that line:
                 four lanes share the GPU: that figure includes queueing behind the other
                 lanes' kernels and is NOT a kernel duration.
   fp32_roofline the whole path's ALGORITHMIC fp32 FLOP/s against the 157.3 TF fp32 peak.  The
-                conv / head GEMMs do not run as fp32 instructions: they are three-term bf16 splits
-                on the bf16 matrix cores (fp32-accurate, fp32 accumulate), so this is a work rate,
+                conv / head GEMMs do not run as fp32 instructions: they are two-term fp16 splits
+                (x = h + 2^-11 l, three MFMAs per K = 16) on the matrix cores (fp32-accurate, fp32
+                accumulate), so this is a work rate,
                 not the utilisation of any one pipe - mixed_roofline is.
   mixed_roofline the bound the kernels as built can reach: matrix-pipe time of the MFMA kernels
                 (committed SQ_INSTS_MFMA x 32 cycles / (1024 SIMDs x 2.4 GHz), profiles/mfma_latest.json)
@@ -478,7 +479,7 @@ def main():
                          "frac": round((pipe_us + valu_us) / batch_period_us, 4),
                          "matrix_pipe_busy_over_timed_region": round(pipe_us / batch_period_us, 4),
                          "kernels": per_k, "source": mj.get("_source", "profiles/mfma_latest.json"),
-                         "note": "GEMM kernels: v_mfma_f32_32x32x16_bf16 on three-term bf16 splits of fp32 operands (6 MFMAs per K = 16, fp32 "
+                         "note": "GEMM kernels: v_mfma_f32_32x32x16_f16 on two-term fp16 splits of fp32 operands (x = h + 2^-11 l: 3 MFMAs per K = 16, fp32 "
                                  "accumulate): 32 matrix-pipe cycles each on one of 1024 SIMDs at 2.4 GHz; other kernels: algorithmic fp32 FLOPs at "
                                  "the 157.3 TF vector peak; batch period = ms_per_step / (chunks / 256)"}
         except (OSError, ValueError, KeyError):
@@ -489,7 +490,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16 encoder (fp32 front end, fp32 accumulate)" if args.bf16 else
-                     "f32 (results fp32-accurate; conv / head GEMMs as 3-term bf16 splits on the bf16 MFMA, fp32 accumulate; front end fp32 VALU)",
+                     "f32 (results fp32-accurate; conv / head GEMMs as two-term fp16 splits, x = h + 2^-11 l, on the f16 MFMA with fp32 accumulate; front end fp32 VALU)",
             "data": "synthetic",
             "step_ms": {"min": round(srt[0], 4), "median": round(srt[len(srt) // 2], 4), "max": round(srt[-1], 4), "n": len(srt),
                         "measured": "events on the caller's stream after every step, read after the closing barrier"},
