@@ -1,33 +1,36 @@
-// fp32-accurate implicit-GEMM convolution on the bf16 matrix cores ("s3": three-term operand split).
+// fp32-accurate implicit-GEMM convolution on the 16-bit matrix cores ("s3": split operands).
 //
 // Replaces, like k_conv_gemm_p3, the conv2d + BatchNorm(eval) + ReLU layers 3.. and the dense head of
 // `encoder(x)` at latent_space_exploration/map_detector_core.py:270 (module built at :175-179).
 //
 // Why: v_mfma_f32_32x32x2_f32 runs at the fp32 VECTOR rate (64 cycles per 32x32x2 = 157 TF chip-wide) and time-shares
 // the SIMD with every VALU instruction beside it (tools/probe/mfma_valu_*.hip): the fp32 GEMM layers sit at 0.55-0.65
-// of a peak that is itself 1/16 of the bf16 one.  An fp32 value is EXACTLY the sum of three bf16 values
-//     x = h + m + l,   h = bf16(x), m = bf16(x - h), l = bf16(x - h - m)      (8 + 8 + 8 significand bits, RNE)
-// and a product of two bf16 values is exact in fp32, so
-//     x * w = hh + hm + mh + mm + hl + lh  (+ ml + lm + ll, each below 2^-23 |x w|: dropped)
-// is six v_mfma_f32_32x32x16_bf16 per K = 16 with fp32 accumulation: 192 cycles against 512 for the same K on the
-// f32 shape, and bf16 MFMAs leave the VALU / LDS / load issue of the SIMD usable beside them.  The result differs from
-// an fp32 fma chain by the dropped terms (<= 2.4e-7 relative per product, random sign) and by the accumulation order
-// inside a 16-deep MFMA: measured against the torch-CPU oracle it is at the level of fp32 rounding noise (tests).
+// of a peak that is itself 1/16 of the 16-bit one.  An fp32 operand is split into 16-bit terms whose products are exact
+// in fp32 and the terms' products are accumulated in fp32 by 16-bit MFMAs:
+//   round 2: three bf16 terms, x = h + m + l (8 + 8 + 8 significand bits), x w = hh + hm + mh + mm + hl + lh: SIX
+//            v_mfma_f32_32x32x16_bf16 per K = 16 (ml, lm, ll below 2^-23 |x w| dropped).  Still the form of k_conv_gemm_f3s below.
+//   round 3: two fp16 terms, x = h + 2^-11 l with h = fp16(x), l = fp16((x - h) 2^11) (11 + 11 bits; x - h is exact in fp32),
+//            x w = h h' + 2^-11 (h l' + l h'): THREE v_mfma_f32_32x32x16_f16 per K = 16, h h' into one accumulator, the
+//            cross terms into a second that is scaled once in the epilogue (2^-22 l l' dropped).  k_conv_gemm_s3 / _s3w here,
+//            k_conv_gemm_f4s / _g4 / _g5 in k_encoder_patch.hip.  What the split itself loses against the float64 product of the
+//            same operands: 1.8e-7 relative, three bf16 terms 1.3e-8, a plain fp32 matmul's rounding 5.9e-7
+//            (tools/split_schemes_model.py); against the torch-CPU fp32 encoder both forms measure 6e-7 .. 1e-6 (tests).
+//            Half the MFMAs, two thirds of the LDS bytes and of the staging stores: conv4 25.8 -> 21.4 us, conv3 (g4) 28.4 -> 20.2.
+//            fp16's range (65 504) holds the encoder's operands - z-scored images, BN + ReLU activations, weights - with room;
+//            below 6e-5 h is subnormal and l keeps the value to an absolute 3e-11.
+// The result differs from an fp32 fma chain by the dropped terms and by the accumulation order inside a 16-deep MFMA.
 // Order is fixed (slice, k-step, term pair): results do not depend on batch size, lanes or tile placement.
 //
-// Data: weights are split ONCE on the host into [n tile][slice][64 n][term][32 k] bf16 (64 LDS row images, contiguous);
-// activations stay fp32 NHWC in HBM and the A tile is split on the way from the staging registers into LDS (44 VALU
-// instructions per thread and slice).  What bounds the kernel at a 256-chunk batch is data movement, not the matrix pipe
-// (in-kernel stamps, profiles/r02_s3_stamps.txt: ~1 400 cycles per slice for 768 cycles of MFMA time on a SIMD's two waves):
-// a 64 x 64 x 32 block needs 20 KB from L2 (64 B/clk/CU at the MFMA rate = the whole vector-cache path) and 24 KB of LDS
-// stores at ~79 B/clk/CU; larger tiles would halve both but a 256-chunk batch has only 512 / 256 tiles of 64 x 64 (conv3 /
-// conv4).  Tried and dropped: activations handed over pre-split (6 B per element, written by the producer's epilogue: A
-// staging a pure copy, no VALU) - 50 % more A bytes and 12 epilogue stores per lane instead of 4 cost more than the VALU
-// work they removed (conv2 33.2 -> 37.9, conv3 22.8 -> 24.6, conv4 25.0 -> 24.1 us); four register stages instead of three
-// (no change: the loop is not latency-bound).
-// LDS rows are packed (192 B) with XOR-swizzled 16-byte slots: fragment reads and staging stores are conflict-free.
-// Geometry, addressing (buffer loads, zero guard for padded taps, scalar tap state) and the transposed-accumulator
-// epilogue are k_conv_gemm_p3's.
+// Data: weights are split ONCE on the host into [n tile][slice][64 n][term][32 k] (64 LDS row images, contiguous);
+// activations stay fp32 NHWC in HBM and the A tile is split on the way from the staging registers into LDS.  What bounds the
+// kernel at a 256-chunk batch is data movement, not the matrix pipe (in-kernel stamps of the three-term form,
+// profiles/r02_s3_stamps.txt: ~1 400 cycles per slice for 768 cycles of MFMA time on a SIMD's two waves); larger tiles halve the
+// bytes per output (k_conv_gemm_s3w below) at the price of fewer workgroups.  Tried and dropped: activations handed over
+// pre-split (written by the producer's epilogue: A staging a pure copy) - more A bytes and epilogue stores cost more than the
+// VALU work they removed; four register stages instead of three (no change: the loop is not latency-bound).
+// LDS rows are packed (128 B: [h | l] x 32 fp16) with XOR-swizzled 16-byte slots: fragment reads and staging stores are
+// conflict-free.  Geometry, addressing (buffer loads, zero guard for padded taps, scalar tap state) and the
+// transposed-accumulator epilogue are k_conv_gemm_p3's.
 #include "amph_internal.h"
 
 #include <algorithm>

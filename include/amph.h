@@ -100,10 +100,10 @@ const char* amph_last_error(const amph_ctx* ctx);   /* ctx may be NULL: create-t
  *                            evaluated in double, the scale cast to float32 once; 1 = numpy 2.x (NEP 50):
  *                            float32 throughout.  The scales differ by 1 ulp on about a third of all chunks,
  *                            which the PCM16 re-quantisation behind it turns into whole LSBs
- *   "split_gemm"       0/1   GEMM-shaped layers behind the fused pair (and the head) on the bf16 matrix cores with three-term
- *                            split operands: x = h + m + l exactly, six v_mfma_f32_32x32x16_bf16 per K = 16, fp32
- *                            accumulation - as close to the torch-CPU fp32 result as the f32-MFMA kernels (1e-6), which 0
- *                            selects; results differ from those in the last bits (default 1)
+ *   "split_gemm"       0/1   GEMM-shaped layers behind the fused pair (and the head) on the f16 matrix cores with two-term
+ *                            split operands: x = h + 2^-11 l (h, l fp16: 22 significand bits), three v_mfma_f32_32x32x16_f16
+ *                            per K = 16, fp32 accumulation - as close to the torch-CPU fp32 result as the f32-MFMA kernels
+ *                            (1e-6), which 0 selects; results differ from those in the last bits (default 1)
  *   "split_fused"      0/1   ... the fused conv1 + conv2 kernel too (default 1)
  *   "rms_chunk_path_over" 1.. PCM16 rows of more than this many numpy chunks (8 192 samples) are normalised by the (row, chunk) + (row, tile)
  *                            kernel pair instead of one workgroup per row (default 2; same bits)

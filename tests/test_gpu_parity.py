@@ -335,8 +335,8 @@ def test_fused_first_two_layers_equal_unfused_bitwise(env, name):
 
 
 def test_split_operand_gemm_layers_are_fp32_accurate_and_batch_independent(env, capsys):
-    """The GEMM layers behind the fused pair run on the bf16 matrix cores with three-term split operands ("split_gemm",
-    default on; csrc/k_encoder_split.hip): x = h + m + l exactly, six bf16 MFMAs per K = 16, fp32 accumulation.  Against the
+    """The GEMM layers behind the fused pair run on the matrix cores with two-term fp16 split operands ("split_gemm",
+    default on; csrc/k_encoder_split.hip): x = h + 2^-11 l, three f16 MFMAs per K = 16, fp32 accumulation.  Against the
     torch-CPU fp32 oracle they must be as close as the f32-MFMA kernels are (1e-5 bar; both measure ~1e-6), must not depend
     on batch composition, and the two forms must agree to fp32 rounding noise.  Shapes: thesis-shape at 64 x 64 and at the
     reference's 192 x 64 image, `tiny` (C_in % 32 != 0 in layer 2: the split kernel only takes the head there)."""
@@ -367,7 +367,7 @@ def test_split_operand_gemm_layers_are_fp32_accurate_and_batch_independent(env, 
         _assert_latents(out[1][0], out[0][0], 5e-6)
         e = [max(rel_l2(out[v][0][r], mu_o.numpy()[r]) for r in range(45)) for v in (0, 1)]
         with capsys.disabled():
-            print(f"\n[split GEMM, {preset}/{name}] max rel L2 of mu vs torch-CPU fp32: f32 MFMA {e[0]:.2e}, bf16 x 3 MFMA {e[1]:.2e}")
+            print(f"\n[split GEMM, {preset}/{name}] max rel L2 of mu vs torch-CPU fp32: f32 MFMA {e[0]:.2e}, fp16 x 2 MFMA {e[1]:.2e}")
 
 
 def test_patch_resident_fused_pair_matches_oracle_and_other_forms(env, capsys):
