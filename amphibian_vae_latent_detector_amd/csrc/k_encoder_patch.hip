@@ -232,7 +232,9 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_f4s(ConvGemmParams p, Patc
         for (int i = 0; tile < g.n_tiles; tile += gridDim.x, ++i) {
             const int nt = tile + (int)gridDim.x;
             AMPH_F4_T(q_a)
-            AMPH_F4_FETCH_IMG(nt < g.n_tiles ? nt : tile)            // lands under the arithmetic below
+            // (round 3: only the second tile's image rows are staged here - from the third on the CONSUMERS do it, in the half of a tile
+            // period they used to wait for this role, which bounds the tile since the two-term split halved their MFMA stream)
+            if (i == 0) AMPH_F4_FETCH_IMG(nt < g.n_tiles ? nt : tile)  // lands under the arithmetic below
 #ifdef AMPH_STAMPS
             unsigned long long q_f, q_g, q_g1, q_g2;
             AMPH_F4_T(q_f)
@@ -302,7 +304,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_f4s(ConvGemmParams p, Patc
             q_s2 += q_f - q_a; q_s3 += q_g - q_f;
             q_p0 += q_g1 - q_f; q_p1 += q_g2 - q_g1; q_p2 += q_g - q_g2;
 #endif
-            AMPH_F4_WRITE_IMG(img_stage + ((i + 1) & 1) * 2 * img_pl)   // that buffer's last read came before the previous X
+            if (i == 0) AMPH_F4_WRITE_IMG(img_stage + ((i + 1) & 1) * 2 * img_pl)   // that buffer's last read came before the previous X
             AMPH_F4_T(q_b)
             __syncthreads();                                         // X: patch i complete (the consumers are done with patch i - 1)
             __syncthreads();                                         // Y
@@ -373,6 +375,24 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_f4s(ConvGemmParams p, Patc
     for (int tile = blockIdx.x; tile < g.n_tiles; tile += gridDim.x, ++i) {
         const char* pb = ((i & 1) ? patch1 : patch0) + a_base;
         AMPH_F4_T(q_a)
+        // the image rows of tile i + 2 (the producers build patch i + 1 from the other stage buffer meanwhile): requested here, split and
+        // stored behind the multiply.  Element e = tid + 256 u of the [2 PR + 1][img_row] stage: row r = image row 4 oh0 - 3 + r, column c - 3
+        const int st_tile = tile + 2 * (int)gridDim.x;
+        const bool st_on = st_tile < g.n_tiles;                      // wave-uniform
+        float pf[6];
+        if (st_on) {
+            const int b_ = f4_div_small(st_tile, g.tiles_per_image, rcp_tpi), tr_ = st_tile - b_ * g.tiles_per_image;
+            const int ir0_ = 4 * tr_ * g.n_oh - 3;
+            const float* img_ = p.img + ((long long)b_ * p.H0 + ir0_) * p.W0;
+            const float rcp_ir = 1.0f / (float)g.img_row;
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const int e = tid + 256 * u;
+                const int r = f4_div_small(e, g.img_row, rcp_ir), ic = e - r * g.img_row - 3;
+                const bool ok_ = e < g.n_img && ic >= 0 && ic < p.W0 && (unsigned)(ir0_ + r) < (unsigned)p.H0;
+                pf[u] = *(ok_ ? img_ + r * p.W0 + ic : p.zeros);
+            }
+        }
         f32x16 acc0, acc1, accl0, accl1;                             // per row tile: h h' | the cross terms
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; accl0[r] = 0.0f; accl1[r] = 0.0f; }
@@ -402,6 +422,19 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_f4s(ConvGemmParams p, Patc
 #undef AMPH_F4_FR
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc0[r] = fmaf(accl0[r], kG4Lo, acc0[r]); acc1[r] = fmaf(accl1[r], kG4Lo, acc1[r]); }
+        if (st_on) {
+            uint16_t* dst = img_stage + (i & 1) * 2 * img_pl;        // tile i + 2's stage buffer: last read while patch i was built
+#pragma unroll
+            for (int k2 = 0; k2 < 3; ++k2) {
+                uint32_t h_, l_;
+                g4_split2(pf[2 * k2], pf[2 * k2 + 1], h_, l_);
+                const int e0 = tid + 256 * (2 * k2), e1 = e0 + 256;
+                uint16_t* d0_ = dst + (e0 < g.n_img ? e0 : g.n_img);   // lanes past the last element store to the plane's pad element
+                uint16_t* d1_ = dst + (e1 < g.n_img ? e1 : g.n_img);
+                d0_[0] = (uint16_t)h_; d0_[img_pl] = (uint16_t)l_;
+                d1_[0] = (uint16_t)(h_ >> 16); d1_[img_pl] = (uint16_t)(l_ >> 16);
+            }
+        }
         // the partial sum of the row tile this wave does not own goes to the partner (same ct, other K half)
         AMPH_F4_T(q_b)
         f32x16 keep, send;
