@@ -451,6 +451,29 @@ def test_register_resident_weight_conv_layers_match_oracle_and_staged_kernel(env
               % (e[0], e[1], e[2], e[3]))
 
 
+def test_two_term_fp16_split_holds_its_accuracy_across_input_magnitudes(env, capsys):
+    """The matrix-core layers multiply fp32 operands as two fp16 terms (x = h + 2^-11 l; csrc/k_encoder_split.hip header): fp16's range is
+    the one thing the three-term bf16 form did not have to think about.  Images scaled by 1e-3 (most layer-1 activations below fp16's
+    smallest normal: h subnormal, l carries the value), 1 and 60 (activations in the hundreds; |x| must stay below 65 504) must all meet
+    the 1e-5 bar (relative L2 per row) against the torch-CPU fp32 encoder, and every output must be finite."""
+    cfg = env.PRESETS["bench-1s"]
+    enc, tenc, spec = _encoders(env, "thesis-shape", cfg=cfg, max_batch=32)
+    sess = enc.session(cfg)
+    base = np.random.default_rng(31).standard_normal((24, 1, cfg.target_frames, cfg.n_mels)).astype(np.float32)
+    worst = {}
+    for scale in (1e-3, 1.0, 60.0):
+        x = torch.from_numpy(base * np.float32(scale))
+        with torch.no_grad():
+            mu_o, lv_o = tenc(x)
+        mu, lv = sess.encoder_forward(x)
+        assert torch.isfinite(mu).all() and torch.isfinite(lv).all()
+        # (per-row relative L2: at scale 60 the latents reach the hundreds and an element near zero is a cancellation in ANY fp32 evaluation)
+        worst[scale] = max(max(rel_l2(mu.cpu().numpy()[r], mu_o.numpy()[r]), rel_l2(lv.cpu().numpy()[r], lv_o.numpy()[r])) for r in range(24))
+        assert worst[scale] <= 1e-5, (scale, worst[scale])
+    with capsys.disabled():
+        print("\n[two-term fp16 split] max rel L2 of mu vs torch-CPU fp32 at image scale " + ", ".join(f"{k:g}: {v:.2e}" for k, v in worst.items()))
+
+
 @pytest.mark.parametrize("preset", ["bench-1s", "ref-default", "bench-1s-128"])
 def test_wide_tile_staged_gemm_is_bit_identical_to_the_64_row_tile(env, capsys, preset):
     """The staged split GEMM on 128 x 128 tiles ("wide_gemm"; csrc/k_encoder_split.hip, k_conv_gemm_s3w: what multi-lane calls use
