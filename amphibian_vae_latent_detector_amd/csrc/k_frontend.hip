@@ -1076,7 +1076,8 @@ __global__ __launch_bounds__(64 * NW) void k_stft_mel(StftParams p, int n_tiles)
 // mel power [n_frames][n_mels] the workgroup holds in LDS.  Same arithmetic as k_dbnorm (separately rounded dB terms, sums
 // in double, two-pass std); the mel power never reaches HBM (-3.7 MB written, -1.9 MB read and one launch less per 256 rows).
 __device__ __forceinline__ float to_db(float s, float ref_db);
-template <int NT, int C = 8>
+// HAVE_MAX: the caller's waves have left the maxima of the values they wrote in redf[0 .. NT / 64) (and passed a barrier): no max pass
+template <int NT, int C = 8, bool HAVE_MAX = false>
 __device__ __forceinline__ void db_row_from_lds(const float* mp, int T, int M, int TT, int layout, float* out, double* red, unsigned long long* dbg = nullptr) {
 #ifdef AMPH_STAMPS
 #define AMPH_DB_T(k_) if (dbg && threadIdx.x == 0) { unsigned long long t_; asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); dbg[k_] = t_; }
@@ -1093,10 +1094,12 @@ __device__ __forceinline__ void db_row_from_lds(const float* mp, int T, int M, i
     float mx = -INFINITY;
 #pragma unroll
     for (int j = 0; j < C; ++j) { const int i = tid + NT * j; v[j] = i < n ? mp[i] : -INFINITY; mx = fmaxf(mx, v[j]); }
-    for (int i = tid + NT * C; i < n; i += NT) mx = fmaxf(mx, mp[i]);
-    mx = wave_max_dpp(mx);
-    if (lane == 63) redf[w] = mx;
-    __syncthreads();
+    if (!HAVE_MAX) {
+        for (int i = tid + NT * C; i < n; i += NT) mx = fmaxf(mx, mp[i]);
+        mx = wave_max_dpp(mx);
+        if (lane == 63) redf[w] = mx;
+        __syncthreads();
+    }
     AMPH_DB_T(0)
     mx = redf[0];
 #pragma unroll
@@ -1162,9 +1165,9 @@ __device__ __forceinline__ void db_row_from_lds(const float* mp, int T, int M, i
     }
 }
 
-template <int NT, int C = 8>
+template <int NT, int C = 8, bool HAVE_MAX = false>
 __device__ __attribute__((noinline)) void db_row_call(const float* mp, int T, int M, int TT, int layout, float* out, double* red) {
-    db_row_from_lds<NT, C>(mp, T, M, TT, layout, out, red);
+    db_row_from_lds<NT, C, HAVE_MAX>(mp, T, M, TT, layout, out, red);
 }
 
 // ----------------------------------------------------------------------------
@@ -1691,7 +1694,9 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
     // Pairs are handed out DYNAMICALLY (an LDS counter per row; wave w starts with pair w): the SIMD issues oldest-wave-first, so its
     // first wave runs a pair in ~12.6 k cycles, its second in ~20 k, its third in ~35 k (profiles/r03_stft_pair_timeline.txt) - with
     // a fixed pr = wave + 12 i the first waves idle at the end while the SIMD that drew the row's 29th pair still works
+    float* const db_redf = reinterpret_cast<float*>(reinterpret_cast<double*>(mp_row + ((p.n_frames * p.n_mels + 3) & ~3)) + 16);   // db_row_from_lds's redf
     for (int row = blockIdx.x; row < n_rows; row += gridDim.x) {
+        float wmax = -INFINITY;                             // the largest mel power this wave has stored for the row (fused dB stage: its max pass)
         for (int pr = wave, pr_next = 0; pr < n_pairs; pr = pr_next) {
             // packed pairs: element j of the lane's TWO sequences (sample parity 0 / 1) side by side - dft16_pk
             amph_f2 XR[16], XI[16];
@@ -1919,7 +1924,7 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
                     sa += amph_f2{dpp_xor1(sa.x), dpp_xor1(sa.y)};
                     sa += amph_f2{dpp_xor2(sa.x), dpp_xor2(sa.y)};
                     const int m = 16 * r + (lane >> 2);
-                    if (q == 0 && m < p.n_mels) { out_a[m] = sa.x; if (has_b) out_b[m] = sa.y; }
+                    if (q == 0 && m < p.n_mels) { out_a[m] = sa.x; wmax = fmaxf(wmax, sa.x); if (has_b) { out_b[m] = sa.y; wmax = fmaxf(wmax, sa.y); } }
                 }
             }
             wave_lds_sync();                                // the scratch is rewritten by the next pair
@@ -1943,10 +1948,14 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
             if (tid == 0) *next_pair = NW;
             __syncthreads();
         }
+        if (fuse_db) {                                      // (every wave, also one without pairs: -inf)
+            const float wm = wave_max_dpp(wmax);
+            if (lane == 63) db_redf[wave] = wm;
+        }
         if (fuse_db && row + (int)gridDim.x < n_rows) {
             __syncthreads();
             if (tid == 0) *next_pair = NW;
-            db_row_call<kThreads>(mp_row, p.n_frames, p.n_mels, p.db_target_frames, p.db_layout,
+            db_row_call<kThreads, 8, true>(mp_row, p.n_frames, p.n_mels, p.db_target_frames, p.db_layout,
                                   p.db_out + (long long)row * p.db_target_frames * p.n_mels,
                                   reinterpret_cast<double*>(mp_row + ((p.n_frames * p.n_mels + 3) & ~3)));
             __syncthreads();
@@ -1968,7 +1977,7 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
 #ifdef AMPH_STAMPS
         if (tid == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); tl[6] = t_; }
 #endif
-        db_row_from_lds<kThreads>(mp_row, p.n_frames, p.n_mels, p.db_target_frames, p.db_layout,
+        db_row_from_lds<kThreads, 8, true>(mp_row, p.n_frames, p.n_mels, p.db_target_frames, p.db_layout,
                                   p.db_out + (long long)last_row * p.db_target_frames * p.n_mels,
                                   reinterpret_cast<double*>(mp_row + ((p.n_frames * p.n_mels + 3) & ~3))
 #ifdef AMPH_STAMPS
