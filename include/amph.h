@@ -140,7 +140,8 @@ const char* amph_last_error(const amph_ctx* ctx);   /* ctx may be NULL: create-t
  *                            k_stft_pair (a pair per wave, 32 points per lane) / k_stft_pair2 (a pair per half wave).  Mel power
  *                            within 5e-7 of the row's peak of the frame-per-wave kernels' (0 selects those)
  *   "stft_pair_waves"  8..12 waves per workgroup of that kernel (8, 10, 11, 12 at n_fft 2048; 8 or 12 at 1024); amph_create picks
- *                            the largest whose LDS image fits; results do not depend on it
+ *                            the largest whose LDS image fits; 10, 11 and 12 give identical bits, the 8-wave build differs
+ *                            from them in the last bits (3e-7 of a row's peak mel power: another FMA contraction)
  *   "stft_pair_tw_lds" 0/1   its stage-1 twiddles in LDS when the image still fits 160 KB (default 1), else buffer loads
  *   "stft_prenorm"     0/1   PCM16 input with apply_rms: the RMS kernel also writes the normalised, re-quantised PCM16
  *                            rows (what 00_normalize_dataset_rms.py puts on disk) and the STFT kernel reads those
