@@ -2525,7 +2525,7 @@ void launch_rms_scale_pcm16(const int16_t* in, long long row_stride, const int32
         hipLaunchKernelGGL((k_rms_scale<int16_t, 256, 1>), dim3(n_rows, n_chunks), dim3(256), (rms_scale_lds<int16_t, 1>()), s, in, row_stride, lengths, n_in,
                            scale, ok, static_cast<int16_t*>(nullptr), NormPad{}, scale_f64, chunk_sums, n_chunks);
         const int total_out = (pad.lead > 0 ? pad.n_fix : n_in) + 2 * pad.lead;
-        const int tiles = norm_out ? std::max(1, std::min(64, total_out / (2 * 256 * 16))) : 1;      // ~16 dwords per thread
+        const int tiles = norm_out ? std::max(1, std::min(64, total_out / (2 * 256 * 8))) : 1;       // ~8 dwords per thread (16: 21.1 us for K0 on 256 one-second rows, 8: 19.3, 4: 19.9)
 #ifdef AMPH_ABL_SKIP
         if (!(g_abl_skip_k0 & 2))
 #endif
