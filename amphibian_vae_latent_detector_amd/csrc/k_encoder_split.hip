@@ -62,9 +62,15 @@ constexpr int kSWRow = 192;              // bytes per (n, slice) in the split we
 // scaled once in the epilogue.  Measured against the float64 product of the same operands: 1.8e-7 relative (bf16 x 3: 1.3e-8, a plain fp32
 // matmul 5.9e-7 - tools/split_schemes_model.py), i.e. still below the rounding noise of fp32 accumulation.  fp16's range holds the encoder's
 // operands with room (|x| < 65 504; below 6e-5 the split keeps an absolute 3e-11).
-constexpr int kHRow = 128;               // LDS bytes per row: [h | l] x 32 fp16; 16-byte slot j of row r at 16 (j ^ ((r >> 2) & 3))
+constexpr int kHRow = 128;               // LDS bytes per row: [h | l] x 32 fp16; 16-byte slot j of row r at 16 (j ^ h_sw(r))
 constexpr int kHBuf = 64 * kHRow;        // bytes per 64-row operand tile per slice buffer
 constexpr int kHWRow = 128;              // bytes per (n, slice) in the two-term weight matrix
+
+// Slot swizzle of the slice buffers (tools/lds_swizzle_model.py): a ds_read_b128 lane group holds 8 even and 8 odd rows (row parity =
+// half of the 256-byte bank row), so the 8 slots of the rows of one parity must differ - three bits from r >> 1; a ds_write_b64 group
+// (16 lanes = rows r, r + 1 x 64 bytes of one term, banks mod 32) needs the two rows' terms in opposite halves - bit 2 from r & 1.
+// (Until r03d: (r >> 2) & 3, two bits - every fragment read and A store 2-way conflicted, 43 % of the kernel's LDS cycles.)
+__device__ __forceinline__ int h_sw(int r) { return ((r >> 1) & 7) ^ ((r & 1) << 2); }
 
 __device__ __forceinline__ int s3_div_small(int n, int d, float rcp) {
     int q = (int)((float)n * rcp);
@@ -203,30 +209,30 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm_s3(ConvGemmParams p) {
 #define AMPH_S3_LOADA_ADV(q) { AMPH_S3_LOADA(q) AMPH_S3_ADV() }
 
     // stage q -> LDS buffer buf_: B rows are the LDS image already; A rows are split here
-    const int st_a = r0 * kHRow + 16 * ((c4 >> 1) ^ ((r0 >> 2) & 3)) + 8 * (c4 & 1);     // (row r0 + 32 has the same swizzle)
+    const int st_a = r0 * kHRow + 16 * ((c4 >> 1) ^ h_sw(r0)) + 8 * (c4 & 1);             // (row r0 + 32 has the same swizzle; the l term at st_a ^ 64)
     int st_b0, st_b1;                                  // byte o of the block -> LDS row o / 128, swizzled slot of column o % 128
     {
         const int o0 = 16 * tid, o1 = o0 + 4096;
-#define AMPH_S3_SW(o_) (((o_) / kHWRow) * kHRow + 16 * ((((o_) % kHWRow) >> 4) ^ ((((o_) / kHWRow) >> 2) & 3)))
+#define AMPH_S3_SW(o_) (((o_) / kHWRow) * kHRow + 16 * ((((o_) % kHWRow) >> 4) ^ h_sw((o_) / kHWRow)))
         st_b0 = AMPH_S3_SW(o0); st_b1 = AMPH_S3_SW(o1);
 #undef AMPH_S3_SW
     }
-#define AMPH_S3_SPLIT_ROW(v_, dst_)                                                        \
+#define AMPH_S3_SPLIT_ROW(v_, base_, off_)                                                 \
     {                                                                                      \
         uint32_t h0, l0, h1, l1;                                                           \
         h2_split2(v_.x, v_.y, h0, l0);                                                     \
         h2_split2(v_.z, v_.w, h1, l1);                                                     \
-        *reinterpret_cast<uint2*>(dst_) = make_uint2(h0, h1);                              \
-        *reinterpret_cast<uint2*>(dst_ + 64) = make_uint2(l0, l1);                         \
+        *reinterpret_cast<uint2*>((base_) + (off_)) = make_uint2(h0, h1);                  \
+        *reinterpret_cast<uint2*>((base_) + ((off_) ^ 64)) = make_uint2(l0, l1);           \
     }
 #define AMPH_S3_STORE(q, buf_)                                                             \
     {                                                                                      \
-        char* a_ = As + (buf_) * kHBuf + st_a;                                             \
+        char* a_ = As + (buf_) * kHBuf;                                                    \
         char* b_ = Bs + (buf_) * kHBuf;                                                    \
         *reinterpret_cast<uint4*>(b_ + st_b0) = sb##q##a;                                  \
         *reinterpret_cast<uint4*>(b_ + st_b1) = sb##q##b;                                  \
-        AMPH_S3_SPLIT_ROW(sa##q##x, a_)                                                    \
-        AMPH_S3_SPLIT_ROW(sa##q##y, (a_ + 32 * kHRow))                                     \
+        AMPH_S3_SPLIT_ROW(sa##q##x, a_, st_a)                                              \
+        AMPH_S3_SPLIT_ROW(sa##q##y, a_ + 32 * kHRow, st_a)                                 \
     }
 
     f32x16 acc, accl;                                  // h h' | h l' + l h' (x 2^-11 in the epilogue)
@@ -244,14 +250,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm_s3(ConvGemmParams p) {
         AMPH_S3_BN(0) AMPH_S3_BN(1) AMPH_S3_BN(2) AMPH_S3_BN(3)
 #undef AMPH_S3_BN
     }
-    // fragment addresses: lane l holds row (l & 31), k = 16 kstep + 8 (l >> 5) + j of each term
-    // (slot 4 t + 2 kstep + (l >> 5) of the row; the swizzle touches the low two bits only, so the two terms stay 64 bytes apart)
-    const int swl = ((lane & 31) >> 2) & 3;
-    const char* a_rd0 = As + (row_tile * 32 + (lane & 31)) * kHRow + 16 * ((lane >> 5) ^ swl);
-    const char* a_rd1 = As + (row_tile * 32 + (lane & 31)) * kHRow + 16 * ((2 + (lane >> 5)) ^ swl);
-    const char* b_rd0 = Bs + (col_tile * 32 + (lane & 31)) * kHRow + 16 * ((lane >> 5) ^ swl);
-    const char* b_rd1 = Bs + (col_tile * 32 + (lane & 31)) * kHRow + 16 * ((2 + (lane >> 5)) ^ swl);
-#define AMPH_S3_FRAG(base_, buf_, ks_, t_) __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>((base_##ks_) + (buf_) * kHBuf + 64 * (t_)))
+    // fragment addresses: lane l holds row (l & 31), k = 16 kstep + 8 (l >> 5) + j of each term: slot (4 t + 2 kstep + (l >> 5)) ^ h_sw(row)
+    // of the row - one offset per (kstep, term), the same for both operands (32-row tiles: row & 15 is the lane's)
+    const int swl = h_sw(lane & 31);
+    const char* a_rdb = As + (row_tile * 32 + (lane & 31)) * kHRow;
+    const char* b_rdb = Bs + (col_tile * 32 + (lane & 31)) * kHRow;
+    const int rd_o00 = 16 * ((lane >> 5) ^ swl), rd_o01 = rd_o00 ^ 64, rd_o10 = 16 * ((2 + (lane >> 5)) ^ swl), rd_o11 = rd_o10 ^ 64;
+#define AMPH_S3_FRAG(base_, buf_, ks_, t_) __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>((base_##b) + (buf_) * kHBuf + rd_o##ks_##t_))
     // weights as the FIRST operand: transposed accumulator (lane = output row m, registers 4g .. 4g + 3 = channels), see p3
 #define AMPH_S3_MFMA(a_, w_, x_) a_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(w_, x_, a_, 0, 0, 0);
 #define AMPH_S3_READ6(pre_, buf_, ks_)                                                     \
@@ -264,8 +269,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm_s3(ConvGemmParams p) {
         *reinterpret_cast<uint4*>(b_ + st_b0) = sb##q##a;                                  \
         *reinterpret_cast<uint4*>(b_ + st_b1) = sb##q##b;                                  \
     }
-#define AMPH_S3_ST_AX(q, buf_) { char* a_ = As + (buf_) * kHBuf + st_a; AMPH_S3_SPLIT_ROW(sa##q##x, a_) }
-#define AMPH_S3_ST_AY(q, buf_) { char* a_ = As + (buf_) * kHBuf + st_a + 32 * kHRow; AMPH_S3_SPLIT_ROW(sa##q##y, a_) }
+#define AMPH_S3_ST_AX(q, buf_) { char* a_ = As + (buf_) * kHBuf; AMPH_S3_SPLIT_ROW(sa##q##x, a_, st_a) }
+#define AMPH_S3_ST_AY(q, buf_) { char* a_ = As + (buf_) * kHBuf + 32 * kHRow; AMPH_S3_SPLIT_ROW(sa##q##y, a_, st_a) }
 #if defined(AMPH_S3_ABL_NOLOAD)            /* timing-only ablations (make ablations_s3; never shipped) */
 #define AMPH_S3_LOOPLOAD(QL) AMPH_S3_ADV()
 #else
@@ -466,12 +471,12 @@ __global__ __launch_bounds__(512, 1) void k_conv_gemm_s3w(ConvGemmParams p) {
     }
 #define AMPH_W_LOAD(q) { AMPH_W_LOADB(q) AMPH_W_LOADA(q) AMPH_S3_ADV() }
 #define AMPH_W_LOADA_ADV(q) { AMPH_W_LOADA(q) AMPH_S3_ADV() }
-    const int st_a = r0 * kHRow + 16 * ((c4 >> 1) ^ ((r0 >> 2) & 3)) + 8 * (c4 & 1);     // (row r0 + 64 has the same swizzle)
+    const int st_a = r0 * kHRow + 16 * ((c4 >> 1) ^ h_sw(r0)) + 8 * (c4 & 1);             // (row r0 + 64 has the same swizzle; the l term at st_a ^ 64)
     int st_b[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int o = 16 * bt + 4096 * i, row = o / kHWRow, col = o % kHWRow;
-        st_b[i] = (64 * bh + row) * kHRow + 16 * ((col >> 4) ^ ((row >> 2) & 3));
+        st_b[i] = (64 * bh + row) * kHRow + 16 * ((col >> 4) ^ h_sw(row));
     }
 #define AMPH_W_ST_B(q, buf_)                                                               \
     {                                                                                      \
@@ -479,7 +484,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_gemm_s3w(ConvGemmParams p) {
         *reinterpret_cast<uint4*>(b_ + st_b[0]) = sb[q][0];                                \
         *reinterpret_cast<uint4*>(b_ + st_b[1]) = sb[q][1];                                \
     }
-#define AMPH_W_ST_A(q, buf_, i_) { char* a_ = As + (buf_) * kWBuf + st_a + (i_) * 64 * kHRow; AMPH_S3_SPLIT_ROW(sa[q][i_], a_) }
+#define AMPH_W_ST_A(q, buf_, i_) { char* a_ = As + (buf_) * kWBuf + (i_) * 64 * kHRow; AMPH_S3_SPLIT_ROW(sa[q][i_], a_, st_a) }
 
     f32x16 acc[2], accl[2];                            // per row tile: h h' | h l' + l h' (x 2^-11 in the epilogue)
 #pragma unroll
@@ -491,17 +496,19 @@ __global__ __launch_bounds__(512, 1) void k_conv_gemm_s3w(ConvGemmParams p) {
     float* const bn = reinterpret_cast<float*>(smem + 6 * kWBuf);       // [2][128]
     if (tid < 256) bn[tid] = (tid < 128 ? p.scale : p.shift)[n_blk + (tid & 127)];
     // fragment addresses (s3's): lane l holds row (l & 31), k = 16 kstep + 8 (l >> 5) + j of each term
-    const int swl = ((lane & 31) >> 2) & 3;
-    const char* a_rd[2] = {As + (rg * 64 + (lane & 31)) * kHRow + 16 * ((lane >> 5) ^ swl), As + (rg * 64 + (lane & 31)) * kHRow + 16 * ((2 + (lane >> 5)) ^ swl)};
-    const char* b_rd[2] = {Bs + (ct * 32 + (lane & 31)) * kHRow + 16 * ((lane >> 5) ^ swl), Bs + (ct * 32 + (lane & 31)) * kHRow + 16 * ((2 + (lane >> 5)) ^ swl)};
+    const int swl = h_sw(lane & 31);
+    const char* a_rdb = As + (rg * 64 + (lane & 31)) * kHRow;
+    const char* b_rdb = Bs + (ct * 32 + (lane & 31)) * kHRow;
+    const int rd_o[2][2] = {{16 * ((lane >> 5) ^ swl), (16 * ((lane >> 5) ^ swl)) ^ 64},       // [kstep][term]
+                            {16 * ((2 + (lane >> 5)) ^ swl), (16 * ((2 + (lane >> 5)) ^ swl)) ^ 64}};
     struct Frag { f16x8 x[2][2], w[2]; };                // [row tile][term], [term]
 #define AMPH_W_FR(ptr_) __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(ptr_))
 #define AMPH_W_READ9(f_, buf_, ks_)                                                        \
     {                                                                                      \
         _Pragma("unroll") for (int q_ = 0; q_ < 2; ++q_) {                                 \
-            f_.x[0][q_] = AMPH_W_FR(a_rd[ks_] + (buf_) * kWBuf + 64 * q_);                 \
-            f_.x[1][q_] = AMPH_W_FR(a_rd[ks_] + (buf_) * kWBuf + 32 * kHRow + 64 * q_);    \
-            f_.w[q_] = AMPH_W_FR(b_rd[ks_] + (buf_) * kWBuf + 64 * q_);                    \
+            f_.x[0][q_] = AMPH_W_FR(a_rdb + (buf_) * kWBuf + rd_o[ks_][q_]);               \
+            f_.x[1][q_] = AMPH_W_FR(a_rdb + (buf_) * kWBuf + 32 * kHRow + rd_o[ks_][q_]);  \
+            f_.w[q_] = AMPH_W_FR(b_rdb + (buf_) * kWBuf + rd_o[ks_][q_]);                  \
         }                                                                                  \
     }
     // term pair (w term, x term) on both row tiles; weights first: transposed accumulator (lane = output row, registers = channels)
