@@ -93,7 +93,7 @@ __device__ __forceinline__ int s3_div_small(int n, int d, float rcp) {
 #define AMPH_S3_T(v_)
 #endif
 
-__global__ __launch_bounds__(256, 2) void k_conv_gemm_s3(ConvGemmParams p) {
+__global__ __launch_bounds__(256, 3) void k_conv_gemm_s3(ConvGemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef AMPH_STAMPS
     unsigned long long q_t0 = 0, q_t1 = 0, q_t2 = 0, q_t3 = 0, q_ta = 0, q_tb = 0;
@@ -239,16 +239,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm_s3(ConvGemmParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[r] = 0.0f; accl[r] = 0.0f; }
     const int row_tile = wave >> 1, col_tile = wave & 1;
-    float4 e_sc0, e_sc1, e_sc2, e_sc3, e_sh0, e_sh1, e_sh2, e_sh3;
-    {
-        const int nb = n_blk + col_tile * 32 + 4 * (lane >> 5);
-        const bool bn = p.epilogue == 0;
-        const float* zsrc = p.zeros;                    // (split-K form: the constants are unused; any readable address)
-#define AMPH_S3_BN(g)                                                                      \
-        e_sc##g = *reinterpret_cast<const float4*>((bn ? p.scale : zsrc) + ((bn && nb + 8 * g < p.N) ? nb + 8 * g : 0)); \
-        e_sh##g = *reinterpret_cast<const float4*>((bn ? p.shift : zsrc) + ((bn && nb + 8 * g < p.N) ? nb + 8 * g : 0));
-        AMPH_S3_BN(0) AMPH_S3_BN(1) AMPH_S3_BN(2) AMPH_S3_BN(3)
-#undef AMPH_S3_BN
+    // BN constants of the tile's 64 channels wait in LDS for the epilogue (32 registers through the loop otherwise: with them the kernel
+    // needed 198 and two workgroups shared a CU - conv4's 768 workgroups at a 256-chunk batch ran as one and a half rounds of 512)
+    float* const bn_lds = reinterpret_cast<float*>(smem + 6 * kHBuf);   // [2][64]
+    if (tid < 128) {
+        const int n = n_blk + (tid & 63);
+        bn_lds[tid] = (p.epilogue == 0 && n < p.N) ? (tid < 64 ? p.scale : p.shift)[n] : 0.0f;
     }
     // fragment addresses: lane l holds row (l & 31), k = 16 kstep + 8 (l >> 5) + j of each term: slot (4 t + 2 kstep + (l >> 5)) ^ h_sw(row)
     // of the row - one offset per (kstep, term), the same for both operands (32-row tiles: row & 15 is the lane's)
@@ -365,8 +361,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm_s3(ConvGemmParams p) {
                     float4 v = make_float4(fmaf(accl[4 * g], kH2Lo, acc[4 * g]), fmaf(accl[4 * g + 1], kH2Lo, acc[4 * g + 1]),       \
                                            fmaf(accl[4 * g + 2], kH2Lo, acc[4 * g + 2]), fmaf(accl[4 * g + 3], kH2Lo, acc[4 * g + 3])); \
                     if (p.epilogue == 0) {                                                 \
-                        v.x = fmaxf(fmaf(v.x, e_sc##g.x, e_sh##g.x), 0.0f); v.y = fmaxf(fmaf(v.y, e_sc##g.y, e_sh##g.y), 0.0f); \
-                        v.z = fmaxf(fmaf(v.z, e_sc##g.z, e_sh##g.z), 0.0f); v.w = fmaxf(fmaf(v.w, e_sc##g.w, e_sh##g.w), 0.0f); \
+                        const float4 e_sc = *reinterpret_cast<const float4*>(bn_lds + n0 - n_blk), e_sh = *reinterpret_cast<const float4*>(bn_lds + 64 + n0 - n_blk); \
+                        v.x = fmaxf(fmaf(v.x, e_sc.x, e_sh.x), 0.0f); v.y = fmaxf(fmaf(v.y, e_sc.y, e_sh.y), 0.0f); \
+                        v.z = fmaxf(fmaf(v.z, e_sc.z, e_sh.z), 0.0f); v.w = fmaxf(fmaf(v.w, e_sc.w, e_sh.w), 0.0f); \
                     }                                                                      \
                     *reinterpret_cast<float4*>(ybase + (long long)m * p.N + n0) = v;       \
                 }                                                                          \
@@ -974,16 +971,16 @@ void launch_conv_gemm_f3s(const ConvGemmParams& p, hipStream_t s) {
             int nb8 = -1, nb4 = -1, nbs = -1;
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb8, k_conv_gemm_f3s<8>, 256, conv_gemm_f3s_lds(p));
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb4, k_conv_gemm_f3s<4>, 256, conv_gemm_f3s_lds(p));
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbs, k_conv_gemm_s3, 256, (size_t)6 * kHBuf);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbs, k_conv_gemm_s3, 256, (size_t)6 * kHBuf + 512);
             fprintf(stderr, "[amph] occupancy (workgroups per CU): f3s<8> %d, f3s<4> %d (lds %zu, n_patch %d), s3 %d (lds %zu)\n", nb8, nb4,
-                    conv_gemm_f3s_lds(p), n_patch, nbs, (size_t)6 * kHBuf);
+                    conv_gemm_f3s_lds(p), n_patch, nbs, (size_t)6 * kHBuf + 512);
         }
     }
     if (n_patch <= 256 * 4) hipLaunchKernelGGL(k_conv_gemm_f3s<4>, grid, dim3(256), conv_gemm_f3s_lds(p), s, p);
     else hipLaunchKernelGGL(k_conv_gemm_f3s<8>, grid, dim3(256), conv_gemm_f3s_lds(p), s, p);
 }
 
-constexpr size_t kS3Lds = (size_t)6 * kHBuf;           // 49 152 B: three workgroups per CU
+constexpr size_t kS3Lds = (size_t)6 * kHBuf + 512;     // 49 664 B (slice buffers + the tile's BN constants): three workgroups per CU
 
 bool conv_gemm_s3_ok(const ConvGemmParams& p) {
     const unsigned long long span = (unsigned long long)p.M / (p.OH * p.OW) * p.H * p.W * p.C_in * 4ull + p.x_guard;     // 32-bit lane offsets
