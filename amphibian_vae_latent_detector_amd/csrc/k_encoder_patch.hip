@@ -56,11 +56,17 @@ template <> struct G4Frag<1> { typedef bf16x8 type; };
 __device__ __forceinline__ f32x16 g4_mfma(const bf16x8& w, const bf16x8& x, const f32x16& c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, x, c, 0, 0, 0); }
 __device__ __forceinline__ f32x16 g4_mfma(const f16x8& w, const f16x8& x, const f32x16& c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(w, x, c, 0, 0, 0); }
 constexpr float kG4Lo = 1.0f / 2048.0f;
-__device__ __forceinline__ void g4_split2(float x0, float x1, uint32_t& h, uint32_t& l) {     // (h2_split2 of k_encoder_split.hip)
+// (h2_lo_terms / h2_split2 of k_encoder_split.hip: l = fp16((x - h) 2^11) as one v_fma_mix per value, exact before its one rounding)
+__device__ __forceinline__ uint32_t g4_lo_terms(uint32_t h, float t0, float t1) {
+    uint32_t l;
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %1, %2, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=&v"(l) : "v"(h), "s"(-2048.0f), "v"(t0), "v"(t1));
+    return l;
+}
+__device__ __forceinline__ void g4_split2(float x0, float x1, uint32_t& h, uint32_t& l) {
     const amph_h2v hp = {(_Float16)x0, (_Float16)x1};
     h = __builtin_bit_cast(uint32_t, hp);
-    const amph_h2v lp = {(_Float16)((x0 - (float)hp.x) * 2048.0f), (_Float16)((x1 - (float)hp.y) * 2048.0f)};
-    l = __builtin_bit_cast(uint32_t, lp);
+    l = g4_lo_terms(h, x0 * 2048.0f, x1 * 2048.0f);
 }
 
 constexpr int kPPix = 144;               // bytes per patch pixel: [h | l] x 32 fp16 (the two-term split of k_encoder_split.hip) + 16 B pad (9 slots: odd)
@@ -200,19 +206,15 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_f4s(ConvGemmParams p, Patc
 #define AMPH_F4_SPLIT_PAIRS(n_, x_, h_, l_)                                                \
         {                                                                                  \
             float r_[2 * (n_)];                                                            \
-            amph_h2v hp_[n_];                                                              \
             _Pragma("unroll") for (int k = 0; k < (n_); ++k) {                             \
-                hp_[k] = amph_h2v{(_Float16)x_[2 * k], (_Float16)x_[2 * k + 1]};           \
-                h_[k] = __builtin_bit_cast(uint32_t, hp_[k]);                              \
+                const amph_h2v hp_ = {(_Float16)x_[2 * k], (_Float16)x_[2 * k + 1]};       \
+                h_[k] = __builtin_bit_cast(uint32_t, hp_);                                 \
             }                                                                              \
             _Pragma("unroll") for (int k = 0; k < (n_); ++k) {                             \
-                r_[2 * k] = (x_[2 * k] - (float)hp_[k].x) * 2048.0f;                       \
-                r_[2 * k + 1] = (x_[2 * k + 1] - (float)hp_[k].y) * 2048.0f;               \
+                r_[2 * k] = x_[2 * k] * 2048.0f;                                           \
+                r_[2 * k + 1] = x_[2 * k + 1] * 2048.0f;                                   \
             }                                                                              \
-            _Pragma("unroll") for (int k = 0; k < (n_); ++k) {                             \
-                const amph_h2v lp_ = {(_Float16)r_[2 * k], (_Float16)r_[2 * k + 1]};       \
-                l_[k] = __builtin_bit_cast(uint32_t, lp_);                                 \
-            }                                                                              \
+            _Pragma("unroll") for (int k = 0; k < (n_); ++k) l_[k] = g4_lo_terms(h_[k], r_[2 * k], r_[2 * k + 1]); \
         }
 #define AMPH_F4_WRITE_IMG(dst_)                                                            \
         {                                                                                  \

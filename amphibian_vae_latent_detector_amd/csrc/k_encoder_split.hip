@@ -46,12 +46,19 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 amph_h2 __attribute__((ext_vector_type(2)));
 constexpr float kH2Lo = 1.0f / 2048.0f;          // weight of the cross-term accumulator
 // x -> (h, l) pairs of two values: h = fp16(x) (RNE), l = fp16((x - h) 2^11) - x - h is exact in fp32
+// The low terms of a pair, l = fp16((x - h) 2^11), with one v_fma_mix per value: fma(h, -2^11, 2^11 x) is exact in fp32 (x - h is), so
+// the conversion to fp16 is the only rounding - the same bits as subtract, multiply, convert (tools/probe/h2_split_mix.hip: 2^24
+// pairs), five instructions per pair instead of ten (the compiler converts h back to fp32 per value for the subtraction).
+__device__ __forceinline__ uint32_t h2_lo_terms(uint32_t h, float t0, float t1) {
+    uint32_t l;
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %1, %2, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=&v"(l) : "v"(h), "s"(-2048.0f), "v"(t0), "v"(t1));
+    return l;
+}
 __device__ __forceinline__ void h2_split2(float x0, float x1, uint32_t& h, uint32_t& l) {
     const amph_h2 hp = {(_Float16)x0, (_Float16)x1};
     h = __builtin_bit_cast(uint32_t, hp);
-    const float r0 = (x0 - (float)hp.x) * 2048.0f, r1 = (x1 - (float)hp.y) * 2048.0f;
-    const amph_h2 lp = {(_Float16)r0, (_Float16)r1};
-    l = __builtin_bit_cast(uint32_t, lp);
+    l = h2_lo_terms(h, x0 * 2048.0f, x1 * 2048.0f);
 }
 
 constexpr int kSBK = 32;                 // K elements per slice (one tap's 32-channel group)
