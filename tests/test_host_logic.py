@@ -593,3 +593,14 @@ def test_pad_block_layout_of_the_virtual_shards():
     for shards in (1, 3, 4, 8, 16):
         got = pfolder.encode_resident_shards(FakeSession(), x, shards)
         assert torch.equal(got, x[:, :3].float() * 2.0), shards
+
+
+def test_lds_swizzle_model_of_the_staged_gemm_is_conflict_free():
+    """tools/lds_swizzle_model.py: the slot swizzle h_sw of k_conv_gemm_s3 / _s3w (csrc/k_encoder_split.hip) costs 16 array cycles per
+    fragment read and 8 per staging store under the gfx950 banking rules - no conflicts; the two-bit swizzle it replaced 32 / 16 / 8."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("lds_swizzle_model", Path(__file__).resolve().parents[1] / "tools" / "lds_swizzle_model.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.slice_cycles(mod.new) == (16, 8, 8)
+    assert mod.slice_cycles(mod.old) == (32, 16, 8)
