@@ -398,7 +398,7 @@ int build_frontend(amph_ctx* c) {
         float* tw2 = pt.data() + 16 * 64 * 2;
         for (int m = 0; m < 16; ++m) {
             float* e0 = tw2 + 4 * m;
-            float* e1 = tw2 + 4 * (16 + m);
+            float* e1 = tw2 + 4 * (17 + m);                 // (row stride 17: k_frontend.hip kPairTw2S)
             e0[0] = e0[1] = 1.0f; e0[2] = e0[3] = 0.0f;
             for (int u = 0; u < 2; ++u) {
                 const double a = -2.0 * PI * (double)(2 * m + u) / 64.0;

@@ -1532,7 +1532,10 @@ constexpr int kPairExS = 68;                        // exchange row stride in fl
 constexpr int kPairScratch = 32 * kPairExS * 4;     // per-wave scratch: exchange tile, then partner tile, then the two power spectra
 constexpr int kPairPStride = kPairScratch / 8;      // floats between the two power spectra (1088 >= 1025 + tail)
 constexpr int kPairZS = 96;                         // partner tile row stride in floats (columns >= 32 shifted by 16 banks; lane' 0 reads one row further: same bank as column 0)
-constexpr int kPairWinBytes = 16 * 64 * 8, kPairTw2Bytes = 2 * 32 * 8, kPairTw1Bytes = 16 * 64 * 16;
+// (stage-2 twiddles: [2][17] 16-byte pairs - the h = 0 and h = 1 lanes of a ds_read_b128 group read entries m and 17 + m: with 16 + m
+//  the two addresses shared their banks, every one of the 16 reads per pair 2-way conflicted)
+constexpr int kPairTw2S = 17;
+constexpr int kPairWinBytes = 16 * 64 * 8, kPairTw2Bytes = 2 * kPairTw2S * 16, kPairTw1Bytes = 16 * 64 * 16;
 
 // Y[k + 16 p] = E[k] +- W32^k O[k]: e = DFT16 of the even inputs (X[k] at DFT16_POS(k)), o = of the odd ones, in place
 __device__ __forceinline__ void dft32_combine(float (&er)[16], float (&ei)[16], float (&orr)[16], float (&oi)[16]) {
@@ -1567,7 +1570,7 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float2* win = reinterpret_cast<const float2*>(smem);                      // [16][64] (w[n], w[n + 1]) 2^-15
-    const float4* tw2 = reinterpret_cast<const float4*>(smem + kPairWinBytes);      // [2][16] twiddle pairs
+    const float4* tw2 = reinterpret_cast<const float4*>(smem + kPairWinBytes);      // [2][17] twiddle pairs (16 used)
     const int meta_bytes = (p.n_mels * 12 + 15) & ~15;
     const int melw_bytes = p.mel_w_floats * 4;
     constexpr int kTab = kPairWinBytes + kPairTw2Bytes + (TWL ? kPairTw1Bytes : 0);
@@ -1809,7 +1812,7 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
             for (int g = 0; g < 4; ++g) {
                 float4 t2[4];
 #pragma unroll
-                for (int m = 0; m < 4; ++m) t2[m] = tw2[h * 16 + 4 * g + m];
+                for (int m = 0; m < 4; ++m) t2[m] = tw2[h * kPairTw2S + 4 * g + m];
 #pragma unroll
                 for (int m4 = 0; m4 < 4; ++m4) {
                     const int m = 4 * g + m4;
