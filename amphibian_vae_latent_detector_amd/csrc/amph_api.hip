@@ -96,6 +96,9 @@ struct amph_ctx {
     std::vector<unsigned char> radial_key; // the detector (K, D, centroids, thresholds, ranks) last uploaded for K6
     float* d_pair_tables = nullptr;        // k_stft_pair: window pairs + stage-2 twiddles (packed LDS image); nullptr: configuration not covered
     float2* d_pair_tw1 = nullptr;          // k_stft_pair: stage-1 twiddles (global memory)
+    int32_t* d_pair_mel_meta = nullptr;    // k_stft_pair: per (round, lane quad) (start bin, steps, weight offset, output band) - build_pair_mel
+    float* d_pair_mel_w = nullptr;         // k_stft_pair: the filters' weights in that kernel's lane order
+    int pair_mel_w_floats = 0;
     bool stft_indep = true;                // k_stft_mel_w (independent waves) rather than the tile-synchronous k_stft_mel
     int stft_grid = 0;                     // persistent STFT workgroups (0 = fill the chip)
     int rms_chunk_path_over = 2;           // PCM16 rows of more numpy chunks than this: (row, chunk) + (row, tile) kernel pair
@@ -297,6 +300,116 @@ enum { ST_RMS = 0, ST_STFT = 1, ST_DBNORM = 2, ST_CONV0 = 3 };
 int stage_head_gemm(const amph_ctx* c) { return ST_CONV0 + c->spec.n_conv; }
 int stage_head_reduce(const amph_ctx* c) { return ST_CONV0 + c->spec.n_conv + 1; }
 
+// k_stft_pair's mel tables (n_fft 2048).  The kernel gives a filter to a lane QUAD; per 16-bin step lane q of the quad reads the
+// (|A|^2, |B|^2) pairs of bins 2q, 2q + 1 (16 bytes at 16 q of the step's 128 bytes) and 8 + 2q, 8 + 2q + 1 (at 64 + 16 q): a quad's read is
+// 64 CONTIGUOUS bytes.  A ds_read_b128 lane group holds four quads - {0, 3, 5, 6}, {1, 2, 4, 7}, {8, 11, 13, 14}, {9, 10, 12, 15} - and is
+// conflict-free when their four 64-byte windows tile the 256-byte bank row, i.e. when the start bins, in units of 4 bins (32 bytes) mod 8,
+// are {0, 2, 4, 6} or {1, 3, 5, 7}.  A filter's start may move down by multiples of 4 bins as long as its round's 16-bin steps still
+// cover its last bin, and which filter sits on which quad is free (the band index travels in the table): a small exact search per round
+// of 16 filters finds such an arrangement (all four rounds of the 64-band bench preset; tools/mel_read_bank_model.py: 316 -> 104 array
+// cycles of power reads per pair of frames).  No arrangement: the filters keep their order and starts (correct, conflicts as before).
+// meta: [rounds][16 quads] x (start, steps, weight offset, band or -1); weights: per quad 16 floats per step in lane order
+// (q, j) -> bin offset {2q, 2q + 1, 8 + 2q, 8 + 2q + 1}[j], strides as d_mel_w's (an odd number of 64-byte slots per filter).
+namespace {
+struct PairMelSearch {
+    int nf;                       // filters of the round
+    std::vector<int> cand[16];    // per filter: allowed residues o = (start / 4) % 8
+    int grp_of[16], o_of[16];
+    bool used[16];
+    bool fits(const int* g, int par, int* o_out) const {
+        static const int perms[24][4] = {{0,1,2,3},{0,1,3,2},{0,2,1,3},{0,2,3,1},{0,3,1,2},{0,3,2,1},{1,0,2,3},{1,0,3,2},{1,2,0,3},{1,2,3,0},{1,3,0,2},{1,3,2,0},
+                                         {2,0,1,3},{2,0,3,1},{2,1,0,3},{2,1,3,0},{2,3,0,1},{2,3,1,0},{3,0,1,2},{3,0,2,1},{3,1,0,2},{3,1,2,0},{3,2,0,1},{3,2,1,0}};
+        for (const auto& pm : perms) {
+            bool ok = true;
+            for (int j = 0; j < 4 && ok; ++j) {
+                const int need = par + 2 * pm[j];
+                if (g[j] >= nf) continue;         // a padding slot takes any residue
+                ok = std::find(cand[g[j]].begin(), cand[g[j]].end(), need) != cand[g[j]].end();
+            }
+            if (ok) { for (int j = 0; j < 4; ++j) o_out[j] = par + 2 * pm[j]; return true; }
+        }
+        return false;
+    }
+    bool solve(int grp) {
+        if (grp == 4) return true;
+        int a = 0;
+        while (a < 16 && used[a]) ++a;
+        int g[4] = {a, 0, 0, 0};
+        used[a] = true;
+        for (int b = a + 1; b < 16; ++b) if (!used[b])
+            for (int cc = b + 1; cc < 16; ++cc) if (!used[cc])
+                for (int d = cc + 1; d < 16; ++d) if (!used[d]) {
+                    g[1] = b; g[2] = cc; g[3] = d;
+                    for (int par = 0; par < 2; ++par) {
+                        int o[4];
+                        if (!fits(g, par, o)) continue;
+                        used[b] = used[cc] = used[d] = true;
+                        for (int j = 0; j < 4; ++j) { grp_of[g[j]] = grp; o_of[g[j]] = o[j]; }
+                        if (solve(grp + 1)) return true;
+                        used[b] = used[cc] = used[d] = false;
+                    }
+                }
+        used[a] = false;
+        return false;
+    }
+};
+}  // namespace
+
+static void build_pair_mel(const std::vector<float>& basis, int n_mels, int F, std::vector<int32_t>& meta, std::vector<float>& wv) {
+    static const int kGroupQuads[4][4] = {{0, 3, 5, 6}, {1, 2, 4, 7}, {8, 11, 13, 14}, {9, 10, 12, 15}};
+    const int n_rounds = (n_mels + 15) / 16;
+    meta.assign((size_t)n_rounds * 16 * 4, 0);
+    wv.clear();
+    for (int r = 0; r < n_rounds; ++r) {
+        const int m0 = 16 * r, nf = std::min(16, n_mels - m0);
+        int first[16], last[16], round_steps = 1;
+        for (int j = 0; j < nf; ++j) {
+            first[j] = last[j] = -1;
+            for (int k = 0; k < F; ++k)
+                if (basis[(size_t)(m0 + j) * F + k] != 0.0f) { if (first[j] < 0) first[j] = k; last[j] = k; }
+            if (first[j] >= 0) round_steps = std::max(round_steps, (last[j] - (first[j] & ~3) + 16) / 16);
+        }
+        PairMelSearch ss;
+        ss.nf = nf;
+        for (int j = 0; j < 16; ++j) { ss.used[j] = false; ss.grp_of[j] = -1; ss.o_of[j] = 0; }
+        for (int j = 0; j < nf; ++j) {
+            if (first[j] < 0) { for (int o = 0; o < 8; ++o) ss.cand[j].push_back(o); continue; }       // an empty filter: any start
+            const int lo = std::max(0, last[j] - 16 * round_steps + 1);
+            for (int st = first[j] & ~3; st >= lo; st -= 4)
+                if (std::find(ss.cand[j].begin(), ss.cand[j].end(), (st / 4) % 8) == ss.cand[j].end()) ss.cand[j].push_back((st / 4) % 8);
+        }
+        int quad_of[16], start_of[16];
+        if (ss.solve(0)) {
+            int fill[4] = {0, 0, 0, 0};
+            for (int j = 0; j < 16; ++j) {
+                quad_of[j] = kGroupQuads[ss.grp_of[j]][fill[ss.grp_of[j]]++];
+                if (j >= nf) continue;
+                int st = first[j] < 0 ? 0 : (first[j] & ~3);
+                while (first[j] >= 0 && (st / 4) % 8 != ss.o_of[j]) st -= 4;        // the largest allowed start with the residue (it exists: cand)
+                start_of[j] = first[j] < 0 ? 4 * ss.o_of[j] : st;
+            }
+        } else {
+            for (int j = 0; j < 16; ++j) { quad_of[j] = j; start_of[j] = (j < nf && first[j] >= 0) ? (first[j] & ~3) : 0; }
+        }
+        int filt_of_quad[16];
+        for (int j = 0; j < 16; ++j) filt_of_quad[quad_of[j]] = j;
+        for (int t = 0; t < 16; ++t) {                 // quads in order: the weight strides keep a lane group's reads on different banks
+            const int j = filt_of_quad[t];
+            const bool live = j < nf;
+            const int st = live ? start_of[j] : 0;
+            int32_t* e = meta.data() + ((size_t)r * 16 + t) * 4;
+            e[0] = st; e[1] = round_steps; e[2] = (int32_t)wv.size(); e[3] = live ? m0 + j : -1;
+            for (int i = 0; i < round_steps; ++i)
+                for (int q = 0; q < 4; ++q)
+                    for (int u = 0; u < 4; ++u) {
+                        const int k = st + 16 * i + (u < 2 ? 2 * q + u : 8 + 2 * q + (u - 2));
+                        wv.push_back(live && k < F ? basis[(size_t)(m0 + j) * F + k] : 0.0f);
+                    }
+            if ((round_steps & 1) == 0) wv.insert(wv.end(), 16, 0.0f);
+        }
+    }
+}
+
 int build_frontend(amph_ctx* c) {
     const amph_frontend_config& f = c->cfg;
     if (f.n_fft != 2048 && f.n_fft != 1024)
@@ -418,6 +531,12 @@ int build_frontend(amph_ctx* c) {
             }
         HIP_TRY(c, upload(&c->d_pair_tables, pt));
         HIP_TRY(c, upload(&c->d_pair_tw1, tw1));
+        std::vector<int32_t> pm;
+        std::vector<float> pw;
+        build_pair_mel(c->mel_basis, f.n_mels, F, pm, pw);
+        c->pair_mel_w_floats = (int)pw.size();
+        HIP_TRY(c, upload(&c->d_pair_mel_meta, pm));
+        HIP_TRY(c, upload(&c->d_pair_mel_w, pw));
     }
     // k_stft_pair2 (n_fft 1024, hop 256): lane' l (0..31) reads samples 64 j' + 2 l + e and owns column 2 (l & 15) + (l >> 4)
     if (stft_pair2_ok(n_fft, f.hop_length, c->mel_p_tail)) {
@@ -902,7 +1021,7 @@ int run_encoder(amph_ctx* c, Workspace& w, const float* d_x, int nb, float* d_mu
 // can this context run the dB / z-score stage inside the STFT kernel (one workgroup per row, the row's mel power in LDS)?
 // LDS image of the pair kernel this context would use (k_stft_pair at n_fft 2048, k_stft_pair2 at 1024)
 size_t pair_lds(const amph_ctx* c, int nw, bool fused) {
-    return c->cfg.n_fft == 2048 ? stft_pair_lds_bytes(c->n_frames, c->cfg.n_mels, c->mel_w_floats, nw, fused)
+    return c->cfg.n_fft == 2048 ? stft_pair_lds_bytes(c->n_frames, c->cfg.n_mels, c->pair_mel_w_floats, nw, fused)
                                 : stft_pair2_lds_bytes(c->n_frames, c->cfg.n_mels, c->mel_w_floats, nw, fused);
 }
 size_t pair_tw1_lds(const amph_ctx* c) { return c->cfg.n_fft == 2048 ? stft_pair_tw1_lds_bytes() : stft_pair2_tw1_lds_bytes(); }
@@ -937,6 +1056,7 @@ StftParams make_stft(amph_ctx* c, const WaveSrc& src, float* melpow, float* db_o
     // the pair kernel where it applies (launch_stft_mel checks the source rows); with the fused dB stage its LDS image must fit
     if (c->stft_pair && c->d_pair_tables && pair_lds(c, c->stft_pair_waves, db_out != nullptr) <= 160 * 1024) {
         p.pair_tables = c->d_pair_tables; p.pair_tw1 = c->d_pair_tw1; p.pair_waves = c->stft_pair_waves;
+        p.pair_mel_meta = c->d_pair_mel_meta; p.pair_mel_w = c->d_pair_mel_w; p.pair_mel_w_floats = c->pair_mel_w_floats;
         p.pair_tw_lds = c->stft_pair_tw_lds ? 1 : 0;
     }
 #ifdef AMPH_STAMPS
@@ -1167,7 +1287,7 @@ void amph_destroy(amph_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     auto fr = [](void* p) { if (p) (void)hipFree(p); };
-    fr(c->d_tables); fr(c->d_tw_a); fr(c->d_pair_tables); fr(c->d_pair_tw1);
+    fr(c->d_tables); fr(c->d_tw_a); fr(c->d_pair_tables); fr(c->d_pair_tw1); fr(c->d_pair_mel_meta); fr(c->d_pair_mel_w);
     fr(c->d_mel_start); fr(c->d_mel_len); fr(c->d_mel_wofs); fr(c->d_mel_w);
     fr(c->d_first_w); fr(c->d_first_scale); fr(c->d_first_shift);
     for (auto& g : c->gemm) { fr(g.d_w); fr(g.d_w_s3); fr(g.d_w_h2); fr(g.d_w_f4); fr(g.d_w_f4b); fr(g.d_w_bf16); fr(g.d_scale); fr(g.d_shift); }

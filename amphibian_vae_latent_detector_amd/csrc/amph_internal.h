@@ -54,6 +54,9 @@ struct StftParams {
     // k_stft_pair (two frames per wave as one complex FFT; nullptr: that kernel is not used)
     const float* pair_tables;  // packed LDS image: window pairs [16][64][2] (x 2^-15) | stage-2 twiddles [2][32][2]
     const float2* pair_tw1;    // [31][64] W_2048^(col(lane) k1), k1 = 1..31 (read from global memory)
+    const int32_t* pair_mel_meta;   // k_stft_pair (n_fft 2048): [rounds][16 lane quads] x (start bin, steps, weight offset, band or -1) - amph_api.hip build_pair_mel
+    const float* pair_mel_w;        // ... and the weights in that kernel's lane order
+    int pair_mel_w_floats;
     int pair_waves;            // waves per workgroup of that kernel (8, 10 or 12)
     int pair_tw_lds;           // keep pair_tw1 in LDS when the image still fits 160 KB
     // per-context launch choices (were process-wide globals until round 3)

@@ -1571,11 +1571,12 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float2* win = reinterpret_cast<const float2*>(smem);                      // [16][64] (w[n], w[n + 1]) 2^-15
     const float4* tw2 = reinterpret_cast<const float4*>(smem + kPairWinBytes);      // [2][17] twiddle pairs (16 used)
-    const int meta_bytes = (p.n_mels * 12 + 15) & ~15;
-    const int melw_bytes = p.mel_w_floats * 4;
+    const int n_meta = ((p.n_mels + 15) >> 4) * 16;       // (round, lane quad) entries of pair_mel_meta
+    const int meta_bytes = n_meta * 16;
+    const int melw_bytes = p.pair_mel_w_floats * 4;
     constexpr int kTab = kPairWinBytes + kPairTw2Bytes + (TWL ? kPairTw1Bytes : 0);
     const float4* tw1_l = reinterpret_cast<const float4*>(smem + kPairWinBytes + kPairTw2Bytes) + lane;      // [16][64] (wr_k, wr_k+16, wi_k, wi_k+16) (TWL)
-    int3* mel_meta = reinterpret_cast<int3*>(smem + kTab);
+    int4* mel_meta = reinterpret_cast<int4*>(smem + kTab);
     float* mel_w = reinterpret_cast<float*>(smem + kTab + meta_bytes);
     char* wbase = smem + kTab + meta_bytes + melw_bytes + wave * kPairScratch;
     float* T = reinterpret_cast<float*>(wbase);
@@ -1641,11 +1642,12 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
         for (int u = 0; u < UW; ++u) { const int i = tid + kThreads * u; vw[u] = i < NWIN ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f); }
 #pragma unroll
         for (int u = 0; u < UT; ++u) { const int i = tid + kThreads * u; vt[u] = i < NT1 ? s1[i] : make_float4(0.f, 0.f, 0.f, 0.f); }
-        int3 mm_ = make_int3(0, 0, 0);
-        if (tid < p.n_mels) mm_ = make_int3(p.mel_start[tid], p.mel_len[tid], p.mel_wofs[tid]);
-        const float4* wsrc = reinterpret_cast<const float4*>(p.mel_w);
+        const int4* msrc = reinterpret_cast<const int4*>(p.pair_mel_meta);
+        int4 mm_ = make_int4(0, 0, 0, -1);
+        if (tid < n_meta) mm_ = msrc[tid];
+        const float4* wsrc = reinterpret_cast<const float4*>(p.pair_mel_w);
         float4* wdst = reinterpret_cast<float4*>(mel_w);
-        const int n4 = p.mel_w_floats >> 2;
+        const int n4 = p.pair_mel_w_floats >> 2;
         for (int base = 0; base < n4; base += 2 * kThreads) {
             const int i0 = base + tid, i1 = i0 + kThreads;
             float4 v0 = i0 < n4 ? wsrc[i0] : make_float4(0.f, 0.f, 0.f, 0.f), v1 = i1 < n4 ? wsrc[i1] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1654,8 +1656,8 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
             if (i0 < n4) wdst[i0] = v0;
             if (i1 < n4) wdst[i1] = v1;
         }
-        for (int m = tid + kThreads; m < p.n_mels; m += kThreads) mel_meta[m] = make_int3(p.mel_start[m], p.mel_len[m], p.mel_wofs[m]);
-        if (tid < p.n_mels) mel_meta[tid] = mm_;
+        for (int m = tid + kThreads; m < n_meta; m += kThreads) mel_meta[m] = msrc[m];
+        if (tid < n_meta) mel_meta[tid] = mm_;
         if (tid == 0) *next_pair = NW;                   // pairs 0 .. NW - 1 are the waves' first ones
 #pragma unroll
         for (int u = 0; u < UW; ++u) { const int i = tid + kThreads * u; if (i < NWIN) dst[i] = vw[u]; }
@@ -1883,7 +1885,10 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
 #endif
             // ---- mel rows of both frames at once: 4 lanes per filter, 4 bins per lane and step; the accumulators are (frame a, frame b)
             //      pairs, a bin's two powers one 8-byte LDS element.  Four steps are requested at a time; even steps -> first
-            //      accumulator, odd -> second, as in k_stft_mel_w
+            //      accumulator, odd -> second, as in k_stft_mel_w.  Lane q of a quad takes bins 2q, 2q + 1 and 8 + 2q, 8 + 2q + 1 of a
+            //      step: a quad's read is 64 contiguous bytes, and the host has placed the filters on the quads (and moved their start
+            //      bins) so that the four quads of a ds_read_b128 lane group tile the 256-byte bank row (build_pair_mel, amph_api.hip:
+            //      316 -> 104 array cycles of power reads per pair; the band index comes from the table)
             {
                 const int q = lane & 3;
                 const int n_rounds = (p.n_mels + 15) >> 4;
@@ -1891,12 +1896,13 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
                 const bool has_b = fa + 1 < p.n_frames;     // wave-uniform
                 float* out_a = fuse_db ? mp_row + fa * p.n_mels : p.melpow + ((long long)row * p.n_frames + fa) * p.n_mels;
                 float* out_b = out_a + p.n_mels;
-                int3 mt = mel_meta[min(lane >> 2, p.n_mels - 1)];
+                int4 mt = mel_meta[lane >> 2];
                 for (int r = 0; r < n_rounds; ++r) {
                     const int steps = __builtin_amdgcn_readfirstlane(mt.y);
                     const float4* w = reinterpret_cast<const float4*>(mel_w + mt.z) + q;
-                    const float4* pp = reinterpret_cast<const float4*>(P2 + mt.x) + 2 * q;     // bins 4 q, 4 q + 1 | 4 q + 2, 4 q + 3 of a step
-                    if (r + 1 < n_rounds) mt = mel_meta[min(16 * (r + 1) + (lane >> 2), p.n_mels - 1)];
+                    const float4* pp = reinterpret_cast<const float4*>(P2 + mt.x) + q;         // bins 2 q, 2 q + 1 | (+ 4:) 8 + 2 q, 8 + 2 q + 1 of a step
+                    const int m = mt.w;                         // the band this quad computes (-1: none)
+                    if (r + 1 < n_rounds) mt = mel_meta[16 * (r + 1) + (lane >> 2)];
                     amph_f2 a0 = {0.0f, 0.0f}, a1 = {0.0f, 0.0f};
 #define AMPH_MEL_FMA2(acc_, w_, x_, y_)                                                    \
     acc_ += w_.x * amph_f2{x_.x, x_.y}; acc_ += w_.y * amph_f2{x_.z, x_.w}; acc_ += w_.z * amph_f2{y_.x, y_.y}; acc_ += w_.w * amph_f2{y_.z, y_.w};
@@ -1904,7 +1910,7 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
                     for (; i0 + 4 <= steps; i0 += 4) {
                         float4 wq[4], xq[4], yq[4];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) { wq[u] = w[4 * (i0 + u)]; xq[u] = pp[8 * (i0 + u)]; yq[u] = pp[8 * (i0 + u) + 1]; }
+                        for (int u = 0; u < 4; ++u) { wq[u] = w[4 * (i0 + u)]; xq[u] = pp[8 * (i0 + u)]; yq[u] = pp[8 * (i0 + u) + 4]; }
                         AMPH_MEL_FMA2(a0, wq[0], xq[0], yq[0])
                         AMPH_MEL_FMA2(a1, wq[1], xq[1], yq[1])
                         AMPH_MEL_FMA2(a0, wq[2], xq[2], yq[2])
@@ -1913,21 +1919,20 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
                     if (i0 + 2 <= steps) {
                         float4 wq[2], xq[2], yq[2];
 #pragma unroll
-                        for (int u = 0; u < 2; ++u) { wq[u] = w[4 * (i0 + u)]; xq[u] = pp[8 * (i0 + u)]; yq[u] = pp[8 * (i0 + u) + 1]; }
+                        for (int u = 0; u < 2; ++u) { wq[u] = w[4 * (i0 + u)]; xq[u] = pp[8 * (i0 + u)]; yq[u] = pp[8 * (i0 + u) + 4]; }
                         AMPH_MEL_FMA2(a0, wq[0], xq[0], yq[0])
                         AMPH_MEL_FMA2(a1, wq[1], xq[1], yq[1])
                         i0 += 2;
                     }
                     if (i0 < steps) {
-                        const float4 w0 = w[4 * i0], x0 = pp[8 * i0], y0 = pp[8 * i0 + 1];
+                        const float4 w0 = w[4 * i0], x0 = pp[8 * i0], y0 = pp[8 * i0 + 4];
                         AMPH_MEL_FMA2(a0, w0, x0, y0)
                     }
 #undef AMPH_MEL_FMA2
                     amph_f2 sa = a0 + a1;
                     sa += amph_f2{dpp_xor1(sa.x), dpp_xor1(sa.y)};
                     sa += amph_f2{dpp_xor2(sa.x), dpp_xor2(sa.y)};
-                    const int m = 16 * r + (lane >> 2);
-                    if (q == 0 && m < p.n_mels) { out_a[m] = sa.x; wmax = fmaxf(wmax, sa.x); if (has_b) { out_b[m] = sa.y; wmax = fmaxf(wmax, sa.y); } }
+                    if (q == 0 && m >= 0) { out_a[m] = sa.x; wmax = fmaxf(wmax, sa.x); if (has_b) { out_b[m] = sa.y; wmax = fmaxf(wmax, sa.y); } }
                 }
             }
             wave_lds_sync();                                // the scratch is rewritten by the next pair
@@ -2260,7 +2265,7 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair2(StftParams p, int n_rows
 }
 
 size_t stft_pair_lds_bytes(int n_frames, int n_mels, int mel_w_floats, int n_waves, bool fused) {
-    const size_t meta = ((size_t)n_mels * 12 + 15) & ~(size_t)15;
+    const size_t meta = (size_t)((n_mels + 15) / 16) * 16 * 16;            // (round, lane quad) entries of 16 bytes
     const size_t mp = fused ? (((size_t)n_frames * n_mels + 3) & ~(size_t)3) * 4 + 16 * 8 + 16 * 4 : 0;
     return (size_t)kPairWinBytes + kPairTw2Bytes + meta + (size_t)mel_w_floats * 4 + (size_t)n_waves * kPairScratch + 16 + mp;      // (16: the pair counter)
 }
@@ -2373,7 +2378,7 @@ void launch_stft_mel(const StftParams& p, int n_rows, int sample_is_pcm16, int n
     if (p.pair_tables && sample_is_pcm16 && p.src.lead == p.n_fft / 2 && stft_pair_ok(p.n_fft, p.hop, p.p_tail)) {
         // one persistent workgroup per row (and CU): the row's pairs of frames go round-robin over its waves
         const int nw = p.pair_waves;
-        size_t lds = stft_pair_lds_bytes(p.n_frames, p.n_mels, p.mel_w_floats, nw, p.db_out != nullptr);
+        size_t lds = stft_pair_lds_bytes(p.n_frames, p.n_mels, p.pair_mel_w_floats, nw, p.db_out != nullptr);
         const bool twl = p.pair_tw_lds && lds + kPairTw1Bytes <= 160 * 1024;      // stage-1 twiddles in LDS when they fit
         if (twl) lds += kPairTw1Bytes;
         const dim3 grid((unsigned)std::min(n_rows, p.grid_wgs > 0 ? p.grid_wgs : g_num_cus)), block(64 * nw);

@@ -2,7 +2,10 @@
 """LDS bank model of the mel phase of k_stft_pair (csrc/k_frontend.hip): 16 filters per round on 16 lane quads, 16 bins per quad and step,
 the pair's power spectra as P2[k] = (|A[k]|^2, |B[k]|^2) 8-byte elements, weights zero padded per filter (amph_api.hip build_frontend).
 Counts the ds_read_b128 array cycles per pair for (a) the kernel's lane -> bin map (lane q of a quad: bins 4q..4q+3 as two reads) and
-(b) a map whose reads are contiguous per quad (bins 2q, 2q+1 | 8+2q, 8+2q+1), with the real Slaney filter bounds of a preset.  CPU only."""
+(b) a map whose reads are contiguous per quad (bins 2q, 2q+1 | 8+2q, 8+2q+1) and (c) that map with the filters placed on the quads and their
+start bins moved so that the four quads of a lane group tile the bank row - the search of build_pair_mel (csrc/amph_api.hip), restated -
+with the real Slaney filter bounds of the bench preset.  CPU only."""
+import itertools
 import sys
 import numpy as np
 
@@ -43,6 +46,44 @@ def slaney_bounds(sr, n_fft, n_mels, fmin, fmax):
     return out
 
 
+GROUP_QUADS = [[0, 3, 5, 6], [1, 2, 4, 7], [8, 11, 13, 14], [9, 10, 12, 15]]
+
+
+def place_round(fl, rs):
+    """16 (first, last) bins -> per filter (quad, start) with every lane group's starts / 4 mod 8 = {0, 2, 4, 6} or {1, 3, 5, 7}; None: no such placement"""
+    cands = []
+    for f, l in fl:
+        lo = max(0, l - 16 * rs + 1)
+        cands.append(sorted({(st // 4) % 8 for st in range(f & ~3, lo - 1, -4)}))
+
+    def solve(rem, groups):
+        if not rem:
+            return groups
+        a = rem[0]
+        for trio in itertools.combinations(rem[1:], 3):
+            g = (a,) + trio
+            for par in (0, 1):
+                for perm in itertools.permutations([par, par + 2, par + 4, par + 6]):
+                    if all(perm[j] in cands[g[j]] for j in range(4)):
+                        got = solve([x for x in rem if x not in g], groups + [(g, perm)])
+                        if got is not None:
+                            return got
+                        break
+        return None
+    sol = solve(list(range(16)), [])
+    if sol is None:
+        return None
+    out = [None] * 16
+    for gi, (g, perm) in enumerate(sol):
+        for j in range(4):
+            f = fl[g[j]][0]
+            st = f & ~3
+            while (st // 4) % 8 != perm[j]:
+                st -= 4
+            out[g[j]] = (GROUP_QUADS[gi][j], st)
+    return out
+
+
 def main():
     sr, n_fft, n_mels = 22050, 2048, 64
     fmax = float(sys.argv[1]) if len(sys.argv) > 1 else sr / 2
@@ -69,7 +110,31 @@ def main():
                 n_rd += 1
         res[name] = (w_c, x_c, n_rd)
         print(f"{name}: {n_rd} steps per pair; weight reads {w_c} array cycles (conflict-free {4 * n_rd}), power reads {x_c} (conflict-free {8 * n_rd})")
+    # (c) the placed arrangement
+    w_c = x_c = n_rd = 0
+    wn = 0
+    for r in range(n_mels // 16):
+        rs = steps[16 * r]
+        placed = place_round(bounds[16 * r:16 * r + 16], rs)
+        assert placed is not None, f"round {r}: no conflict-free placement"
+        st_q, wo_q = [0] * 16, [0] * 16
+        for j, (quad, st) in enumerate(placed):
+            st_q[quad] = st
+        for t in range(16):
+            wo_q[t] = wn
+            wn += 16 * rs + (16 if rs % 2 == 0 else 0)
+        for i in range(rs):
+            w_c += b128_cycles([4 * (wo_q[l >> 2] + 16 * i + 4 * (l & 3)) for l in range(64)])
+            for part in range(2):
+                x_c += b128_cycles([8 * (st_q[l >> 2] + 16 * i) + 16 * (l & 3) + 64 * part for l in range(64)])
+            n_rd += 1
+    print(f"contiguous per quad + placed filters (build_pair_mel): weight reads {w_c} array cycles (conflict-free {4 * n_rd}), power reads {x_c} (conflict-free {8 * n_rd})")
+    res["placed"] = (w_c, x_c, n_rd)
+    assert x_c == 8 * n_rd and w_c == 4 * n_rd
     print("steps per round:", [steps[16 * r] for r in range(n_mels // 16)], " filter starts of round 0:", start[:16])
+
+
+    return res
 
 
 if __name__ == "__main__":
