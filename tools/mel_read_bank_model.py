@@ -84,9 +84,9 @@ def place_round(fl, rs):
     return out
 
 
-def main():
+def main(fmax=None):
     sr, n_fft, n_mels = 22050, 2048, 64
-    fmax = float(sys.argv[1]) if len(sys.argv) > 1 else sr / 2
+    fmax = sr / 2 if fmax is None else fmax
     F = 1 + n_fft // 2
     bounds = slaney_bounds(sr, n_fft, n_mels, 0.0, fmax)
     start, steps, wofs, wn = [], [], [], 0
@@ -138,4 +138,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    main(float(sys.argv[1]) if len(sys.argv) > 1 else None)
