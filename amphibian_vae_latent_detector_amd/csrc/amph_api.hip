@@ -306,7 +306,7 @@ int stage_head_reduce(const amph_ctx* c) { return ST_CONV0 + c->spec.n_conv + 1;
 // conflict-free when their four 64-byte windows tile the 256-byte bank row, i.e. when the start bins, in units of 4 bins (32 bytes) mod 8,
 // are {0, 2, 4, 6} or {1, 3, 5, 7}.  A filter's start may move down by multiples of 4 bins as long as its round's 16-bin steps still
 // cover its last bin, and which filter sits on which quad is free (the band index travels in the table): a small exact search per round
-// of 16 filters finds such an arrangement (all four rounds of the 64-band bench preset; tools/mel_read_bank_model.py: 316 -> 104 array
+// of 16 filters finds such an arrangement (all four rounds of the 64-band bench preset; tools/mel_read_bank_model.py: 302 -> 104 array
 // cycles of power reads per pair of frames).  No arrangement: the filters keep their order and starts (correct, conflicts as before).
 // meta: [rounds][16 quads] x (start, steps, weight offset, band or -1); weights: per quad 16 floats per step in lane order
 // (q, j) -> bin offset {2q, 2q + 1, 8 + 2q, 8 + 2q + 1}[j], strides as d_mel_w's (an odd number of 64-byte slots per filter).

@@ -1888,7 +1888,7 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
             //      accumulator, odd -> second, as in k_stft_mel_w.  Lane q of a quad takes bins 2q, 2q + 1 and 8 + 2q, 8 + 2q + 1 of a
             //      step: a quad's read is 64 contiguous bytes, and the host has placed the filters on the quads (and moved their start
             //      bins) so that the four quads of a ds_read_b128 lane group tile the 256-byte bank row (build_pair_mel, amph_api.hip:
-            //      316 -> 104 array cycles of power reads per pair; the band index comes from the table)
+            //      302 -> 104 array cycles of power reads per pair; the band index comes from the table)
             {
                 const int q = lane & 3;
                 const int n_rounds = (p.n_mels + 15) >> 4;

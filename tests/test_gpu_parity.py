@@ -278,6 +278,36 @@ def test_pair_of_frames_stft_kernel_against_oracle_and_the_frame_per_wave_kernel
     sess.close()
 
 
+@pytest.mark.parametrize("n_mels,fmin,fmax", [(40, 0.0, 11025.0), (80, 50.0, 8000.0), (128, 0.0, 11025.0), (24, 300.0, 3000.0), (64, 150.0, 10000.0)])
+def test_pair_kernel_mel_tables_for_other_filter_banks(env, n_mels, fmin, fmax):
+    """k_stft_pair takes its mel filters from tables the host arranges per round of 16 filters (build_pair_mel, csrc/amph_api.hip: which
+    filter sits on which lane quad, start bins moved down inside the slack of the round's steps so that a lane group's reads tile the
+    LDS bank row; the band index travels in the table).  Other filter banks than the bench preset's - band counts that are not multiples
+    of 16, narrow and wide bands, rounds for which no arrangement exists - against the CPU restatement of librosa's melspectrogram
+    (map_detector_core.py:219-228) and against k_stft_mel_w: mel power within 2e-6 / 1e-6 of the row's peak, every band written."""
+    import dataclasses
+    cfg = dataclasses.replace(env.PRESETS["bench-1s"], n_mels=n_mels, fmin=fmin, fmax=fmax)
+    B = 6
+    sess = env.AmphSession(cfg, None, None, DEV, max_batch=B)
+    pcm = env.synth([0, 1, 2, 3, 4, 49], cfg.n_samples, cfg.sr)
+    want = []
+    for r in range(B):
+        yr = env.ofe.normalize_pcm16_chunk(pcm[r], True)[0]
+        want.append(env.ofe.melspectrogram(yr, cfg.sr, cfg.n_fft, cfg.hop_length, cfg.n_mels, cfg.fmin, cfg.fmax).T)
+    want = np.stack(want)
+    sess.configure("stft_pair", 0)
+    old = sess.mel_pcm16(pcm, apply_rms=True, layout=1, want_power=True)[1].cpu().numpy()
+    sess.configure("stft_pair", 1)
+    got = sess.mel_pcm16(pcm, apply_rms=True, layout=1, want_power=True)[1].cpu().numpy()
+    assert got.shape == want.shape == (B, cfg.raw_frames, n_mels)
+    peak = np.maximum(want.max(axis=(1, 2)), 1e-30)
+    ep = (np.abs(got - want).max(axis=(1, 2)) / peak).max()
+    eo = (np.abs(got - old).max(axis=(1, 2)) / peak).max()
+    assert ep <= 2e-6 and eo <= 1e-6, (ep, eo)
+    assert (got[:5].max(axis=1) > 0).all()              # every band of the non-silent rows carries energy: none was left unwritten
+    sess.close()
+
+
 def test_fix_length_padding_truncation_and_ragged_lengths(env, fe):
     cfg = env.cfg
     N = cfg.n_samples

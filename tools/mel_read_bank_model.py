@@ -84,11 +84,11 @@ def place_round(fl, rs):
     return out
 
 
-def main(fmax=None):
-    sr, n_fft, n_mels = 22050, 2048, 64
+def main(fmin=150.0, fmax=None):
+    sr, n_fft, n_mels = 22050, 2048, 64          # PRESETS["bench-1s"]: fmin 150, fmax sr / 2
     fmax = sr / 2 if fmax is None else fmax
     F = 1 + n_fft // 2
-    bounds = slaney_bounds(sr, n_fft, n_mels, 0.0, fmax)
+    bounds = slaney_bounds(sr, n_fft, n_mels, fmin, fmax)
     start, steps, wofs, wn = [], [], [], 0
     for m0 in range(0, n_mels, 16):
         rs = max((bounds[m][1] - (bounds[m][0] & ~3) + 16) // 16 for m in range(m0, min(m0 + 16, n_mels)) if bounds[m][0] >= 0)
@@ -138,4 +138,4 @@ def main(fmax=None):
 
 
 if __name__ == "__main__":
-    main(float(sys.argv[1]) if len(sys.argv) > 1 else None)
+    main(float(sys.argv[1]) if len(sys.argv) > 1 else 150.0, float(sys.argv[2]) if len(sys.argv) > 2 else None)
