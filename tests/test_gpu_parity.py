@@ -284,7 +284,7 @@ def test_pair_kernel_mel_tables_for_other_filter_banks(env, n_mels, fmin, fmax):
     filter sits on which lane quad, start bins moved down inside the slack of the round's steps so that a lane group's reads tile the
     LDS bank row; the band index travels in the table).  Other filter banks than the bench preset's - band counts that are not multiples
     of 16, narrow and wide bands, rounds for which no arrangement exists - against the CPU restatement of librosa's melspectrogram
-    (map_detector_core.py:219-228) and against k_stft_mel_w: mel power within 2e-6 / 1e-6 of the row's peak, every band written."""
+    (map_detector_core.py:219-228) and against k_stft_mel_w: mel power within 2e-6 of the row's peak, every band written."""
     import dataclasses
     cfg = dataclasses.replace(env.PRESETS["bench-1s"], n_mels=n_mels, fmin=fmin, fmax=fmax)
     B = 6
@@ -303,7 +303,7 @@ def test_pair_kernel_mel_tables_for_other_filter_banks(env, n_mels, fmin, fmax):
     peak = np.maximum(want.max(axis=(1, 2)), 1e-30)
     ep = (np.abs(got - want).max(axis=(1, 2)) / peak).max()
     eo = (np.abs(got - old).max(axis=(1, 2)) / peak).max()
-    assert ep <= 2e-6 and eo <= 1e-6, (ep, eo)
+    assert ep <= 2e-6 and eo <= 2e-6, (ep, eo)           # (two fp32 summation orders against each other: each within ~1e-6 of the oracle)
     assert (got[:5].max(axis=1) > 0).all()              # every band of the non-silent rows carries energy: none was left unwritten
     sess.close()
 
