@@ -230,6 +230,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--prewarm", type=int, default=40,
+                    help="untimed passes BEFORE the W warm-up steps (not counted in W): the GPU has idled through the CPU baseline leg and the "
+                         "set-up, and its first ~100 ms of work run 5 %% slower (10 steps after 2 warm-up steps: 3.47 M chunks/s, 200 after "
+                         "20: 3.68 M - profiles/r03_bench_warmup_sweep.txt); 0 = none")
     ap.add_argument("--chunks", type=int, default=10000, help="chunks per GPU per step (config 2: 10k)")
     ap.add_argument("--batch", type=int, default=256, help="chunks per kernel launch (config 2: 256)")
     ap.add_argument("--preset", default="bench-1s")
@@ -340,6 +344,8 @@ def main():
     dom = max(range(len(stages)), key=lambda i: stages[i]["total_ms"])
     n_lanes = args.lanes if args.lanes > 0 else 4
     sess.configure("lanes", n_lanes)
+    for _ in range(max(0, args.prewarm)):              # see --prewarm: brings the GPU out of its idle state; W below is untouched
+        step()
     for _ in range(max(1, args.warmup - 1)):
         step()
     sess.profile_enable(True, only_stage=dom)          # two event records per batch inside the timed region
@@ -501,7 +507,7 @@ def main():
                                     f"resident in HBM, ") +
                                    f"preset {args.preset}, {args.spec} VAE encoder (latent_dim {D}), "
                                    f"batch {args.batch}, RMS normalise + mel + encoder, " + ("bf16 encoder" if args.bf16 else "fp32"),
-                       "chunks_per_gpu": args.chunks, "batch": args.batch, "lanes": n_lanes,
+                       "chunks_per_gpu": args.chunks, "batch": args.batch, "lanes": n_lanes, "prewarm_steps": max(0, args.prewarm),
                        **({"knobs": list(args.knob)} if args.knob else {}),
                        "parallelism": f"dp{world} (chunk shards, 1 all-gather)" if not args.config3 else f"1 GPU, {args.shards} virtual shards"},
             "roofline": roof,
