@@ -8,7 +8,10 @@ dB/standardise -> thesis-shape VAE encoder -> mu) over the BASELINE.json configs
 workload: 10 000 synthetic chunks resident in HBM, processed in batches of 256, fp32.
 With N > 1 every rank holds its own 10 000-chunk shard (weak scaling, one process per
 GPU) and the step ends with the single RCCL all-gather that concatenates the latent
-matrix.  Rank 0 prints ONE JSON line.
+matrix.  Rank 0 prints ONE JSON line.  Before the W warm-up steps come `--prewarm` (default 40)
+untimed passes: the GPU idles through the set-up and the CPU baseline leg, and its first
+~100 ms of work afterwards run ~5 % slower (profiles/r03_bench_warmup_sweep.txt); the
+timed region is exactly the K steps, bracketed by barrier + synchronize.
 
 Extra objects on that line:
   roofline      the dominant kernel (largest share of GPU time in a fully instrumented
