@@ -1123,13 +1123,16 @@ __device__ __forceinline__ void db_row_from_lds(const float* mp, int T, int M, i
     for (int j = 0; j < C; ++j) if (tid + NT * j < n) { const float dlt = v[j] - mean; acc += (double)(dlt * dlt); }
     for (int i = tid + NT * C; i < n; i += NT) { const float dlt = to_db(mp[i], ref_db) - mean; acc += (double)(dlt * dlt); }
     acc = wave_sum_dpp(acc);
-    __syncthreads();                                     // every wave has read the first sums
-    if (lane == 63) red[w] = acc;
+    // the second sums go BESIDE the first ones when there are at most 12 waves (doubles 12 .. 23 of the scratch: the unused tail of red and
+    // redf, whose last read - the row maximum - lies behind the barrier above): no barrier to wait for the readers of the first sums
+    double* const red2 = NWV <= 12 ? red + 12 : red;
+    if (NWV > 12) __syncthreads();                       // every wave has read the first sums
+    if (lane == 63) red2[w] = acc;
     __syncthreads();
     AMPH_DB_T(3)
     tot = 0.0;
 #pragma unroll
-    for (int g = 0; g < NWV; ++g) tot += red[g];
+    for (int g = 0; g < NWV; ++g) tot += red2[g];
     const float sd = sqrtf((float)(tot / (double)n));
     const float den = sd + 1e-8f;
     AMPH_DB_T(4)
