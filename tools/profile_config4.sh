@@ -12,7 +12,7 @@ B="python3 bench.py --preset bench-1s-128 --cpu-seconds 0 --no-detect"
 $B --bf16 > $OUT/bench_bf16.json 2> $OUT/bench.err || exit 1
 $B > $OUT/bench_f32.json 2>> $OUT/bench.err || exit 1
 echo "bench: bf16 $(python3 -c "import json;print(json.load(open('$OUT/bench_bf16.json'))['value'])") f32 $(python3 -c "import json;print(json.load(open('$OUT/bench_f32.json'))['value'])")"
-PM="$B --bf16 --steps 2 --warmup 1 --chunks 5120 --lanes 1"
+PM="$B --bf16 --steps 2 --warmup 1 --prewarm 0 --chunks 5120 --lanes 1"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_bf16 -- $B --bf16 --steps 5 --warmup 2 --lanes 1 > /dev/null 2> $OUT/stats_bf16.err || echo "stats failed"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_f32 -- $B --steps 5 --warmup 2 --lanes 1 > /dev/null 2> $OUT/stats_f32.err || echo "stats f32 failed"
 rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -- $PM > /dev/null 2> $OUT/pmc_mfma.err || echo "mfma failed"
