@@ -99,6 +99,7 @@ def _load() -> C.CDLL:
         "amph_mel_power_f32": (C.c_int, [vp, f32p, C.c_int, C.c_int, i32p, f32p, vp]),
         "amph_mel_pcm16": (C.c_int, [vp, i16p, C.c_int, C.c_int, i32p, C.c_int, C.c_int, f32p, f32p, vp]),
         "amph_encoder_forward": (C.c_int, [vp, f32p, C.c_int, f32p, f32p, vp]),
+        "amph_range_status": (C.c_int, [vp, C.c_int]),
         "amph_encode_pcm16": (C.c_int, [vp, i16p, C.c_int64, C.c_int, i32p, C.c_int, f32p, f32p, i32p, vp]),
         "amph_encode_f32": (C.c_int, [vp, f32p, C.c_int64, C.c_int, i32p, C.c_int, f32p, f32p, i32p, vp]),
         "amph_encode_pcm16_host": (C.c_int, [vp, i16p, C.c_int64, C.c_int, i32p, C.c_int, f32p, f32p, i32p]),
@@ -131,7 +132,7 @@ def _load() -> C.CDLL:
 EXPORTED_SYMBOLS = (
     "amph_abi_version", "amph_create", "amph_destroy", "amph_last_error", "amph_configure", "amph_raw_frames", "amph_latent_dim",
     "amph_max_batch", "amph_get_mel_basis", "amph_rms_normalize_f32", "amph_rms_normalize_pcm16", "amph_mel_f32",
-    "amph_mel_power_f32", "amph_mel_pcm16", "amph_encoder_forward", "amph_encode_pcm16", "amph_encode_f32", "amph_encode_pcm16_host",
+    "amph_mel_power_f32", "amph_mel_pcm16", "amph_encoder_forward", "amph_range_status", "amph_encode_pcm16", "amph_encode_f32", "amph_encode_pcm16_host",
     "amph_decide_radial", "amph_fit_radial", "amph_decide_map", "amph_resample_length", "amph_resample_f32", "amph_wav_read_pcm16", "amph_wav_read_many", "amph_host_alloc", "amph_host_free",
     "amph_profile_enable", "amph_profile_stage_count", "amph_profile_stage_name", "amph_profile_read",
     "amph_profile_reset",

@@ -150,7 +150,12 @@ struct amph_ctx {
     int wide_gemm = -1;                    // staged GEMM layers on 128 x 128 tiles (k_conv_gemm_s3w: a quarter of the workgroups, each ~1.6x as long; same results).
                                            // -1: when the call's batches run on several lanes (a batch then costs the sum of its kernels' CU-time, not of their
                                            // durations: profiles/r03_stage_skip_sweep.txt) and the grid still has a workgroup for a quarter of the CUs; 0 / 1: never / always
-    int active_lanes = 1;                  // lanes the running call spreads its batches over (set by the batch loop)
+    // fp16 range of the two-term split (k_encoder_split.hip): x = h + 2^-11 l needs |x| < 65 520
+    int* h_range_flag = nullptr;           // host-coherent word the split kernels raise when an output - the next layer's operand - is out of range
+    int* d_range_flag = nullptr;           // its device address
+    float img_limit = 0.0f;                // largest |image value| for which the layer-1 activation the fused pair builds in LDS provably stays in range
+                                           // (0: the layer-1 weights themselves are not splittable)
+    float img_bound = 0.0f;                // what the front end can produce: |z-score| <= sqrt(n - 1) of the T_raw x M values it standardises
     int patch_gemm_wgs = 0;                // workgroups of that kernel (0: four tiles each, at most half the CUs)
     bool bf16_pair = true;                 // bf16 encoder: layers 1 + 2 in bf16 proper (k_conv_gemm_f4b) instead of fp32-accurate with a bf16 epilogue
     bool patch_fused = true;               // ... in its patch-resident form where the shape allows (k_conv_gemm_f4s)
@@ -621,6 +626,21 @@ int build_encoder(amph_ctx* c, const float* hw, size_t n_floats) {
             HIP_TRY(c, upload(&c->d_first_w, wf));
             HIP_TRY(c, upload(&c->d_first_scale, alpha));
             HIP_TRY(c, upload(&c->d_first_shift, shift));
+            // fp16 range of the fused pair's layer 1 (k_conv_gemm_f4s splits the image, these weights and the layer-1 activation it builds in
+            // LDS into fp16 terms): |a1[c]| <= (sum_t |w1[t][c]|) |alpha_c| X + |shift_c| for |image| <= X.  img_limit = the largest X for which every
+            // channel stays below 65 504 (and the image itself does); 0 when a weight is not splittable.
+            {
+                double lim = 65504.0 * (1.0 - 1e-4);
+                bool okw = true;
+                for (int o = 0; o < l.c_out; ++o) {
+                    double l1 = 0.0;
+                    for (int t = 0; t < kk; ++t) { const double a = std::fabs((double)w[(size_t)o * kk + t]); l1 += a; okw = okw && a < 65504.0; }
+                    const double gain = l1 * std::fabs((double)alpha[o]), sh = std::fabs((double)shift[o]);
+                    okw = okw && std::isfinite(gain) && std::isfinite(sh) && sh < 65504.0;
+                    if (okw && gain > 0.0) lim = std::min(lim, (65504.0 * (1.0 - 1e-4) - sh) / gain);
+                }
+                c->img_limit = okw && lim > 0.0 ? (float)lim : 0.0f;
+            }
             ConvFirstParams& p = c->first;
             p.w = c->d_first_w; p.scale = c->d_first_scale; p.shift = c->d_first_shift;
             p.H = Hin; p.W = Win; p.OH = hs[i]; p.OW = wsz[i]; p.C_out = l.c_out;
@@ -635,11 +655,17 @@ int build_encoder(amph_ctx* c, const float* hw, size_t n_floats) {
                     for (int t = 0; t < kk; ++t)
                         wg[(size_t)o * K_pad + (size_t)t * l.c_in + ci] = w[((size_t)o * l.c_in + ci) * kk + t];
             HIP_TRY(c, upload(&gl.d_w, wg));
+            // two-term fp16 weights exist only for |w| < 65 504 (h = fp16(w) is inf above): a layer with larger or non-finite weights keeps
+            // d_w_h2 / d_w_f4 null and runs on the f32-MFMA kernels (the three-term bf16 split of the fused pair has fp32's range)
+            bool h2_ok = true;
+            for (const float v : wg) h2_ok = h2_ok && std::fabs(v) < 65504.0f;      // (false for NaN too)
             if (l.c_in % 32 == 0) {
-                std::vector<uint16_t> w3((size_t)n_pad * K_pad * 3);
-                conv_gemm_s3_split_weights(wg.data(), n_pad, K_pad, w3.data());
-                HIP_TRY(c, upload(&gl.d_w_s3, w3));
-                {
+                if (i == 1) {                                       // k_conv_gemm_f3s: the fused pair only
+                    std::vector<uint16_t> w3((size_t)n_pad * K_pad * 3);
+                    conv_gemm_s3_split_weights(wg.data(), n_pad, K_pad, w3.data());
+                    HIP_TRY(c, upload(&gl.d_w_s3, w3));
+                }
+                if (h2_ok) {
                     std::vector<uint16_t> w2((size_t)n_pad * K_pad * 2);
                     conv_gemm_h2_split_weights(wg.data(), n_pad, K_pad, w2.data());
                     HIP_TRY(c, upload(&gl.d_w_h2, w2));
@@ -654,7 +680,7 @@ int build_encoder(amph_ctx* c, const float* hw, size_t n_floats) {
                     conv_gemm_f4b_fragment_weights(wg.data(), n_pad, K_pad, wb.data());
                     HIP_TRY(c, upload(&gl.d_w_f4b, wb));
                 }
-                if ((i == 1 && K_pad == 288) || (i > 1 && (l.c_in == 64 || l.c_in == 128) && K_pad == 9 * l.c_in)) {   // k_conv_gemm_f4s / _g4 / _g5: two fp16 terms
+                if (h2_ok && ((i == 1 && K_pad == 288) || (i > 1 && (l.c_in == 64 || l.c_in == 128) && K_pad == 9 * l.c_in))) {   // k_conv_gemm_f4s / _g4 / _g5: two fp16 terms
                     std::vector<uint16_t> wf((size_t)n_pad * K_pad * 2);
                     conv_gemm_h2_fragment_weights(wg.data(), n_pad, K_pad, wf.data());
                     HIP_TRY(c, upload(&gl.d_w_f4, wf));
@@ -694,7 +720,9 @@ int build_encoder(amph_ctx* c, const float* hw, size_t n_floats) {
         }
         GemmLayer gl;
         HIP_TRY(c, upload(&gl.d_w, wg));
-        if (flat % 32 == 0) {                            // the head only runs through k_conv_gemm_s3: the two-term fp16 weights
+        bool h2_ok = true;
+        for (const float v : wg) h2_ok = h2_ok && std::fabs(v) < 65504.0f;
+        if (flat % 32 == 0 && h2_ok) {                   // the head only runs through k_conv_gemm_s3: the two-term fp16 weights
             std::vector<uint16_t> w2((size_t)n_pad * K_pad * 2);
             conv_gemm_h2_split_weights(wg.data(), n_pad, K_pad, w2.data());
             HIP_TRY(c, upload(&gl.d_w_h2, w2));
@@ -835,7 +863,10 @@ void build_stages(amph_ctx* c) {
 }
 
 // encoder on ws_image-like input; x is [nb][T][M]
-int run_encoder(amph_ctx* c, Workspace& w, const float* d_x, int nb, float* d_mu, float* d_logvar, hipStream_t s) {
+// lanes: how many lanes the CALL spreads its batches over (picks the tile form of the staged GEMM layers: "wide_gemm");
+// img_checked: the image is known to stay below c->img_limit (the front end's own images when img_bound < img_limit; for a caller's
+// tensor amph_encoder_forward runs k_range_check first and the fused pair raises nothing itself for layer 1)
+int run_encoder(amph_ctx* c, Workspace& w, const float* d_x, int nb, float* d_mu, float* d_logvar, hipStream_t s, int lanes, bool img_checked) {
     const int n_gemm = (int)c->gemm.size();
     if (c->bf16_encoder) {
         // layers 1 + 2: the fused split-operand kernel (fp32 layer 1 recomputed in the staging, fp32-accurate layer 2 on the bf16
@@ -853,7 +884,7 @@ int run_encoder(amph_ctx* c, Workspace& w, const float* d_x, int nb, float* d_mu
                 p.y_bf16 = 1;
                 launch_conv_gemm_f4b(p, c->gemm[0].d_w_f4b, c->patch_wgs, s);
                 gi0 = 1;
-            } else if (c->patch_fused && c->gemm[0].d_w_f4 && conv_gemm_f4s_ok(p)) {
+            } else if (c->patch_fused && c->gemm[0].d_w_f4 && img_checked && conv_gemm_f4s_ok(p)) {
                 StageTimer t(c, ST_CONV0 + 1, s);
                 p.y_bf16 = 1;
                 launch_conv_gemm_f4s(p, c->gemm[0].d_w_f4, c->patch_wgs, s);
@@ -924,6 +955,7 @@ int run_encoder(amph_ctx* c, Workspace& w, const float* d_x, int nb, float* d_mu
         p.M = nb * p.OH * p.OW;
         p.img = nullptr;
         p.zeros = c->d_zeros;
+        p.range_flag = head ? nullptr : c->d_range_flag;       // (only the two-term fp16 kernels look at it; the head's output is not split again)
         int bm = 128;
         if (head) { p.y = w.partial; bm = 64; }
         else {
@@ -955,6 +987,7 @@ int run_encoder(amph_ctx* c, Workspace& w, const float* d_x, int nb, float* d_mu
         ConvFirstParams p = c->first;
         p.x = d_x;
         p.y = w.act[0];
+        p.range_flag = c->split_gemm ? c->d_range_flag : nullptr;     // its output may be the next layer's split operand
         launch_conv_first(p, nb, s);
     }
     for (int gi = 0; gi < n_gemm; ++gi) {
@@ -970,7 +1003,7 @@ int run_encoder(amph_ctx* c, Workspace& w, const float* d_x, int nb, float* d_mu
 #endif
         StageTimer t(c, head ? stage_head_gemm(c) : ST_CONV0 + 1 + gi, s);
         const bool fused_here = fuse && gi == 0;
-        if (c->split_gemm && c->split_fused && c->patch_fused && fused_here && c->gemm[gi].d_w_f4 && conv_gemm_f4s_ok(prm[gi])) {
+        if (c->split_gemm && c->split_fused && c->patch_fused && fused_here && c->gemm[gi].d_w_f4 && img_checked && conv_gemm_f4s_ok(prm[gi])) {
 #ifdef AMPH_STAMPS
             c->gstamp_wgs[gi] = std::min(prm[gi].M / 64, c->patch_wgs > 0 ? c->patch_wgs : std::max(1, std::min(amph::g_num_cus / 2, (prm[gi].M / 64 + 7) / 8)));
             c->gstamp_f4s = true;                               // rows of 16: consumer wave 0 in [0..7], producer wave 4 in [8..15]
@@ -998,7 +1031,7 @@ int run_encoder(amph_ctx* c, Workspace& w, const float* d_x, int nb, float* d_mu
         if (c->split_gemm && !fused_here && c->gemm[gi].d_w_h2 && conv_gemm_s3_ok(prm[gi])) {
             ConvGemmParams ps = prm[gi];
             ps.w = reinterpret_cast<const float*>(c->gemm[gi].d_w_h2);
-            const bool wide = c->wide_gemm > 0 || (c->wide_gemm < 0 && c->active_lanes > 1 && (long long)((ps.M + 127) / 128) * (ps.N / 128) * 4 >= amph::g_num_cus);
+            const bool wide = c->wide_gemm > 0 || (c->wide_gemm < 0 && lanes > 1 && (long long)((ps.M + 127) / 128) * (ps.N / 128) * 4 >= amph::g_num_cus);
             if (wide && !head && conv_gemm_s3w_ok(ps)) launch_conv_gemm_s3w(ps, s);
             else launch_conv_gemm_s3(ps, s);
             continue;
@@ -1158,7 +1191,6 @@ int encode_common(amph_ctx* c, const void* d_wave, bool pcm16, int64_t n_rows, i
     // fork: batches go round-robin over the lanes; lane 0 runs on the caller's stream
     const int64_t n_batches = (n_rows + c->max_batch - 1) / c->max_batch;
     const int L = (int)std::min<int64_t>((int64_t)c->lanes.size(), std::max<int64_t>(n_batches, 1));
-    c->active_lanes = L;
     if (L > 1) {
         HIP_TRY(c, hipEventRecord(c->ev_fork, s));
         for (int l = 1; l < L; ++l) HIP_TRY(c, hipStreamWaitEvent(c->lanes[l].stream, c->ev_fork, 0));
@@ -1181,7 +1213,8 @@ int encode_common(amph_ctx* c, const void* d_wave, bool pcm16, int64_t n_rows, i
         rc = run_frontend(c, w, wv, pcm16, nb, n_in, d_len ? d_len + off : nullptr, apply_rms, d_rms_ok ? d_rms_ok + off : nullptr,
                           w.melpow, ls, fdb ? w.image : nullptr, 1);
         if (rc == AMPH_OK && !fdb) rc = run_dbnorm(c, w.melpow, nb, 1, w.image, ls);
-        if (rc == AMPH_OK) rc = run_encoder(c, w, w.image, nb, d_mu + off * D, d_logvar ? d_logvar + off * D : nullptr, ls);
+        if (rc == AMPH_OK) rc = run_encoder(c, w, w.image, nb, d_mu + off * D, d_logvar ? d_logvar + off * D : nullptr, ls, L,
+                                            c->img_bound < c->img_limit);
         if (rc == AMPH_OK) rc = check_launch(c, "encode");
     }
     for (int l = 1; l < L; ++l) {           // join (on failure too: the caller's stream must not run ahead of the lanes)
@@ -1231,6 +1264,14 @@ int amph_create(const amph_frontend_config* cfg, const amph_encoder_spec* spec, 
         }
     }
     if (rc == AMPH_OK) rc = alloc_workspace(c);
+    if (rc == AMPH_OK) {
+        // the word the two-term fp16 kernels raise (host-coherent memory: visible to the host once the raising kernel's stream has synchronised)
+        hipError_t e = hipHostMalloc((void**)&c->h_range_flag, 64, hipHostMallocMapped);
+        if (e == hipSuccess) { *c->h_range_flag = 0; e = hipHostGetDevicePointer((void**)&c->d_range_flag, c->h_range_flag, 0); }
+        if (e != hipSuccess) rc = fail(c, AMPH_ERR_HIP, "range flag: %s", hipGetErrorString(e));
+        // power_to_db -> z-score over the T_raw x M array (map_detector_core.py:229-232): |z| <= sqrt(n - 1) whatever the signal
+        c->img_bound = std::sqrt((float)c->n_frames * (float)c->cfg.n_mels);
+    }
     if (rc == AMPH_OK) {
         build_stages(c);
         // STFT workgroup shape: 12 waves (one 768-thread workgroup per CU, three waves per SIMD) with one
@@ -1298,6 +1339,7 @@ void amph_destroy(amph_ctx* c) {
     fr(c->d_rs_win); fr(c->d_rs_delta);
     fr(c->d_fit_off); fr(c->d_fit_mu); fr(c->d_fit_stats); fr(c->d_fit_rho);
     fr(c->d_map_means); fr(c->d_map_prec); fr(c->d_map_logdet); fr(c->d_map_lprior);
+    if (c->h_range_flag) (void)hipHostFree(c->h_range_flag);
     for (int i = 0; i < 2; ++i) {
         if (c->pin_in[i]) (void)hipHostFree(c->pin_in[i]);
         fr(c->dev_in[i]); fr(c->dev_len[i]);
@@ -1622,13 +1664,23 @@ int amph_encoder_forward(amph_ctx* c, const float* d_x, int n_rows, float* d_mu,
     hipStream_t s = (hipStream_t)stream;
     const size_t per = (size_t)c->cfg.target_frames * c->cfg.n_mels;
     const int D = c->latent;
-    c->active_lanes = 1;
+    // the caller's tensor, not the front end's z-scored image: its values are tested against the limit the fused pair's fp16 terms need
+    const bool split_first = c->split_gemm && c->img_limit > 0.0f;
+    if (split_first && n_rows > 0) launch_range_check(d_x, (long long)n_rows * (long long)per, c->img_limit, c->d_range_flag, s);
     for (int off = 0; off < n_rows; off += c->max_batch) {
         const int nb = std::min(c->max_batch, n_rows - off);
-        const int rc = run_encoder(c, c->lanes[0], d_x + (size_t)off * per, nb, d_mu + (size_t)off * D, d_logvar ? d_logvar + (size_t)off * D : nullptr, s);
+        const int rc = run_encoder(c, c->lanes[0], d_x + (size_t)off * per, nb, d_mu + (size_t)off * D, d_logvar ? d_logvar + (size_t)off * D : nullptr, s, 1,
+                                   split_first);
         if (rc != AMPH_OK) return rc;
     }
     return check_launch(c, "encoder_forward");
+}
+
+int amph_range_status(amph_ctx* c, int clear) {
+    if (!c || !c->h_range_flag) return 0;
+    const int v = *reinterpret_cast<volatile int*>(c->h_range_flag) != 0 ? 1 : 0;
+    if (clear) *reinterpret_cast<volatile int*>(c->h_range_flag) = 0;
+    return v;
 }
 
 int amph_encode_pcm16(amph_ctx* c, const int16_t* d_pcm, int64_t n_rows, int n_in, const int32_t* d_lengths, int apply_rms,
@@ -1641,8 +1693,26 @@ int amph_encode_f32(amph_ctx* c, const float* d_wave, int64_t n_rows, int n_in, 
     return encode_common(c, d_wave, false, n_rows, n_in, d_lengths, apply_rms, d_mu, d_logvar, d_rms_ok, (hipStream_t)stream);
 }
 
+static int encode_pcm16_host_once(amph_ctx* c, const int16_t* h_pcm, int64_t n_rows, int n_in, const int32_t* h_lengths,
+                                  int apply_rms, float* h_mu, float* h_logvar, int32_t* h_rms_ok);
+
 int amph_encode_pcm16_host(amph_ctx* c, const int16_t* h_pcm, int64_t n_rows, int n_in, const int32_t* h_lengths,
                            int apply_rms, float* h_mu, float* h_logvar, int32_t* h_rms_ok) {
+    if (!c) return AMPH_ERR_INVALID_ARG;
+    const int before = amph_range_status(c, 0);
+    int rc = encode_pcm16_host_once(c, h_pcm, n_rows, n_in, h_lengths, apply_rms, h_mu, h_logvar, h_rms_ok);
+    // this entry point synchronises, so it can act on the fp16-range flag itself: an activation the two-term split cannot hold
+    // -> the call runs again on the f32-MFMA kernels, and the context stays on them (its data are outside the split's range)
+    if (rc == AMPH_OK && !before && amph_range_status(c, 1)) {
+        c->split_gemm = false;
+        c->split_fused = false;
+        rc = encode_pcm16_host_once(c, h_pcm, n_rows, n_in, h_lengths, apply_rms, h_mu, h_logvar, h_rms_ok);
+    }
+    return rc;
+}
+
+static int encode_pcm16_host_once(amph_ctx* c, const int16_t* h_pcm, int64_t n_rows, int n_in, const int32_t* h_lengths,
+                                  int apply_rms, float* h_mu, float* h_logvar, int32_t* h_rms_ok) {
     if (!c) return AMPH_ERR_INVALID_ARG;
     if (!c->has_encoder) return fail(c, AMPH_ERR_INVALID_ARG, "context was created without encoder weights");
     if (n_rows < 0 || n_in <= 0 || (n_rows > 0 && (!h_pcm || !h_mu))) return fail(c, AMPH_ERR_INVALID_ARG, "bad encode arguments");

@@ -138,6 +138,7 @@ struct ConvFirstParams {     // C_in == 1 direct convolution, NHWC output
     const float* shift;      // [C_out] BN beta' = (bias - mean) * alpha + beta
     float* y;                // [B][OH][OW][C_out]
     int H, W, OH, OW, C_out, k, stride, pad;
+    int* range_flag;         // nullable: raised when an output is no fp16 split operand (kH2Max below)
 };
 
 struct ConvGemmParams {      // implicit GEMM: M = B*OH*OW, N = C_out, K = k*k*C_in (kh, kw, ci)
@@ -161,6 +162,8 @@ struct ConvGemmParams {      // implicit GEMM: M = B*OH*OW, N = C_out, K = k*k*C
     int x_guard;             // bytes of ZEROS in front of x (same allocation): padded taps of k_conv_gemm_p3 read there
     int y_bf16;              // k_conv_gemm_f3s only: write the output as bf16 NHWC (the bf16 encoder's layer 3 reads it)
     int flags;               // (first-generation kernel only; bit 0: static issue priority from the wave's slot on its SIMD - always 0 since round 3)
+    int* range_flag;         // nullable; two-term fp16 split kernels (epilogue 0): set to 1 when an output - the NEXT layer's split operand - is
+                             // at or above fp16's 65 504 or NaN (kH2Max below); host-visible word, read after the stream has synchronised
 #ifdef AMPH_STAMPS
     unsigned long long* stamps;   // diagnostic build: [workgroup][role][4]
 #endif
@@ -175,6 +178,7 @@ struct HeadReduceParams {    // mu/logvar = sum_s partial[s] + bias
 };
 
 void launch_conv_first(const ConvFirstParams& p, int n_rows, hipStream_t s);
+void launch_range_check(const float* x, long long n, float limit, int* flag, hipStream_t s);   // *flag = 1 if any |x[i]| >= limit or NaN
 extern int g_num_cus;      // compute units of the device (a property of the hardware, not a knob)
 bool conv_gemm_can_fuse(const ConvGemmParams& p, int bm);
 size_t conv_gemm_x_guard(int k, int W, int C_in);          // zero guard k_conv_gemm_p3 needs in front of its input
@@ -210,6 +214,12 @@ void launch_conv_first_bf16(const ConvFirstParams& p, int n_rows, hipStream_t s)
 void launch_conv_gemm_bf16(const ConvGemmParams& p, int bm, hipStream_t s);
 
 #ifdef __HIPCC__
+// The two-term fp16 split x = h + 2^-11 l (k_encoder_split.hip) exists for |x| < 65 520 only: h = fp16(x) is inf above and the low
+// term -inf.  Every kernel whose output feeds such a split tests its pre-ReLU values with this (true for >= 65 504, +inf and NaN;
+// large negative values are zeroed by the ReLU) and raises ConvGemmParams::range_flag; amph_range_status reports it.
+constexpr float kH2Max = 65504.0f;
+__device__ __forceinline__ bool h2_unsplittable(float t) { return !(t < kH2Max); }
+
 // sum((z - mu)^2) over n <= 128 elements in numpy's float32 pairwise order (n < 8 sequential; else eight strided accumulators
 // combined ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) plus a sequential tail): np.sum(a * a) of 09_evaluate_wav_detection.py:354-355 and
 // each row of l2_norm_rows, 08_fit_radial_detector.py:105-106

@@ -55,10 +55,10 @@ __global__ __launch_bounds__(256) void k_conv_first(ConvFirstParams p, long long
     const float4 sc = *reinterpret_cast<const float4*>(p.scale + 4 * cg);
     const float4 sh = *reinterpret_cast<const float4*>(p.shift + 4 * cg);
     float4 o;
-    o.x = fmaxf(fmaf(acc.x, sc.x, sh.x), 0.0f);
-    o.y = fmaxf(fmaf(acc.y, sc.y, sh.y), 0.0f);
-    o.z = fmaxf(fmaf(acc.z, sc.z, sh.z), 0.0f);
-    o.w = fmaxf(fmaf(acc.w, sc.w, sh.w), 0.0f);
+    o.x = fmaf(acc.x, sc.x, sh.x); o.y = fmaf(acc.y, sc.y, sh.y); o.z = fmaf(acc.z, sc.z, sh.z); o.w = fmaf(acc.w, sc.w, sh.w);
+    // the next layer may take this tensor as an fp16 split operand (amph_internal.h kH2Max)
+    if (p.range_flag && (h2_unsplittable(o.x) | h2_unsplittable(o.y) | h2_unsplittable(o.z) | h2_unsplittable(o.w))) *p.range_flag = 1;
+    o.x = fmaxf(o.x, 0.0f); o.y = fmaxf(o.y, 0.0f); o.z = fmaxf(o.z, 0.0f); o.w = fmaxf(o.w, 0.0f);
     *reinterpret_cast<float4*>(p.y + pix * p.C_out + 4 * cg) = o;
 }
 
@@ -66,6 +66,25 @@ void launch_conv_first(const ConvFirstParams& p, int n_rows, hipStream_t s) {
     const long long total = (long long)n_rows * p.OH * p.OW * (p.C_out >> 2);
     const unsigned blocks = (unsigned)((total + 255) / 256);
     hipLaunchKernelGGL(k_conv_first, dim3(blocks), dim3(256), 0, s, p, total);
+}
+
+// amph_encoder_forward's input is the CALLER's tensor: before a kernel splits it into fp16 terms (and builds a layer-1 activation from
+// it whose bound `limit` was derived at create), raise the flag for any value at or beyond the limit, or NaN
+__global__ __launch_bounds__(256) void k_range_check(const float* __restrict__ x, long long n4, long long n, float limit, int* flag) {
+    bool bad = false;
+    const long long g = (long long)blockIdx.x * 256 + threadIdx.x, step = (long long)gridDim.x * 256;
+    for (long long i = g; i < n4; i += step) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        bad |= !(fabsf(v.x) < limit) | !(fabsf(v.y) < limit) | !(fabsf(v.z) < limit) | !(fabsf(v.w) < limit);
+    }
+    for (long long i = 4 * n4 + g; i < n; i += step) bad |= !(fabsf(x[i]) < limit);      // the tail (everything when x is not 16-byte aligned)
+    if (bad) *flag = 1;
+}
+void launch_range_check(const float* x, long long n, float limit, int* flag, hipStream_t s) {
+    if (n <= 0 || !flag) return;
+    const long long n4 = (reinterpret_cast<uintptr_t>(x) & 15) == 0 ? n / 4 : 0;
+    const unsigned blocks = (unsigned)std::min<long long>(1024, std::max<long long>(1, (std::max(n4, n - 4 * n4) + 255) / 256));
+    hipLaunchKernelGGL(k_range_check, dim3(blocks), dim3(256), 0, s, x, n4, n, limit, flag);
 }
 
 // ----------------------------------------------------------------------------

@@ -374,6 +374,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_f4s(ConvGemmParams p, Patc
     const unsigned long long q_start = q_d - q_t0;
 #endif
     int i = 0;
+    bool bad = false;                                                // an output conv3's fp16 split cannot hold (amph_internal.h kH2Max)
     for (int tile = blockIdx.x; tile < g.n_tiles; tile += gridDim.x, ++i) {
         const char* pb = ((i & 1) ? patch1 : patch0) + a_base;
         AMPH_F4_T(q_a)
@@ -464,10 +465,12 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_f4s(ConvGemmParams p, Patc
                     const int n0 = n_blk + ct * 32 + 8 * gq + 4 * (lane >> 5);             \
                     if (n0 < p.N) {                                                        \
                         float4 v;                                                          \
-                        v.x = fmaxf(fmaf(AMPH_F4_SUM(gq, x), e_sc##gq.x, e_sh##gq.x), 0.0f); \
-                        v.y = fmaxf(fmaf(AMPH_F4_SUM(gq, y), e_sc##gq.y, e_sh##gq.y), 0.0f); \
-                        v.z = fmaxf(fmaf(AMPH_F4_SUM(gq, z), e_sc##gq.z, e_sh##gq.z), 0.0f); \
-                        v.w = fmaxf(fmaf(AMPH_F4_SUM(gq, w), e_sc##gq.w, e_sh##gq.w), 0.0f); \
+                        v.x = fmaf(AMPH_F4_SUM(gq, x), e_sc##gq.x, e_sh##gq.x);            \
+                        v.y = fmaf(AMPH_F4_SUM(gq, y), e_sc##gq.y, e_sh##gq.y);            \
+                        v.z = fmaf(AMPH_F4_SUM(gq, z), e_sc##gq.z, e_sh##gq.z);            \
+                        v.w = fmaf(AMPH_F4_SUM(gq, w), e_sc##gq.w, e_sh##gq.w);            \
+                        bad |= h2_unsplittable(v.x) | h2_unsplittable(v.y) | h2_unsplittable(v.z) | h2_unsplittable(v.w); \
+                        v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f); \
                         if (p.y_bf16) {                                                    \
                             const amph_bf16x2 lo_ = {(__bf16)v.x, (__bf16)v.y}, hi_ = {(__bf16)v.z, (__bf16)v.w};   /* RNE */ \
                             *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.y) + (long long)m * p.N + n0) =       \
@@ -489,6 +492,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_f4s(ConvGemmParams p, Patc
         }
 #endif
     }
+    if (bad && p.range_flag && !p.y_bf16) *p.range_flag = 1;         // (a bf16 output has fp32's range)
 #ifdef AMPH_STAMPS
     if (tid == 0 && p.stamps) {       // consumer wave 0: start-up | multiply | partial sums + barrier X | barrier Y | (producer: build) | lifetime ticks | (producer: barriers) | start
         unsigned long long* o = p.stamps + (size_t)blockIdx.x * 16;
@@ -912,6 +916,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_g4(ConvGemmParams p, G4Geo
     AMPH_F4_T(q_a)
     q_start = q_a - q_t0;
 #endif
+    bool bad = false;                                                    // an output the next layer's fp16 split cannot hold (amph_internal.h kH2Max)
     for (; tile < g.n_tiles; tile += gridDim.x) {
         // ---- (1) the tile's input into the patch: split, stage by stage over the 2 NV pairs of this thread (bf16 input: copied)
         AMPH_F4_T(q_a)
@@ -1028,7 +1033,11 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_g4(ConvGemmParams p, G4Geo
                 const int m = m_img * (OW * OW) + 32 * t + px;          // output pixel index: tiles are whole images
                 if (n0 < p.N && m < p.M) {
 #pragma unroll
-                    for (int r = 0; r < RPO; ++r) sum[r] = fmaxf(fmaf(sum[r], e_sc[r], e_sh[r]), 0.0f);
+                    for (int r = 0; r < RPO; ++r) {
+                        const float t_ = fmaf(sum[r], e_sc[r], e_sh[r]);
+                        if (TERMS != 1) bad |= h2_unsplittable(t_);
+                        sum[r] = fmaxf(t_, 0.0f);
+                    }
                     if (TERMS == 1) {                                  // bf16 NHWC
                         uint16_t* yo = reinterpret_cast<uint16_t*>(p.y) + (long long)m * p.N + n0;
                         const amph_bf16x2 lo_ = {(__bf16)sum[0], (__bf16)sum[1]}, hi_ = {(__bf16)sum[2 % RPO], (__bf16)sum[3 % RPO]};
@@ -1054,6 +1063,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_g4(ConvGemmParams p, G4Geo
             }
         }
     }
+    if (bad && p.range_flag) *p.range_flag = 1;
 #ifdef AMPH_STAMPS
     if (tid == 0 && p.stamps) {       // wave 0: start-up (weights + first image landed) | patch build | barrier | multiply | barrier | exchange + epilogue
         unsigned long long* o = p.stamps + (size_t)(blockIdx.x + gridDim.x * blockIdx.y) * 8;
@@ -1176,6 +1186,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_g5(ConvGemmParams p, G5Geo
     }
     AMPH_G5_ZERO_COL()
     float4* const inbox = reinterpret_cast<float4*>(patch);
+    bool bad = false;                                                    // an output the next layer's fp16 split cannot hold (amph_internal.h kH2Max)
     for (; tile < g.n_tiles; tile += gridDim.x) {
         // ---- (1) the tile's input into the patch (fp32: split in two fp16 terms; bf16: copied)
         if (TERMS == 1) {
@@ -1271,7 +1282,11 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_g5(ConvGemmParams p, G5Geo
             const int m = tile * 64 + 32 * t + px;                       // a tile = 64 consecutive output pixels (TH whole rows)
             if (n_own < p.N && m < p.M) {
 #pragma unroll
-                for (int r = 0; r < RPO; ++r) sum[r] = fmaxf(fmaf(sum[r], e_sc[r], e_sh[r]), 0.0f);
+                for (int r = 0; r < RPO; ++r) {
+                    const float t_ = fmaf(sum[r], e_sc[r], e_sh[r]);
+                    if (TERMS != 1) bad |= h2_unsplittable(t_);
+                    sum[r] = fmaxf(t_, 0.0f);
+                }
                 if (TERMS == 1) {
                     uint16_t* yo = reinterpret_cast<uint16_t*>(p.y) + (long long)m * p.N + n_own;
                     const amph_bf16x2 lo_ = {(__bf16)sum[0], (__bf16)sum[1]}, hi_ = {(__bf16)sum[2], (__bf16)sum[3]};
@@ -1282,6 +1297,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_g5(ConvGemmParams p, G5Geo
         __syncthreads();                                                 // the inbox is read: the next tile's patch may be written
         AMPH_G5_ZERO_COL()                                               // (overwritten by the inbox)
     }
+    if (bad && p.range_flag) *p.range_flag = 1;
 #undef AMPH_G5_FETCH
 #undef AMPH_G5_ZERO_COL
 }

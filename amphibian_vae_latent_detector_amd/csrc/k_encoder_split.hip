@@ -360,6 +360,7 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm_s3(ConvGemmParams p) {
     {
         const int m = m_blk + row_tile * 32 + (lane & 31);
         float* ybase = p.y + (p.epilogue == 1 ? (long long)blockIdx.z * p.M * p.N : 0ll);
+        bool bad = false;                               // an output the next layer's fp16 split cannot hold (amph_internal.h kH2Max)
         if (m < p.M) {
 #define AMPH_S3_OUT(g)                                                                     \
             {                                                                              \
@@ -369,8 +370,9 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm_s3(ConvGemmParams p) {
                                            fmaf(accl[4 * g + 2], kH2Lo, acc[4 * g + 2]), fmaf(accl[4 * g + 3], kH2Lo, acc[4 * g + 3])); \
                     if (p.epilogue == 0) {                                                 \
                         const float4 e_sc = *reinterpret_cast<const float4*>(bn_lds + n0 - n_blk), e_sh = *reinterpret_cast<const float4*>(bn_lds + 64 + n0 - n_blk); \
-                        v.x = fmaxf(fmaf(v.x, e_sc.x, e_sh.x), 0.0f); v.y = fmaxf(fmaf(v.y, e_sc.y, e_sh.y), 0.0f); \
-                        v.z = fmaxf(fmaf(v.z, e_sc.z, e_sh.z), 0.0f); v.w = fmaxf(fmaf(v.w, e_sc.w, e_sh.w), 0.0f); \
+                        v.x = fmaf(v.x, e_sc.x, e_sh.x); v.y = fmaf(v.y, e_sc.y, e_sh.y); v.z = fmaf(v.z, e_sc.z, e_sh.z); v.w = fmaf(v.w, e_sc.w, e_sh.w); \
+                        bad |= h2_unsplittable(v.x) | h2_unsplittable(v.y) | h2_unsplittable(v.z) | h2_unsplittable(v.w); \
+                        v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f); \
                     }                                                                      \
                     *reinterpret_cast<float4*>(ybase + (long long)m * p.N + n0) = v;       \
                 }                                                                          \
@@ -378,6 +380,7 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm_s3(ConvGemmParams p) {
             AMPH_S3_OUT(0) AMPH_S3_OUT(1) AMPH_S3_OUT(2) AMPH_S3_OUT(3)
 #undef AMPH_S3_OUT
         }
+        if (bad && p.range_flag) *p.range_flag = 1;
     }
 #ifdef AMPH_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -569,6 +572,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_gemm_s3w(ConvGemmParams p) {
         AMPH_S3_STEPS_0_11(AMPH_S3_X)
 #undef AMPH_S3_X
     }
+    bool bad = false;                                   // an output the next layer's fp16 split cannot hold (amph_internal.h kH2Max)
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int m = m_blk + rg * 64 + t * 32 + (lane & 31);
@@ -580,13 +584,15 @@ __global__ __launch_bounds__(512, 1) void k_conv_gemm_s3w(ConvGemmParams p) {
                     const float4 e_sc = *reinterpret_cast<const float4*>(bn + n0 - n_blk), e_sh = *reinterpret_cast<const float4*>(bn + 128 + n0 - n_blk);
                     float4 v = make_float4(fmaf(accl[t][4 * g], kH2Lo, acc[t][4 * g]), fmaf(accl[t][4 * g + 1], kH2Lo, acc[t][4 * g + 1]),
                                            fmaf(accl[t][4 * g + 2], kH2Lo, acc[t][4 * g + 2]), fmaf(accl[t][4 * g + 3], kH2Lo, acc[t][4 * g + 3]));
-                    v.x = fmaxf(fmaf(v.x, e_sc.x, e_sh.x), 0.0f); v.y = fmaxf(fmaf(v.y, e_sc.y, e_sh.y), 0.0f);
-                    v.z = fmaxf(fmaf(v.z, e_sc.z, e_sh.z), 0.0f); v.w = fmaxf(fmaf(v.w, e_sc.w, e_sh.w), 0.0f);
+                    v.x = fmaf(v.x, e_sc.x, e_sh.x); v.y = fmaf(v.y, e_sc.y, e_sh.y); v.z = fmaf(v.z, e_sc.z, e_sh.z); v.w = fmaf(v.w, e_sc.w, e_sh.w);
+                    bad |= h2_unsplittable(v.x) | h2_unsplittable(v.y) | h2_unsplittable(v.z) | h2_unsplittable(v.w);
+                    v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
                     *reinterpret_cast<float4*>(p.y + (long long)m * p.N + n0) = v;
                 }
             }
         }
     }
+    if (bad && p.range_flag) *p.range_flag = 1;
 #undef AMPH_W_LOADB
 #undef AMPH_W_LOADA
 #undef AMPH_W_LOAD

@@ -11,6 +11,8 @@ and streams.
 from __future__ import annotations
 
 import ctypes as C
+import warnings
+from collections import OrderedDict
 from pathlib import Path
 from typing import Dict, Optional, Tuple
 
@@ -220,20 +222,49 @@ class AmphSession:
                                            _ptr(out), _ptr(pw), self._stream()))
         return (out, pw) if want_power else out
 
-    def encoder_forward(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    # -- the fp16 range of the default GEMM arithmetic (include/amph.h, amph_range_status)
+    def range_overflow(self, clear: bool = True) -> bool:
+        """True when a kernel of this context met a value the two-term fp16 split cannot hold (>= 65 504 or NaN) since the last
+        clear: the latents of those calls are not valid.  Synchronises the current stream first."""
+        torch.cuda.current_stream(self.device).synchronize()
+        return bool(N.lib.amph_range_status(self._ctx, 1 if clear else 0))
+
+    def _rerun_in_f32_if_out_of_range(self, run):
+        """The reference's module is fp32 with fp32's range (map_detector_core.py:175-179, :270).  After `run()`: if the range flag is
+        up, this context moves to the f32-MFMA kernels for good ("split_gemm" 0: its checkpoint / data are outside the split's range)
+        and the call runs again."""
+        if not self.range_overflow():
+            return
+        warnings.warn("an activation or input of this encoder is outside fp16's range (>= 65 504 or NaN): the two-term fp16 GEMM path "
+                      "cannot represent it; this context now runs the f32-MFMA kernels (amph_configure split_gemm = 0)", RuntimeWarning,
+                      stacklevel=3)
+        self.configure("split_gemm", 0)
+        self.configure("split_fused", 0)
+        run()
+        self.range_overflow()
+
+    def encoder_forward(self, x: torch.Tensor, check_range: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
         x = self._dev(x, torch.float32)
         if x.ndim != 4 or x.shape[1] != 1 or x.shape[2] != self.cfg.target_frames or x.shape[3] != self.cfg.n_mels:
             raise RuntimeError(f"encoder expects [B,1,{self.cfg.target_frames},{self.cfg.n_mels}], got {tuple(x.shape)}")
         B, D = x.shape[0], self.latent_dim
         mu = torch.empty((B, D), dtype=torch.float32, device=self.device)
         lv = torch.empty((B, D), dtype=torch.float32, device=self.device)
-        with torch.cuda.device(self.device):
-            self._chk(N.lib.amph_encoder_forward(self._ctx, _ptr(x), B, _ptr(mu), _ptr(lv), self._stream()))
+
+        def run():
+            with torch.cuda.device(self.device):
+                self._chk(N.lib.amph_encoder_forward(self._ctx, _ptr(x), B, _ptr(mu), _ptr(lv), self._stream()))
+        run()
+        if check_range:
+            self._rerun_in_f32_if_out_of_range(run)
         return mu, lv
 
-    def encode(self, wave, lengths=None, apply_rms: bool = False, want_logvar: bool = False, out_mu=None):
+    def encode(self, wave, lengths=None, apply_rms: bool = False, want_logvar: bool = False, out_mu=None, check_range: bool = True):
         """Fused chunk -> latent.  wave: [B, n_in] int16 (PCM16) or float32, device or host.
-        Returns (mu [B,D], logvar or None, rms_ok [B] int32) as device tensors."""
+        Returns (mu [B,D], logvar or None, rms_ok [B] int32) as device tensors.
+        check_range (default): synchronise the stream and, should an activation have left the range of the two-term fp16 GEMM
+        arithmetic, run the call again on the f32-MFMA kernels (include/amph.h, amph_range_status).  A caller that keeps calls in
+        flight passes False and asks `range_overflow()` at its own synchronisation point."""
         wave = torch.as_tensor(wave) if not torch.is_tensor(wave) else wave
         is_pcm = wave.dtype == torch.int16
         wave = self._dev(wave, torch.int16 if is_pcm else torch.float32)
@@ -245,9 +276,14 @@ class AmphSession:
         lv = torch.empty((B, D), dtype=torch.float32, device=self.device) if want_logvar else None
         ok = torch.empty(B, dtype=torch.int32, device=self.device)
         fn = N.lib.amph_encode_pcm16 if is_pcm else N.lib.amph_encode_f32
-        with torch.cuda.device(self.device):
-            self._chk(fn(self._ctx, _ptr(wave), B, wave.shape[1], _ptr(lens), 1 if apply_rms else 0, _ptr(mu), _ptr(lv),
-                         _ptr(ok), self._stream()))
+
+        def run():
+            with torch.cuda.device(self.device):
+                self._chk(fn(self._ctx, _ptr(wave), B, wave.shape[1], _ptr(lens), 1 if apply_rms else 0, _ptr(mu), _ptr(lv),
+                             _ptr(ok), self._stream()))
+        run()
+        if check_range:
+            self._rerun_in_f32_if_out_of_range(run)
         return mu, lv, ok
 
     def encode_host(self, pcm: np.ndarray, lengths=None, apply_rms: bool = False):
@@ -371,6 +407,7 @@ class HipEncoder:
         self.max_batch = max_batch
         self._blob = pack_weights(spec, state)
         self._sessions: Dict[FrontendConfig, AmphSession] = {}
+        self._file_sessions: "OrderedDict[FrontendConfig, AmphSession]" = OrderedDict()
 
     # nn.Module-flavoured no-ops the reference's callers use (map_detector_core.py:179)
     def eval(self):
@@ -389,6 +426,26 @@ class HipEncoder:
         if s is None:
             s = AmphSession(cfg, self.spec, self._blob, self.device, self.max_batch)
             self._sessions[cfg] = s
+        return s
+
+    WHOLE_FILE_SESSIONS = 2      # contexts kept for the duration <= 0 path (one per distinct file length; least recently used goes)
+
+    def whole_file_session(self, cfg: FrontendConfig) -> AmphSession:
+        """A context for ONE whole file of cfg.n_samples samples (map_detector_core.py:212, duration <= 0: no pad / truncate): batch 1 on
+        one lane - its workspaces scale with the file's frame count, so a 256-row, four-lane context per distinct length would keep
+        gigabytes per file - and only the last WHOLE_FILE_SESSIONS lengths stay alive (the evicted context is destroyed: its device
+        memory returns to the allocator)."""
+        if (cfg.target_frames, cfg.n_mels) != (self.spec.in_frames, self.spec.in_mels):
+            raise RuntimeError(f"front end produces [{cfg.target_frames},{cfg.n_mels}] but the encoder was built for "
+                               f"[{self.spec.in_frames},{self.spec.in_mels}]")
+        s = self._file_sessions.pop(cfg, None)
+        if s is None:
+            s = AmphSession(cfg, self.spec, self._blob, self.device, 1)
+            s.configure("lanes", 1)
+        self._file_sessions[cfg] = s
+        while len(self._file_sessions) > self.WHOLE_FILE_SESSIONS:
+            _, old = self._file_sessions.popitem(last=False)
+            old.close()
         return s
 
     def _any_session(self) -> AmphSession:

@@ -22,6 +22,7 @@ process.  There is no CPU path: `device` must be a `cuda` device.
 from __future__ import annotations
 
 import json
+from collections import OrderedDict
 from pathlib import Path
 from typing import Any, Dict, Optional
 
@@ -180,11 +181,25 @@ def PRESETS_FOR_RESAMPLE(sr: int) -> FrontendConfig:
 
 
 _frontend_sessions: Dict[tuple, AmphSession] = {}
+_file_frontend_sessions: "OrderedDict[tuple, AmphSession]" = OrderedDict()
+_FILE_SESSIONS = 2               # whole-file front-end contexts kept (one per distinct file length; least recently used goes)
 
 
-def _frontend_session(cfg: FrontendConfig, device) -> AmphSession:
+def _frontend_session(cfg: FrontendConfig, device, whole_file: bool = False) -> AmphSession:
+    """whole_file: a context for ONE file of cfg.n_samples samples (duration <= 0): batch 1, one lane, and only the last
+    _FILE_SESSIONS lengths stay alive - its workspaces scale with the file's length (HipEncoder.whole_file_session)."""
     dev = torch.device(device if device is not None else "cuda")
     key = (cfg, dev.index if dev.index is not None else torch.cuda.current_device())
+    if whole_file:
+        s = _file_frontend_sessions.pop(key, None)
+        if s is None:
+            s = AmphSession(cfg, None, None, dev, max_batch=1)
+            s.configure("lanes", 1)
+        _file_frontend_sessions[key] = s
+        while len(_file_frontend_sessions) > _FILE_SESSIONS:
+            _, old = _file_frontend_sessions.popitem(last=False)
+            old.close()
+        return s
     s = _frontend_sessions.get(key)
     if s is None:
         s = AmphSession(cfg, None, None, dev, max_batch=64)
@@ -211,7 +226,7 @@ def wav_to_mel(wav_path: Path, *, sr: int, duration: float, n_mels: int, fmin: f
     if not duration > 0:                                  # whole file (ref :212: no pad / truncate step)
         y = _whole_file(Path(wav_path), sr, device)
         cfg = _config(sr, duration, n_mels, fmin, fmax, hop_length, n_fft, target_frames, whole_file_samples=y.shape[0])
-        return _frontend_session(cfg, device).mel(y[None], layout=0)[0].cpu()
+        return _frontend_session(cfg, device, whole_file=True).mel(y[None], layout=0)[0].cpu()
     cfg = _config(sr, duration, n_mels, fmin, fmax, hop_length, n_fft, target_frames)
     sess = _frontend_session(cfg, device)
     y, n_valid = _load_wave(Path(wav_path), cfg, device)
@@ -258,12 +273,13 @@ def encode_wav_to_latent(encoder, wav_path: Path, device: torch.device, *, sr: i
     else:
         cfg = _config(sr, duration, n_mels, fmin, fmax, hop_length, n_fft, target_frames)
         y, n_valid = _load_wave(Path(wav_path), cfg, device)
+    whole = not duration > 0
     if isinstance(encoder, HipEncoder):
-        sess = encoder.session(cfg)
+        sess = encoder.whole_file_session(cfg) if whole else encoder.session(cfg)
         mu, _, _ = sess.encode(y[None], lengths=np.array([n_valid], dtype=np.int32), apply_rms=False)
         return _adapt_output((mu,))
     # a caller-supplied module (any callable on x = [1,1,T,M]): HIP front end + the reference adapter
-    sess = _frontend_session(cfg, device)
+    sess = _frontend_session(cfg, device, whole_file=whole)
     if y.dtype == np.int16:
         y = y.astype(np.float32) / np.float32(32768.0)
     x = sess.mel(y[None], lengths=np.array([n_valid], dtype=np.int32), layout=1).unsqueeze(1)

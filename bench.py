@@ -8,10 +8,15 @@ dB/standardise -> thesis-shape VAE encoder -> mu) over the BASELINE.json configs
 workload: 10 000 synthetic chunks resident in HBM, processed in batches of 256, fp32.
 With N > 1 every rank holds its own 10 000-chunk shard (weak scaling, one process per
 GPU) and the step ends with the single RCCL all-gather that concatenates the latent
-matrix.  Rank 0 prints ONE JSON line.  Before the W warm-up steps come `--prewarm` (default 40)
-untimed passes: the GPU idles through the set-up and the CPU baseline leg, and its first
-~100 ms of work afterwards run ~5 % slower (profiles/r03_bench_warmup_sweep.txt); the
-timed region is exactly the K steps, bracketed by barrier + synchronize.
+matrix.  `python bench.py --gpus N` starts its N ranks itself (one child process per GPU,
+amphibian_vae_latent_detector_amd/launcher.py; the parent never touches the GPU); under
+`python -m torch.distributed.run --nproc-per-node N` the ranks already exist and it just runs.
+Rank 0 prints ONE JSON line.  Before the W warm-up steps come `--prewarm` (default 40)
+untimed passes: the GPU idles through the set-up (the synthetic chunks are made on the host), and
+its first ~100 ms of work afterwards run ~5 % slower (profiles/r03_bench_warmup_sweep.txt); the
+timed region is exactly the K steps, bracketed by barrier + synchronize.  `value_cold` is the same
+K steps measured BEFORE those passes (W warm-up steps only), so the two effects can be told apart.
+The CPU baseline leg runs last.
 
 Extra objects on that line:
   roofline      the dominant kernel (largest share of GPU time in a fully instrumented
@@ -20,8 +25,9 @@ Extra objects on that line:
                 processes / that kernel's mean launch duration ALONE on the GPU (HIP events
                 on its launch stream, one lane: the figure `rocprofv3 --kernel-trace --stats`
                 of `bench.py --lanes 1` reproduces, profiles/*_lanes1.csv), against 8 TB/s.
-                `traffic` = HBM bytes per launch from the committed PMC profile, corrected
-                as MI355X_MICROARCH.md prescribes (FETCH_SIZE x 2 + WRITE_SIZE).
+                `traffic` (= `traffic_from_committed_profile`) = HBM bytes per launch from the
+                COMMITTED rocprofv3 PMC profile of this configuration (bench.py cannot profile
+                itself), corrected as MI355X_MICROARCH.md prescribes (FETCH_SIZE x 2 + WRITE_SIZE).
                 `in_timed_region` = the same kernel bracketed inside the timed region, where
                 four lanes share the GPU: that figure includes queueing behind the other
                 lanes' kernels and is NOT a kernel duration.
@@ -43,6 +49,11 @@ Extra objects on that line:
                 HBM traffic and its ratio to the kernel's own algorithmic bytes.
   detect        BASELINE configs[4] leg: encode + radial decision on the device
                 (10_benchmark_folder_detection.py:387-418 as radial.detect_chunks).
+  value_f32_mfma the same steps with every GEMM layer on the true f32 MFMA kernels ("split_gemm" 0: fp32 operands,
+                v_mfma_f32_32x32x2_f32) - the reference's own arithmetic beside the headline's two-term fp16 split.
+  from_files    end to end from WAV files (parse on the host threads -> pinned -> HBM -> encode), files/s per
+                loader thread count; pcie_inclusive: host rows through amph_encode_pcm16_host.  Never the headline.
+  config4       BASELINE configs[3]: preset bench-1s-128 (n_fft 1024 / hop 256 / 128 bands), bf16 encoder, 3 steps.
   cpu_baseline  the CPU oracle driven like the reference's batch-1 loop
                 (08_fit_radial_detector.py:488-503) on a bounded sample, rank 0, N = 1.
 
@@ -189,7 +200,37 @@ def detect_leg(enc, sess, cfg, pcm, mu, args, dev):
     return {"value": round(reps * args.chunks / dt, 1), "unit": "chunks/s (encode + radial decision)", "reps": reps,
             "detected_frac": round(float((pred >= 0).mean()), 4),
             "note": "radial.detect_chunks' device path: amph_encode_pcm16 + amph_decide_radial (K6) per 10 000-chunk call, "
-                    "includes the per-call upload of centroids / thresholds and a stream sync; decisions stay on the device"}
+                    "the detector's centroids / thresholds are uploaded once (cached by content), one stream sync per call; decisions stay on the device"}
+
+
+def config4_leg(pcm, args, dev):
+    """BASELINE configs[3]: preset bench-1s-128 (n_fft 1024 / hop 256 / 128 mel bands -> 96 x 128 image), thesis-shape encoder in bf16
+    (weights, activations, bf16 MFMA, fp32 accumulate), the same resident chunks; its parity bar is the relaxed one (tests: 2e-3 vs a
+    bf16-emulating torch encoder), so it is reported beside the headline, never as it."""
+    from amphibian_vae_latent_detector_amd import PRESETS, SPECS
+    from amphibian_vae_latent_detector_amd.encoder import HipEncoder, random_init_state
+    cfg4 = PRESETS["bench-1s-128"]
+    spec4 = SPECS["thesis-shape"](cfg4.target_frames, cfg4.n_mels)
+    enc4 = HipEncoder(spec4, random_init_state(spec4, seed=0), dev, max_batch=args.batch)
+    s4 = enc4.session(cfg4)
+    s4.configure("bf16_encoder", 1)
+    mu4 = torch.empty((pcm.shape[0], spec4.latent_dim), dtype=torch.float32, device=dev)
+    for _ in range(3):
+        s4.encode(pcm, apply_rms=True, out_mu=mu4, check_range=False)
+    torch.cuda.synchronize(dev)
+    t1 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        s4.encode(pcm, apply_rms=True, out_mu=mu4, check_range=False)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t1
+    out = {"value": round(reps * pcm.shape[0] / dt, 1), "unit": "chunks/s", "steps": reps, "ms_per_step": round(dt / reps * 1e3, 4),
+           "dtype": "bf16 encoder (fp32 front end, fp32 accumulate)", "finite": bool(torch.isfinite(mu4).all().item()),
+           "config": {"workload": f"BASELINE.json configs[3]: {pcm.shape[0]} chunks resident in HBM, preset bench-1s-128 (n_fft {cfg4.n_fft}, hop "
+                                  f"{cfg4.hop_length}, {cfg4.n_mels} mel bands, image {cfg4.target_frames} x {cfg4.n_mels}), thesis-shape encoder, bf16, "
+                                  f"batch {args.batch}"}}
+    s4.close()
+    return out
 
 
 def config3_fit(mu, plan, args, sess=None):
@@ -242,9 +283,12 @@ def main():
     ap.add_argument("--preset", default="bench-1s")
     ap.add_argument("--spec", default="thesis-shape")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="0 disables the CPU baseline leg")
-    ap.add_argument("--pcie", action="store_true", help="also time the host-buffer (PCIe-inclusive) entry point")
-    ap.add_argument("--files", type=int, default=0, help="also time the end-to-end folder ingest on this many WAV files "
-                                                         "(written to a temp dir first; parse + H2D + encode; never the headline value)")
+    ap.add_argument("--pcie", type=int, default=-1, help="time the host-buffer (PCIe-inclusive) entry point: 1 / 0; default: on for a plain "
+                                                         "one-GPU run (no --knob / --config3)")
+    ap.add_argument("--files", type=int, default=-1, help="time the end-to-end folder ingest on this many WAV files (written to a temp dir "
+                                                          "first; parse + H2D + encode; never the headline value); default 8000 for a plain "
+                                                          "one-GPU run, 0 = off")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip value_f32_mfma, config4, from_files and pcie_inclusive (profiling runs)")
     ap.add_argument("--lanes", type=int, default=0, help="HIP streams the batches are spread over (0 = library default)")
     ap.add_argument("--config3", action="store_true", help="BASELINE configs[2] on one GPU: --chunks (default 100000) resident chunks as "
                                                            "--shards contiguous virtual shards + the 08 fit on the host")
@@ -260,14 +304,25 @@ def main():
     if args.config3 and args.chunks == 10000:
         args.chunks = 100000
 
+    from amphibian_vae_latent_detector_amd import launcher
+    if args.gpus > 1 and not launcher.under_launcher():
+        # one process per GPU, started here: nothing has touched the GPU yet (device_count() does not initialise HIP on this
+        # image), the ranks are CHILD processes and this parent only forwards rank 0's JSON line and the worst exit code
+        n_dev = torch.cuda.device_count()
+        if n_dev < args.gpus:
+            sys.exit(f"--gpus {args.gpus}: only {n_dev} GPU(s) visible to this process (torch.cuda.device_count())")
+        sys.exit(launcher.launch_ranks([sys.executable, str(Path(__file__).resolve()), *sys.argv[1:]], args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit(f"--gpus {args.gpus} needs one process per GPU: launch with "
-                     f"python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...")
         sys.exit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
+    plain = world == 1 and not args.knob and not args.config3 and not args.no_extra_legs and args.preset == "bench-1s" \
+        and args.spec == "thesis-shape" and not args.bf16
+    if args.files < 0:
+        args.files = 8000 if plain else 0
+    if args.pcie < 0:
+        args.pcie = 1 if plain else 0
     import torch.distributed as dist
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X; there is no CPU fallback")
@@ -321,7 +376,7 @@ def main():
         if args.config3:
             mu.copy_(_folder.encode_resident_shards(sess, pcm, args.shards, apply_rms=True))
             return
-        sess.encode(pcm, apply_rms=True, out_mu=mu)
+        sess.encode(pcm, apply_rms=True, out_mu=mu, check_range=False)     # (range flag read after the timed region)
         if use_dist:
             # the one exchange step: concatenate the latent matrix.  (Issued asynchronously, so that it ran under the next step's
             # encode on two alternating buffers, it cost more than it hid: 1.50 M against 1.95 M chunks/s on one GPU under
@@ -347,6 +402,26 @@ def main():
     dom = max(range(len(stages)), key=lambda i: stages[i]["total_ms"])
     n_lanes = args.lanes if args.lanes > 0 else 4
     sess.configure("lanes", n_lanes)
+
+    def timed(k):
+        """k steps bracketed by barrier + synchronize on both sides; max over ranks; -> seconds"""
+        fence()
+        t_a = time.perf_counter()
+        for _ in range(k):
+            step()
+        fence()
+        dt_ = time.perf_counter() - t_a
+        if use_dist:
+            t_ = torch.tensor([dt_], dtype=torch.float64, device=dev)
+            dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+            dt_ = float(t_.item())
+        return dt_
+
+    # value_cold: W - 1 warm-up steps + the K steps with NO pre-warm passes - the GPU has idled for seconds while the host made the
+    # synthetic chunks (what `--prewarm 0` measures as the headline)
+    for _ in range(max(1, args.warmup - 1)):
+        step()
+    cold_s = timed(args.steps)
     for _ in range(max(0, args.prewarm)):              # see --prewarm: brings the GPU out of its idle state; W below is untouched
         step()
     for _ in range(max(1, args.warmup - 1)):
@@ -373,7 +448,29 @@ def main():
             sys.exit("all-gather did not return this rank's latents in place 0")
     prof = sess.profile_read()[dom]
     sess.profile_enable(False)
+    range_overflow = sess.range_overflow()             # the flag the two-term fp16 kernels raised inside the timed region, if any (include/amph.h)
     files_leg = from_files_leg(enc, cfg, pcm_host, args, dev, world, rank, use_dist, dist) if args.files > 0 else None
+
+    # value_f32_mfma: the same step with every GEMM layer on the true f32-MFMA kernels (fp32 operands, v_mfma_f32_32x32x2_f32: the
+    # reference's own arithmetic) - the headline's two-term fp16 split sits beside it in one record
+    f32_leg = None
+    if plain and not args.bf16:
+        mu_split = mu.clone()
+        sess.configure("split_gemm", 0)
+        sess.configure("split_fused", 0)
+        step()
+        k32 = max(3, min(5, args.steps))
+        dt32 = timed(k32)
+        d = (mu - mu_split).norm(dim=1) / mu_split.norm(dim=1).clamp_min(1e-12)
+        f32_leg = {"value": round(world * args.chunks * k32 / dt32, 1), "unit": "chunks/s", "steps": k32,
+                   "ms_per_step": round(dt32 / k32 * 1e3, 4),
+                   "max_rel_l2_vs_headline_latents": float(d.max().item()),
+                   "note": "amph_configure split_gemm 0 / split_fused 0: conv2..conv4 and the head as f32-input MFMA kernels "
+                           "(k_conv_gemm_f3 / _p3, v_mfma_f32_32x32x2_f32, fp32 operands end to end); same workload, lanes and batch"}
+        sess.configure("split_gemm", 1)
+        sess.configure("split_fused", 1)
+        step()
+        torch.cuda.synchronize(dev)
 
     if rank == 0:
         peak_mfma = 2500.0 if args.bf16 else PEAK_F32_MFMA_TFLOPS      # dense bf16 MFMA peak / f32-input MFMA peak
@@ -393,8 +490,14 @@ def main():
             try:
                 tj = json.load(open(ROOT / "profiles" / "traffic_latest.json"))
                 traffic_src = tj.get("_source", "profiles/traffic_latest.json")
+                # the profile is keyed by KERNEL; a stage that launches two kernels (K0: chunk sums, then fold + apply) owns both
+                alias = {"rms_apply": "rms_scale", "rms_fold_apply": "rms_scale"}
+                not_on_path = ("k_decide_radial", "conv4_wide")
                 for k, e in tj["kernels"].items():
-                    traffic[k] = int(e["fetch_kb"] * 1024 * 2 + e["write_kb"] * 1024)
+                    if k in not_on_path:
+                        continue
+                    k = alias.get(k, k)
+                    traffic[k] = traffic.get(k, 0) + int(e["fetch_kb"] * 1024 * 2 + e["write_kb"] * 1024)
             except (OSError, ValueError, KeyError):
                 pass
         rocprof_iso = {}
@@ -434,7 +537,7 @@ def main():
         ach = alg_bytes * iso_cpl / (iso_ms * 1e-3) / 1e9
         roof = {"kernel": name, "bound": "hbm", "achieved": round(ach, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                 "frac": round(ach / PEAK_HBM_GBS, 5),
-                "traffic": traffic.get(name),
+                "traffic": traffic.get(name), "traffic_from_committed_profile": traffic.get(name),
                 "algorithmic_bytes_per_launch": int(alg_bytes * iso_cpl),
                 "avg_launch_ms": round(iso_ms, 5), "launches": int(stages[dom]["launches"]), "chunks_per_launch": round(iso_cpl, 1),
                 "measured": "HIP events on the launch stream, 1 lane (kernel alone on the GPU), one whole step",
@@ -456,7 +559,7 @@ def main():
                                    "concurrent_lanes": n_lanes,
                                    "note": "event bracket around the same kernel while the other lanes' kernels share the GPU: "
                                            "queue-inclusive, not a kernel duration"}
-        # ---- mixed roofline: what the kernels AS BUILT are bounded by (matrix pipe for the split-bf16 GEMMs, fp32 VALU for the rest)
+        # ---- mixed roofline: what the kernels AS BUILT are bounded by (matrix pipe for the two-term fp16 split GEMMs, fp32 VALU for the rest)
         mixed = None
         try:
             mj = json.load(open(ROOT / "profiles" / "mfma_latest.json"))
@@ -498,6 +601,8 @@ def main():
             "metric": "1 s audio chunks encoded to latent/sec", "value": round(value, 1), "unit": "chunks/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "value_cold": round(total_chunks / cold_s, 1),
+            "fp16_split_range_overflow": bool(range_overflow),
             "dtype": "bf16 encoder (fp32 front end, fp32 accumulate)" if args.bf16 else
                      "f32 (results fp32-accurate; conv / head GEMMs as two-term fp16 splits, x = h + 2^-11 l, on the f16 MFMA with fp32 accumulate; front end fp32 VALU)",
             "data": "synthetic",
@@ -516,8 +621,8 @@ def main():
             "roofline": roof,
             "fp32_roofline": {"algorithmic_flops_per_chunk": int(alg_flops), "achieved_TFLOPs_per_gpu": round(per_gpu * alg_flops / 1e12, 2),
                               "peak_TFLOPs": PEAK_F32_MFMA_TFLOPS, "frac": round(per_gpu * alg_flops / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                              "note": "ALGORITHMIC fp32 FLOP/s against the f32 peak; the GEMM kernels run split bf16 on the bf16 matrix cores "
-                                      "(mixed_roofline prices them): a work rate, not a pipe utilisation.  The path is compute-bound "
+                              "note": "ALGORITHMIC fp32 FLOP/s against the f32 peak; the GEMM kernels run two-term fp16 splits on the f16 matrix cores "
+                                      "(v_mfma_f32_32x32x16_f16; mixed_roofline prices them): a work rate, not a pipe utilisation.  The path is compute-bound "
                                       "(algorithmic intensity ~750 FLOP/B), not HBM-bound"},
             **({"mixed_roofline": mixed} if mixed else {}),
             "hbm_roofline": {"algorithmic_bytes_per_chunk": alg_bytes, "achieved_GBps_per_gpu": round(per_gpu * alg_bytes / 1e9, 2),
@@ -530,13 +635,21 @@ def main():
                             "rank0_block_equals_own_latents": True,      # (checked above: a mismatch exits)
                             "note": "dist.all_gather_into_tensor of the [chunks, D] fp32 latent matrix, inside the timed step"}
         if traffic:
-            tot = sum(traffic.get(k["kernel"], 0) for k in kernels)
+            tot = sum(traffic.values())                   # every kernel of the batch (both K0 kernels: the alias above)
             line["path_traffic"] = {"bytes_per_batch": int(tot), "algorithmic_bytes_per_batch": int(alg_bytes * args.batch),
-                                    "ratio": round(tot / (alg_bytes * args.batch), 2), "source": traffic_src}
+                                    "ratio": round(tot / (alg_bytes * args.batch), 2), "source": traffic_src,
+                                    "by_stage": {k: int(v) for k, v in sorted(traffic.items())},
+                                    "note": "sum over profiles/traffic_latest.json (FETCH_SIZE x 2 + WRITE_SIZE per kernel of one 256-chunk "
+                                            "batch) against 256 x A; from the committed rocprofv3 PMC passes, not measured in this run"}
         if world == 1 and not args.no_detect and not args.config3:
             line["detect"] = detect_leg(enc, sess, cfg, pcm, mu, args, dev)
         if args.config3:
             line["config3_fit"] = config3_fit(mu, plan, args, sess)
+        if f32_leg:
+            line["value_f32_mfma"] = f32_leg["value"]
+            line["f32_mfma"] = f32_leg
+        if plain:
+            line["config4"] = config4_leg(pcm, args, dev)
         if world == 1 and args.pcie:
             # host-resident PCM16 -> (pinned staging ->) H2D on a copy stream overlapped with compute -> latents back.  Two forms of
             # the caller's buffer: pageable rows (staged through the library's pinned double buffer) and rows the caller already

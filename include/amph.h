@@ -210,6 +210,19 @@ int amph_encoder_forward(amph_ctx* ctx, const float* d_x, int n_rows,
                          float* d_mu, float* d_logvar, void* stream);
 
 /* -------------------------------------------------------------------------
+ * Range of the default arithmetic.  With "split_gemm" 1 (default) the conv / head GEMMs run fp32 operands as two fp16 terms
+ * (x = h + 2^-11 l), which exist for |x| < 65 504 only.  Weights are tested at amph_create (a layer whose weights are outside
+ * takes the f32-MFMA kernel); ACTIVATIONS depend on the data: every kernel whose output is the next layer's split operand tests
+ * its values and raises a per-context flag, and amph_encoder_forward tests the caller's tensor first.  The reference module
+ * (map_detector_core.py:175-179, any checkpoint, fp32) has no such limit, so a raised flag means: the latents of the calls since
+ * the last clear are NOT valid (they may be NaN) - amph_configure(ctx, "split_gemm", 0) (+ "split_fused", 0) and run them again.
+ * amph_range_status reads the flag (1 = raised) and clears it when `clear` != 0; meaningful once the streams of the calls in
+ * question have synchronised.  amph_encode_pcm16_host, which synchronises, does all of this itself (and leaves the context on
+ * the f32-MFMA kernels).  The Python binding (AmphSession.encode / encoder_forward) does the same after its calls.
+ * ------------------------------------------------------------------------- */
+int amph_range_status(amph_ctx* ctx, int clear);
+
+/* -------------------------------------------------------------------------
  * encode — the fused chunk -> latent path: [rms_normalize + PCM16 write/read
  * (00_normalize_dataset_rms.py:51-57)] -> wav_to_mel -> encoder -> mu
  * (encode_wav_to_latent, map_detector_core.py:240-300, for n_rows chunks at once;

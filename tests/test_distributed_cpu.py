@@ -148,3 +148,25 @@ def test_eight_ranks_on_thirteen_files_empty_tail_ranks_and_padded_blocks(tmp_pa
 def test_gather_rows_pads_and_trims_single_process():
     x = torch.arange(12, dtype=torch.float32).reshape(4, 3)
     assert torch.equal(pfolder.gather_rows(x, 4, 3), x[:3])
+
+
+@pytest.mark.timeout(300)
+def test_launcher_starts_eight_ranks_and_forwards_rank_zero(tmp_path):
+    """`python bench.py --gpus N` starts its own ranks (launcher.launch_ranks): 8 children over gloo run a stub step; the parent's
+    stdout carries rank 0's lines only, the return code is 0; a rank that dies makes the job fail with its code and ends the others."""
+    import io
+    import json
+    from amphibian_vae_latent_detector_amd import launcher
+    stub = str(Path(__file__).with_name("_rank_stub.py"))
+    out, err = io.StringIO(), io.StringIO()
+    rc = launcher.launch_ranks([sys.executable, stub], 8, out=out, err=err)
+    assert rc == 0, err.getvalue()
+    lines = [ln for ln in out.getvalue().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec == {"world_size": 8, "ranks": list(range(8)), "local_rank": 0, "local_world_size": 8}
+    assert "rank 0 chatter" in out.getvalue() and "rank 3 chatter" not in out.getvalue() and "rank 3 chatter" in err.getvalue()
+    out2, err2 = io.StringIO(), io.StringIO()
+    rc2 = launcher.launch_ranks([sys.executable, stub, "2"], 4, out=out2, err=err2)         # rank 2 exits 7 before the rendezvous
+    assert rc2 == 7 and "rank 2 exited with 7" in err2.getvalue()
+    assert not launcher.under_launcher({}) and launcher.under_launcher({"RANK": "0", "WORLD_SIZE": "1"})

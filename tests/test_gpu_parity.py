@@ -504,6 +504,103 @@ def test_two_term_fp16_split_holds_its_accuracy_across_input_magnitudes(env, cap
         print("\n[two-term fp16 split] max rel L2 of mu vs torch-CPU fp32 at image scale " + ", ".join(f"{k:g}: {v:.2e}" for k, v in worst.items()))
 
 
+def test_fp16_split_range_guard_images_weights_and_activations(env, capsys):
+    """The reference's encoder is an fp32 nn.Module loaded from ANY checkpoint (map_detector_core.py:160-179, strict=False) and called
+    on any tensor (:270); the default GEMM arithmetic here splits fp32 operands into two fp16 terms, which exist below 65 504 only
+    (include/amph.h, amph_range_status).  Three ways out of that range, each of which must end in finite latents within 1e-5 of the
+    torch-CPU fp32 encoder - never a silent NaN:
+      (a) images scaled by 1e3 / 1e4 / 1e5 through encoder_forward: the input test / an activation test raises the flag, the binding
+          re-runs the call on the f32-MFMA kernels and says so (RuntimeWarning);
+      (b) a checkpoint whose conv3 weights exceed 65 504 (scaled by 2e6, the BN scale divided by it: the same function): amph_create
+          leaves that layer on the f32-MFMA kernel - no flag, no warning;
+      (c) a checkpoint whose conv2 activations pass 65 504 at ordinary image scale (BN gamma of layer 2 x 4000): the epilogue that
+          writes them raises the flag; also through the fused chunk -> latent entry point (encode) and amph_encode_pcm16_host."""
+    import warnings
+    cfg = env.PRESETS["bench-1s"]
+    spec = env.SPECS["thesis-shape"](cfg.target_frames, cfg.n_mels)
+    base = np.random.default_rng(32).standard_normal((12, 1, cfg.target_frames, cfg.n_mels)).astype(np.float32)
+    report = []
+
+    def worst(a, b):
+        return max(rel_l2(a[r], b[r]) for r in range(a.shape[0]))
+
+    # (a) the caller's tensor
+    enc, tenc, _ = _encoders(env, "thesis-shape", cfg=cfg, max_batch=16)
+    for scale in (1e3, 1e4, 1e5):
+        sess = env.AmphSession(cfg, spec, enc._blob, DEV, max_batch=16)          # a fresh context: the fallback is sticky per context
+        x = torch.from_numpy(base * np.float32(scale))
+        with torch.no_grad():
+            mu_o, lv_o = tenc(x)
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            mu, lv = sess.encoder_forward(x)
+        assert torch.isfinite(mu).all() and torch.isfinite(lv).all(), scale
+        w = max(worst(mu.cpu().numpy(), mu_o.numpy()), worst(lv.cpu().numpy(), lv_o.numpy()))
+        assert w <= 1e-5, (scale, w)
+        tripped = any("fp16" in str(r.message) for r in rec)
+        report.append(f"image x {scale:g}: {w:.2e} ({'f32-MFMA re-run' if tripped else 'split path'})")
+        if scale >= 1e4:
+            assert tripped                                # activations of 1e4-scaled images pass 65 504 in conv2 / conv3
+        # without the check the flag stays readable and the split path's result is what it is (possibly NaN): nothing silent
+        sess2 = env.AmphSession(cfg, spec, enc._blob, DEV, max_batch=16)
+        sess2.encoder_forward(x, check_range=False)
+        assert sess2.range_overflow(clear=False) == tripped and sess2.range_overflow() == tripped and not sess2.range_overflow()
+        sess.close(); sess2.close()
+
+    # (b) weights outside fp16's range: decided at create
+    state = env.random_init_state(spec, seed=0)
+    big = {k: np.array(v, copy=True) for k, v in state.items()}
+    big["conv.2.weight"] *= np.float32(2e6)
+    big["bn.2.running_var"] = big["bn.2.running_var"] * np.float32(4e12)        # alpha = gamma / sqrt(var + eps) shrinks by 2e6
+    big["bn.2.running_mean"] *= np.float32(2e6)
+    big["conv.2.bias"] *= np.float32(2e6)
+    enc_b = env.HipEncoder(spec, big, DEV, max_batch=16)
+    tenc_b = env.oenc.build_torch_encoder(spec.to_dict(), big)
+    x = torch.from_numpy(base)
+    with torch.no_grad():
+        mu_o, _ = tenc_b(x)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        mu, _ = enc_b.session(cfg).encoder_forward(x)
+    assert torch.isfinite(mu).all() and not rec
+    w = worst(mu.cpu().numpy(), mu_o.numpy())
+    assert w <= 1e-5, w
+    report.append(f"conv3 weights x 2e6: {w:.2e} (layer on the f32-MFMA kernel from amph_create on)")
+
+    # (c) activations outside fp16's range at ordinary inputs
+    hot = {k: np.array(v, copy=True) for k, v in state.items()}
+    hot["bn.1.weight"] *= np.float32(4000.0)
+    hot["bn.1.bias"] *= np.float32(4000.0)
+    tenc_h = env.oenc.build_torch_encoder(spec.to_dict(), hot)
+    with torch.no_grad():
+        mu_o, _ = tenc_h(x)
+        a2 = torch.relu(tenc_h.bn[1](tenc_h.conv[1](torch.relu(tenc_h.bn[0](tenc_h.conv[0](x))))))
+    assert float(a2.max()) > 65504.0                       # the case is what it claims to be
+    enc_h = env.HipEncoder(spec, hot, DEV, max_batch=16)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        mu, _ = enc_h.session(cfg).encoder_forward(x)
+    assert torch.isfinite(mu).all() and any("fp16" in str(r.message) for r in rec)
+    w = worst(mu.cpu().numpy(), mu_o.numpy())
+    assert w <= 1e-5, w
+    report.append(f"BN gamma of layer 2 x 4000: {w:.2e} (flag raised by conv2's epilogue, f32-MFMA re-run)")
+    # ... and through the chunk -> latent entry points, device and host form
+    pcm = env.synth(np.arange(40, 52), cfg.n_samples, cfg.sr)
+    z_o = _oracle_latents(env, tenc_h, pcm, cfg)
+    enc_h2 = env.HipEncoder(spec, hot, DEV, max_batch=16)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        z, _, _ = enc_h2.session(cfg).encode(pcm, apply_rms=True)
+    assert any("fp16" in str(r.message) for r in rec)
+    _assert_latents(z.cpu().numpy(), z_o)
+    enc_h3 = env.HipEncoder(spec, hot, DEV, max_batch=16)
+    z_h, _ = enc_h3.session(cfg).encode_host(pcm, apply_rms=True)
+    _assert_latents(z_h, z_o)
+    assert np.array_equal(z_h, z.cpu().numpy())           # both ended on the same f32-MFMA kernels
+    with capsys.disabled():
+        print("\n[fp16 split range guard] max rel L2 of the latents vs torch-CPU fp32: " + "; ".join(report))
+
+
 @pytest.mark.parametrize("preset", ["bench-1s", "ref-default", "bench-1s-128"])
 def test_wide_tile_staged_gemm_is_bit_identical_to_the_64_row_tile(env, capsys, preset):
     """The staged split GEMM on 128 x 128 tiles ("wide_gemm"; csrc/k_encoder_split.hip, k_conv_gemm_s3w: what multi-lane calls use
@@ -1183,6 +1280,21 @@ def test_map_detector_core_surface(env, tmp_path):
     wav_b = tmp_path / "other_length.wav"
     synth.write_wav_pcm16(wav_b, synth.synth_chunk_pcm16(3, 30011, cfg.sr), cfg.sr)
     assert np.abs(core.wav_to_mel(wav_b, **dict(kw0, duration=-1.0)).numpy() - env.ofe.wav_to_mel(wav_b, **kw0)).max() <= 1e-4
+    # whole files of several lengths (none a multiple of hop) through the ENCODER: each against the oracle; the contexts are batch-1 /
+    # one-lane and only the last two lengths stay alive, so device memory stops growing after the second (a 256-row, four-lane
+    # context per length kept ~0.4 GB each for one-second files and gigabytes for minute-long ones)
+    torch.cuda.synchronize()
+    used = []
+    for k, n in enumerate((22550, 30011, 26113, 33331, 24007, 28001)):
+        wk = tmp_path / f"len_{n}.wav"
+        synth.write_wav_pcm16(wk, synth.synth_chunk_pcm16(10 + k, n, cfg.sr), cfg.sr)
+        zk = core.encode_wav_to_latent(encoder, wk, torch.device("cuda"), **kw0)
+        _assert_latents(zk[None], env.oenc.encode_mel_to_latent(tenc, env.ofe.wav_to_mel(wk, **kw0))[None])
+        torch.cuda.synchronize()
+        free, total = torch.cuda.mem_get_info()
+        used.append(total - free)
+    assert len(encoder._file_sessions) == 2
+    assert max(used[2:]) - used[1] < 64 * 2 ** 20, [u >> 20 for u in used]      # no growth past the second length (allocator granularity aside)
     # stereo file: channel mean on the float path
     st = np.stack([q, q], axis=1)
     synth.write_wav_pcm16(tmp_path / "st.wav", st, cfg.sr)

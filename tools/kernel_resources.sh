@@ -1,8 +1,9 @@
 #!/bin/bash
 # Print VGPR/AGPR/SGPR/spill/LDS/occupancy per kernel of the HIP sources (compile-only, no GPU needed).
 cd "$(dirname "$0")/../amphibian_vae_latent_detector_amd/csrc"
-for f in k_frontend k_encoder; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I../../include -c $f.hip -o /tmp/$f.res.o \
+for f in k_frontend k_encoder k_encoder_split k_encoder_patch k_encoder_bf16; do
+  EXTRA=""; case $f in k_encoder_split|k_encoder_patch) EXTRA="-fno-slp-vectorize";; esac
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I../../include $EXTRA -c $f.hip -o /tmp/$f.res.o \
     -Rpass-analysis=kernel-resource-usage 2>&1 | python3 -c '
 import sys,re
 cur={}
