@@ -106,6 +106,7 @@ struct amph_ctx {
     int stft_pair_waves = 10;              // its workgroup: 8, 10, 11 or 12 waves; amph_create picks the largest whose LDS image, stage-1 twiddles
                                            // included, fits (1 s rows with the fused dB stage: 11 - 29 pairs on 11 waves are 3 rounds, at most 8 pairs per SIMD)
     bool stft_pair_tw_lds = true;          // its stage-1 twiddles in LDS when the image still fits
+    bool stft_k0_fuse = true;              // rms_normalize at the head of k_stft_pair's row loop instead of K0's own launches (same bits)
     int mel_w_floats = 0, mel_p_tail = 0;
     int32_t *d_mel_start = nullptr, *d_mel_len = nullptr, *d_mel_wofs = nullptr;
     float* d_mel_w = nullptr;
@@ -291,6 +292,9 @@ struct StageTimer {
             (void)hipEventRecord(a, s);
             c->last_stream = s;
         }
+    }
+    void cancel() {                            // nothing was launched in this stage after all: give the events back
+        if (on) { c->event_pool.push_back(a); c->event_pool.push_back(b); on = false; }
     }
     ~StageTimer() {
         if (on) {
@@ -1106,9 +1110,13 @@ int run_frontend(amph_ctx* c, Workspace& w, const void* d_wave, bool pcm16, int 
     WaveSrc src{};
     src.wave = d_wave; src.row_stride = n_in; src.lengths = d_len; src.n_in = n_in;
     src.scale = nullptr; src.requant = 0;
+    bool k0 = false;                               // K0 runs inside the STFT kernel ("stft_k0_fuse")
+    NormPad k0_pad{};
+    int32_t* k0_ok = nullptr;
     if (apply_rms) {
         StageTimer t(c, ST_RMS, s);
         int32_t* okp = d_rms_ok ? d_rms_ok : w.ok;
+        k0_ok = okp;
         int16_t* norm = nullptr;
         // PCM16 rows: materialise the normalised, re-quantised samples once (the file 00_normalize_dataset_rms.py would have
         // written), inside the K0 launch, instead of normalising inside the STFT kernel, whose independent waves would each
@@ -1126,7 +1134,14 @@ int run_frontend(amph_ctx* c, Workspace& w, const void* d_wave, bool pcm16, int 
             if (rc != AMPH_OK) return rc;
             norm = w.norm16;
         }
-        if (pcm16) {
+        // K0 inside the pair kernel: the workgroup that owns a row normalises it itself (rms_scale_row at the head of k_stft_pair's row loop) -
+        // no K0 launch; the STFT stage's timer then covers both
+        const bool k0_fused = pcm16 && norm && pad.lead > 0 && c->stft_k0_fuse && c->cfg.n_fft == 2048 && pair_path(c, true) &&
+                              pair_lds(c, c->stft_pair_waves, db_out != nullptr) <= 160 * 1024 && stft_pair_can_fuse_k0(n_in, c->stft_pair_waves);
+        if (k0_fused) {
+            t.cancel();
+            k0 = true;
+        } else if (pcm16) {
             const int rcs = ensure_chunk_sums(c, w, n_in, s);
             if (rcs != AMPH_OK) return rcs;
 #ifdef AMPH_ABL_SKIP
@@ -1141,6 +1156,7 @@ int run_frontend(amph_ctx* c, Workspace& w, const void* d_wave, bool pcm16, int 
             src.wave = norm; src.scale = nullptr; src.requant = 0;
             if (pad.lead > 0) { src.lead = pad.lead; src.row_stride = pad.out_stride; src.lengths = nullptr; src.n_in = pad.n_fix + 2 * pad.lead; }
         }
+        k0_pad = pad;
     } else {
         if (d_rms_ok) (void)hipMemsetAsync(d_rms_ok, 0, (size_t)nb * sizeof(int32_t), s);
         // PCM16 rows used as they are: the same fix_length'd, centre-padded copy, by a copy kernel (timed with the RMS stage)
@@ -1160,7 +1176,14 @@ int run_frontend(amph_ctx* c, Workspace& w, const void* d_wave, bool pcm16, int 
 #ifdef AMPH_ABL_SKIP
         if (!(g_abl_skip & 2))
 #endif
-        launch_stft_mel(make_stft(c, src, melpow, db_out, db_layout), nb, pcm16 ? 1 : 0, c->stft_waves, s);
+        {
+            StftParams sp = make_stft(c, src, melpow, db_out, db_layout);
+            if (k0) {
+                sp.k0_in = (const int16_t*)d_wave; sp.k0_row_stride = n_in; sp.k0_lengths = d_len; sp.k0_n_in = n_in;
+                sp.k0_scale_f64 = c->rms_f64_scale; sp.k0_scale = w.scale; sp.k0_ok = k0_ok; sp.k0_pad = k0_pad;
+            }
+            launch_stft_mel(sp, nb, pcm16 ? 1 : 0, c->stft_waves, s);
+        }
     }
     return AMPH_OK;
 }
@@ -1364,6 +1387,7 @@ int amph_configure(amph_ctx* c, const char* key, int value) {
     if (!std::strcmp(key, "stft_fuse_db")) { c->stft_fuse_db = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "stft_pair")) { c->stft_pair = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "stft_pair_tw_lds")) { c->stft_pair_tw_lds = value != 0; return AMPH_OK; }
+    if (!std::strcmp(key, "stft_k0_fuse")) { c->stft_k0_fuse = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "stft_pair_waves")) {
         const bool okv = c->cfg.n_fft == 2048 ? (value == 8 || value == 10 || value == 11 || value == 12) : (value == 8 || value == 12);
         if (!okv) return fail(c, AMPH_ERR_INVALID_ARG, "stft_pair_waves must be 8, 10, 11 or 12 (n_fft 2048) / 8 or 12 (n_fft 1024)");

@@ -59,6 +59,16 @@ struct StftParams {
     int pair_mel_w_floats;
     int pair_waves;            // waves per workgroup of that kernel (8, 10 or 12)
     int pair_tw_lds;           // keep pair_tw1 in LDS when the image still fits 160 KB
+    // K0 inside k_stft_pair ("stft_k0_fuse", round 4): k0_in != nullptr -> the workgroup that owns a row runs rms_normalize on it first
+    // (rms_scale_row: numpy's summation order, the scale, the normalised / re-quantised / centre-padded PCM16 row written to src.wave,
+    // which its waves then read) - K0's two launches per batch are gone.  src describes the rows it WRITES (lead, row_stride).
+    const int16_t* k0_in;      // raw PCM16 rows
+    long long k0_row_stride;
+    const int32_t* k0_lengths; // nullable
+    int k0_n_in, k0_scale_f64;
+    float* k0_scale;           // [B] out
+    int32_t* k0_ok;            // [B] out (nullable)
+    NormPad k0_pad;
     // per-context launch choices (were process-wide globals until round 3)
     int indep;                 // 1: k_stft_mel_w (independent waves), 0: the tile-synchronous k_stft_mel
     int grid_wgs;              // persistent workgroups; 0 = fill the chip
@@ -103,6 +113,7 @@ int stft_mel_scratch_floats(int n_fft);   // floats of per-frame scratch the pow
 hipError_t stft_mel_configure(int lds_bytes);   // raises the dynamic-LDS limit of the STFT kernels
 // the pair kernel (k_stft_pair): LDS image, packed table size, and the configurations it covers
 size_t stft_pair_lds_bytes(int n_frames, int n_mels, int mel_w_floats, int n_waves, bool fused);
+bool stft_pair_can_fuse_k0(int n_in, int n_waves);      // K0 at the head of the row loop: the row fits one LDS pass aliased onto the waves' scratch
 int stft_pair_table_bytes();
 size_t stft_pair_tw1_lds_bytes();
 bool stft_pair_ok(int n_fft, int hop, int p_tail);

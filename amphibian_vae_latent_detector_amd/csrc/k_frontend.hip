@@ -178,33 +178,37 @@ constexpr int kRmsThreads = 1024;
 
 // TH threads per workgroup, CH numpy chunks staged per pass: <T, 1024, 4 | 2> for whole rows (one workgroup per row), <int16_t, 256, 1>
 // for the chunk-sums mode on long rows (one workgroup per chunk: 8 x the workgroups, each a fraction of the latency chain)
+// The body of K0 for ONE row on a workgroup of TH threads (smem: rms_scale_lds<T, CH>() bytes, 16-byte aligned): k_rms_scale below, and - since
+// round 4 - the head of k_stft_pair's row loop ("stft_k0_fuse": the row's workgroup normalises it itself, two launches less per batch).
+// Ends without a barrier: the caller synchronises before smem is reused or norm_out is read.
 template <typename T, int TH, int CH>
-__global__ __launch_bounds__(TH) void k_rms_scale(const T* __restrict__ in, long long row_stride,
-                                                   const int32_t* __restrict__ lengths, int n_in,
-                                                   float* __restrict__ scale, int32_t* __restrict__ ok, int16_t* __restrict__ norm_out,
-                                                   NormPad pad, int scale_f64, float* __restrict__ chunk_sums, int chunk_stride) {
+__device__ __forceinline__ void rms_scale_row(char* smem, const int tid, const int row, const int pass_y, const T* __restrict__ in, long long row_stride,
+                                              const int32_t* __restrict__ lengths, int n_in,
+                                              float* __restrict__ scale, int32_t* __restrict__ ok, int16_t* __restrict__ norm_out,
+                                              const NormPad& pad, int scale_f64, float* __restrict__ chunk_sums, int chunk_stride) {
 #pragma clang fp contract(off)
     // chunk_sums != nullptr (rows longer than one pass): workgroup (row, y) sums ONE pass - numpy chunks CH y .. CH y + CH - 1 -
     // and writes their sums; k_rms_fold_apply folds them in order.  Same leaves, same tree.
     constexpr int kChunksPerPass = CH, kRmsThreads = TH;
     constexpr int kPassElems = kChunksPerPass * kNpChunk;
     constexpr int kVec = 16 / (int)sizeof(T);            // elements per 16-byte LDS read
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     float* heap = reinterpret_cast<float*>(smem);        // [kChunksPerPass][256]: nodes 1 .. 255 of a tree of depth <= 7
     char* img = smem + kChunksPerPass * 256 * 4;
-    const int row = blockIdx.x, tid = threadIdx.x;
     const T* x = in + (long long)row * row_stride;
     const int n = lengths ? min(lengths[row], n_in) : n_in;
     const int n_chunks = (n + kNpChunk - 1) / kNpChunk;
     float total = 0.0f;                                  // thread 0 only
-    const int c_first = chunk_sums ? (int)blockIdx.y * kChunksPerPass : 0;
+    const int c_first = chunk_sums ? pass_y * kChunksPerPass : 0;
     const int c_last = chunk_sums ? min(n_chunks, c_first + kChunksPerPass) : n_chunks;
     for (int c0 = c_first; c0 < c_last; c0 += kChunksPerPass) {
         // ---- stage this pass's samples, coalesced (dword granules when the row is 4-byte aligned)
         const int e0 = c0 * kNpChunk, ne = min(kPassElems, n - e0);
         // every load of a batch is issued before the first LDS write: a 1 s / 22.05 kHz row (11 025 dwords) is ONE batch,
         // i.e. one global round trip (batches of 8 loads per thread were six serialised round trips: 16 -> 10 us)
-        constexpr int U = sizeof(T) == 2 ? (kPassElems / 2 + kRmsThreads - 1) / kRmsThreads : (kPassElems + kRmsThreads - 1) / kRmsThreads;   // one batch per pass
+        // (at most 16 per batch: the 640- / 704- / 768-thread workgroups of k_stft_pair stage a one-second row - 11 025 dwords - in one batch too,
+        //  a full 32 768-sample pass in two)
+        constexpr int U0 = sizeof(T) == 2 ? (kPassElems / 2 + kRmsThreads - 1) / kRmsThreads : (kPassElems + kRmsThreads - 1) / kRmsThreads;   // one batch per pass
+        constexpr int U = U0 < 16 ? U0 : 16;
         if (sizeof(T) == 2 && (((uintptr_t)(x + e0)) & 3u) == 0) {
             const uint32_t* src = reinterpret_cast<const uint32_t*>(x + e0);
             const int nd = ne >> 1;
@@ -419,8 +423,17 @@ __global__ __launch_bounds__(TH) void k_rms_scale(const T* __restrict__ in, long
     }
 }
 
+template <typename T, int TH, int CH>
+__global__ __launch_bounds__(TH) void k_rms_scale(const T* __restrict__ in, long long row_stride,
+                                                   const int32_t* __restrict__ lengths, int n_in,
+                                                   float* __restrict__ scale, int32_t* __restrict__ ok, int16_t* __restrict__ norm_out,
+                                                   NormPad pad, int scale_f64, float* __restrict__ chunk_sums, int chunk_stride) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    rms_scale_row<T, TH, CH>(smem, threadIdx.x, blockIdx.x, blockIdx.y, in, row_stride, lengths, n_in, scale, ok, norm_out, pad, scale_f64, chunk_sums, chunk_stride);
+}
+
 template <typename T, int CH = NpPass<T>::kChunks>
-static size_t rms_scale_lds() {
+static constexpr size_t rms_scale_lds() {
     constexpr int kChunksPerPass = CH;
     return (size_t)kChunksPerPass * 256 * 4 + (size_t)kChunksPerPass * kNpChunk * sizeof(T) + (size_t)kChunksPerPass * 64 * 16;
 }
@@ -1566,7 +1579,10 @@ __device__ __forceinline__ void dft32_combine(float (&er)[16], float (&ei)[16], 
 
 // TWL: the stage-1 twiddles (15.5 KB) live in LDS and are read where they are used; otherwise they are buffer loads issued a phase
 // ahead (62 registers in flight across the first DFTs: at three waves per SIMD the allocator spills)
-template <int NW, int HJ, bool TWL>
+// K0F: rms_normalize of the row at the head of the row loop (StftParams::k0_*): rms_scale_row on this workgroup, its LDS image aliased
+// onto the waves' scratch (unused until the first pair), the normalised padded row written to src.wave and read back from L2 by the
+// pairs.  Bit-identical to the separate K0 launches (the same function).
+template <int NW, int HJ, bool TWL, bool K0F = false>
 __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows) {
     constexpr int kThreads = 64 * NW;
     constexpr int ND = 16 + HJ;                         // dwords per lane and pair
@@ -1628,8 +1644,9 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
 #pragma unroll
         for (int j = 16; j < ND; ++j) nx[j] = full ? __builtin_amdgcn_raw_buffer_load_b32(rs_x, lane4, base + 256 * j, 0) : 0u;
     };
-    // (the first pair's samples come from HBM: requested BEFORE the tables are staged, the two latencies overlap)
-    if ((int)blockIdx.x < n_rows && wave < ((p.n_frames + 1) >> 1)) fetch(blockIdx.x, wave);
+    // (the first pair's samples come from HBM: requested BEFORE the tables are staged, the two latencies overlap; with K0F the row
+    // does not exist yet - it is fetched behind rms_scale_row)
+    if (!K0F && (int)blockIdx.x < n_rows && wave < ((p.n_frames + 1) >> 1)) fetch(blockIdx.x, wave);
 
     // ---- once per workgroup: window pairs + stage-2 twiddles (one packed array), stage-1 twiddles (TWL), mel rows (x 1/4: see above).  Every load is requested before the
     //      first store: one global round trip (beside the sample fetch above), not one per table
@@ -1704,6 +1721,20 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
     // a fixed pr = wave + 12 i the first waves idle at the end while the SIMD that drew the row's 29th pair still works
     float* const db_redf = reinterpret_cast<float*>(reinterpret_cast<double*>(mp_row + ((p.n_frames * p.n_mels + 3) & ~3)) + 16);   // db_row_from_lds's redf
     for (int row = blockIdx.x; row < n_rows; row += gridDim.x) {
+        if (K0F) {
+            // every wave is past the previous row's pairs and dB stage (barriers at the end of the loop body): the scratch is free
+            // (the thread index is made opaque PER ROW: everything rms_scale_row derives from it would otherwise be hoisted in front of the
+            //  row loop and sit in registers across the pair loop - inlined naively the kernel spilled ~90 registers, as a real call the
+            //  callee saved and restored 70)
+            int tid_k0 = tid;
+            asm volatile("" : "+v"(tid_k0));
+            rms_scale_row<int16_t, kThreads, 4>(smem + kTab + meta_bytes + melw_bytes, tid_k0, row, 0, p.k0_in, p.k0_row_stride, p.k0_lengths, p.k0_n_in,
+                                                p.k0_scale, p.k0_ok, const_cast<int16_t*>(reinterpret_cast<const int16_t*>(p.src.wave)), p.k0_pad,
+                                                p.k0_scale_f64, nullptr, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's part of the row has reached L2 ...
+            __syncthreads();                                      // ... and so has everybody's: no line of it is in this CU's L1 yet
+            if (wave < n_pairs) fetch(row, wave);
+        }
         float wmax = -INFINITY;                             // the largest mel power this wave has stored for the row (fused dB stage: its max pass)
         for (int pr = wave, pr_next = 0; pr < n_pairs; pr = pr_next) {
             // packed pairs: element j of the lane's TWO sequences (sample parity 0 / 1) side by side - dft16_pk
@@ -1879,7 +1910,9 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
                 if (lane == 0) got = atomicAdd(next_pair, 1);
                 pr_next = __builtin_amdgcn_readfirstlane(got);
                 int nrow = row, npr = pr_next;
-                if (npr >= n_pairs) { nrow = row + gridDim.x; npr = wave; }     // nothing left in this row: the wave's first pair of its next row
+                // nothing left in this row: the wave's first pair of its next row - but not with K0F: that row is not written yet, and a
+                // read now would leave its stale lines in this CU's L1 for the real fetch to hit
+                if (npr >= n_pairs) { nrow = K0F ? row : row + gridDim.x; npr = wave; }
                 fetch(min(nrow, n_rows - 1), min(npr, n_pairs - 1));
             }
             AMPH_PHASE_FENCE();
@@ -2284,6 +2317,9 @@ size_t stft_pair2_tw1_lds_bytes() { return kP2Tw1Bytes; }
 bool stft_pair2_ok(int n_fft, int hop, int p_tail) { return n_fft == 1024 && hop == 256 && 513 + p_tail <= kP2PStride; }
 // the configurations the pair kernel covers (the caller also needs PCM16 rows padded by K0: src.lead == n_fft / 2)
 bool stft_pair_ok(int n_fft, int hop, int p_tail) { return n_fft == 2048 && hop == 384 && 1025 + p_tail <= kPairPStride; }
+bool stft_pair_can_fuse_k0(int n_in, int n_waves) {
+    return n_in > 0 && n_in <= 4 * kNpChunk && n_waves >= 10 && rms_scale_lds<int16_t, 4>() <= (size_t)n_waves * kPairScratch;
+}
 
 static int table_bytes_for(int n_fft) { return n_fft == 2048 ? FftGeo<4>::TABLE_BYTES : FftGeo<2>::TABLE_BYTES; }
 
@@ -2329,10 +2365,13 @@ hipError_t stft_mel_configure(int lds_bytes) {
         e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
     }
-    const void* pfns[8] = {reinterpret_cast<const void*>(&k_stft_pair<8, 3, false>), reinterpret_cast<const void*>(&k_stft_pair<10, 3, false>),
-                           reinterpret_cast<const void*>(&k_stft_pair<11, 3, false>), reinterpret_cast<const void*>(&k_stft_pair<12, 3, false>),
-                           reinterpret_cast<const void*>(&k_stft_pair<8, 3, true>), reinterpret_cast<const void*>(&k_stft_pair<10, 3, true>),
-                           reinterpret_cast<const void*>(&k_stft_pair<11, 3, true>), reinterpret_cast<const void*>(&k_stft_pair<12, 3, true>)};
+    const void* pfns[14] = {reinterpret_cast<const void*>(&k_stft_pair<8, 3, false>), reinterpret_cast<const void*>(&k_stft_pair<10, 3, false>),
+                            reinterpret_cast<const void*>(&k_stft_pair<11, 3, false>), reinterpret_cast<const void*>(&k_stft_pair<12, 3, false>),
+                            reinterpret_cast<const void*>(&k_stft_pair<8, 3, true>), reinterpret_cast<const void*>(&k_stft_pair<10, 3, true>),
+                            reinterpret_cast<const void*>(&k_stft_pair<11, 3, true>), reinterpret_cast<const void*>(&k_stft_pair<12, 3, true>),
+                            reinterpret_cast<const void*>(&k_stft_pair<10, 3, false, true>), reinterpret_cast<const void*>(&k_stft_pair<11, 3, false, true>),
+                            reinterpret_cast<const void*>(&k_stft_pair<12, 3, false, true>), reinterpret_cast<const void*>(&k_stft_pair<10, 3, true, true>),
+                            reinterpret_cast<const void*>(&k_stft_pair<11, 3, true, true>), reinterpret_cast<const void*>(&k_stft_pair<12, 3, true, true>)};
     for (const void* f : pfns) {
         e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
@@ -2388,12 +2427,21 @@ void launch_stft_mel(const StftParams& p, int n_rows, int sample_is_pcm16, int n
 #define AMPH_PAIR_LAUNCH(NW_)                                                                              \
     if (twl) hipLaunchKernelGGL((k_stft_pair<NW_, 3, true>), grid, dim3(64 * NW_), lds, s, p, n_rows);   \
     else hipLaunchKernelGGL((k_stft_pair<NW_, 3, false>), grid, dim3(64 * NW_), lds, s, p, n_rows);
+#define AMPH_PAIR_LAUNCH_K0(NW_)                                                                                  \
+    if (twl) hipLaunchKernelGGL((k_stft_pair<NW_, 3, true, true>), grid, dim3(64 * NW_), lds, s, p, n_rows);    \
+    else hipLaunchKernelGGL((k_stft_pair<NW_, 3, false, true>), grid, dim3(64 * NW_), lds, s, p, n_rows);
         (void)block;
-        if (nw == 8) { AMPH_PAIR_LAUNCH(8) }
+        if (p.k0_in) {                                  // (the caller has checked stft_pair_can_fuse_k0)
+            if (nw == 11) { AMPH_PAIR_LAUNCH_K0(11) }
+            else if (nw == 12) { AMPH_PAIR_LAUNCH_K0(12) }
+            else { AMPH_PAIR_LAUNCH_K0(10) }
+        }
+        else if (nw == 8) { AMPH_PAIR_LAUNCH(8) }
         else if (nw == 11) { AMPH_PAIR_LAUNCH(11) }
         else if (nw == 12) { AMPH_PAIR_LAUNCH(12) }
         else { AMPH_PAIR_LAUNCH(10) }
 #undef AMPH_PAIR_LAUNCH
+#undef AMPH_PAIR_LAUNCH_K0
         return;
     }
     if (p.pair_tables && sample_is_pcm16 && p.src.lead == p.n_fft / 2 && stft_pair2_ok(p.n_fft, p.hop, p.p_tail)) {

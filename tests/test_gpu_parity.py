@@ -504,6 +504,41 @@ def test_two_term_fp16_split_holds_its_accuracy_across_input_magnitudes(env, cap
         print("\n[two-term fp16 split] max rel L2 of mu vs torch-CPU fp32 at image scale " + ", ".join(f"{k:g}: {v:.2e}" for k, v in worst.items()))
 
 
+def test_rms_normalize_inside_the_pair_kernel_is_bit_identical_to_its_own_launches(env):
+    """Round 4: the workgroup of k_stft_pair that owns a row runs 00_normalize_dataset_rms.py's rms_normalize + PCM16 write on it itself
+    ("stft_k0_fuse", csrc/k_frontend.hip rms_scale_row) instead of K0's two launches per batch.  Same function, same bits: the image,
+    the latents and the rms_ok flags must be EQUAL with the knob on and off - for whole one-second rows, rows longer than the chunk
+    (the RMS is over the whole file, the STFT over its first second), ragged lengths incl. odd and very short ones, silent rows, and a
+    batch of more rows than workgroups (some workgroups then own two rows: the scratch the row image aliases is reused)."""
+    cfg = env.PRESETS["bench-1s"]
+    enc, tenc, spec = _encoders(env, "thesis-shape", cfg=cfg, max_batch=320)
+    sess = enc.session(cfg)
+    rng = np.random.default_rng(77)
+    for n_rows, n_in, ragged in ((320, cfg.n_samples, False), (37, 30011, True), (300, 22050, True), (5, 32768, False)):
+        pcm = env.synth(np.arange(500, 500 + n_rows), n_in, cfg.sr)
+        pcm[3] = 0                                                          # digital silence: the gate leaves the row unchanged
+        lens = None
+        if ragged:
+            lens = rng.integers(1, n_in + 1, size=n_rows).astype(np.int32)
+            lens[:6] = (n_in, n_in - 1, 1, 2, 1025, 8193)
+        res = {}
+        for knob in (1, 0):
+            sess.configure("stft_k0_fuse", knob)
+            mu, _, ok = sess.encode(pcm, lengths=lens, apply_rms=True)
+            img = sess.mel_pcm16(pcm, lengths=lens, apply_rms=True, layout=1)
+            res[knob] = (mu.clone(), ok.clone(), img.clone())
+        sess.configure("stft_k0_fuse", 1)
+        assert torch.equal(res[1][1], res[0][1]), (n_rows, n_in)
+        assert torch.equal(res[1][2], res[0][2]), (n_rows, n_in)
+        assert torch.equal(res[1][0], res[0][0]), (n_rows, n_in)
+        assert torch.isfinite(res[1][0]).all()
+        assert int(res[1][1][3]) == 0                                       # the silent row was gated
+    # and the fused form against the oracle on a few rows of the plain case
+    pcm = env.synth(np.arange(20, 26), cfg.n_samples, cfg.sr)
+    z, _, _ = sess.encode(pcm, apply_rms=True)
+    _assert_latents(z.cpu().numpy(), _oracle_latents(env, tenc, pcm, cfg))
+
+
 def test_fp16_split_range_guard_images_weights_and_activations(env, capsys):
     """The reference's encoder is an fp32 nn.Module loaded from ANY checkpoint (map_detector_core.py:160-179, strict=False) and called
     on any tensor (:270); the default GEMM arithmetic here splits fp32 operands into two fp16 terms, which exist below 65 504 only
@@ -513,7 +548,7 @@ def test_fp16_split_range_guard_images_weights_and_activations(env, capsys):
           re-runs the call on the f32-MFMA kernels and says so (RuntimeWarning);
       (b) a checkpoint whose conv3 weights exceed 65 504 (scaled by 2e6, the BN scale divided by it: the same function): amph_create
           leaves that layer on the f32-MFMA kernel - no flag, no warning;
-      (c) a checkpoint whose conv2 activations pass 65 504 at ordinary image scale (BN gamma of layer 2 x 4000): the epilogue that
+      (c) a checkpoint whose conv2 activations pass 65 504 at ordinary image scale (BN gamma of layer 2 x 16000): the epilogue that
           writes them raises the flag; also through the fused chunk -> latent entry point (encode) and amph_encode_pcm16_host."""
     import warnings
     cfg = env.PRESETS["bench-1s"]
@@ -569,8 +604,8 @@ def test_fp16_split_range_guard_images_weights_and_activations(env, capsys):
 
     # (c) activations outside fp16's range at ordinary inputs
     hot = {k: np.array(v, copy=True) for k, v in state.items()}
-    hot["bn.1.weight"] *= np.float32(4000.0)
-    hot["bn.1.bias"] *= np.float32(4000.0)
+    hot["bn.1.weight"] *= np.float32(16000.0)
+    hot["bn.1.bias"] *= np.float32(16000.0)
     tenc_h = env.oenc.build_torch_encoder(spec.to_dict(), hot)
     with torch.no_grad():
         mu_o, _ = tenc_h(x)
@@ -583,7 +618,7 @@ def test_fp16_split_range_guard_images_weights_and_activations(env, capsys):
     assert torch.isfinite(mu).all() and any("fp16" in str(r.message) for r in rec)
     w = worst(mu.cpu().numpy(), mu_o.numpy())
     assert w <= 1e-5, w
-    report.append(f"BN gamma of layer 2 x 4000: {w:.2e} (flag raised by conv2's epilogue, f32-MFMA re-run)")
+    report.append(f"BN gamma of layer 2 x 16000: {w:.2e} (flag raised by conv2's epilogue, f32-MFMA re-run)")
     # ... and through the chunk -> latent entry points, device and host form
     pcm = env.synth(np.arange(40, 52), cfg.n_samples, cfg.sr)
     z_o = _oracle_latents(env, tenc_h, pcm, cfg)
