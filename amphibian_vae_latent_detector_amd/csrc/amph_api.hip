@@ -1137,7 +1137,8 @@ int run_frontend(amph_ctx* c, Workspace& w, const void* d_wave, bool pcm16, int 
         // K0 inside the pair kernel: the workgroup that owns a row normalises it itself (rms_scale_row at the head of k_stft_pair's row loop) -
         // no K0 launch; the STFT stage's timer then covers both
         const bool k0_fused = pcm16 && norm && pad.lead > 0 && c->stft_k0_fuse && c->cfg.n_fft == 2048 && pair_path(c, true) &&
-                              pair_lds(c, c->stft_pair_waves, db_out != nullptr) <= 160 * 1024 && stft_pair_can_fuse_k0(n_in, c->stft_pair_waves);
+                              pair_lds(c, c->stft_pair_waves, db_out != nullptr) <= 160 * 1024 && stft_pair_can_fuse_k0(n_in, c->stft_pair_waves) &&
+                              (n_in & 1) == 0 && (reinterpret_cast<uintptr_t>(d_wave) & 3u) == 0;      // (its dword loads: every row 4-byte aligned)
         if (k0_fused) {
             t.cancel();
             k0 = true;

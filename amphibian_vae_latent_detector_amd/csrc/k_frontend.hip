@@ -1577,11 +1577,103 @@ __device__ __forceinline__ void dft32_combine(float (&er)[16], float (&ei)[16], 
     }
 }
 
+// ---- K0 inside k_stft_pair (K0F, round 4): numpy's float32 sum(y^2) of ONE PCM16 row whose samples sit in an LDS image (np_lds_off layout,
+// heap in front of it: [4][256] floats), on the pair kernel's own threads.  Same leaves, same tree, same order as k_rms_scale (the
+// tests compare the two bit for bit); what differs is the mapping: a leaf block on a lane QUAD - lane q holds numpy's accumulators r[2q],
+// r[2q + 1], fed by one aligned dword per 8 elements; (r0 + r1) + (r2 + r3) and the rest of numpy's combine are two DPP butterflies - so
+// the ~175 leaves of a one-second row run on 700 lanes at once instead of 175; squares of the INTEGER samples (fl(q^2) 2^-30 == fl(y^2),
+// y = q / 32768: the power of two commutes with every rounding of the sum), scaled once at the end.
+__device__ __forceinline__ void k0_leaf_sums(char* smem, const int tid, const int n_threads, const int n) {
+#pragma clang fp contract(off)
+    float* heap = reinterpret_cast<float*>(smem);
+    const char* img = smem + 4 * 256 * 4;
+    const int n_chunks = (n + kNpChunk - 1) / kNpChunk;
+    const int q = tid & 3;
+    for (int s = tid >> 2; s < 4 * 128; s += n_threads >> 2) {
+        const int cl = s >> 7, slot = s & 127;
+        if (cl >= n_chunks) break;
+        const int cn = min(kNpChunk, n - cl * kNpChunk);
+        int off, size, lvl, rem = 0;
+        bool owner;
+        if (cn == kNpChunk) { off = (slot & 63) * kNpBlock; size = kNpBlock; lvl = 6; owner = slot < 64; }
+        else {
+            const int D = np_depth(cn);
+            owner = slot < (1 << D);
+            np_walk(cn, owner ? slot : 0, D, off, size, lvl);
+            rem = D - lvl;
+            owner = owner && (slot & ((1 << rem) - 1)) == 0;
+        }
+        if (!owner) continue;
+        const int eb = cl * kNpChunk + off;
+        auto sq = [&](int e) { const float y = (float)*reinterpret_cast<const int16_t*>(img + np_lds_off<int16_t>(e)); return y * y; };
+        float res;
+        if (size < 8) {
+            res = -0.0f;
+            for (int i = 0; i < size; ++i) res = res + sq(eb + i);
+        } else {
+            const int body = size - (size & 7);
+            float r0 = 0.0f, r1 = 0.0f;
+            for (int i = 0; i < body; i += 8) {
+                const uint32_t d = *reinterpret_cast<const uint32_t*>(img + np_lds_off<int16_t>(eb + i + 2 * q));     // (eb, i: multiples of 8 - aligned, inside one 128-block)
+                const float a = (float)(short)(d & 0xFFFFu), b = (float)((int)d >> 16);
+                const float sa = a * a, sb = b * b;
+                r0 = i == 0 ? sa : r0 + sa;
+                r1 = i == 0 ? sb : r1 + sb;
+            }
+            res = r0 + r1;
+            res = res + dpp_xor1(res);
+            res = res + dpp_xor2(res);
+            for (int i = body; i < size; ++i) res = res + sq(eb + i);
+        }
+        if (q == 0) heap[cl * 256 + (1 << lvl) + (slot >> rem)] = res;
+    }
+}
+// the tree of ONE chunk on one wave (lane = path), deepest level first, value = left + right; wave-local ordering only
+__device__ __forceinline__ void k0_chunk_tree(char* smem, const int lane, const int cl, const int n) {
+#pragma clang fp contract(off)
+    float* heap = reinterpret_cast<float*>(smem);
+    const int cn = min(kNpChunk, n - cl * kNpChunk);
+    for (int lvl = 6; lvl >= 0; --lvl) {
+        if (lane < (1 << lvl)) {
+            bool internal = cn == kNpChunk && lvl < 6;
+            if (cn != kNpChunk) {
+                int off, size, reached;
+                np_walk(cn, lane, lvl, off, size, reached);
+                internal = reached == lvl && size > kNpBlock;
+            }
+            if (internal) heap[cl * 256 + (1 << lvl) + lane] = heap[cl * 256 + 2 * ((1 << lvl) + lane)] + heap[cl * 256 + 2 * ((1 << lvl) + lane) + 1];
+        }
+        wave_lds_sync();
+    }
+}
+// chunk roots -> (scale, scaled?) exactly as k_rms_scale's thread 0 (00_normalize_dataset_rms.py:30-36 in the pinned numpy's scalar arithmetic)
+__device__ __forceinline__ void k0_scale_from_roots(const char* smem, const int n, const int scale_f64, float& sc, int& good) {
+#pragma clang fp contract(off)
+    const float* heap = reinterpret_cast<const float*>(smem);
+    const int n_chunks = (n + kNpChunk - 1) / kNpChunk;
+    float total = 0.0f;
+    for (int cl = 0; cl < n_chunks; ++cl) total = cl == 0 ? heap[1] : total + heap[cl * 256 + 1];
+    total = total * (1.0f / 1073741824.0f);                 // the leaves summed fl(q^2): x 2^-30, exact
+    sc = 1.0f; good = 0;
+    if (n > 0) {
+        const float rms = sqrtf(total / (float)n);
+        if (scale_f64) { if (!((double)rms < 1e-4)) { sc = (float)(0.05 / ((double)rms + 1e-8)); good = 1; } }
+        else if (!(rms < 1e-4f)) { sc = 0.05f / (rms + 1e-8f); good = 1; }
+    }
+}
+
 // TWL: the stage-1 twiddles (15.5 KB) live in LDS and are read where they are used; otherwise they are buffer loads issued a phase
 // ahead (62 registers in flight across the first DFTs: at three waves per SIMD the allocator spills)
-// K0F: rms_normalize of the row at the head of the row loop (StftParams::k0_*): rms_scale_row on this workgroup, its LDS image aliased
-// onto the waves' scratch (unused until the first pair), the normalised padded row written to src.wave and read back from L2 by the
-// pairs.  Bit-identical to the separate K0 launches (the same function).
+// K0F (round 4): 00_normalize_dataset_rms.py's rms_normalize + PCM16 write / read of the row INSIDE this kernel (StftParams::k0_*) - K0's two
+// launches per batch and its 48 KB padded copy of every row are gone.  (1) The workgroup sums the row's squares in numpy's order at the
+// head of its row loop (k0_leaf_sums / k0_chunk_tree / k0_scale_from_roots; the row's LDS image is aliased onto the waves' scratch, which
+// is idle until the first pair; the row is requested before the tables are staged: one global round trip for both).  (2) The pairs read the
+// RAW rows: a 64-dword sample row of a pair is one aligned dword load per lane when it lies inside the valid samples, and librosa's
+// centre padding (reflect / zeros), fix_length's zero fill and truncation are index arithmetic on the few rows that touch them (two
+// pairs at each end of a one-second row).  (3) The decode re-quantises: q' = rint(clip(q sc, +-32768) 32767 / 32768) - bit for bit the
+// sample 00 writes to disk (the powers of two commute with the roundings) - once per dword (a sliding window shares it between frame a
+// and frame b), four vector instructions per sample.  First measured form (the row's workgroup WRITING the padded row and reading it
+// back): +12 us in this kernel for 16 us of K0 launches, -2 % end to end (profiles/r04_k0_fuse.txt).
 template <int NW, int HJ, bool TWL, bool K0F = false>
 __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows) {
     constexpr int kThreads = 64 * NW;
@@ -1636,17 +1728,94 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
     // stores hit 32 different banks (with lanes l, l + 32 paired a half owned the even columns only: every store 2-way conflicted)
     const int lane_dw = (lane & 15) + 16 * (lane >> 5) + 32 * ((lane >> 4) & 1);
     const int lane4 = lane_dw * 4, lane16 = lane * 16;
-    auto fetch = [&](int row_, int pr_) {
-        const int base = __builtin_amdgcn_readfirstlane((int)(((long long)row_ * p.src.row_stride) * 2 + (long long)pr_ * p.hop * 4));
-        const bool full = 2 * pr_ + 1 < p.n_frames;        // wave-uniform: the row's last pair may hold one frame only
-#pragma unroll
-        for (int j = 0; j < 16; ++j) nx[j] = __builtin_amdgcn_raw_buffer_load_b32(rs_x, lane4, base + 256 * j, 0);
-#pragma unroll
-        for (int j = 16; j < ND; ++j) nx[j] = full ? __builtin_amdgcn_raw_buffer_load_b32(rs_x, lane4, base + 256 * j, 0) : 0u;
+    const __amdgpu_buffer_rsrc_t rs_raw = __builtin_amdgcn_make_buffer_rsrc(const_cast<int16_t*>(p.k0_in), 0, -1, 0x00020000);
+    auto k0_row_len = [&](int row_) {                        // samples of the row that count (wave-uniform)
+        const int n_ = p.k0_lengths ? min(p.k0_lengths[row_], p.k0_n_in) : p.k0_n_in;
+        return __builtin_amdgcn_readfirstlane(n_);
     };
+    auto fetch = [&](int row_, int pr_) {
+        const bool full = 2 * pr_ + 1 < p.n_frames;        // wave-uniform: the row's last pair may hold one frame only
+        if constexpr (K0F) {
+            // the RAW row: sample row j of the pair = padded samples pr 2 hop + 128 j .. + 127 = raw r0 .. r0 + 127, r0 = that - lead
+            const int lead = p.n_fft >> 1, n_fix = p.n_samples;
+            const int nv = min(k0_row_len(row_), n_fix), nv2 = nv & ~1;
+            const int rbase = __builtin_amdgcn_readfirstlane((int)((long long)row_ * p.k0_row_stride * 2));
+            const int s0 = pr_ * 2 * p.hop - lead;
+#pragma unroll
+            for (int j = 0; j < ND; ++j) {
+                const int r0 = s0 + 128 * j;
+                if (j >= 16 && !full) nx[j] = 0u;
+                else if (r0 >= 0 && r0 + 128 <= nv2) nx[j] = __builtin_amdgcn_raw_buffer_load_b32(rs_raw, lane4, rbase + 2 * r0, 0);
+                else {
+                    // a row that touches the centre padding, fix_length's zeros or the row's last odd sample: per sample
+                    // (np.pad mode="reflect" of the fix_length'd row, map_detector_core.py:212-228; mode 1: zeros)
+                    uint32_t half[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        int sidx = r0 + 2 * lane_dw + e;
+                        if (p.pad_mode == 0) {
+                            sidx = sidx < 0 ? -sidx : sidx;
+                            if (sidx >= n_fix) sidx = 2 * (n_fix - 1) - sidx;
+                        }
+                        const bool in = (unsigned)sidx < (unsigned)nv;
+                        const uint32_t v = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rs_raw, in ? 2 * sidx : 0, rbase, 0);
+                        half[e] = in ? v : 0u;
+                    }
+                    nx[j] = half[0] | (half[1] << 16);
+                }
+            }
+        } else {
+            const int base = __builtin_amdgcn_readfirstlane((int)(((long long)row_ * p.src.row_stride) * 2 + (long long)pr_ * p.hop * 4));
+#pragma unroll
+            for (int j = 0; j < 16; ++j) nx[j] = __builtin_amdgcn_raw_buffer_load_b32(rs_x, lane4, base + 256 * j, 0);
+#pragma unroll
+            for (int j = 16; j < ND; ++j) nx[j] = full ? __builtin_amdgcn_raw_buffer_load_b32(rs_x, lane4, base + 256 * j, 0) : 0u;
+        }
+    };
+    // K0F: the row's samples for the sum of squares, requested here and written to the LDS image behind the tables' loads
+    constexpr int K0U = K0F ? (4 * kNpChunk / 2 + kThreads - 1) / kThreads : 1;
+    uint32_t rowv[K0U];
+    char* const k0_smem = smem + kTab + meta_bytes + melw_bytes;      // heap [4][256] floats | image: aliases the waves' scratch
+    int k0_n = 0;
+    auto k0_request = [&](int row_) {
+        k0_n = k0_row_len(row_);
+        const int rbase = __builtin_amdgcn_readfirstlane((int)((long long)row_ * p.k0_row_stride * 2));
+        const int nd = (k0_n + 1) >> 1;                       // (an odd row's last dword carries its neighbour's first sample: never summed)
+#pragma unroll
+        for (int u = 0; u < K0U; ++u) {
+            const int d = tid + kThreads * u;
+            rowv[u] = d < nd ? __builtin_amdgcn_raw_buffer_load_b32(rs_raw, 4 * d, rbase, 0) : 0u;
+        }
+    };
+    auto k0_image = [&]() {
+        const int nd = (k0_n + 1) >> 1;
+#pragma unroll
+        for (int u = 0; u < K0U; ++u) {
+            const int d = tid + kThreads * u;
+            if (d < nd) *reinterpret_cast<uint32_t*>(k0_smem + 4 * 256 * 4 + np_lds_off<int16_t>(2 * d)) = rowv[u];
+        }
+    };
+    float k0_sc = 1.0f;                                      // the row's scale as the decode applies it (1 for a gated row)
+    // every thread, behind a barrier that follows k0_image(): leaves | barrier | one wave per chunk: its tree | barrier | every wave: the scale
+    auto k0_reduce = [&](int row_) {
+        int tid_o = tid;
+        asm volatile("" : "+v"(tid_o));                      // (opaque per row: nothing derived from it is hoisted across the pair loop)
+        k0_leaf_sums(k0_smem, tid_o, kThreads, k0_n);
+        __syncthreads();
+        if (wave < ((k0_n + kNpChunk - 1) / kNpChunk)) k0_chunk_tree(k0_smem, tid_o & 63, wave, k0_n);
+        __syncthreads();
+        float sc_; int good_;
+        k0_scale_from_roots(k0_smem, k0_n, p.k0_scale_f64, sc_, good_);
+        if (tid == 0) { p.k0_scale[row_] = sc_; if (p.k0_ok) p.k0_ok[row_] = good_; }
+        k0_sc = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(good_ ? sc_ : 1.0f)));
+        __syncthreads();                                     // the image is dead: the waves' scratch is theirs again
+    };
+    if (K0F && (int)blockIdx.x < n_rows) k0_request(blockIdx.x);
     // (the first pair's samples come from HBM: requested BEFORE the tables are staged, the two latencies overlap; with K0F the row
     // does not exist yet - it is fetched behind rms_scale_row)
     if (!K0F && (int)blockIdx.x < n_rows && wave < ((p.n_frames + 1) >> 1)) fetch(blockIdx.x, wave);
+    // (K0F: the raw row needs no K0 before it is read, but the first two pairs of a row touch the padding and their per-sample path waits for
+    //  its loads: requested behind the tables' loads, below, so that the wait covers those too)
 
     // ---- once per workgroup: window pairs + stage-2 twiddles (one packed array), stage-1 twiddles (TWL), mel rows (x 1/4: see above).  Every load is requested before the
     //      first store: one global round trip (beside the sample fetch above), not one per table
@@ -1679,6 +1848,10 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
         for (int m = tid + kThreads; m < n_meta; m += kThreads) mel_meta[m] = msrc[m];
         if (tid < n_meta) mel_meta[tid] = mm_;
         if (tid == 0) *next_pair = NW;                   // pairs 0 .. NW - 1 are the waves' first ones
+        if (K0F && (int)blockIdx.x < n_rows) {
+            k0_image();
+            if (wave < ((p.n_frames + 1) >> 1)) fetch(blockIdx.x, wave);
+        }
 #pragma unroll
         for (int u = 0; u < UW; ++u) { const int i = tid + kThreads * u; if (i < NWIN) dst[i] = vw[u]; }
 #pragma unroll
@@ -1722,18 +1895,10 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
     float* const db_redf = reinterpret_cast<float*>(reinterpret_cast<double*>(mp_row + ((p.n_frames * p.n_mels + 3) & ~3)) + 16);   // db_row_from_lds's redf
     for (int row = blockIdx.x; row < n_rows; row += gridDim.x) {
         if (K0F) {
-            // every wave is past the previous row's pairs and dB stage (barriers at the end of the loop body): the scratch is free
-            // (the thread index is made opaque PER ROW: everything rms_scale_row derives from it would otherwise be hoisted in front of the
-            //  row loop and sit in registers across the pair loop - inlined naively the kernel spilled ~90 registers, as a real call the
-            //  callee saved and restored 70)
-            int tid_k0 = tid;
-            asm volatile("" : "+v"(tid_k0));
-            rms_scale_row<int16_t, kThreads, 4>(smem + kTab + meta_bytes + melw_bytes, tid_k0, row, 0, p.k0_in, p.k0_row_stride, p.k0_lengths, p.k0_n_in,
-                                                p.k0_scale, p.k0_ok, const_cast<int16_t*>(reinterpret_cast<const int16_t*>(p.src.wave)), p.k0_pad,
-                                                p.k0_scale_f64, nullptr, 0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's part of the row has reached L2 ...
-            __syncthreads();                                      // ... and so has everybody's: no line of it is in this CU's L1 yet
-            if (wave < n_pairs) fetch(row, wave);
+            // (rows after the first: every wave is past the previous row's pairs and dB stage - barriers at the end of the loop body - so the
+            //  scratch is free for the image; the first pair of this row was requested at the end of the previous one)
+            if (row != (int)blockIdx.x) { k0_request(row); k0_image(); __syncthreads(); }
+            k0_reduce(row);
         }
         float wmax = -INFINITY;                             // the largest mel power this wave has stored for the row (fused dB stage: its max pass)
         for (int pr = wave, pr_next = 0; pr < n_pairs; pr = pr_next) {
@@ -1749,6 +1914,20 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
 #endif
             AMPH_PSTAMP(0)
             // ---- decode + window: z = w (a + i b); the pair is the two int16 of one dword times the window pair (w[n], w[n + 1])
+            // K0F: every dword is decoded and re-quantised ONCE - q' = rint(clip(q sc, +-32768) (32767 / 32768)), the PCM16 sample
+            // 00_normalize_dataset_rms.py:29-57 writes (x = q / 32768, x sc, clip(+-1), x 32767, rint: the powers of two commute with the
+            // roundings; a gated row has sc = 1 and the clip is the identity) - and serves frame a at j and frame b at j - HJ
+            auto requant = [&](uint32_t d) {
+#pragma clang fp contract(off)
+                amph_f2 t = amph_f2{(float)(short)(d & 0xFFFFu), (float)((int)d >> 16)} * k0_sc;
+                t = amph_f2{__builtin_amdgcn_fmed3f(t.x, -32768.0f, 32768.0f), __builtin_amdgcn_fmed3f(t.y, -32768.0f, 32768.0f)} * (32767.0f / 32768.0f);
+                return amph_f2{__builtin_rintf(t.x), __builtin_rintf(t.y)};
+            };
+            amph_f2 fq[K0F ? ND : 1];
+            if (K0F) {
+#pragma unroll
+                for (int j = 0; j < HJ; ++j) fq[j] = requant(nx[j]);
+            }
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
                 float2 wv[8];
@@ -1757,10 +1936,16 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
 #pragma unroll
                 for (int j8 = 0; j8 < 8; ++j8) {
                     const int j = 8 * g + j8;
-                    const uint32_t da = nx[j], db = nx[j + HJ];
                     const amph_f2 w2 = {wv[j8].x, wv[j8].y};
-                    XR[j] = amph_f2{(float)(short)(da & 0xFFFFu), (float)((int)da >> 16)} * w2;
-                    XI[j] = amph_f2{(float)(short)(db & 0xFFFFu), (float)((int)db >> 16)} * w2;
+                    if constexpr (K0F) {
+                        fq[j + HJ] = requant(nx[j + HJ]);
+                        XR[j] = fq[j] * w2;
+                        XI[j] = fq[j + HJ] * w2;
+                    } else {
+                        const uint32_t da = nx[j], db = nx[j + HJ];
+                        XR[j] = amph_f2{(float)(short)(da & 0xFFFFu), (float)((int)da >> 16)} * w2;
+                        XI[j] = amph_f2{(float)(short)(db & 0xFFFFu), (float)((int)db >> 16)} * w2;
+                    }
                 }
                 if (g == 0) AMPH_PHASE_FENCE();
             }
@@ -1910,9 +2095,7 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
                 if (lane == 0) got = atomicAdd(next_pair, 1);
                 pr_next = __builtin_amdgcn_readfirstlane(got);
                 int nrow = row, npr = pr_next;
-                // nothing left in this row: the wave's first pair of its next row - but not with K0F: that row is not written yet, and a
-                // read now would leave its stale lines in this CU's L1 for the real fetch to hit
-                if (npr >= n_pairs) { nrow = K0F ? row : row + gridDim.x; npr = wave; }
+                if (npr >= n_pairs) { nrow = row + gridDim.x; npr = wave; }     // nothing left in this row: the wave's first pair of its next row
                 fetch(min(nrow, n_rows - 1), min(npr, n_pairs - 1));
             }
             AMPH_PHASE_FENCE();
