@@ -107,6 +107,8 @@ struct amph_ctx {
                                            // included, fits (1 s rows with the fused dB stage: 11 - 29 pairs on 11 waves are 3 rounds, at most 8 pairs per SIMD)
     bool stft_pair_tw_lds = true;          // its stage-1 twiddles in LDS when the image still fits
     bool stft_k0_fuse = true;              // rms_normalize at the head of k_stft_pair's row loop instead of K0's own launches (same bits)
+    int4* d_k0_leaves = nullptr;           // numpy's summation tree for rows of k0_tab_n samples (k0_build_tree), rebuilt when the row length changes
+    int k0_tab_n = -1, k0_n_leaves = 0, k0_tree_d[4] = {-1, -1, -1, -1};
     int mel_w_floats = 0, mel_p_tail = 0;
     int32_t *d_mel_start = nullptr, *d_mel_len = nullptr, *d_mel_wofs = nullptr;
     float* d_mel_w = nullptr;
@@ -1182,6 +1184,22 @@ int run_frontend(amph_ctx* c, Workspace& w, const void* d_wave, bool pcm16, int 
             if (k0) {
                 sp.k0_in = (const int16_t*)d_wave; sp.k0_row_stride = n_in; sp.k0_lengths = d_len; sp.k0_n_in = n_in;
                 sp.k0_scale_f64 = c->rms_f64_scale; sp.k0_scale = w.scale; sp.k0_ok = k0_ok; sp.k0_pad = k0_pad;
+                if (!d_len) {                                   // every row n_in samples long: the summation tree comes from the host
+                    if (c->k0_tab_n != n_in) {
+                        int lv[512][4];
+                        const int nl = k0_build_tree(n_in, lv, 512, c->k0_tree_d);
+                        if (nl > 0) {
+                            HIP_TRY(c, hipDeviceSynchronize());                // (earlier launches of any lane may still read the table: only when the row length changes)
+                            if (!c->d_k0_leaves) HIP_TRY(c, hipMalloc((void**)&c->d_k0_leaves, 512 * sizeof(int4)));
+                            HIP_TRY(c, hipMemcpy(c->d_k0_leaves, lv, (size_t)nl * sizeof(int4), hipMemcpyHostToDevice));
+                            c->k0_tab_n = n_in; c->k0_n_leaves = nl;
+                        } else { c->k0_tab_n = -1; c->k0_n_leaves = 0; }
+                    }
+                    if (c->k0_tab_n == n_in) {
+                        sp.k0_leaves = c->d_k0_leaves; sp.k0_n_leaves = c->k0_n_leaves;
+                        for (int q = 0; q < 4; ++q) sp.k0_tree_d[q] = c->k0_tree_d[q];
+                    }
+                }
             }
             launch_stft_mel(sp, nb, pcm16 ? 1 : 0, c->stft_waves, s);
         }
@@ -1364,6 +1382,7 @@ void amph_destroy(amph_ctx* c) {
     fr(c->d_fit_off); fr(c->d_fit_mu); fr(c->d_fit_stats); fr(c->d_fit_rho);
     fr(c->d_map_means); fr(c->d_map_prec); fr(c->d_map_logdet); fr(c->d_map_lprior);
     if (c->h_range_flag) (void)hipHostFree(c->h_range_flag);
+    fr(c->d_k0_leaves);
     for (int i = 0; i < 2; ++i) {
         if (c->pin_in[i]) (void)hipHostFree(c->pin_in[i]);
         fr(c->dev_in[i]); fr(c->dev_len[i]);

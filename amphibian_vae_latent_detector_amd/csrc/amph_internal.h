@@ -69,6 +69,12 @@ struct StftParams {
     float* k0_scale;           // [B] out
     int32_t* k0_ok;            // [B] out (nullable)
     NormPad k0_pad;
+    // rows of one common length (k0_lengths == nullptr): numpy's summation tree of that length, laid out by the host (k0_build_tree):
+    // per leaf (first element in the row, elements, heap node, -), and per numpy chunk the depth D of its tree when every leaf sits at
+    // depth D (then the chunk's tree is a butterfly over 2^D lanes), else -1; nullptr -> the kernel walks the tree itself
+    const int4* k0_leaves;
+    int k0_n_leaves;
+    int k0_tree_d[4];
     // per-context launch choices (were process-wide globals until round 3)
     int indep;                 // 1: k_stft_mel_w (independent waves), 0: the tile-synchronous k_stft_mel
     int grid_wgs;              // persistent workgroups; 0 = fill the chip
@@ -113,7 +119,10 @@ int stft_mel_scratch_floats(int n_fft);   // floats of per-frame scratch the pow
 hipError_t stft_mel_configure(int lds_bytes);   // raises the dynamic-LDS limit of the STFT kernels
 // the pair kernel (k_stft_pair): LDS image, packed table size, and the configurations it covers
 size_t stft_pair_lds_bytes(int n_frames, int n_mels, int mel_w_floats, int n_waves, bool fused);
-bool stft_pair_can_fuse_k0(int n_in, int n_waves);      // K0 at the head of the row loop: the row fits one LDS pass aliased onto the waves' scratch
+bool stft_pair_can_fuse_k0(int n_in, int n_waves);
+// numpy's pairwise-summation tree of a row of n float32 elements (n <= 4 chunks of 8 192): leaves as (first element, size, heap node = chunk * 256 +
+// node of the chunk's binary heap, 0) in chunk / slot order; tree_d[c] = depth of chunk c's tree when complete, else -1.  Returns the leaf count.
+int k0_build_tree(int n, int (*leaves)[4], int max_leaves, int tree_d[4]);      // K0 at the head of the row loop: the row fits one LDS pass aliased onto the waves' scratch
 int stft_pair_table_bytes();
 size_t stft_pair_tw1_lds_bytes();
 bool stft_pair_ok(int n_fft, int hop, int p_tail);

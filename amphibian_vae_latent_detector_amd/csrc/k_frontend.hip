@@ -1628,6 +1628,70 @@ __device__ __forceinline__ void k0_leaf_sums(char* smem, const int tid, const in
         if (q == 0) heap[cl * 256 + (1 << lvl) + (slot >> rem)] = res;
     }
 }
+// the same with the leaves laid out by the host (k0_build_tree: every row of the call has this length): no tree walk, one round
+__device__ __forceinline__ void k0_leaf_sums_tab(char* smem, const int tid, const int n_threads, const int4* __restrict__ tab, const int n_leaves) {
+#pragma clang fp contract(off)
+    float* heap = reinterpret_cast<float*>(smem);
+    const char* img = smem + 4 * 256 * 4;
+    const int q = tid & 3;
+    for (int li = tid >> 2; li < n_leaves; li += n_threads >> 2) {
+        const int4 lf = tab[li];
+        const int eb = lf.x, size = lf.y;
+        auto sq = [&](int e) { const float y = (float)*reinterpret_cast<const int16_t*>(img + np_lds_off<int16_t>(e)); return y * y; };
+        float res;
+        if (size == kNpBlock && (eb & 127) == 0) {              // a whole aligned block: 16 dwords of one 256-byte LDS row, all requested at once
+            const uint32_t* b = reinterpret_cast<const uint32_t*>(img + np_lds_off<int16_t>(eb)) + q;
+            uint32_t d[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) d[i] = b[4 * i];
+            float r0 = 0.0f, r1 = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float a = (float)(short)(d[i] & 0xFFFFu), c = (float)((int)d[i] >> 16);
+                const float sa = a * a, sb = c * c;
+                r0 = i == 0 ? sa : r0 + sa;
+                r1 = i == 0 ? sb : r1 + sb;
+            }
+            res = r0 + r1;
+            res = res + dpp_xor1(res);
+            res = res + dpp_xor2(res);
+        } else if (size < 8) {
+            res = -0.0f;
+            for (int i = 0; i < size; ++i) res = res + sq(eb + i);
+        } else {
+            const int body = size - (size & 7);
+            float r0 = 0.0f, r1 = 0.0f;
+            for (int i = 0; i < body; i += 8) {
+                const uint32_t d = *reinterpret_cast<const uint32_t*>(img + np_lds_off<int16_t>(eb + i + 2 * q));
+                const float a = (float)(short)(d & 0xFFFFu), c = (float)((int)d >> 16);
+                const float sa = a * a, sb = c * c;
+                r0 = i == 0 ? sa : r0 + sa;
+                r1 = i == 0 ? sb : r1 + sb;
+            }
+            res = r0 + r1;
+            res = res + dpp_xor1(res);
+            res = res + dpp_xor2(res);
+            for (int i = body; i < size; ++i) res = res + sq(eb + i);
+        }
+        if (q == 0) heap[lf.z] = res;
+    }
+}
+// a COMPLETE chunk tree (every leaf at depth D <= 6) on one wave: the 2^D leaves in lanes 0 .. 2^D - 1, node = left + right level by level
+// - a butterfly on the DPP network (sums are commutative: either operand order gives the node's bits).  -> the root, valid in one known lane
+__device__ __forceinline__ void k0_chunk_butterfly(char* smem, const int lane, const int cl, const int D) {
+#pragma clang fp contract(off)
+    float* heap = reinterpret_cast<float*>(smem);
+    float v = lane < (1 << D) ? heap[cl * 256 + (1 << D) + lane] : 0.0f;
+    int src = 0;
+    if (D >= 1) v = v + dpp_f<0xB1>(v);                   // quad_perm [1, 0, 3, 2]
+    if (D >= 2) v = v + dpp_f<0x4E>(v);                   // quad_perm [2, 3, 0, 1]
+    if (D >= 3) v = v + dpp_f<0x141>(v);                  // row_half_mirror
+    if (D >= 4) v = v + dpp_f<0x140>(v);                  // row_mirror
+    if (D >= 5) { v = v + dpp_f_rows<0x142, 0xA>(v, 0.0f); src = 31; }      // row_bcast:15 into rows 1, 3
+    if (D >= 6) { v = v + dpp_f_rows<0x143, 0xC>(v, 0.0f); src = 63; }      // row_bcast:31 into rows 2, 3
+    if (lane == src) heap[cl * 256 + 1] = v;
+    wave_lds_sync();
+}
 // the tree of ONE chunk on one wave (lane = path), deepest level first, value = left + right; wave-local ordering only
 __device__ __forceinline__ void k0_chunk_tree(char* smem, const int lane, const int cl, const int n) {
 #pragma clang fp contract(off)
@@ -1741,28 +1805,37 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
             const int nv = min(k0_row_len(row_), n_fix), nv2 = nv & ~1;
             const int rbase = __builtin_amdgcn_readfirstlane((int)((long long)row_ * p.k0_row_stride * 2));
             const int s0 = pr_ * 2 * p.hop - lead;
+            if (s0 >= 0 && s0 + 128 * (full ? ND : 16) <= nv2) {
+                // every sample of the pair is a sample of the row (25 of a one-second row's 29 pairs): the aligned dword loads of the padded-row form
+                const int base = rbase + 2 * s0;
 #pragma unroll
-            for (int j = 0; j < ND; ++j) {
-                const int r0 = s0 + 128 * j;
-                if (j >= 16 && !full) nx[j] = 0u;
-                else if (r0 >= 0 && r0 + 128 <= nv2) nx[j] = __builtin_amdgcn_raw_buffer_load_b32(rs_raw, lane4, rbase + 2 * r0, 0);
-                else {
-                    // a row that touches the centre padding, fix_length's zeros or the row's last odd sample: per sample
-                    // (np.pad mode="reflect" of the fix_length'd row, map_detector_core.py:212-228; mode 1: zeros)
+                for (int j = 0; j < 16; ++j) nx[j] = __builtin_amdgcn_raw_buffer_load_b32(rs_raw, lane4, base + 256 * j, 0);
+#pragma unroll
+                for (int j = 16; j < ND; ++j) nx[j] = full ? __builtin_amdgcn_raw_buffer_load_b32(rs_raw, lane4, base + 256 * j, 0) : 0u;
+            } else {
+                // the pair touches the centre padding (np.pad mode="reflect" of the fix_length'd row, map_detector_core.py:212-228; mode 1:
+                // zeros), fix_length's zero fill or the row's last odd sample: per sample, through a resource that ends at the row's
+                // last valid sample (a sample outside reads 0 from past its end).  All 2 ND loads first, ONE wait, then the halves are joined.
+                const __amdgpu_buffer_rsrc_t rs_row = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<char*>(reinterpret_cast<const char*>(p.k0_in) + (long long)row_ * p.k0_row_stride * 2), 0, 2 * nv, 0x00020000);
+                uint32_t lo[ND], hi[ND];
+#pragma unroll
+                for (int j = 0; j < ND; ++j) {
                     uint32_t half[2];
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
-                        int sidx = r0 + 2 * lane_dw + e;
+                        int sidx = s0 + 128 * j + 2 * lane_dw + e;
                         if (p.pad_mode == 0) {
                             sidx = sidx < 0 ? -sidx : sidx;
                             if (sidx >= n_fix) sidx = 2 * (n_fix - 1) - sidx;
                         }
-                        const bool in = (unsigned)sidx < (unsigned)nv;
-                        const uint32_t v = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rs_raw, in ? 2 * sidx : 0, rbase, 0);
-                        half[e] = in ? v : 0u;
+                        const bool in = (unsigned)sidx < (unsigned)nv && (j < 16 || full);
+                        half[e] = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rs_row, in ? 2 * sidx : 0x7FFFFFF0, 0, 0);
                     }
-                    nx[j] = half[0] | (half[1] << 16);
+                    lo[j] = half[0]; hi[j] = half[1];
                 }
+#pragma unroll
+                for (int j = 0; j < ND; ++j) nx[j] = lo[j] | (hi[j] << 16);
             }
         } else {
             const int base = __builtin_amdgcn_readfirstlane((int)(((long long)row_ * p.src.row_stride) * 2 + (long long)pr_ * p.hop * 4));
@@ -1800,9 +1873,14 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
     auto k0_reduce = [&](int row_) {
         int tid_o = tid;
         asm volatile("" : "+v"(tid_o));                      // (opaque per row: nothing derived from it is hoisted across the pair loop)
-        k0_leaf_sums(k0_smem, tid_o, kThreads, k0_n);
+        if (p.k0_leaves) k0_leaf_sums_tab(k0_smem, tid_o, kThreads, p.k0_leaves, p.k0_n_leaves);
+        else k0_leaf_sums(k0_smem, tid_o, kThreads, k0_n);
         __syncthreads();
-        if (wave < ((k0_n + kNpChunk - 1) / kNpChunk)) k0_chunk_tree(k0_smem, tid_o & 63, wave, k0_n);
+        if (wave < ((k0_n + kNpChunk - 1) / kNpChunk)) {
+            const int D = p.k0_leaves ? p.k0_tree_d[wave & 3] : -1;       // (wave-uniform: a kernel argument)
+            if (D >= 0) k0_chunk_butterfly(k0_smem, tid_o & 63, wave, D);
+            else k0_chunk_tree(k0_smem, tid_o & 63, wave, k0_n);
+        }
         __syncthreads();
         float sc_; int good_;
         k0_scale_from_roots(k0_smem, k0_n, p.k0_scale_f64, sc_, good_);
@@ -2500,6 +2578,33 @@ size_t stft_pair2_tw1_lds_bytes() { return kP2Tw1Bytes; }
 bool stft_pair2_ok(int n_fft, int hop, int p_tail) { return n_fft == 1024 && hop == 256 && 513 + p_tail <= kP2PStride; }
 // the configurations the pair kernel covers (the caller also needs PCM16 rows padded by K0: src.lead == n_fft / 2)
 bool stft_pair_ok(int n_fft, int hop, int p_tail) { return n_fft == 2048 && hop == 384 && 1025 + p_tail <= kPairPStride; }
+int k0_build_tree(int n, int (*leaves)[4], int max_leaves, int tree_d[4]) {
+    auto split = [](int m) { const int h = m >> 1; return h - (h & 7); };
+    int count = 0;
+    for (int c = 0; c < 4; ++c) tree_d[c] = -1;
+    const int n_chunks = (n + kNpChunk - 1) / kNpChunk;
+    for (int c = 0; c < n_chunks && c < 4; ++c) {
+        const int cn = std::min(kNpChunk, n - c * kNpChunk);
+        int D = 0;
+        for (int m = cn; m > kNpBlock; m -= split(m)) ++D;          // depth of the deepest leaf (the right child is never smaller)
+        bool complete = true;
+        for (int slot = 0; slot < (1 << D); ++slot) {
+            int off = 0, m = cn, l = 0;
+            for (; l < D && m > kNpBlock; ++l) {
+                const int m2 = split(m);
+                if ((slot >> (D - 1 - l)) & 1) { off += m2; m -= m2; } else m = m2;
+            }
+            const int rem = D - l;
+            if (slot & ((1 << rem) - 1)) continue;                  // an early leaf belongs to the slot with zero low bits
+            if (rem) complete = false;
+            if (count >= max_leaves) return -1;
+            leaves[count][0] = c * kNpChunk + off; leaves[count][1] = m; leaves[count][2] = c * 256 + (1 << l) + (slot >> rem); leaves[count][3] = 0;
+            ++count;
+        }
+        tree_d[c] = complete ? D : -1;
+    }
+    return count;
+}
 bool stft_pair_can_fuse_k0(int n_in, int n_waves) {
     return n_in > 0 && n_in <= 4 * kNpChunk && n_waves >= 10 && rms_scale_lds<int16_t, 4>() <= (size_t)n_waves * kPairScratch;
 }
