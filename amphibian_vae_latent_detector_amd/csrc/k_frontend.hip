@@ -1628,45 +1628,36 @@ __device__ __forceinline__ void k0_leaf_sums(char* smem, const int tid, const in
         if (q == 0) heap[cl * 256 + (1 << lvl) + (slot >> rem)] = res;
     }
 }
-// the same with the leaves laid out by the host (k0_build_tree: every row of the call has this length): no tree walk, one round
-__device__ __forceinline__ void k0_leaf_sums_tab(char* smem, const int tid, const int n_threads, const int4* __restrict__ tab, const int n_leaves) {
+// the same with the leaves laid out by the host (k0_build_tree: every row of the call has this length): no tree walk; the first round's table
+// entry was read with the row (lf0); a leaf's <= 16 dwords per lane are requested at once (a leaf never exceeds 128 elements)
+__device__ __forceinline__ void k0_leaf_sums_tab(char* smem, const int tid, const int n_threads, const int4* __restrict__ tab, const int n_leaves, const int4 lf0) {
 #pragma clang fp contract(off)
     float* heap = reinterpret_cast<float*>(smem);
     const char* img = smem + 4 * 256 * 4;
     const int q = tid & 3;
-    for (int li = tid >> 2; li < n_leaves; li += n_threads >> 2) {
-        const int4 lf = tab[li];
+    for (int li = tid >> 2, rnd = 0; li < n_leaves; li += n_threads >> 2, ++rnd) {
+        const int4 lf = rnd == 0 ? lf0 : tab[li];
         const int eb = lf.x, size = lf.y;
         auto sq = [&](int e) { const float y = (float)*reinterpret_cast<const int16_t*>(img + np_lds_off<int16_t>(e)); return y * y; };
         float res;
-        if (size == kNpBlock && (eb & 127) == 0) {              // a whole aligned block: 16 dwords of one 256-byte LDS row, all requested at once
-            const uint32_t* b = reinterpret_cast<const uint32_t*>(img + np_lds_off<int16_t>(eb)) + q;
+        if (size < 8) {
+            res = -0.0f;
+            for (int i = 0; i < size; ++i) res = res + sq(eb + i);
+        } else {
+            const int body = size - (size & 7);
             uint32_t d[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) d[i] = b[4 * i];
+            for (int i = 0; i < 16; ++i) {                      // (eb: a multiple of 8 - every group of 8 lies inside one 128-element LDS row)
+                const int e = eb + 8 * i + 2 * q;
+                d[i] = 8 * i < body ? *reinterpret_cast<const uint32_t*>(img + np_lds_off<int16_t>(e)) : 0u;
+            }
             float r0 = 0.0f, r1 = 0.0f;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const float a = (float)(short)(d[i] & 0xFFFFu), c = (float)((int)d[i] >> 16);
                 const float sa = a * a, sb = c * c;
-                r0 = i == 0 ? sa : r0 + sa;
-                r1 = i == 0 ? sb : r1 + sb;
-            }
-            res = r0 + r1;
-            res = res + dpp_xor1(res);
-            res = res + dpp_xor2(res);
-        } else if (size < 8) {
-            res = -0.0f;
-            for (int i = 0; i < size; ++i) res = res + sq(eb + i);
-        } else {
-            const int body = size - (size & 7);
-            float r0 = 0.0f, r1 = 0.0f;
-            for (int i = 0; i < body; i += 8) {
-                const uint32_t d = *reinterpret_cast<const uint32_t*>(img + np_lds_off<int16_t>(eb + i + 2 * q));
-                const float a = (float)(short)(d & 0xFFFFu), c = (float)((int)d >> 16);
-                const float sa = a * a, sb = c * c;
-                r0 = i == 0 ? sa : r0 + sa;
-                r1 = i == 0 ? sb : r1 + sb;
+                if (i == 0) { r0 = sa; r1 = sb; }
+                else if (8 * i < body) { r0 = r0 + sa; r1 = r1 + sb; }
             }
             res = r0 + r1;
             res = res + dpp_xor1(res);
@@ -1779,6 +1770,14 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
 #define AMPH_PSTAMP(k_)
 #endif
 
+#ifdef AMPH_STAMPS
+    // K0F prologue timeline (thread 0; first region of the stamp buffer, printed by "dump_stamps" as the deltas of slots 0 .. 9):
+    // 0 start | 1 row requested | 2 tables' loads consumed | 3 image written | 4 first fetch | 5 barrier | 6 leaves | 7 barrier + trees + barrier | 8 scale | 9 barrier
+#define AMPH_K0STAMP(k_) if (K0F && tid == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); p.stamps[(size_t)blockIdx.x * 16 + (k_)] = t_; }
+#else
+#define AMPH_K0STAMP(k_)
+#endif
+    AMPH_K0STAMP(0)
     // the next pair's raw dwords: requested before the mel rows of the current pair
     uint32_t nx[ND];
 #pragma unroll
@@ -1821,15 +1820,19 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
                 uint32_t lo[ND], hi[ND];
 #pragma unroll
                 for (int j = 0; j < ND; ++j) {
+                    const int r0 = s0 + 128 * j;                 // (wave-uniform: the rows of the pair that lie inside the row stay dword loads)
+                    lo[j] = 0u; hi[j] = 0u;
+                    if (j >= 16 && !full) continue;
+                    if (r0 >= 0 && r0 + 128 <= nv2) { lo[j] = __builtin_amdgcn_raw_buffer_load_b32(rs_raw, lane4, rbase + 2 * r0, 0); continue; }
                     uint32_t half[2];
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
-                        int sidx = s0 + 128 * j + 2 * lane_dw + e;
+                        int sidx = r0 + 2 * lane_dw + e;
                         if (p.pad_mode == 0) {
                             sidx = sidx < 0 ? -sidx : sidx;
                             if (sidx >= n_fix) sidx = 2 * (n_fix - 1) - sidx;
                         }
-                        const bool in = (unsigned)sidx < (unsigned)nv && (j < 16 || full);
+                        const bool in = (unsigned)sidx < (unsigned)nv;
                         half[e] = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rs_row, in ? 2 * sidx : 0x7FFFFFF0, 0, 0);
                     }
                     lo[j] = half[0]; hi[j] = half[1];
@@ -1846,26 +1849,43 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
         }
     };
     // K0F: the row's samples for the sum of squares, requested here and written to the LDS image behind the tables' loads
-    constexpr int K0U = K0F ? (4 * kNpChunk / 2 + kThreads - 1) / kThreads : 1;
-    uint32_t rowv[K0U];
+    // (16 bytes per lane and instruction: a CU's texture addresser takes ~16 cycles per wave instruction whatever its width - the row as dword
+    //  loads was 264 instructions per CU, 4 200 cycles of issue alone)
+    constexpr int K0U = K0F ? (4 * kNpChunk / 8 + kThreads - 1) / kThreads : 1;
+    uint4 rowv[K0U];
     char* const k0_smem = smem + kTab + meta_bytes + melw_bytes;      // heap [4][256] floats | image: aliases the waves' scratch
     int k0_n = 0;
+    int4 k0_leaf = make_int4(0, 0, 0, 0);                             // this lane quad's leaf of the host-built tree
     auto k0_request = [&](int row_) {
         k0_n = k0_row_len(row_);
         const int rbase = __builtin_amdgcn_readfirstlane((int)((long long)row_ * p.k0_row_stride * 2));
-        const int nd = (k0_n + 1) >> 1;                       // (an odd row's last dword carries its neighbour's first sample: never summed)
+        const int nq = (k0_n + 7) >> 3;                       // (the last 16 bytes may run into the next row / 14 bytes past the input: the resource is unbounded
+                                                              //  and the allocation behind it is the caller's whole [B][n_in] matrix - the very last row reads dwords instead)
+        const bool last_row = row_ == n_rows - 1;
 #pragma unroll
         for (int u = 0; u < K0U; ++u) {
             const int d = tid + kThreads * u;
-            rowv[u] = d < nd ? __builtin_amdgcn_raw_buffer_load_b32(rs_raw, 4 * d, rbase, 0) : 0u;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (d < nq) {
+                if (!last_row || 8 * d + 8 <= ((p.k0_n_in + 1) & ~1)) v = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_raw, 16 * d, rbase, 0));
+                else {
+                    const int nd_row = (p.k0_n_in + 1) >> 1;
+                    uint32_t w4[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w4[e] = 4 * d + e < nd_row ? __builtin_amdgcn_raw_buffer_load_b32(rs_raw, 16 * d + 4 * e, rbase, 0) : 0u;
+                    v = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+                }
+            }
+            rowv[u] = v;
         }
+        if (p.k0_leaves && (tid >> 2) < p.k0_n_leaves) k0_leaf = p.k0_leaves[tid >> 2];
     };
     auto k0_image = [&]() {
-        const int nd = (k0_n + 1) >> 1;
+        const int nq = (k0_n + 7) >> 3;
 #pragma unroll
         for (int u = 0; u < K0U; ++u) {
             const int d = tid + kThreads * u;
-            if (d < nd) *reinterpret_cast<uint32_t*>(k0_smem + 4 * 256 * 4 + np_lds_off<int16_t>(2 * d)) = rowv[u];
+            if (d < nq) *reinterpret_cast<uint4*>(k0_smem + 4 * 256 * 4 + np_lds_off<int16_t>(8 * d)) = rowv[u];
         }
     };
     float k0_sc = 1.0f;                                      // the row's scale as the decode applies it (1 for a gated row)
@@ -1873,8 +1893,10 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
     auto k0_reduce = [&](int row_) {
         int tid_o = tid;
         asm volatile("" : "+v"(tid_o));                      // (opaque per row: nothing derived from it is hoisted across the pair loop)
-        if (p.k0_leaves) k0_leaf_sums_tab(k0_smem, tid_o, kThreads, p.k0_leaves, p.k0_n_leaves);
+        AMPH_K0STAMP(5)
+        if (p.k0_leaves) k0_leaf_sums_tab(k0_smem, tid_o, kThreads, p.k0_leaves, p.k0_n_leaves, k0_leaf);
         else k0_leaf_sums(k0_smem, tid_o, kThreads, k0_n);
+        AMPH_K0STAMP(6)
         __syncthreads();
         if (wave < ((k0_n + kNpChunk - 1) / kNpChunk)) {
             const int D = p.k0_leaves ? p.k0_tree_d[wave & 3] : -1;       // (wave-uniform: a kernel argument)
@@ -1882,13 +1904,17 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
             else k0_chunk_tree(k0_smem, tid_o & 63, wave, k0_n);
         }
         __syncthreads();
+        AMPH_K0STAMP(7)
         float sc_; int good_;
         k0_scale_from_roots(k0_smem, k0_n, p.k0_scale_f64, sc_, good_);
         if (tid == 0) { p.k0_scale[row_] = sc_; if (p.k0_ok) p.k0_ok[row_] = good_; }
         k0_sc = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(good_ ? sc_ : 1.0f)));
+        AMPH_K0STAMP(8)
         __syncthreads();                                     // the image is dead: the waves' scratch is theirs again
+        AMPH_K0STAMP(9)
     };
     if (K0F && (int)blockIdx.x < n_rows) k0_request(blockIdx.x);
+    AMPH_K0STAMP(1)
     // (the first pair's samples come from HBM: requested BEFORE the tables are staged, the two latencies overlap; with K0F the row
     // does not exist yet - it is fetched behind rms_scale_row)
     if (!K0F && (int)blockIdx.x < n_rows && wave < ((p.n_frames + 1) >> 1)) fetch(blockIdx.x, wave);
@@ -1926,9 +1952,12 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
         for (int m = tid + kThreads; m < n_meta; m += kThreads) mel_meta[m] = msrc[m];
         if (tid < n_meta) mel_meta[tid] = mm_;
         if (tid == 0) *next_pair = NW;                   // pairs 0 .. NW - 1 are the waves' first ones
+        AMPH_K0STAMP(2)
         if (K0F && (int)blockIdx.x < n_rows) {
             k0_image();
+            AMPH_K0STAMP(3)
             if (wave < ((p.n_frames + 1) >> 1)) fetch(blockIdx.x, wave);
+            AMPH_K0STAMP(4)
         }
 #pragma unroll
         for (int u = 0; u < UW; ++u) { const int i = tid + kThreads * u; if (i < NWIN) dst[i] = vw[u]; }
