@@ -72,6 +72,8 @@ struct StftParams {
     // rows of one common length (k0_lengths == nullptr): numpy's summation tree of that length, laid out by the host (k0_build_tree):
     // per leaf (first element in the row, elements, heap node, -), and per numpy chunk the depth D of its tree when every leaf sits at
     // depth D (then the chunk's tree is a butterfly over 2^D lanes), else -1; nullptr -> the kernel walks the tree itself
+    const float* k0_chunk_sums;   // nullable: K0F 2 - [B][k0_chunk_stride] sums of squares per numpy chunk, from launch_rms_chunk_sums_pcm16
+    int k0_chunk_stride;
     const int4* k0_leaves;
     int k0_n_leaves;
     int k0_tree_d[4];
@@ -99,6 +101,7 @@ int rms_scale_chunks(int n_in);
 void launch_rms_scale_pcm16(const int16_t* in, long long row_stride, const int32_t* lengths, int n_in,
                             int n_rows, float* scale, int32_t* ok, int scale_f64, int16_t* norm_out, const NormPad& pad, float* chunk_sums,
                             int chunk_path_over, hipStream_t s);
+void launch_rms_chunk_sums_pcm16(const int16_t* in, long long row_stride, const int32_t* lengths, int n_in, int n_rows, float* chunk_sums, hipStream_t s);
 void launch_pad_rows_pcm16(const int16_t* in, long long row_stride, const int32_t* lengths, int n_in, int n_rows, int16_t* out,
                            const NormPad& pad, hipStream_t s);
 void launch_rms_scale_f32(const float* in, long long row_stride, const int32_t* lengths, int n_in,

@@ -1729,7 +1729,9 @@ __device__ __forceinline__ void k0_scale_from_roots(const char* smem, const int 
 // sample 00 writes to disk (the powers of two commute with the roundings) - once per dword (a sliding window shares it between frame a
 // and frame b), four vector instructions per sample.  First measured form (the row's workgroup WRITING the padded row and reading it
 // back): +12 us in this kernel for 16 us of K0 launches, -2 % end to end (profiles/r04_k0_fuse.txt).
-template <int NW, int HJ, bool TWL, bool K0F = false>
+// K0F 2: as 1, but the per-chunk sums of squares come from K0's first kernel (k_rms_scale<int16_t, 256, 1>, StftParams::k0_chunk_sums): no row
+// image, no summation and no barrier in this kernel's prologue - every wave folds the row's <= 4 chunk sums into the scale itself
+template <int NW, int HJ, bool TWL, int K0F = 0>
 __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows) {
     constexpr int kThreads = 64 * NW;
     constexpr int ND = 16 + HJ;                         // dwords per lane and pair
@@ -1851,7 +1853,7 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
     // K0F: the row's samples for the sum of squares, requested here and written to the LDS image behind the tables' loads
     // (16 bytes per lane and instruction: a CU's texture addresser takes ~16 cycles per wave instruction whatever its width - the row as dword
     //  loads was 264 instructions per CU, 4 200 cycles of issue alone)
-    constexpr int K0U = K0F ? (4 * kNpChunk / 8 + kThreads - 1) / kThreads : 1;
+    constexpr int K0U = K0F == 1 ? (4 * kNpChunk / 8 + kThreads - 1) / kThreads : 1;
     uint4 rowv[K0U];
     char* const k0_smem = smem + kTab + meta_bytes + melw_bytes;      // heap [4][256] floats | image: aliases the waves' scratch
     int k0_n = 0;
@@ -1913,7 +1915,7 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
         __syncthreads();                                     // the image is dead: the waves' scratch is theirs again
         AMPH_K0STAMP(9)
     };
-    if (K0F && (int)blockIdx.x < n_rows) k0_request(blockIdx.x);
+    if (K0F == 1 && (int)blockIdx.x < n_rows) k0_request(blockIdx.x);
     AMPH_K0STAMP(1)
     // (the first pair's samples come from HBM: requested BEFORE the tables are staged, the two latencies overlap; with K0F the row
     // does not exist yet - it is fetched behind rms_scale_row)
@@ -1953,12 +1955,8 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
         if (tid < n_meta) mel_meta[tid] = mm_;
         if (tid == 0) *next_pair = NW;                   // pairs 0 .. NW - 1 are the waves' first ones
         AMPH_K0STAMP(2)
-        if (K0F && (int)blockIdx.x < n_rows) {
-            k0_image();
-            AMPH_K0STAMP(3)
-            if (wave < ((p.n_frames + 1) >> 1)) fetch(blockIdx.x, wave);
-            AMPH_K0STAMP(4)
-        }
+        if (K0F == 1 && (int)blockIdx.x < n_rows) k0_image();
+        AMPH_K0STAMP(3)
 #pragma unroll
         for (int u = 0; u < UW; ++u) { const int i = tid + kThreads * u; if (i < NWIN) dst[i] = vw[u]; }
 #pragma unroll
@@ -2001,12 +1999,32 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
     // a fixed pr = wave + 12 i the first waves idle at the end while the SIMD that drew the row's 29th pair still works
     float* const db_redf = reinterpret_cast<float*>(reinterpret_cast<double*>(mp_row + ((p.n_frames * p.n_mels + 3) & ~3)) + 16);   // db_row_from_lds's redf
     for (int row = blockIdx.x; row < n_rows; row += gridDim.x) {
-        if (K0F) {
+        if (K0F == 1) {
             // (rows after the first: every wave is past the previous row's pairs and dB stage - barriers at the end of the loop body - so the
             //  scratch is free for the image; the first pair of this row was requested at the end of the previous one)
             if (row != (int)blockIdx.x) { k0_request(row); k0_image(); __syncthreads(); }
             k0_reduce(row);
         }
+        if (K0F == 2) {
+#pragma clang fp contract(off)
+            // the chunk sums of K0's first kernel, folded in numpy's order (chunk 0 first) into the scale - k_rms_fold_apply's thread 0, on every wave
+            const int n_ = k0_row_len(row);
+            const int n_chunks = (n_ + kNpChunk - 1) / kNpChunk;
+            const float* cs = p.k0_chunk_sums + (long long)row * p.k0_chunk_stride;
+            float total = 0.0f, sc_ = 1.0f;
+            int good_ = 0;
+            for (int c = 0; c < n_chunks; ++c) total = c == 0 ? cs[0] : total + cs[c];
+            if (n_ > 0) {
+                const float rms = sqrtf(total / (float)n_);
+                if (p.k0_scale_f64) { if (!((double)rms < 1e-4)) { sc_ = (float)(0.05 / ((double)rms + 1e-8)); good_ = 1; } }
+                else if (!(rms < 1e-4f)) { sc_ = 0.05f / (rms + 1e-8f); good_ = 1; }
+            }
+            if (tid == 0) { p.k0_scale[row] = sc_; if (p.k0_ok) p.k0_ok[row] = good_; }
+            k0_sc = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(good_ ? sc_ : 1.0f)));
+        }
+        // K0F: the first pair of the workgroup's FIRST row is requested here, behind the last barrier of the prologue - the two pairs at a row's
+        // head touch the padding and take the per-sample path, whose (cold) code and wait would otherwise sit in front of a barrier everybody meets
+        if (K0F && row == (int)blockIdx.x && wave < n_pairs) fetch(row, wave);
         float wmax = -INFINITY;                             // the largest mel power this wave has stored for the row (fused dB stage: its max pass)
         for (int pr = wave, pr_next = 0; pr < n_pairs; pr = pr_next) {
             // packed pairs: element j of the lane's TWO sequences (sample parity 0 / 1) side by side - dft16_pk
@@ -2682,13 +2700,14 @@ hipError_t stft_mel_configure(int lds_bytes) {
         e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
     }
-    const void* pfns[14] = {reinterpret_cast<const void*>(&k_stft_pair<8, 3, false>), reinterpret_cast<const void*>(&k_stft_pair<10, 3, false>),
+    const void* pfns[16] = {reinterpret_cast<const void*>(&k_stft_pair<8, 3, false>), reinterpret_cast<const void*>(&k_stft_pair<10, 3, false>),
                             reinterpret_cast<const void*>(&k_stft_pair<11, 3, false>), reinterpret_cast<const void*>(&k_stft_pair<12, 3, false>),
                             reinterpret_cast<const void*>(&k_stft_pair<8, 3, true>), reinterpret_cast<const void*>(&k_stft_pair<10, 3, true>),
                             reinterpret_cast<const void*>(&k_stft_pair<11, 3, true>), reinterpret_cast<const void*>(&k_stft_pair<12, 3, true>),
-                            reinterpret_cast<const void*>(&k_stft_pair<10, 3, false, true>), reinterpret_cast<const void*>(&k_stft_pair<11, 3, false, true>),
-                            reinterpret_cast<const void*>(&k_stft_pair<12, 3, false, true>), reinterpret_cast<const void*>(&k_stft_pair<10, 3, true, true>),
-                            reinterpret_cast<const void*>(&k_stft_pair<11, 3, true, true>), reinterpret_cast<const void*>(&k_stft_pair<12, 3, true, true>)};
+                            reinterpret_cast<const void*>(&k_stft_pair<10, 3, false, 1>), reinterpret_cast<const void*>(&k_stft_pair<11, 3, false, 1>),
+                            reinterpret_cast<const void*>(&k_stft_pair<12, 3, false, 1>), reinterpret_cast<const void*>(&k_stft_pair<10, 3, true, 1>),
+                            reinterpret_cast<const void*>(&k_stft_pair<11, 3, true, 1>), reinterpret_cast<const void*>(&k_stft_pair<12, 3, true, 1>),
+                            reinterpret_cast<const void*>(&k_stft_pair<12, 3, false, 2>), reinterpret_cast<const void*>(&k_stft_pair<12, 3, true, 2>)};
     for (const void* f : pfns) {
         e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
@@ -2745,10 +2764,14 @@ void launch_stft_mel(const StftParams& p, int n_rows, int sample_is_pcm16, int n
     if (twl) hipLaunchKernelGGL((k_stft_pair<NW_, 3, true>), grid, dim3(64 * NW_), lds, s, p, n_rows);   \
     else hipLaunchKernelGGL((k_stft_pair<NW_, 3, false>), grid, dim3(64 * NW_), lds, s, p, n_rows);
 #define AMPH_PAIR_LAUNCH_K0(NW_)                                                                                  \
-    if (twl) hipLaunchKernelGGL((k_stft_pair<NW_, 3, true, true>), grid, dim3(64 * NW_), lds, s, p, n_rows);    \
-    else hipLaunchKernelGGL((k_stft_pair<NW_, 3, false, true>), grid, dim3(64 * NW_), lds, s, p, n_rows);
+    if (twl) hipLaunchKernelGGL((k_stft_pair<NW_, 3, true, 1>), grid, dim3(64 * NW_), lds, s, p, n_rows);    \
+    else hipLaunchKernelGGL((k_stft_pair<NW_, 3, false, 1>), grid, dim3(64 * NW_), lds, s, p, n_rows);
         (void)block;
-        if (p.k0_in) {                                  // (the caller has checked stft_pair_can_fuse_k0)
+        if (p.k0_in && p.k0_chunk_sums) {               // K0F 2 (12 waves only: the one-second rows of the benchmark)
+            if (twl) hipLaunchKernelGGL((k_stft_pair<12, 3, true, 2>), grid, dim3(64 * 12), lds, s, p, n_rows);
+            else hipLaunchKernelGGL((k_stft_pair<12, 3, false, 2>), grid, dim3(64 * 12), lds, s, p, n_rows);
+        }
+        else if (p.k0_in) {                             // (the caller has checked stft_pair_can_fuse_k0)
             if (nw == 11) { AMPH_PAIR_LAUNCH_K0(11) }
             else if (nw == 12) { AMPH_PAIR_LAUNCH_K0(12) }
             else { AMPH_PAIR_LAUNCH_K0(10) }
@@ -2911,6 +2934,12 @@ void launch_rms_scale_pcm16(const int16_t* in, long long row_stride, const int32
     }
     hipLaunchKernelGGL((k_rms_scale<int16_t, kRmsThreads, NpPass<int16_t>::kChunks>), dim3(n_rows), dim3(kRmsThreads), rms_scale_lds<int16_t>(), s, in, row_stride,
                        lengths, n_in, scale, ok, norm_out, pad, scale_f64, static_cast<float*>(nullptr), 0);
+}
+// K0's first kernel alone: the per-chunk sums of squares of every row (k_stft_pair<.., 2> folds them and normalises in its decode)
+void launch_rms_chunk_sums_pcm16(const int16_t* in, long long row_stride, const int32_t* lengths, int n_in, int n_rows, float* chunk_sums, hipStream_t s) {
+    const int n_chunks = rms_scale_chunks(n_in);
+    hipLaunchKernelGGL((k_rms_scale<int16_t, 256, 1>), dim3(n_rows, n_chunks), dim3(256), (rms_scale_lds<int16_t, 1>()), s, in, row_stride, lengths, n_in,
+                       static_cast<float*>(nullptr), static_cast<int32_t*>(nullptr), static_cast<int16_t*>(nullptr), NormPad{}, 1, chunk_sums, n_chunks);
 }
 // Rows that are NOT RMS-normalised here (apply_rms == 0: files 00_normalize_dataset_rms.py already processed), PCM16: the
 // same fix_length'd, centre-padded copy K0 writes, so that the independent-wave STFT kernel has no edge frames in this mode

@@ -513,6 +513,7 @@ def test_rms_normalize_inside_the_pair_kernel_is_bit_identical_to_its_own_launch
     cfg = env.PRESETS["bench-1s"]
     enc, tenc, spec = _encoders(env, "thesis-shape", cfg=cfg, max_batch=320)
     sess = enc.session(cfg)
+    DEFAULT_K0 = 1
     rng = np.random.default_rng(77)
     for n_rows, n_in, ragged in ((320, cfg.n_samples, False), (37, 30011, True), (300, 22050, True), (5, 32768, False)):
         pcm = env.synth(np.arange(500, 500 + n_rows), n_in, cfg.sr)
@@ -522,15 +523,16 @@ def test_rms_normalize_inside_the_pair_kernel_is_bit_identical_to_its_own_launch
             lens = rng.integers(1, n_in + 1, size=n_rows).astype(np.int32)
             lens[:6] = (n_in, n_in - 1, 1, 2, 1025, 8193)
         res = {}
-        for knob in (1, 0):
+        for knob in (1, 2, 0):                                              # 2: the chunk sums stay a launch, the rest is inside the pair kernel
             sess.configure("stft_k0_fuse", knob)
             mu, _, ok = sess.encode(pcm, lengths=lens, apply_rms=True)
             img = sess.mel_pcm16(pcm, lengths=lens, apply_rms=True, layout=1)
             res[knob] = (mu.clone(), ok.clone(), img.clone())
-        sess.configure("stft_k0_fuse", 1)
-        assert torch.equal(res[1][1], res[0][1]), (n_rows, n_in)
-        assert torch.equal(res[1][2], res[0][2]), (n_rows, n_in)
-        assert torch.equal(res[1][0], res[0][0]), (n_rows, n_in)
+        sess.configure("stft_k0_fuse", DEFAULT_K0)
+        for knob in (1, 2):
+            assert torch.equal(res[knob][1], res[0][1]), (knob, n_rows, n_in)
+            assert torch.equal(res[knob][2], res[0][2]), (knob, n_rows, n_in)
+            assert torch.equal(res[knob][0], res[0][0]), (knob, n_rows, n_in)
         assert torch.isfinite(res[1][0]).all()
         assert int(res[1][1][3]) == 0                                       # the silent row was gated
     # and the fused form against the oracle on a few rows of the plain case
