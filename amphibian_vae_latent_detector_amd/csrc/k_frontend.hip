@@ -1919,7 +1919,17 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
     AMPH_K0STAMP(1)
     // (the first pair's samples come from HBM: requested BEFORE the tables are staged, the two latencies overlap; with K0F the row
     // does not exist yet - it is fetched behind rms_scale_row)
-    if (!K0F && (int)blockIdx.x < n_rows && wave < ((p.n_frames + 1) >> 1)) fetch(blockIdx.x, wave);
+    // K0F: the order in which a row's pairs are drawn.  The two pairs at each end of a row touch the centre padding and take the per-sample
+    // path (more loads, a wait, code that is cold at its first use): they are neither the waves' first pairs (in front of the tables' barrier)
+    // nor the row's last (its tail), but the first four drawn from the queue - draw i -> pair i + 2 | 0, n - 2, 1, n - 1 | i - 2
+    const int n_pairs_k = (p.n_frames + 1) >> 1;
+    auto pair_of = [&](int i) {
+        if (!K0F || n_pairs_k < NW + 4) return i;
+        if (i < NW) return i + 2;
+        if (i < NW + 4) return (i - NW) & 1 ? n_pairs_k - 2 + ((i - NW) >> 1) : (i - NW) >> 1;
+        return i - 2;
+    };
+    if (K0F != 1 && (int)blockIdx.x < n_rows && wave < n_pairs_k) fetch(blockIdx.x, pair_of(wave));
     // (K0F: the raw row needs no K0 before it is read, but the first two pairs of a row touch the padding and their per-sample path waits for
     //  its loads: requested behind the tables' loads, below, so that the wait covers those too)
 
@@ -2024,9 +2034,10 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
         }
         // K0F: the first pair of the workgroup's FIRST row is requested here, behind the last barrier of the prologue - the two pairs at a row's
         // head touch the padding and take the per-sample path, whose (cold) code and wait would otherwise sit in front of a barrier everybody meets
-        if (K0F && row == (int)blockIdx.x && wave < n_pairs) fetch(row, wave);
+        if (K0F == 1 && row == (int)blockIdx.x && wave < n_pairs) fetch(row, pair_of(wave));
         float wmax = -INFINITY;                             // the largest mel power this wave has stored for the row (fused dB stage: its max pass)
-        for (int pr = wave, pr_next = 0; pr < n_pairs; pr = pr_next) {
+        for (int pi = wave, pr_next = 0; pi < n_pairs; pi = pr_next) {
+            const int pr = pair_of(pi);                     // (identity without K0F)
             // packed pairs: element j of the lane's TWO sequences (sample parity 0 / 1) side by side - dft16_pk
             amph_f2 XR[16], XI[16];
             float4 tw[16];
@@ -2221,7 +2232,7 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
                 pr_next = __builtin_amdgcn_readfirstlane(got);
                 int nrow = row, npr = pr_next;
                 if (npr >= n_pairs) { nrow = row + gridDim.x; npr = wave; }     // nothing left in this row: the wave's first pair of its next row
-                fetch(min(nrow, n_rows - 1), min(npr, n_pairs - 1));
+                fetch(min(nrow, n_rows - 1), pair_of(min(npr, n_pairs - 1)));
             }
             AMPH_PHASE_FENCE();
 #ifdef AMPH_STAMPS
