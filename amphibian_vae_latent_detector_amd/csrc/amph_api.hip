@@ -106,9 +106,7 @@ struct amph_ctx {
     int stft_pair_waves = 10;              // its workgroup: 8, 10, 11 or 12 waves; amph_create picks the largest whose LDS image, stage-1 twiddles
                                            // included, fits (1 s rows with the fused dB stage: 11 - 29 pairs on 11 waves are 3 rounds, at most 8 pairs per SIMD)
     bool stft_pair_tw_lds = true;          // its stage-1 twiddles in LDS when the image still fits
-    int stft_k0_fuse = 1;                  // rms_normalize inside k_stft_pair instead of K0's own launches (same bits): 1 = all of it, 2 = the chunk sums stay a launch
-    int4* d_k0_leaves = nullptr;           // numpy's summation tree for rows of k0_tab_n samples (k0_build_tree), rebuilt when the row length changes
-    int k0_tab_n = -1, k0_n_leaves = 0, k0_tree_d[4] = {-1, -1, -1, -1};
+    bool stft_k0_fuse = true;              // K0's fold + apply + padded copy inside k_stft_pair (its chunk sums stay a launch); same bits
     int mel_w_floats = 0, mel_p_tail = 0;
     int32_t *d_mel_start = nullptr, *d_mel_len = nullptr, *d_mel_wofs = nullptr;
     float* d_mel_w = nullptr;
@@ -1114,7 +1112,6 @@ int run_frontend(amph_ctx* c, Workspace& w, const void* d_wave, bool pcm16, int 
     src.scale = nullptr; src.requant = 0;
     bool k0 = false;                               // K0 runs inside the STFT kernel ("stft_k0_fuse")
     const float* k0_sums = nullptr;                // ... except its chunk sums (mode 2)
-    NormPad k0_pad{};
     int32_t* k0_ok = nullptr;
     if (apply_rms) {
         StageTimer t(c, ST_RMS, s);
@@ -1137,20 +1134,17 @@ int run_frontend(amph_ctx* c, Workspace& w, const void* d_wave, bool pcm16, int 
             if (rc != AMPH_OK) return rc;
             norm = w.norm16;
         }
-        // K0 inside the pair kernel: the workgroup that owns a row normalises it itself (rms_scale_row at the head of k_stft_pair's row loop) -
-        // no K0 launch; the STFT stage's timer then covers both
+        // K0's fold + apply inside the pair kernel (k_frontend.hip, K0F): only the per-chunk sums of squares are launched here; the kernel
+        // reads the raw rows and re-quantises in its decode - no padded normalised copy
         const bool k0_fused = pcm16 && norm && pad.lead > 0 && c->stft_k0_fuse && c->cfg.n_fft == 2048 && pair_path(c, true) &&
                               pair_lds(c, c->stft_pair_waves, db_out != nullptr) <= 160 * 1024 && stft_pair_can_fuse_k0(n_in, c->stft_pair_waves) &&
                               (n_in & 1) == 0 && (reinterpret_cast<uintptr_t>(d_wave) & 3u) == 0;      // (its dword loads: every row 4-byte aligned)
-        if (k0_fused && c->stft_k0_fuse == 2 && c->stft_pair_waves == 12) {
+        if (k0_fused) {
             const int rcs = ensure_chunk_sums(c, w, n_in, s);
             if (rcs != AMPH_OK) return rcs;
             launch_rms_chunk_sums_pcm16((const int16_t*)d_wave, n_in, d_len, n_in, nb, w.chunk_sums, s);
             k0 = true;
             k0_sums = w.chunk_sums;
-        } else if (k0_fused) {
-            t.cancel();
-            k0 = true;
         } else if (pcm16) {
             const int rcs = ensure_chunk_sums(c, w, n_in, s);
             if (rcs != AMPH_OK) return rcs;
@@ -1166,7 +1160,6 @@ int run_frontend(amph_ctx* c, Workspace& w, const void* d_wave, bool pcm16, int 
             src.wave = norm; src.scale = nullptr; src.requant = 0;
             if (pad.lead > 0) { src.lead = pad.lead; src.row_stride = pad.out_stride; src.lengths = nullptr; src.n_in = pad.n_fix + 2 * pad.lead; }
         }
-        k0_pad = pad;
     } else {
         if (d_rms_ok) (void)hipMemsetAsync(d_rms_ok, 0, (size_t)nb * sizeof(int32_t), s);
         // PCM16 rows used as they are: the same fix_length'd, centre-padded copy, by a copy kernel (timed with the RMS stage)
@@ -1190,24 +1183,8 @@ int run_frontend(amph_ctx* c, Workspace& w, const void* d_wave, bool pcm16, int 
             StftParams sp = make_stft(c, src, melpow, db_out, db_layout);
             if (k0) {
                 sp.k0_in = (const int16_t*)d_wave; sp.k0_row_stride = n_in; sp.k0_lengths = d_len; sp.k0_n_in = n_in;
-                sp.k0_scale_f64 = c->rms_f64_scale; sp.k0_scale = w.scale; sp.k0_ok = k0_ok; sp.k0_pad = k0_pad;
+                sp.k0_scale_f64 = c->rms_f64_scale; sp.k0_scale = w.scale; sp.k0_ok = k0_ok;
                 sp.k0_chunk_sums = k0_sums; sp.k0_chunk_stride = rms_scale_chunks(n_in);
-                if (!d_len && !k0_sums) {                                   // every row n_in samples long: the summation tree comes from the host
-                    if (c->k0_tab_n != n_in) {
-                        int lv[512][4];
-                        const int nl = k0_build_tree(n_in, lv, 512, c->k0_tree_d);
-                        if (nl > 0) {
-                            HIP_TRY(c, hipDeviceSynchronize());                // (earlier launches of any lane may still read the table: only when the row length changes)
-                            if (!c->d_k0_leaves) HIP_TRY(c, hipMalloc((void**)&c->d_k0_leaves, 512 * sizeof(int4)));
-                            HIP_TRY(c, hipMemcpy(c->d_k0_leaves, lv, (size_t)nl * sizeof(int4), hipMemcpyHostToDevice));
-                            c->k0_tab_n = n_in; c->k0_n_leaves = nl;
-                        } else { c->k0_tab_n = -1; c->k0_n_leaves = 0; }
-                    }
-                    if (c->k0_tab_n == n_in) {
-                        sp.k0_leaves = c->d_k0_leaves; sp.k0_n_leaves = c->k0_n_leaves;
-                        for (int q = 0; q < 4; ++q) sp.k0_tree_d[q] = c->k0_tree_d[q];
-                    }
-                }
             }
             launch_stft_mel(sp, nb, pcm16 ? 1 : 0, c->stft_waves, s);
         }
@@ -1390,7 +1367,6 @@ void amph_destroy(amph_ctx* c) {
     fr(c->d_fit_off); fr(c->d_fit_mu); fr(c->d_fit_stats); fr(c->d_fit_rho);
     fr(c->d_map_means); fr(c->d_map_prec); fr(c->d_map_logdet); fr(c->d_map_lprior);
     if (c->h_range_flag) (void)hipHostFree(c->h_range_flag);
-    fr(c->d_k0_leaves);
     for (int i = 0; i < 2; ++i) {
         if (c->pin_in[i]) (void)hipHostFree(c->pin_in[i]);
         fr(c->dev_in[i]); fr(c->dev_len[i]);
@@ -1415,7 +1391,7 @@ int amph_configure(amph_ctx* c, const char* key, int value) {
     if (!std::strcmp(key, "stft_fuse_db")) { c->stft_fuse_db = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "stft_pair")) { c->stft_pair = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "stft_pair_tw_lds")) { c->stft_pair_tw_lds = value != 0; return AMPH_OK; }
-    if (!std::strcmp(key, "stft_k0_fuse")) { if (value < 0 || value > 2) return AMPH_ERR_INVALID_ARG; c->stft_k0_fuse = value; return AMPH_OK; }
+    if (!std::strcmp(key, "stft_k0_fuse")) { c->stft_k0_fuse = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "stft_pair_waves")) {
         const bool okv = c->cfg.n_fft == 2048 ? (value == 8 || value == 10 || value == 11 || value == 12) : (value == 8 || value == 12);
         if (!okv) return fail(c, AMPH_ERR_INVALID_ARG, "stft_pair_waves must be 8, 10, 11 or 12 (n_fft 2048) / 8 or 12 (n_fft 1024)");

@@ -59,24 +59,17 @@ struct StftParams {
     int pair_mel_w_floats;
     int pair_waves;            // waves per workgroup of that kernel (8, 10 or 12)
     int pair_tw_lds;           // keep pair_tw1 in LDS when the image still fits 160 KB
-    // K0 inside k_stft_pair ("stft_k0_fuse", round 4): k0_in != nullptr -> the workgroup that owns a row runs rms_normalize on it first
-    // (rms_scale_row: numpy's summation order, the scale, the normalised / re-quantised / centre-padded PCM16 row written to src.wave,
-    // which its waves then read) - K0's two launches per batch are gone.  src describes the rows it WRITES (lead, row_stride).
+    // K0 inside k_stft_pair ("stft_k0_fuse", round 4; k_frontend.hip, K0F): k0_in != nullptr -> the kernel reads the RAW PCM16 rows, folds the
+    // per-chunk sums of squares K0's first kernel left in k0_chunk_sums into each row's scale and re-quantises in its decode; src then only
+    // describes the geometry (lead = n_fft / 2), its buffer is not read
     const int16_t* k0_in;      // raw PCM16 rows
     long long k0_row_stride;
     const int32_t* k0_lengths; // nullable
     int k0_n_in, k0_scale_f64;
     float* k0_scale;           // [B] out
     int32_t* k0_ok;            // [B] out (nullable)
-    NormPad k0_pad;
-    // rows of one common length (k0_lengths == nullptr): numpy's summation tree of that length, laid out by the host (k0_build_tree):
-    // per leaf (first element in the row, elements, heap node, -), and per numpy chunk the depth D of its tree when every leaf sits at
-    // depth D (then the chunk's tree is a butterfly over 2^D lanes), else -1; nullptr -> the kernel walks the tree itself
-    const float* k0_chunk_sums;   // nullable: K0F 2 - [B][k0_chunk_stride] sums of squares per numpy chunk, from launch_rms_chunk_sums_pcm16
+    const float* k0_chunk_sums;   // [B][k0_chunk_stride] sums of squares per numpy chunk (launch_rms_chunk_sums_pcm16)
     int k0_chunk_stride;
-    const int4* k0_leaves;
-    int k0_n_leaves;
-    int k0_tree_d[4];
     // per-context launch choices (were process-wide globals until round 3)
     int indep;                 // 1: k_stft_mel_w (independent waves), 0: the tile-synchronous k_stft_mel
     int grid_wgs;              // persistent workgroups; 0 = fill the chip
@@ -122,10 +115,7 @@ int stft_mel_scratch_floats(int n_fft);   // floats of per-frame scratch the pow
 hipError_t stft_mel_configure(int lds_bytes);   // raises the dynamic-LDS limit of the STFT kernels
 // the pair kernel (k_stft_pair): LDS image, packed table size, and the configurations it covers
 size_t stft_pair_lds_bytes(int n_frames, int n_mels, int mel_w_floats, int n_waves, bool fused);
-bool stft_pair_can_fuse_k0(int n_in, int n_waves);
-// numpy's pairwise-summation tree of a row of n float32 elements (n <= 4 chunks of 8 192): leaves as (first element, size, heap node = chunk * 256 +
-// node of the chunk's binary heap, 0) in chunk / slot order; tree_d[c] = depth of chunk c's tree when complete, else -1.  Returns the leaf count.
-int k0_build_tree(int n, int (*leaves)[4], int max_leaves, int tree_d[4]);      // K0 at the head of the row loop: the row fits one LDS pass aliased onto the waves' scratch
+bool stft_pair_can_fuse_k0(int n_in, int n_waves);      // the K0F form of k_stft_pair covers this row length / workgroup shape
 int stft_pair_table_bytes();
 size_t stft_pair_tw1_lds_bytes();
 bool stft_pair_ok(int n_fft, int hop, int p_tail);

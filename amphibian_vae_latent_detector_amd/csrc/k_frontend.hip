@@ -1577,161 +1577,20 @@ __device__ __forceinline__ void dft32_combine(float (&er)[16], float (&ei)[16], 
     }
 }
 
-// ---- K0 inside k_stft_pair (K0F, round 4): numpy's float32 sum(y^2) of ONE PCM16 row whose samples sit in an LDS image (np_lds_off layout,
-// heap in front of it: [4][256] floats), on the pair kernel's own threads.  Same leaves, same tree, same order as k_rms_scale (the
-// tests compare the two bit for bit); what differs is the mapping: a leaf block on a lane QUAD - lane q holds numpy's accumulators r[2q],
-// r[2q + 1], fed by one aligned dword per 8 elements; (r0 + r1) + (r2 + r3) and the rest of numpy's combine are two DPP butterflies - so
-// the ~175 leaves of a one-second row run on 700 lanes at once instead of 175; squares of the INTEGER samples (fl(q^2) 2^-30 == fl(y^2),
-// y = q / 32768: the power of two commutes with every rounding of the sum), scaled once at the end.
-__device__ __forceinline__ void k0_leaf_sums(char* smem, const int tid, const int n_threads, const int n) {
-#pragma clang fp contract(off)
-    float* heap = reinterpret_cast<float*>(smem);
-    const char* img = smem + 4 * 256 * 4;
-    const int n_chunks = (n + kNpChunk - 1) / kNpChunk;
-    const int q = tid & 3;
-    for (int s = tid >> 2; s < 4 * 128; s += n_threads >> 2) {
-        const int cl = s >> 7, slot = s & 127;
-        if (cl >= n_chunks) break;
-        const int cn = min(kNpChunk, n - cl * kNpChunk);
-        int off, size, lvl, rem = 0;
-        bool owner;
-        if (cn == kNpChunk) { off = (slot & 63) * kNpBlock; size = kNpBlock; lvl = 6; owner = slot < 64; }
-        else {
-            const int D = np_depth(cn);
-            owner = slot < (1 << D);
-            np_walk(cn, owner ? slot : 0, D, off, size, lvl);
-            rem = D - lvl;
-            owner = owner && (slot & ((1 << rem) - 1)) == 0;
-        }
-        if (!owner) continue;
-        const int eb = cl * kNpChunk + off;
-        auto sq = [&](int e) { const float y = (float)*reinterpret_cast<const int16_t*>(img + np_lds_off<int16_t>(e)); return y * y; };
-        float res;
-        if (size < 8) {
-            res = -0.0f;
-            for (int i = 0; i < size; ++i) res = res + sq(eb + i);
-        } else {
-            const int body = size - (size & 7);
-            float r0 = 0.0f, r1 = 0.0f;
-            for (int i = 0; i < body; i += 8) {
-                const uint32_t d = *reinterpret_cast<const uint32_t*>(img + np_lds_off<int16_t>(eb + i + 2 * q));     // (eb, i: multiples of 8 - aligned, inside one 128-block)
-                const float a = (float)(short)(d & 0xFFFFu), b = (float)((int)d >> 16);
-                const float sa = a * a, sb = b * b;
-                r0 = i == 0 ? sa : r0 + sa;
-                r1 = i == 0 ? sb : r1 + sb;
-            }
-            res = r0 + r1;
-            res = res + dpp_xor1(res);
-            res = res + dpp_xor2(res);
-            for (int i = body; i < size; ++i) res = res + sq(eb + i);
-        }
-        if (q == 0) heap[cl * 256 + (1 << lvl) + (slot >> rem)] = res;
-    }
-}
-// the same with the leaves laid out by the host (k0_build_tree: every row of the call has this length): no tree walk; the first round's table
-// entry was read with the row (lf0); a leaf's <= 16 dwords per lane are requested at once (a leaf never exceeds 128 elements)
-__device__ __forceinline__ void k0_leaf_sums_tab(char* smem, const int tid, const int n_threads, const int4* __restrict__ tab, const int n_leaves, const int4 lf0) {
-#pragma clang fp contract(off)
-    float* heap = reinterpret_cast<float*>(smem);
-    const char* img = smem + 4 * 256 * 4;
-    const int q = tid & 3;
-    for (int li = tid >> 2, rnd = 0; li < n_leaves; li += n_threads >> 2, ++rnd) {
-        const int4 lf = rnd == 0 ? lf0 : tab[li];
-        const int eb = lf.x, size = lf.y;
-        auto sq = [&](int e) { const float y = (float)*reinterpret_cast<const int16_t*>(img + np_lds_off<int16_t>(e)); return y * y; };
-        float res;
-        if (size < 8) {
-            res = -0.0f;
-            for (int i = 0; i < size; ++i) res = res + sq(eb + i);
-        } else {
-            const int body = size - (size & 7);
-            uint32_t d[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {                      // (eb: a multiple of 8 - every group of 8 lies inside one 128-element LDS row)
-                const int e = eb + 8 * i + 2 * q;
-                d[i] = 8 * i < body ? *reinterpret_cast<const uint32_t*>(img + np_lds_off<int16_t>(e)) : 0u;
-            }
-            float r0 = 0.0f, r1 = 0.0f;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float a = (float)(short)(d[i] & 0xFFFFu), c = (float)((int)d[i] >> 16);
-                const float sa = a * a, sb = c * c;
-                if (i == 0) { r0 = sa; r1 = sb; }
-                else if (8 * i < body) { r0 = r0 + sa; r1 = r1 + sb; }
-            }
-            res = r0 + r1;
-            res = res + dpp_xor1(res);
-            res = res + dpp_xor2(res);
-            for (int i = body; i < size; ++i) res = res + sq(eb + i);
-        }
-        if (q == 0) heap[lf.z] = res;
-    }
-}
-// a COMPLETE chunk tree (every leaf at depth D <= 6) on one wave: the 2^D leaves in lanes 0 .. 2^D - 1, node = left + right level by level
-// - a butterfly on the DPP network (sums are commutative: either operand order gives the node's bits).  -> the root, valid in one known lane
-__device__ __forceinline__ void k0_chunk_butterfly(char* smem, const int lane, const int cl, const int D) {
-#pragma clang fp contract(off)
-    float* heap = reinterpret_cast<float*>(smem);
-    float v = lane < (1 << D) ? heap[cl * 256 + (1 << D) + lane] : 0.0f;
-    int src = 0;
-    if (D >= 1) v = v + dpp_f<0xB1>(v);                   // quad_perm [1, 0, 3, 2]
-    if (D >= 2) v = v + dpp_f<0x4E>(v);                   // quad_perm [2, 3, 0, 1]
-    if (D >= 3) v = v + dpp_f<0x141>(v);                  // row_half_mirror
-    if (D >= 4) v = v + dpp_f<0x140>(v);                  // row_mirror
-    if (D >= 5) { v = v + dpp_f_rows<0x142, 0xA>(v, 0.0f); src = 31; }      // row_bcast:15 into rows 1, 3
-    if (D >= 6) { v = v + dpp_f_rows<0x143, 0xC>(v, 0.0f); src = 63; }      // row_bcast:31 into rows 2, 3
-    if (lane == src) heap[cl * 256 + 1] = v;
-    wave_lds_sync();
-}
-// the tree of ONE chunk on one wave (lane = path), deepest level first, value = left + right; wave-local ordering only
-__device__ __forceinline__ void k0_chunk_tree(char* smem, const int lane, const int cl, const int n) {
-#pragma clang fp contract(off)
-    float* heap = reinterpret_cast<float*>(smem);
-    const int cn = min(kNpChunk, n - cl * kNpChunk);
-    for (int lvl = 6; lvl >= 0; --lvl) {
-        if (lane < (1 << lvl)) {
-            bool internal = cn == kNpChunk && lvl < 6;
-            if (cn != kNpChunk) {
-                int off, size, reached;
-                np_walk(cn, lane, lvl, off, size, reached);
-                internal = reached == lvl && size > kNpBlock;
-            }
-            if (internal) heap[cl * 256 + (1 << lvl) + lane] = heap[cl * 256 + 2 * ((1 << lvl) + lane)] + heap[cl * 256 + 2 * ((1 << lvl) + lane) + 1];
-        }
-        wave_lds_sync();
-    }
-}
-// chunk roots -> (scale, scaled?) exactly as k_rms_scale's thread 0 (00_normalize_dataset_rms.py:30-36 in the pinned numpy's scalar arithmetic)
-__device__ __forceinline__ void k0_scale_from_roots(const char* smem, const int n, const int scale_f64, float& sc, int& good) {
-#pragma clang fp contract(off)
-    const float* heap = reinterpret_cast<const float*>(smem);
-    const int n_chunks = (n + kNpChunk - 1) / kNpChunk;
-    float total = 0.0f;
-    for (int cl = 0; cl < n_chunks; ++cl) total = cl == 0 ? heap[1] : total + heap[cl * 256 + 1];
-    total = total * (1.0f / 1073741824.0f);                 // the leaves summed fl(q^2): x 2^-30, exact
-    sc = 1.0f; good = 0;
-    if (n > 0) {
-        const float rms = sqrtf(total / (float)n);
-        if (scale_f64) { if (!((double)rms < 1e-4)) { sc = (float)(0.05 / ((double)rms + 1e-8)); good = 1; } }
-        else if (!(rms < 1e-4f)) { sc = 0.05f / (rms + 1e-8f); good = 1; }
-    }
-}
-
 // TWL: the stage-1 twiddles (15.5 KB) live in LDS and are read where they are used; otherwise they are buffer loads issued a phase
 // ahead (62 registers in flight across the first DFTs: at three waves per SIMD the allocator spills)
-// K0F (round 4): 00_normalize_dataset_rms.py's rms_normalize + PCM16 write / read of the row INSIDE this kernel (StftParams::k0_*) - K0's two
-// launches per batch and its 48 KB padded copy of every row are gone.  (1) The workgroup sums the row's squares in numpy's order at the
-// head of its row loop (k0_leaf_sums / k0_chunk_tree / k0_scale_from_roots; the row's LDS image is aliased onto the waves' scratch, which
-// is idle until the first pair; the row is requested before the tables are staged: one global round trip for both).  (2) The pairs read the
-// RAW rows: a 64-dword sample row of a pair is one aligned dword load per lane when it lies inside the valid samples, and librosa's
-// centre padding (reflect / zeros), fix_length's zero fill and truncation are index arithmetic on the few rows that touch them (two
-// pairs at each end of a one-second row).  (3) The decode re-quantises: q' = rint(clip(q sc, +-32768) 32767 / 32768) - bit for bit the
-// sample 00 writes to disk (the powers of two commute with the roundings) - once per dword (a sliding window shares it between frame a
-// and frame b), four vector instructions per sample.  First measured form (the row's workgroup WRITING the padded row and reading it
-// back): +12 us in this kernel for 16 us of K0 launches, -2 % end to end (profiles/r04_k0_fuse.txt).
-// K0F 2: as 1, but the per-chunk sums of squares come from K0's first kernel (k_rms_scale<int16_t, 256, 1>, StftParams::k0_chunk_sums): no row
-// image, no summation and no barrier in this kernel's prologue - every wave folds the row's <= 4 chunk sums into the scale itself
-template <int NW, int HJ, bool TWL, int K0F = 0>
+// K0F (round 4, "stft_k0_fuse"): 00_normalize_dataset_rms.py's rms_normalize + PCM16 write / read of the row inside this kernel, except the
+// per-chunk sums of squares, which stay K0's first kernel (k_rms_scale<int16_t, 256, 1>, StftParams::k0_chunk_sums); K0's second kernel
+// (fold + apply) and its 48 KB padded copy of every row are gone.  (1) Every wave folds the row's <= 4 chunk sums into the scale itself, in
+// numpy's order and the pinned numpy's scalar arithmetic (no LDS, no barrier).  (2) The pairs read the RAW rows: a pair whose samples all lie
+// inside the row (25 of a one-second row's 29) is the padded-row form's aligned dword loads; librosa's centre padding (reflect / zeros),
+// fix_length's zero fill and truncation are index arithmetic on the pairs that touch them - and those are drawn from the MIDDLE of the
+// row's queue (pair_of), neither in front of the tables' barrier nor in the row's tail.  (3) The decode re-quantises: q' = rint(clip(q sc,
+// +-32768) 32767 / 32768) - bit for bit the sample 00 writes to disk (the powers of two commute with the roundings) - once per dword (a
+// sliding window shares it between frame a and frame b), three vector instructions per sample.  Measured forms, incl. the two that put
+// the summation itself into this kernel's prologue and lost (cold one-shot code, the row's first touch from HBM with the whole CU waiting,
+// three barriers): profiles/r04_k0_fuse.txt.
+template <int NW, int HJ, bool TWL, bool K0F = false>
 __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows) {
     constexpr int kThreads = 64 * NW;
     constexpr int ND = 16 + HJ;                         // dwords per lane and pair
@@ -1772,14 +1631,6 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
 #define AMPH_PSTAMP(k_)
 #endif
 
-#ifdef AMPH_STAMPS
-    // K0F prologue timeline (thread 0; first region of the stamp buffer, printed by "dump_stamps" as the deltas of slots 0 .. 9):
-    // 0 start | 1 row requested | 2 tables' loads consumed | 3 image written | 4 first fetch | 5 barrier | 6 leaves | 7 barrier + trees + barrier | 8 scale | 9 barrier
-#define AMPH_K0STAMP(k_) if (K0F && tid == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); p.stamps[(size_t)blockIdx.x * 16 + (k_)] = t_; }
-#else
-#define AMPH_K0STAMP(k_)
-#endif
-    AMPH_K0STAMP(0)
     // the next pair's raw dwords: requested before the mel rows of the current pair
     uint32_t nx[ND];
 #pragma unroll
@@ -1850,75 +1701,7 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
             for (int j = 16; j < ND; ++j) nx[j] = full ? __builtin_amdgcn_raw_buffer_load_b32(rs_x, lane4, base + 256 * j, 0) : 0u;
         }
     };
-    // K0F: the row's samples for the sum of squares, requested here and written to the LDS image behind the tables' loads
-    // (16 bytes per lane and instruction: a CU's texture addresser takes ~16 cycles per wave instruction whatever its width - the row as dword
-    //  loads was 264 instructions per CU, 4 200 cycles of issue alone)
-    constexpr int K0U = K0F == 1 ? (4 * kNpChunk / 8 + kThreads - 1) / kThreads : 1;
-    uint4 rowv[K0U];
-    char* const k0_smem = smem + kTab + meta_bytes + melw_bytes;      // heap [4][256] floats | image: aliases the waves' scratch
-    int k0_n = 0;
-    int4 k0_leaf = make_int4(0, 0, 0, 0);                             // this lane quad's leaf of the host-built tree
-    auto k0_request = [&](int row_) {
-        k0_n = k0_row_len(row_);
-        const int rbase = __builtin_amdgcn_readfirstlane((int)((long long)row_ * p.k0_row_stride * 2));
-        const int nq = (k0_n + 7) >> 3;                       // (the last 16 bytes may run into the next row / 14 bytes past the input: the resource is unbounded
-                                                              //  and the allocation behind it is the caller's whole [B][n_in] matrix - the very last row reads dwords instead)
-        const bool last_row = row_ == n_rows - 1;
-#pragma unroll
-        for (int u = 0; u < K0U; ++u) {
-            const int d = tid + kThreads * u;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (d < nq) {
-                if (!last_row || 8 * d + 8 <= ((p.k0_n_in + 1) & ~1)) v = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_raw, 16 * d, rbase, 0));
-                else {
-                    const int nd_row = (p.k0_n_in + 1) >> 1;
-                    uint32_t w4[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) w4[e] = 4 * d + e < nd_row ? __builtin_amdgcn_raw_buffer_load_b32(rs_raw, 16 * d + 4 * e, rbase, 0) : 0u;
-                    v = make_uint4(w4[0], w4[1], w4[2], w4[3]);
-                }
-            }
-            rowv[u] = v;
-        }
-        if (p.k0_leaves && (tid >> 2) < p.k0_n_leaves) k0_leaf = p.k0_leaves[tid >> 2];
-    };
-    auto k0_image = [&]() {
-        const int nq = (k0_n + 7) >> 3;
-#pragma unroll
-        for (int u = 0; u < K0U; ++u) {
-            const int d = tid + kThreads * u;
-            if (d < nq) *reinterpret_cast<uint4*>(k0_smem + 4 * 256 * 4 + np_lds_off<int16_t>(8 * d)) = rowv[u];
-        }
-    };
     float k0_sc = 1.0f;                                      // the row's scale as the decode applies it (1 for a gated row)
-    // every thread, behind a barrier that follows k0_image(): leaves | barrier | one wave per chunk: its tree | barrier | every wave: the scale
-    auto k0_reduce = [&](int row_) {
-        int tid_o = tid;
-        asm volatile("" : "+v"(tid_o));                      // (opaque per row: nothing derived from it is hoisted across the pair loop)
-        AMPH_K0STAMP(5)
-        if (p.k0_leaves) k0_leaf_sums_tab(k0_smem, tid_o, kThreads, p.k0_leaves, p.k0_n_leaves, k0_leaf);
-        else k0_leaf_sums(k0_smem, tid_o, kThreads, k0_n);
-        AMPH_K0STAMP(6)
-        __syncthreads();
-        if (wave < ((k0_n + kNpChunk - 1) / kNpChunk)) {
-            const int D = p.k0_leaves ? p.k0_tree_d[wave & 3] : -1;       // (wave-uniform: a kernel argument)
-            if (D >= 0) k0_chunk_butterfly(k0_smem, tid_o & 63, wave, D);
-            else k0_chunk_tree(k0_smem, tid_o & 63, wave, k0_n);
-        }
-        __syncthreads();
-        AMPH_K0STAMP(7)
-        float sc_; int good_;
-        k0_scale_from_roots(k0_smem, k0_n, p.k0_scale_f64, sc_, good_);
-        if (tid == 0) { p.k0_scale[row_] = sc_; if (p.k0_ok) p.k0_ok[row_] = good_; }
-        k0_sc = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(good_ ? sc_ : 1.0f)));
-        AMPH_K0STAMP(8)
-        __syncthreads();                                     // the image is dead: the waves' scratch is theirs again
-        AMPH_K0STAMP(9)
-    };
-    if (K0F == 1 && (int)blockIdx.x < n_rows) k0_request(blockIdx.x);
-    AMPH_K0STAMP(1)
-    // (the first pair's samples come from HBM: requested BEFORE the tables are staged, the two latencies overlap; with K0F the row
-    // does not exist yet - it is fetched behind rms_scale_row)
     // K0F: the order in which a row's pairs are drawn.  The two pairs at each end of a row touch the centre padding and take the per-sample
     // path (more loads, a wait, code that is cold at its first use): they are neither the waves' first pairs (in front of the tables' barrier)
     // nor the row's last (its tail), but the first four drawn from the queue - draw i -> pair i + 2 | 0, n - 2, 1, n - 1 | i - 2
@@ -1929,9 +1712,7 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
         if (i < NW + 4) return (i - NW) & 1 ? n_pairs_k - 2 + ((i - NW) >> 1) : (i - NW) >> 1;
         return i - 2;
     };
-    if (K0F != 1 && (int)blockIdx.x < n_rows && wave < n_pairs_k) fetch(blockIdx.x, pair_of(wave));
-    // (K0F: the raw row needs no K0 before it is read, but the first two pairs of a row touch the padding and their per-sample path waits for
-    //  its loads: requested behind the tables' loads, below, so that the wait covers those too)
+    if ((int)blockIdx.x < n_rows && wave < n_pairs_k) fetch(blockIdx.x, pair_of(wave));
 
     // ---- once per workgroup: window pairs + stage-2 twiddles (one packed array), stage-1 twiddles (TWL), mel rows (x 1/4: see above).  Every load is requested before the
     //      first store: one global round trip (beside the sample fetch above), not one per table
@@ -1964,9 +1745,6 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
         for (int m = tid + kThreads; m < n_meta; m += kThreads) mel_meta[m] = msrc[m];
         if (tid < n_meta) mel_meta[tid] = mm_;
         if (tid == 0) *next_pair = NW;                   // pairs 0 .. NW - 1 are the waves' first ones
-        AMPH_K0STAMP(2)
-        if (K0F == 1 && (int)blockIdx.x < n_rows) k0_image();
-        AMPH_K0STAMP(3)
 #pragma unroll
         for (int u = 0; u < UW; ++u) { const int i = tid + kThreads * u; if (i < NWIN) dst[i] = vw[u]; }
 #pragma unroll
@@ -2009,13 +1787,7 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
     // a fixed pr = wave + 12 i the first waves idle at the end while the SIMD that drew the row's 29th pair still works
     float* const db_redf = reinterpret_cast<float*>(reinterpret_cast<double*>(mp_row + ((p.n_frames * p.n_mels + 3) & ~3)) + 16);   // db_row_from_lds's redf
     for (int row = blockIdx.x; row < n_rows; row += gridDim.x) {
-        if (K0F == 1) {
-            // (rows after the first: every wave is past the previous row's pairs and dB stage - barriers at the end of the loop body - so the
-            //  scratch is free for the image; the first pair of this row was requested at the end of the previous one)
-            if (row != (int)blockIdx.x) { k0_request(row); k0_image(); __syncthreads(); }
-            k0_reduce(row);
-        }
-        if (K0F == 2) {
+        if (K0F) {
 #pragma clang fp contract(off)
             // the chunk sums of K0's first kernel, folded in numpy's order (chunk 0 first) into the scale - k_rms_fold_apply's thread 0, on every wave
             const int n_ = k0_row_len(row);
@@ -2032,9 +1804,6 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
             if (tid == 0) { p.k0_scale[row] = sc_; if (p.k0_ok) p.k0_ok[row] = good_; }
             k0_sc = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(good_ ? sc_ : 1.0f)));
         }
-        // K0F: the first pair of the workgroup's FIRST row is requested here, behind the last barrier of the prologue - the two pairs at a row's
-        // head touch the padding and take the per-sample path, whose (cold) code and wait would otherwise sit in front of a barrier everybody meets
-        if (K0F == 1 && row == (int)blockIdx.x && wave < n_pairs) fetch(row, pair_of(wave));
         float wmax = -INFINITY;                             // the largest mel power this wave has stored for the row (fused dB stage: its max pass)
         for (int pi = wave, pr_next = 0; pi < n_pairs; pi = pr_next) {
             const int pr = pair_of(pi);                     // (identity without K0F)
@@ -2636,36 +2405,7 @@ size_t stft_pair2_tw1_lds_bytes() { return kP2Tw1Bytes; }
 bool stft_pair2_ok(int n_fft, int hop, int p_tail) { return n_fft == 1024 && hop == 256 && 513 + p_tail <= kP2PStride; }
 // the configurations the pair kernel covers (the caller also needs PCM16 rows padded by K0: src.lead == n_fft / 2)
 bool stft_pair_ok(int n_fft, int hop, int p_tail) { return n_fft == 2048 && hop == 384 && 1025 + p_tail <= kPairPStride; }
-int k0_build_tree(int n, int (*leaves)[4], int max_leaves, int tree_d[4]) {
-    auto split = [](int m) { const int h = m >> 1; return h - (h & 7); };
-    int count = 0;
-    for (int c = 0; c < 4; ++c) tree_d[c] = -1;
-    const int n_chunks = (n + kNpChunk - 1) / kNpChunk;
-    for (int c = 0; c < n_chunks && c < 4; ++c) {
-        const int cn = std::min(kNpChunk, n - c * kNpChunk);
-        int D = 0;
-        for (int m = cn; m > kNpBlock; m -= split(m)) ++D;          // depth of the deepest leaf (the right child is never smaller)
-        bool complete = true;
-        for (int slot = 0; slot < (1 << D); ++slot) {
-            int off = 0, m = cn, l = 0;
-            for (; l < D && m > kNpBlock; ++l) {
-                const int m2 = split(m);
-                if ((slot >> (D - 1 - l)) & 1) { off += m2; m -= m2; } else m = m2;
-            }
-            const int rem = D - l;
-            if (slot & ((1 << rem) - 1)) continue;                  // an early leaf belongs to the slot with zero low bits
-            if (rem) complete = false;
-            if (count >= max_leaves) return -1;
-            leaves[count][0] = c * kNpChunk + off; leaves[count][1] = m; leaves[count][2] = c * 256 + (1 << l) + (slot >> rem); leaves[count][3] = 0;
-            ++count;
-        }
-        tree_d[c] = complete ? D : -1;
-    }
-    return count;
-}
-bool stft_pair_can_fuse_k0(int n_in, int n_waves) {
-    return n_in > 0 && n_in <= 4 * kNpChunk && n_waves >= 10 && rms_scale_lds<int16_t, 4>() <= (size_t)n_waves * kPairScratch;
-}
+bool stft_pair_can_fuse_k0(int n_in, int n_waves) { return n_in > 0 && n_in <= 4 * kNpChunk && n_waves == 12; }
 
 static int table_bytes_for(int n_fft) { return n_fft == 2048 ? FftGeo<4>::TABLE_BYTES : FftGeo<2>::TABLE_BYTES; }
 
@@ -2711,14 +2451,11 @@ hipError_t stft_mel_configure(int lds_bytes) {
         e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
     }
-    const void* pfns[16] = {reinterpret_cast<const void*>(&k_stft_pair<8, 3, false>), reinterpret_cast<const void*>(&k_stft_pair<10, 3, false>),
+    const void* pfns[10] = {reinterpret_cast<const void*>(&k_stft_pair<8, 3, false>), reinterpret_cast<const void*>(&k_stft_pair<10, 3, false>),
                             reinterpret_cast<const void*>(&k_stft_pair<11, 3, false>), reinterpret_cast<const void*>(&k_stft_pair<12, 3, false>),
                             reinterpret_cast<const void*>(&k_stft_pair<8, 3, true>), reinterpret_cast<const void*>(&k_stft_pair<10, 3, true>),
                             reinterpret_cast<const void*>(&k_stft_pair<11, 3, true>), reinterpret_cast<const void*>(&k_stft_pair<12, 3, true>),
-                            reinterpret_cast<const void*>(&k_stft_pair<10, 3, false, 1>), reinterpret_cast<const void*>(&k_stft_pair<11, 3, false, 1>),
-                            reinterpret_cast<const void*>(&k_stft_pair<12, 3, false, 1>), reinterpret_cast<const void*>(&k_stft_pair<10, 3, true, 1>),
-                            reinterpret_cast<const void*>(&k_stft_pair<11, 3, true, 1>), reinterpret_cast<const void*>(&k_stft_pair<12, 3, true, 1>),
-                            reinterpret_cast<const void*>(&k_stft_pair<12, 3, false, 2>), reinterpret_cast<const void*>(&k_stft_pair<12, 3, true, 2>)};
+                            reinterpret_cast<const void*>(&k_stft_pair<12, 3, false, true>), reinterpret_cast<const void*>(&k_stft_pair<12, 3, true, true>)};
     for (const void* f : pfns) {
         e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
@@ -2774,25 +2511,16 @@ void launch_stft_mel(const StftParams& p, int n_rows, int sample_is_pcm16, int n
 #define AMPH_PAIR_LAUNCH(NW_)                                                                              \
     if (twl) hipLaunchKernelGGL((k_stft_pair<NW_, 3, true>), grid, dim3(64 * NW_), lds, s, p, n_rows);   \
     else hipLaunchKernelGGL((k_stft_pair<NW_, 3, false>), grid, dim3(64 * NW_), lds, s, p, n_rows);
-#define AMPH_PAIR_LAUNCH_K0(NW_)                                                                                  \
-    if (twl) hipLaunchKernelGGL((k_stft_pair<NW_, 3, true, 1>), grid, dim3(64 * NW_), lds, s, p, n_rows);    \
-    else hipLaunchKernelGGL((k_stft_pair<NW_, 3, false, 1>), grid, dim3(64 * NW_), lds, s, p, n_rows);
         (void)block;
-        if (p.k0_in && p.k0_chunk_sums) {               // K0F 2 (12 waves only: the one-second rows of the benchmark)
-            if (twl) hipLaunchKernelGGL((k_stft_pair<12, 3, true, 2>), grid, dim3(64 * 12), lds, s, p, n_rows);
-            else hipLaunchKernelGGL((k_stft_pair<12, 3, false, 2>), grid, dim3(64 * 12), lds, s, p, n_rows);
-        }
-        else if (p.k0_in) {                             // (the caller has checked stft_pair_can_fuse_k0)
-            if (nw == 11) { AMPH_PAIR_LAUNCH_K0(11) }
-            else if (nw == 12) { AMPH_PAIR_LAUNCH_K0(12) }
-            else { AMPH_PAIR_LAUNCH_K0(10) }
+        if (p.k0_in) {                                  // K0F (12 waves: the one-second rows of the benchmark; the caller has checked)
+            if (twl) hipLaunchKernelGGL((k_stft_pair<12, 3, true, true>), grid, dim3(64 * 12), lds, s, p, n_rows);
+            else hipLaunchKernelGGL((k_stft_pair<12, 3, false, true>), grid, dim3(64 * 12), lds, s, p, n_rows);
         }
         else if (nw == 8) { AMPH_PAIR_LAUNCH(8) }
         else if (nw == 11) { AMPH_PAIR_LAUNCH(11) }
         else if (nw == 12) { AMPH_PAIR_LAUNCH(12) }
         else { AMPH_PAIR_LAUNCH(10) }
 #undef AMPH_PAIR_LAUNCH
-#undef AMPH_PAIR_LAUNCH_K0
         return;
     }
     if (p.pair_tables && sample_is_pcm16 && p.src.lead == p.n_fft / 2 && stft_pair2_ok(p.n_fft, p.hop, p.p_tail)) {
