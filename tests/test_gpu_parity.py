@@ -631,10 +631,11 @@ def test_fp16_split_range_guard_images_weights_and_activations(env, capsys):
         warnings.simplefilter("always")
         z, _, _ = enc_h2.session(cfg).encode(pcm, apply_rms=True)
     assert any("fp16" in str(r.message) for r in rec)
-    _assert_latents(z.cpu().numpy(), z_o)
+    # (per-row relative L2: the latents of this checkpoint reach 4e4, an element near zero is a cancellation in ANY fp32 evaluation)
+    assert worst(z.cpu().numpy(), z_o) <= 1e-5
     enc_h3 = env.HipEncoder(spec, hot, DEV, max_batch=16)
     z_h, _ = enc_h3.session(cfg).encode_host(pcm, apply_rms=True)
-    _assert_latents(z_h, z_o)
+    assert worst(z_h, z_o) <= 1e-5
     assert np.array_equal(z_h, z.cpu().numpy())           # both ended on the same f32-MFMA kernels
     with capsys.disabled():
         print("\n[fp16 split range guard] max rel L2 of the latents vs torch-CPU fp32: " + "; ".join(report))
