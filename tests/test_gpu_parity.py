@@ -543,6 +543,49 @@ def test_rms_normalize_inside_the_pair_kernel_is_bit_identical_to_its_own_launch
     _assert_latents(z.cpu().numpy(), _oracle_latents(env, tenc, pcm, cfg))
 
 
+def test_normalize_dataset_rms_tool_writes_what_00_writes(env, tmp_path, capsys):
+    """00_normalize_dataset_rms.py's process_folder / main (:41-81) on K0: `<split>_norm/<species>/<name>.wav` for every file of every
+    split that exists, mono PCM16 at --sr, also for a file the silence gate leaves unchanged (:55-57).  The bytes of each output file
+    must equal the oracle's float_to_pcm16(rms_normalize(pcm16_to_float(q))) - the whole file, whatever its length; a stereo file goes
+    through the general loader (channel mean) and the float32 kernel."""
+    from amphibian_vae_latent_detector_amd import normalize_dataset_rms as nd
+    from amphibian_vae_latent_detector_amd import synth
+    sr = 22050
+    base = tmp_path / "lse"
+    files = {}
+    for split, sp, specs in (("train_chunks", "Boana_faber", [(0, 22050), (1, 22050), (49, 22050), (3, 30011)]),
+                             ("train_chunks", "Scinax_sp", [(4, 22050), (5, 9001)]),
+                             ("val_chunks", "Boana_faber", [(6, 22050)])):
+        d = base / split / sp
+        d.mkdir(parents=True)
+        for i, n in specs:
+            q = synth.synth_chunk_pcm16(i, n, sr)
+            synth.write_wav_pcm16(d / f"chunk_{i:06d}.wav", q, sr)
+            files[(split, sp, f"chunk_{i:06d}.wav")] = q
+    st = np.stack([synth.synth_chunk_pcm16(7, 8000, sr), synth.synth_chunk_pcm16(8, 8000, sr)], axis=1)
+    synth.write_wav_pcm16(base / "val_chunks" / "Boana_faber" / "stereo.wav", st, sr)
+    assert nd.main(["--base-dir", str(base), "--sr", str(sr)]) == 0
+    out = capsys.readouterr().out
+    assert "No existe" in out and "test_chunks" in out and "Dataset normalizado listo" in out         # the missing split is reported, as 00 does
+    assert not (base / "test_chunks_norm").exists()
+    for (split, sp, name), q in files.items():
+        got, rate = env.ofe.read_wav_pcm16(base / f"{split}_norm" / sp / name)
+        got = got[:, 0]
+        want = env.ofe.float_to_pcm16(env.ofe.rms_normalize(env.ofe.pcm16_to_float(q))[0])
+        assert rate == sr and got.shape == want.shape and np.array_equal(got, want), (split, sp, name)
+    silent, _ = env.ofe.read_wav_pcm16(base / "train_chunks_norm" / "Boana_faber" / "chunk_000049.wav")
+    assert not silent.any()                                                                           # written although gated
+    got, _ = env.ofe.read_wav_pcm16(base / "val_chunks_norm" / "Boana_faber" / "stereo.wav")
+    got = got[:, 0]
+    y = (st.astype(np.float32) / np.float32(32768.0)).mean(axis=1).astype(np.float32)
+    want = env.ofe.float_to_pcm16(env.ofe.rms_normalize(y)[0])
+    assert got.shape == want.shape and np.abs(got.astype(np.int32) - want.astype(np.int32)).max() <= 1
+    # the single-signal function of the same module
+    y1, ok1 = nd.rms_normalize(env.ofe.pcm16_to_float(files[("train_chunks", "Boana_faber", "chunk_000000.wav")]))
+    w1, wok = env.ofe.rms_normalize(env.ofe.pcm16_to_float(files[("train_chunks", "Boana_faber", "chunk_000000.wav")]))
+    assert ok1 == bool(wok) and np.array_equal(y1, w1)
+
+
 def test_fp16_split_range_guard_images_weights_and_activations(env, capsys):
     """The reference's encoder is an fp32 nn.Module loaded from ANY checkpoint (map_detector_core.py:160-179, strict=False) and called
     on any tensor (:270); the default GEMM arithmetic here splits fp32 operands into two fp16 terms, which exist below 65 504 only
