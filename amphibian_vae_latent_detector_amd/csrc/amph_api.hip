@@ -94,6 +94,9 @@ struct amph_ctx {
     float* d_tables = nullptr;             // packed LDS image of the STFT tables
     float2* d_tw_a = nullptr;              // stage-A twiddles (global memory)
     std::vector<unsigned char> radial_key; // the detector (K, D, centroids, thresholds, ranks) last uploaded for K6
+    bool generic_stft = false;             // n_fft other than 1024 / 2048, or an odd hop: k_stft_generic (+ the separate dB kernel)
+    float* d_gen_win = nullptr;            // ... its periodic Hann window [n_fft]
+    float2* d_gen_tw = nullptr;            // ... and twiddles W_n^k, k < n_fft / 2
     float* d_pair_tables = nullptr;        // k_stft_pair: window pairs + stage-2 twiddles (packed LDS image); nullptr: configuration not covered
     float2* d_pair_tw1 = nullptr;          // k_stft_pair: stage-1 twiddles (global memory)
     int32_t* d_pair_mel_meta = nullptr;    // k_stft_pair: per (round, lane quad) (start bin, steps, weight offset, output band) - build_pair_mel
@@ -421,9 +424,12 @@ static void build_pair_mel(const std::vector<float>& basis, int n_mels, int F, s
 
 int build_frontend(amph_ctx* c) {
     const amph_frontend_config& f = c->cfg;
-    if (f.n_fft != 2048 && f.n_fft != 1024)
-        return fail(c, AMPH_ERR_UNSUPPORTED, "n_fft=%d: this build implements n_fft = 1024 and 2048", f.n_fft);
-    if (f.hop_length <= 0 || (f.hop_length & 1)) return fail(c, AMPH_ERR_UNSUPPORTED, "hop_length must be positive and even");
+    // the tuned kernels cover n_fft 1024 / 2048 with an even hop; every other power of two from 64 to 8192 and any hop take the general
+    // kernel (k_stft_generic).  librosa also accepts an n_fft that is no power of two (map_detector_core.py:219-228): not implemented.
+    if (f.n_fft < 64 || f.n_fft > 8192 || (f.n_fft & (f.n_fft - 1)))
+        return fail(c, AMPH_ERR_UNSUPPORTED, "n_fft=%d: this build implements the powers of two from 64 to 8192", f.n_fft);
+    if (f.hop_length <= 0) return fail(c, AMPH_ERR_INVALID_ARG, "hop_length must be positive");
+    c->generic_stft = (f.n_fft != 2048 && f.n_fft != 1024) || (f.hop_length & 1);
     if (f.n_samples <= 0 || f.n_mels <= 0 || f.target_frames <= 0 || f.sr <= 0)
         return fail(c, AMPH_ERR_INVALID_ARG, "non-positive front-end parameter");
     if (f.pad_mode == 0 && f.n_samples <= f.n_fft / 2)
@@ -434,10 +440,21 @@ int build_frontend(amph_ctx* c) {
 
     const int n_fft = f.n_fft, Nc = n_fft / 2, TLO = Nc / 256, L = 16 * TLO;
     const double PI = 3.14159265358979323846;
+    if (c->generic_stft) {
+        std::vector<float> gw(n_fft);
+        std::vector<float2> gt(n_fft / 2);
+        for (int n = 0; n < n_fft; ++n) gw[n] = (float)(0.5 - 0.5 * std::cos(2.0 * PI * (double)n / (double)n_fft));      // scipy get_window("hann", fftbins=True)
+        for (int k = 0; k < n_fft / 2; ++k) {
+            const double a = -2.0 * PI * (double)k / (double)n_fft;
+            gt[k] = make_float2((float)std::cos(a), (float)std::sin(a));
+        }
+        HIP_TRY(c, upload(&c->d_gen_win, gw));
+        HIP_TRY(c, upload(&c->d_gen_tw, gt));
+    }
     // packed table image (layout = the kernel's LDS image): half window | tw_b | tw_post; tw_a separately
-    std::vector<float> tab(stft_mel_table_bytes(n_fft) / 4, 0.0f);
-    std::vector<float2> twa(15 * L);
-    {
+    std::vector<float> tab(c->generic_stft ? 0 : stft_mel_table_bytes(n_fft) / 4, 0.0f);
+    std::vector<float2> twa(c->generic_stft ? 0 : 15 * L);
+    if (!c->generic_stft) {
         float* win = tab.data();                                  // w[0..1024]; w[n] == w[N - n] covers the rest
         for (int n = 0; n <= n_fft / 2; ++n) win[n] = (float)(0.5 - 0.5 * std::cos(2.0 * PI * (double)n / (double)n_fft));
         for (int k1 = 1; k1 < 16; ++k1)
@@ -459,8 +476,10 @@ int build_frontend(amph_ctx* c) {
             twp[2 * k + 1] = (float)std::sin(a);
         }
     }
-    HIP_TRY(c, upload(&c->d_tw_a, twa));
-    HIP_TRY(c, upload(&c->d_tables, tab));
+    if (!c->generic_stft) {
+        HIP_TRY(c, upload(&c->d_tw_a, twa));
+        HIP_TRY(c, upload(&c->d_tables, tab));
+    }
 
     const int F = 1 + n_fft / 2;
     c->mel_basis = mel_filterbank(f.sr, n_fft, f.n_mels, f.fmin, f.fmax);
@@ -496,7 +515,7 @@ int build_frontend(amph_ctx* c) {
         }
     }
     c->mel_p_tail = std::max(p_tail, 0);
-    if (F + c->mel_p_tail > stft_mel_scratch_floats(n_fft))
+    if (!c->generic_stft && F + c->mel_p_tail > stft_mel_scratch_floats(n_fft))
         return fail(c, AMPH_ERR_UNSUPPORTED, "mel rows reach past the per-frame scratch");
     HIP_TRY(c, upload(&c->d_mel_start, st));
     HIP_TRY(c, upload(&c->d_mel_len, ln));
@@ -505,7 +524,7 @@ int build_frontend(amph_ctx* c) {
     HIP_TRY(c, upload(&c->d_mel_w, wv));
     // k_stft_pair (n_fft 2048, hop 384): lane l reads samples 128 j' + 2 l + e and owns column col(l) = 2 (l & 31) + (l >> 5)
     // of the first stage (tools/fft_pair_model.py)
-    if (stft_pair_ok(n_fft, f.hop_length, c->mel_p_tail)) {
+    if (!c->generic_stft && stft_pair_ok(n_fft, f.hop_length, c->mel_p_tail)) {
         std::vector<float> pt(stft_pair_table_bytes() / 4, 0.0f);
         // lane l reads dword dw(l) of every 64-dword sample row (k_stft_pair: lanes l, l + 16 share a column pair)
         auto lane_dw = [](int l) { return (l & 15) + 16 * (l >> 5) + 32 * ((l >> 4) & 1); };
@@ -548,7 +567,7 @@ int build_frontend(amph_ctx* c) {
         HIP_TRY(c, upload(&c->d_pair_mel_w, pw));
     }
     // k_stft_pair2 (n_fft 1024, hop 256): lane' l (0..31) reads samples 64 j' + 2 l + e and owns column 2 (l & 15) + (l >> 4)
-    if (stft_pair2_ok(n_fft, f.hop_length, c->mel_p_tail)) {
+    if (!c->generic_stft && stft_pair2_ok(n_fft, f.hop_length, c->mel_p_tail)) {
         std::vector<float> pt(stft_pair2_table_bytes() / 4, 0.0f);
         for (int j = 0; j < 16; ++j)
             for (int l = 0; l < 32; ++l)
@@ -1068,7 +1087,7 @@ bool pair_path(const amph_ctx* c, bool pcm16) {
 }
 // pcm16_rows: the call's input is PCM16 (those rows take a pair kernel when the context has one)
 bool can_fuse_db(const amph_ctx* c, bool pcm16_rows = false) {
-    if (!c->stft_fuse_db || !c->stft_indep) return false;
+    if (!c->stft_fuse_db || !c->stft_indep || c->generic_stft) return false;
     if (pair_path(c, pcm16_rows)) return pair_lds(c, c->stft_pair_waves, true) <= 160 * 1024;
     return stft_mel_can_fuse_db(c->cfg.n_fft, c->n_frames, c->cfg.n_mels, c->mel_w_floats, c->stft_waves);
 }
@@ -1123,7 +1142,7 @@ int run_frontend(amph_ctx* c, Workspace& w, const void* d_wave, bool pcm16, int 
         // redo it for the 81 % of a frame they share with their neighbours (6 VALU instructions per sample against 2 for a
         // plain PCM16 decode)
         NormPad pad{};
-        if (pcm16 && c->stft_prenorm) {
+        if (pcm16 && c->stft_prenorm && !c->generic_stft) {
             // with the independent-wave STFT kernel the rows are written as that kernel wants to read them: fix_length'd and
             // centre padded, so that no frame needs index reflection
             if (c->stft_indep && c->stft_prepad) {
@@ -1163,7 +1182,7 @@ int run_frontend(amph_ctx* c, Workspace& w, const void* d_wave, bool pcm16, int 
     } else {
         if (d_rms_ok) (void)hipMemsetAsync(d_rms_ok, 0, (size_t)nb * sizeof(int32_t), s);
         // PCM16 rows used as they are: the same fix_length'd, centre-padded copy, by a copy kernel (timed with the RMS stage)
-        if (pcm16 && c->stft_prenorm && c->stft_prepad && c->stft_indep) {
+        if (pcm16 && c->stft_prenorm && c->stft_prepad && c->stft_indep && !c->generic_stft) {
             StageTimer t(c, ST_RMS, s);
             NormPad pad{};
             pad.lead = c->cfg.n_fft / 2; pad.n_fix = c->cfg.n_samples; pad.mode = c->cfg.pad_mode;
@@ -1186,7 +1205,8 @@ int run_frontend(amph_ctx* c, Workspace& w, const void* d_wave, bool pcm16, int 
                 sp.k0_scale_f64 = c->rms_f64_scale; sp.k0_scale = w.scale; sp.k0_ok = k0_ok;
                 sp.k0_chunk_sums = k0_sums; sp.k0_chunk_stride = rms_scale_chunks(n_in);
             }
-            launch_stft_mel(sp, nb, pcm16 ? 1 : 0, c->stft_waves, s);
+            if (c->generic_stft) launch_stft_generic(sp, nb, pcm16 ? 1 : 0, c->d_gen_win, c->d_gen_tw, s);
+            else launch_stft_mel(sp, nb, pcm16 ? 1 : 0, c->stft_waves, s);
         }
     }
     return AMPH_OK;
@@ -1305,13 +1325,17 @@ int amph_create(const amph_frontend_config* cfg, const amph_encoder_spec* spec, 
         // wave-iteration of frames per tile when that fits the 160 KB of LDS, else 4 waves x 8 frames.
         // The kernel is bound by the LDS round trips of a frame, so the third wave per SIMD is worth
         // 73 -> 52 us per 256 one-second chunks (tools/sweep.py frames_per_block=8,12 stft_waves=4,12).
-        {
+        if (!c->generic_stft) {
             const int slots = c->cfg.n_fft == 2048 ? 1 : 2;
             const size_t l12 = stft_mel_lds_bytes(c->cfg.n_fft, c->cfg.hop_length, 12 * slots, c->cfg.n_mels, c->mel_w_floats, 12);
             if (l12 <= 160 * 1024) { c->stft_waves = 12; c->frames_per_block = 12 * slots; }
         }
-        int lds = (int)stft_mel_lds_bytes(c->cfg.n_fft, c->cfg.hop_length, c->frames_per_block, c->cfg.n_mels, c->mel_w_floats, c->stft_waves);
-        if (lds > 160 * 1024) rc = fail(c, AMPH_ERR_UNSUPPORTED, "frame tile needs %d bytes of LDS", lds);
+        int lds = c->generic_stft ? 0 : (int)stft_mel_lds_bytes(c->cfg.n_fft, c->cfg.hop_length, c->frames_per_block, c->cfg.n_mels, c->mel_w_floats, c->stft_waves);
+        if (c->generic_stft) {
+            if ((size_t)(c->cfg.n_fft / 2 + 1 + c->mel_p_tail) * 4 > (size_t)c->cfg.n_fft * 8) rc = fail(c, AMPH_ERR_UNSUPPORTED, "mel rows reach past the frame's LDS");
+            else if (amph::stft_mel_configure(1) != hipSuccess) rc = fail(c, AMPH_ERR_HIP, "hipFuncSetAttribute failed");       // (K0's kernels: their LDS limit is raised there too)
+        }
+        else if (lds > 160 * 1024) rc = fail(c, AMPH_ERR_UNSUPPORTED, "frame tile needs %d bytes of LDS", lds);
         else {
             for (int nw : {4, 12})                  // the fused dB stage keeps a row's mel power in LDS too
                 if (stft_mel_can_fuse_db(c->cfg.n_fft, c->n_frames, c->cfg.n_mels, c->mel_w_floats, nw))
@@ -1355,6 +1379,7 @@ void amph_destroy(amph_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     auto fr = [](void* p) { if (p) (void)hipFree(p); };
+    fr(c->d_gen_win); fr(c->d_gen_tw);
     fr(c->d_tables); fr(c->d_tw_a); fr(c->d_pair_tables); fr(c->d_pair_tw1); fr(c->d_pair_mel_meta); fr(c->d_pair_mel_w);
     fr(c->d_mel_start); fr(c->d_mel_len); fr(c->d_mel_wofs); fr(c->d_mel_w);
     fr(c->d_first_w); fr(c->d_first_scale); fr(c->d_first_shift);

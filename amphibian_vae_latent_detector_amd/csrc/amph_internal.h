@@ -125,6 +125,8 @@ int stft_pair2_table_bytes();
 size_t stft_pair2_tw1_lds_bytes();
 bool stft_pair2_ok(int n_fft, int hop, int p_tail);
 void launch_dbnorm(const DbNormParams& p, int n_rows, hipStream_t s);
+// the general STFT + mel kernel: any power-of-two n_fft in 64 .. 8192, any hop (win: [n_fft] periodic Hann, tw: [n_fft / 2] W_n^k; melpow only)
+void launch_stft_generic(const StftParams& p, int n_rows, int sample_is_pcm16, const float* win, const float2* tw, hipStream_t s);
 
 struct ResampleParams {      // resampy's resample_f for rows of equal length
     const float* x;          // [rows][in_stride]

@@ -2543,6 +2543,78 @@ void launch_stft_mel(const StftParams& p, int n_rows, int sample_is_pcm16, int n
 }
 
 // ----------------------------------------------------------------------------
+// K1/K2, general form (round 4): any power-of-two n_fft from 64 to 8192 and ANY hop_length - every reference CLI exposes both
+// (07_encode_wav_to_latent.py:429-430, 08_fit_radial_detector.py:353-354) and librosa.feature.melspectrogram takes any value
+// (map_detector_core.py:219-228); the tuned kernels above cover n_fft 1024 / 2048 with an even hop.  One 256-thread workgroup per
+// (frame, row): fix_length + centre padding (reflect / zeros) + RMS scale / PCM16 re-quantisation as index arithmetic and
+// normalise_sample per sample, periodic Hann window, an in-place radix-2 FFT of the frame in LDS (bit-reversed load, one barrier per
+// stage, twiddles from a host table), |X|^2, the mel rows from the same tables the tuned kernels read.  Not tuned: it exists so
+// that a configuration the reference accepts is not refused.
+// ----------------------------------------------------------------------------
+template <bool PCM16>
+__global__ __launch_bounds__(256) void k_stft_generic(StftParams p, const float* __restrict__ win, const float2* __restrict__ tw, int log2n) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2* x = reinterpret_cast<float2*>(smem);           // [n_fft] complex; afterwards the power spectrum (float [n_fft/2 + 1 + tail]) in front
+    const int tid = threadIdx.x, t = blockIdx.x, row = blockIdx.y;
+    const int n = p.n_fft, N = p.n_samples;
+    const char* rowp = reinterpret_cast<const char*>(p.src.wave) + (long long)row * p.src.row_stride * (PCM16 ? 2 : 4);
+    const int len = min(p.src.lengths ? min(p.src.lengths[row], p.src.n_in) : p.src.n_in, N);      // fix_length: truncate / zero pad to N
+    const float sc = p.src.scale ? p.src.scale[row] : 1.0f;
+    for (int i = tid; i < n; i += 256) {
+        int sidx = t * p.hop + i - (n >> 1);                // centre = True: the frame starts n_fft / 2 before t * hop
+        bool pad0 = false;
+        if (p.pad_mode == 0) {                              // np.pad(mode="reflect")
+            if (sidx < 0) sidx = -sidx;
+            if (sidx >= N) sidx = 2 * (N - 1) - sidx;
+        } else pad0 = sidx < 0 || sidx >= N;
+        float v = pad0 ? 0.0f : load_sample<PCM16>(rowp, sidx, len);
+        v = normalise_sample(p.src, v, sc) * win[i];
+        x[__brev((unsigned)i) >> (32 - log2n)] = make_float2(v, 0.0f);
+    }
+    __syncthreads();
+    for (int s = 1; s <= log2n; ++s) {
+        const int half = 1 << (s - 1);
+        for (int j = tid; j < (n >> 1); j += 256) {
+            const int k = j & (half - 1);
+            const int i0 = ((j >> (s - 1)) << s) + k, i1 = i0 + half;
+            const float2 w = tw[k << (log2n - s)];          // W_n^(k n / 2^s)
+            const float2 a = x[i0], b = x[i1];
+            const float tr = b.x * w.x - b.y * w.y, ti = b.x * w.y + b.y * w.x;
+            x[i0] = make_float2(a.x + tr, a.y + ti);
+            x[i1] = make_float2(a.x - tr, a.y - ti);
+        }
+        __syncthreads();
+    }
+    const int F = (n >> 1) + 1;
+    float pw[17];                                           // (n_fft <= 8192: at most 17 bins per thread)
+    int cnt = 0;
+    for (int k = tid; k < F; k += 256) { const float2 z = x[k]; pw[cnt++] = z.x * z.x + z.y * z.y; }
+    __syncthreads();
+    float* P = reinterpret_cast<float*>(smem);
+    cnt = 0;
+    for (int k = tid; k < F; k += 256) P[k] = pw[cnt++];
+    for (int k = F + tid; k < F + p.p_tail; k += 256) P[k] = 0.0f;       // the padded mel rows read there
+    __syncthreads();
+    for (int m = tid; m < p.n_mels; m += 256) {
+        const float* w = p.mel_w + p.mel_wofs[m];
+        const float* pp = P + p.mel_start[m];
+        const int ne = 16 * p.mel_len[m];
+        float a0 = 0.0f, a1 = 0.0f;
+        for (int e = 0; e + 1 < ne; e += 2) { a0 = fmaf(w[e], pp[e], a0); a1 = fmaf(w[e + 1], pp[e + 1], a1); }
+        p.melpow[((long long)row * p.n_frames + t) * p.n_mels + m] = a0 + a1;
+    }
+}
+void launch_stft_generic(const StftParams& p, int n_rows, int sample_is_pcm16, const float* win, const float2* tw, hipStream_t s) {
+    if (n_rows <= 0 || p.n_frames <= 0) return;
+    int log2n = 0;
+    while ((1 << log2n) < p.n_fft) ++log2n;
+    const size_t lds = std::max((size_t)p.n_fft * 8, (size_t)(p.n_fft / 2 + 1 + p.p_tail) * 4);
+    const dim3 grid((unsigned)p.n_frames, (unsigned)n_rows);
+    if (sample_is_pcm16) hipLaunchKernelGGL((k_stft_generic<true>), grid, dim3(256), lds, s, p, win, tw, log2n);
+    else hipLaunchKernelGGL((k_stft_generic<false>), grid, dim3(256), lds, s, p, win, tw, log2n);
+}
+
+// ----------------------------------------------------------------------------
 // K3: power_to_db(ref=max, amin=1e-10, top_db=80) -> z-score over the whole
 // [M, T_raw] array (population std) -> centre crop / zero pad -> [T, M] or [M, T].
 // One 256-thread block per chunk; dB values are recomputed per pass.

@@ -1134,10 +1134,58 @@ def test_bf16_encoder_path(env, preset, name, capsys):
     _assert_latents(mu_fp32.cpu().numpy(), mu32.numpy(), 1e-5)       # switching back restores the fp32 path
 
 
+@pytest.mark.parametrize("n_fft,hop", [(512, 128), (4096, 1024), (256, 100), (2048, 385), (1024, 255), (8192, 2048)])
+def test_general_stft_kernel_other_n_fft_and_odd_hops_against_the_oracle(env, capsys, n_fft, hop):
+    """Every reference CLI exposes --n-fft and --hop (07_encode_wav_to_latent.py:429-430, 08_fit_radial_detector.py:353-354) and librosa
+    takes any value (map_detector_core.py:219-228); the tuned kernels cover n_fft 1024 / 2048 with an even hop, everything else (powers
+    of two from 64 to 8192, any hop) runs k_stft_generic + the separate dB kernel.  Against the oracle: mel power within 1e-5 of the
+    row's peak, the standardised image within 1e-4, for float32 rows (ragged lengths, a silent row) and for PCM16 rows through the RMS
+    stage; and the latents of the tiny encoder on such a front end at the 1e-4 bar."""
+    from dataclasses import replace
+    base = env.PRESETS["bench-1s"]
+    cfg = replace(base, n_fft=n_fft, hop_length=hop, n_mels=48, target_frames=64)
+    sess = env.AmphSession(cfg, None, None, DEV, max_batch=8)
+    pcm = env.synth([0, 1, 2, 49, 4, 5], cfg.n_samples, cfg.sr)
+    y = env.ofe.pcm16_to_float(pcm)
+    lens = np.array([cfg.n_samples, cfg.n_samples - 1, 9001, cfg.n_samples, cfg.n_samples // 2 + 7, cfg.n_samples], np.int32)
+    kw = cfg.mel_kwargs()
+    pw = sess.mel_power(y, lengths=lens).cpu().numpy()                     # [B, T_raw, M]
+    img = sess.mel(y, lengths=lens, layout=0).cpu().numpy()                # [B, M, T]
+    worst_p = worst_i = 0.0
+    for r in range(len(lens)):
+        yr = y[r, :lens[r]]
+        yr = np.pad(yr, (0, cfg.n_samples - yr.shape[0]))
+        want_p = env.ofe.melspectrogram(yr, cfg.sr, n_fft, hop, cfg.n_mels, cfg.fmin, cfg.fmax)          # [M, T_raw]
+        peak = max(float(want_p.max()), 1e-30)
+        assert pw[r].shape == want_p.T.shape
+        worst_p = max(worst_p, float(np.abs(pw[r] - want_p.T).max()) / peak)
+        want_i = env.ofe.wave_to_mel(yr, **kw)
+        worst_i = max(worst_i, float(np.abs(img[r] - want_i).max()))
+    assert worst_p <= 1e-5 and worst_i <= 1e-4, (worst_p, worst_i)
+    assert not pw[3].any()                                                 # digital silence stays exactly zero
+    # PCM16 rows through the RMS stage (00_normalize_dataset_rms.py + its PCM16 write / read)
+    img16 = sess.mel_pcm16(pcm, apply_rms=True, layout=0).cpu().numpy()
+    w16 = 0.0
+    for r in range(pcm.shape[0]):
+        yn, _ = env.ofe.normalize_pcm16_chunk(pcm[r], True)
+        w16 = max(w16, float(np.abs(img16[r] - env.ofe.wave_to_mel(yn, **kw)).max()))
+    assert w16 <= 1e-4, w16
+    spec = env.SPECS["tiny"](cfg.target_frames, cfg.n_mels)
+    state = env.random_init_state(spec, seed=0)
+    enc = env.HipEncoder(spec, state, DEV, max_batch=8)
+    z, _, _ = enc.session(cfg).encode(pcm, apply_rms=True)
+    _assert_latents(z.cpu().numpy(), _oracle_latents(env, env.oenc.build_torch_encoder(spec.to_dict(), state), pcm, cfg))
+    with capsys.disabled():
+        print(f"\n[k_stft_generic, n_fft {n_fft} / hop {hop}] mel power vs oracle: {worst_p:.2e} of the row's peak; image: {worst_i:.2e}; PCM16 + RMS image: {w16:.2e}")
+    sess.close()
+
+
 def test_unsupported_and_invalid_configurations_raise(env):
     from dataclasses import replace
     with pytest.raises(env.N.AmphError, match="AMPH_ERR_UNSUPPORTED"):
-        env.AmphSession(replace(env.cfg, n_fft=4096), None, None, DEV)
+        env.AmphSession(replace(env.cfg, n_fft=3000), None, None, DEV)           # no power of two (the general kernel's FFT is radix-2)
+    with pytest.raises(env.N.AmphError, match="AMPH_ERR_UNSUPPORTED"):
+        env.AmphSession(replace(env.cfg, n_fft=16384), None, None, DEV)
     with pytest.raises(env.N.AmphError, match="AMPH_ERR_UNSUPPORTED"):
         env.AmphSession(replace(env.cfg, duration=0.02), None, None, DEV)        # reflect pad longer than the chunk
     spec = env.SPECS["tiny"](64, 64)
