@@ -111,6 +111,7 @@ def _load() -> C.CDLL:
         "amph_resample_f32": (C.c_int, [vp, f32p, C.c_int, C.c_int, C.c_int, C.c_int, f64p, C.c_int, C.c_int, f32p, C.c_int, vp]),
         "amph_wav_read_pcm16": (C.c_int, [C.c_char_p, C.c_int, i16p, C.c_int, C.POINTER(C.c_int32)]),
         "amph_wav_read_many": (C.c_int, [C.POINTER(C.c_char_p), C.c_int, C.c_int, i16p, C.c_int, i32p, i32p, C.c_int]),
+        "amph_wav_sizes": (C.c_int, [C.POINTER(C.c_char_p), C.c_int, vp, C.c_int]),
         "amph_host_alloc": (vp, [C.c_size_t]),
         "amph_host_free": (None, [vp]),
         "amph_profile_enable": (C.c_int, [vp, C.c_int]),
@@ -133,7 +134,7 @@ EXPORTED_SYMBOLS = (
     "amph_abi_version", "amph_create", "amph_destroy", "amph_last_error", "amph_configure", "amph_raw_frames", "amph_latent_dim",
     "amph_max_batch", "amph_get_mel_basis", "amph_rms_normalize_f32", "amph_rms_normalize_pcm16", "amph_mel_f32",
     "amph_mel_power_f32", "amph_mel_pcm16", "amph_encoder_forward", "amph_range_status", "amph_encode_pcm16", "amph_encode_f32", "amph_encode_pcm16_host",
-    "amph_decide_radial", "amph_fit_radial", "amph_decide_map", "amph_resample_length", "amph_resample_f32", "amph_wav_read_pcm16", "amph_wav_read_many", "amph_host_alloc", "amph_host_free",
+    "amph_decide_radial", "amph_fit_radial", "amph_decide_map", "amph_resample_length", "amph_resample_f32", "amph_wav_read_pcm16", "amph_wav_read_many", "amph_wav_sizes", "amph_host_alloc", "amph_host_free",
     "amph_profile_enable", "amph_profile_stage_count", "amph_profile_stage_name", "amph_profile_read",
     "amph_profile_reset",
 )

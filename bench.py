@@ -141,9 +141,9 @@ def from_files_leg(enc, cfg, pcm_host, args, dev, world, rank, use_dist, dist):
             pth = Path(td) / f"chunk_{i:06d}.wav"
             write_wav_pcm16(pth, pcm_host[i % pcm_host.shape[0]], cfg.sr)
             paths.append(pth)
-        sweep = sorted({t for t in (8, 16, 32, 64, 128, share) if t <= share}) or [share]
+        sweep = sorted({t for t in (2, 4, 8, 16, 32, 64, min(share, 128)) if t <= share}) or [share]
         _folder.encode_paths(enc, paths[:min(512, len(paths))], cfg, apply_rms=True, loader_threads=share)   # warm-up
-        by_threads, failed = {}, 0
+        by_threads, per_thread, failed = {}, {}, 0
         for threads in sweep:
             sync()
             t1 = time.perf_counter()
@@ -155,6 +155,7 @@ def from_files_leg(enc, cfg, pcm_host, args, dev, world, rank, use_dist, dist):
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 dt = float(t.item())
             by_threads[threads] = round(world * args.files / dt, 1)
+            per_thread[threads] = round(world * args.files / dt / threads, 1)
             failed = int((st_f != 0).sum())
 
         # the floor under any loader: open + read + close of every file, no parsing, no GPU (same thread pool size)
@@ -169,7 +170,8 @@ def from_files_leg(enc, cfg, pcm_host, args, dev, world, rank, use_dist, dist):
         sync()
     best_t = max(by_threads, key=by_threads.get)
     return {"value": by_threads[best_t], "unit": "files/s (all ranks)", "files_per_rank": args.files, "ranks": world,
-            "loader_threads_per_rank": best_t, "files_per_s_by_loader_threads": by_threads, "cpus_in_affinity_mask": n_aff,
+            "loader_threads_per_rank": best_t, "files_per_s_by_loader_threads": by_threads, "files_per_s_per_thread": per_thread,
+            "cpus_in_affinity_mask": n_aff,
             "cpu_share_per_rank": share, "python_open_read_floor_files_per_s_rank0": open_read_floor, "failed_rank0": failed,
             "note": "folder.encode_paths on every rank at once: amph_wav_read_many on the host thread pool (affinity / ranks threads) -> "
                     "pinned -> HBM -> encode (file-level RMS); page cache warm; max over ranks of the wall time; never the headline value"}
@@ -649,7 +651,9 @@ def main():
             line["value_f32_mfma"] = f32_leg["value"]
             line["f32_mfma"] = f32_leg
         if plain:
+            sess.configure("lanes", 1)                  # (frees the main context's three lane streams: the second context's lanes get hardware queues of their own)
             line["config4"] = config4_leg(pcm, args, dev)
+            sess.configure("lanes", n_lanes)
         if world == 1 and args.pcie:
             # host-resident PCM16 -> (pinned staging ->) H2D on a copy stream overlapped with compute -> latents back.  Two forms of
             # the caller's buffer: pageable rows (staged through the library's pinned double buffer) and rows the caller already

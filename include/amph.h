@@ -325,6 +325,9 @@ int amph_resample_f32(amph_ctx* ctx, const float* d_in, int n_rows, int n_in, in
  * ------------------------------------------------------------------------- */
 int amph_wav_read_pcm16(const char* path, int expect_sr, int16_t* h_out, int max_samples,
                         int32_t* out_len);
+/* Sizes in bytes of n_files files (-1: no such file), by a pool of host threads: what the folder loop needs to size its rows
+ * (08_fit_radial_detector.py:477-503 reads every file whole) without a Python-level stat() per file. */
+int amph_wav_sizes(const char* const* paths, int n_files, int64_t* h_sizes, int n_threads);
 int amph_wav_read_many(const char* const* paths, int n_files, int expect_sr,
                        int16_t* h_out, int max_samples, int32_t* h_lengths,
                        int32_t* h_status, int n_threads);

@@ -399,6 +399,51 @@ def test_read_many_flags_bad_files(tmp_path):
     assert np.array_equal(pcm[0, :2000], synth.synth_chunk_pcm16(0, 2000, 22050)) and not pcm[0, 2000:].any()
 
 
+def test_read_many_across_directories_trailing_chunks_relative_names_and_sizes(tmp_path, monkeypatch):
+    """Round 4's reader: openat on per-thread directory descriptors + one preadv per canonical file.  Files of SIX directories in one
+    call (the descriptor cache holds four), a canonical file with a LIST chunk BEHIND its samples (those bytes are not samples: the data
+    chunk's size rules), a data chunk longer than the file (truncated: keep what is there), a bare file name relative to the working
+    directory, a missing directory; amph_wav_sizes over the same list; a PathArray window in the middle of the list."""
+    import struct
+    paths, want = [], []
+    for d in range(6):
+        sub = tmp_path / f"sp{d}"
+        sub.mkdir()
+        for i in range(3):
+            q = synth.synth_chunk_pcm16(10 * d + i, 500 + 10 * i, 22050)
+            synth.write_wav_pcm16(sub / f"c{i}.wav", q, 22050)
+            paths.append(sub / f"c{i}.wav")
+            want.append(q)
+    q = synth.synth_chunk_pcm16(77, 300, 22050)
+    head = b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 1, 1, 22050, 44100, 2, 16)
+    body = b"data" + struct.pack("<I", 600) + q.tobytes() + b"LIST" + struct.pack("<I", 8) + b"\x7f" * 8
+    (tmp_path / "sp0" / "tail.wav").write_bytes(b"RIFF" + struct.pack("<I", len(head) + len(body)) + head + body)
+    paths.append(tmp_path / "sp0" / "tail.wav"); want.append(q)
+    body = b"data" + struct.pack("<I", 2000) + q[:100].tobytes()                          # claims 1000 samples, holds 100
+    (tmp_path / "sp1" / "short.wav").write_bytes(b"RIFF" + struct.pack("<I", len(head) + len(body)) + head + body)
+    paths.append(tmp_path / "sp1" / "short.wav"); want.append(q[:100])
+    synth.write_wav_pcm16(tmp_path / "bare.wav", q, 22050)
+    monkeypatch.chdir(tmp_path)
+    paths.append("bare.wav"); want.append(q)
+    paths.append(tmp_path / "no_such_dir" / "c.wav"); want.append(None)
+    rows = np.full((len(paths), 640), 7, np.int16)
+    lengths, status = wavio.read_many_into(rows, paths, 22050, n_threads=3)
+    for i, w in enumerate(want):
+        if w is None:
+            assert status[i] == N.AMPH_ERR_IO and lengths[i] == 0 and not rows[i].any()
+            continue
+        assert status[i] == 0 and lengths[i] == len(w), (i, status[i], lengths[i])
+        assert np.array_equal(rows[i, :len(w)], w) and not rows[i, len(w):].any(), i
+    sizes = wavio.file_sizes(paths, n_threads=2)
+    assert sizes[-1] == -1 and sizes[0] == 44 + 2 * 500 and sizes[-2] == 44 + 600
+    pa = wavio.PathArray(paths)
+    rows2 = np.zeros((4, 640), np.int16)
+    l2, s2 = wavio.read_many_into(rows2, pa, 22050, n_threads=2, offset=5)
+    assert np.array_equal(rows2, rows[5:9]) and l2.tolist() == lengths[5:9].tolist() and not s2.any()
+    with pytest.raises(IndexError):
+        pa.window(len(paths) - 1, 2)
+
+
 # ------------------------------------------------------------------ folder driver (host logic, fake encode)
 def _fake_encode(paths):
     """Deterministic stand-in for the HIP encode: a vector derived from the file name."""
