@@ -60,18 +60,40 @@ def _dist_info(group=None) -> Tuple[int, int]:
     return 0, 1
 
 
+def _cgroup_cpus() -> Optional[float]:
+    """CPUs' worth of time this process's cgroup may use per period (cgroup v2 cpu.max, v1 cfs quota), None when unlimited / unknown."""
+    try:
+        txt = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if txt and txt[0] != "max":
+            return float(txt[0]) / float(txt[1])
+    except (OSError, ValueError, IndexError):
+        pass
+    try:
+        q = float(Path("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read_text())
+        per = float(Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text())
+        if q > 0 and per > 0:
+            return q / per
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def default_loader_threads(world: int = 1) -> int:
-    """Host threads this rank's WAV reader uses when the caller names none: the CPUs of the process's affinity mask divided by the
-    ranks that share the node (LOCAL_WORLD_SIZE under torch.distributed.run, else the group's size), between 1 and 32 - eight
-    ranks of one node each taking the whole mask only fight over the same cores (a 1-GPU box: 16 cores' worth, 135-153 k files/s
-    at 8-32 threads, falling beyond)."""
+    """Host threads this rank's WAV reader uses when the caller names none: the CPUs this process may actually use - its affinity mask,
+    cut to its cgroup's CPU quota where there is one - divided by the ranks that share the node (LOCAL_WORLD_SIZE under
+    torch.distributed.run, else the group's size), between 1 and 16.  More threads than CPUs' worth of quota is far worse than too few:
+    the 1-GPU box shows 256 CPUs in the mask and gives the job about 16 - 340 k files/s at 8 - 16 threads, 50 k at 32 (the cgroup is
+    throttled for the rest of every period), and eight ranks of one node each taking the whole mask only fight over the same cores."""
     import os
     n_aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 8)
+    quota = _cgroup_cpus()
+    if quota is not None:
+        n_aff = max(1, min(n_aff, int(quota)))
     try:
         local = int(os.environ.get("LOCAL_WORLD_SIZE", "0"))
     except ValueError:
         local = 0
-    return max(1, min(32, n_aff // max(1, local if local > 0 else world)))
+    return max(1, min(16, n_aff // max(1, local if local > 0 else world)))
 
 
 def encode_paths(encoder, paths: Sequence[Path], cfg: FrontendConfig, *, apply_rms: bool = False,

@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import ctypes as C
 import struct
+import sys
 from pathlib import Path
 from typing import Optional, Sequence, Tuple
 
@@ -124,20 +125,30 @@ PINNED = PinnedRows()
 
 
 class PathArray:
-    """The paths of a file list as ONE C array of char* (built once: str(Path).encode() and the ctypes array cost ~1.5 us per
-    file, as much as the native reader needs for the file itself at 16 threads); `window(off, n)` is a view for one batch."""
+    """The paths of a file list as ONE C array of char* into ONE bytes blob (built once per list: per-file str(Path).encode() + a
+    ctypes c_char_p each cost ~1.5 us per file - as much as the native reader needs for the file itself at 16 threads); `window(off, n)`
+    is the view of one batch."""
 
     def __init__(self, paths: Sequence):
         import os
-        self._bytes = [p if isinstance(p, bytes) else os.fsencode(p) for p in paths]
-        self.n = len(self._bytes)
-        self._arr = (C.c_char_p * max(1, self.n))(*self._bytes)
+        strs = [p if type(p) is str else os.fsdecode(p) if isinstance(p, bytes) else os.fspath(p) for p in paths]
+        self.n = len(strs)
+        blob = "\0".join(strs).encode(sys.getfilesystemencoding(), "surrogateescape") + b"\0"
+        if len(blob) == sum(map(len, strs)) + self.n:             # one byte per character: offsets straight from the str lengths
+            lens = np.fromiter(map(len, strs), dtype=np.int64, count=self.n)
+        else:
+            lens = np.fromiter((len(os.fsencode(x)) for x in strs), dtype=np.int64, count=self.n)
+        self._blob = C.create_string_buffer(blob, len(blob))
+        offs = np.zeros(max(1, self.n), dtype=np.uint64)
+        if self.n > 1:
+            offs[1:self.n] = np.cumsum(lens[:-1] + 1).astype(np.uint64)
+        self._ptrs = offs + np.uint64(C.addressof(self._blob))    # uint64 [n]: a char* array in all but name
 
     def window(self, off: int = 0, n: Optional[int] = None):
         n = self.n - off if n is None else n
         if off < 0 or n < 0 or off + n > self.n:
             raise IndexError("PathArray.window out of range")
-        return C.cast(C.byref(self._arr, off * C.sizeof(C.c_char_p)), C.POINTER(C.c_char_p)), n
+        return C.cast(C.c_void_p(self._ptrs.ctypes.data + 8 * off), C.POINTER(C.c_char_p)), n
 
 
 def file_sizes(paths, n_threads: int = 8) -> np.ndarray:

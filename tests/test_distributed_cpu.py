@@ -141,7 +141,9 @@ def test_eight_ranks_on_thirteen_files_empty_tail_ranks_and_padded_blocks(tmp_pa
         d = np.load(out / f"w8_rank{r}.npz")
         assert np.array_equal(d["Z"], Z1.numpy()) and np.array_equal(d["st"], st1), r
         assert (int(d["lo"]), int(d["hi"])) == shards[r] and int(d["per"]) == 2
-        assert int(d["threads"]) == max(1, min(32, n_aff // 8))
+        quota = pfolder._cgroup_cpus()
+        cpus = n_aff if quota is None else max(1, min(n_aff, int(quota)))      # (the affinity mask cut to the cgroup's CPU quota)
+        assert int(d["threads"]) == max(1, min(16, cpus // 8))
     assert st1[4] != 0 and not st1[np.arange(13) != 4].any()
 
 
