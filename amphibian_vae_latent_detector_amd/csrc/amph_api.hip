@@ -112,6 +112,7 @@ struct amph_ctx {
                                            // included, fits (1 s rows with the fused dB stage: 11 - 29 pairs on 11 waves are 3 rounds, at most 8 pairs per SIMD)
     bool stft_pair_tw_lds = true;          // its stage-1 twiddles in LDS when the image still fits
     bool stft_k0_fuse = true;              // K0's fold + apply + padded copy inside k_stft_pair (its chunk sums stay a launch); same bits
+    bool stft_pair_rows2 = true;           // ... with two rows per workgroup and pair queue when the batch has more rows than half the CUs (same bits)
     int mel_w_floats = 0, mel_p_tail = 0;
     int32_t *d_mel_start = nullptr, *d_mel_len = nullptr, *d_mel_wofs = nullptr;
     float* d_mel_w = nullptr;
@@ -1206,6 +1207,7 @@ int run_frontend(amph_ctx* c, Workspace& w, const void* d_wave, bool pcm16, int 
                 sp.k0_in = (const int16_t*)d_wave; sp.k0_row_stride = n_in; sp.k0_lengths = d_len; sp.k0_n_in = n_in;
                 sp.k0_scale_f64 = c->rms_f64_scale; sp.k0_scale = w.scale; sp.k0_ok = k0_ok;
                 sp.k0_chunk_sums = k0_sums; sp.k0_chunk_stride = rms_scale_chunks(n_in);
+                sp.pair_rows2 = c->stft_pair_rows2 ? 1 : 0;
             }
             if (c->generic_stft) launch_stft_generic(sp, nb, pcm16 ? 1 : 0, c->d_gen_win, c->d_gen_tw, s);
             else launch_stft_mel(sp, nb, pcm16 ? 1 : 0, c->stft_waves, s);
@@ -1419,6 +1421,7 @@ int amph_configure(amph_ctx* c, const char* key, int value) {
     if (!std::strcmp(key, "stft_pair")) { c->stft_pair = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "stft_pair_tw_lds")) { c->stft_pair_tw_lds = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "stft_k0_fuse")) { c->stft_k0_fuse = value != 0; return AMPH_OK; }
+    if (!std::strcmp(key, "stft_pair_rows2")) { c->stft_pair_rows2 = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "stft_pair_waves")) {
         const bool okv = c->cfg.n_fft == 2048 ? (value == 8 || value == 10 || value == 11 || value == 12) : (value == 8 || value == 12);
         if (!okv) return fail(c, AMPH_ERR_INVALID_ARG, "stft_pair_waves must be 8, 10, 11 or 12 (n_fft 2048) / 8 or 12 (n_fft 1024)");

@@ -70,6 +70,7 @@ struct StftParams {
     int32_t* k0_ok;            // [B] out (nullable)
     const float* k0_chunk_sums;   // [B][k0_chunk_stride] sums of squares per numpy chunk (launch_rms_chunk_sums_pcm16)
     int k0_chunk_stride;
+    int pair_rows2;            // K0F + fused dB stage: two rows per workgroup and pair queue when the batch is large enough ("stft_pair_rows2")
     // per-context launch choices (were process-wide globals until round 3)
     int indep;                 // 1: k_stft_mel_w (independent waves), 0: the tile-synchronous k_stft_mel
     int grid_wgs;              // persistent workgroups; 0 = fill the chip
@@ -114,7 +115,7 @@ int stft_mel_table_bytes(int n_fft);
 int stft_mel_scratch_floats(int n_fft);   // floats of per-frame scratch the power spectrum + tail may use
 hipError_t stft_mel_configure(int lds_bytes);   // raises the dynamic-LDS limit of the STFT kernels
 // the pair kernel (k_stft_pair): LDS image, packed table size, and the configurations it covers
-size_t stft_pair_lds_bytes(int n_frames, int n_mels, int mel_w_floats, int n_waves, bool fused);
+size_t stft_pair_lds_bytes(int n_frames, int n_mels, int mel_w_floats, int n_waves, bool fused, int rows = 1);   // rows: mel-power images kept in LDS (2: the G2 form)
 bool stft_pair_can_fuse_k0(int n_in, int n_waves);      // the K0F form of k_stft_pair covers this row length / workgroup shape
 int stft_pair_table_bytes();
 size_t stft_pair_tw1_lds_bytes();

@@ -1590,7 +1590,11 @@ __device__ __forceinline__ void dft32_combine(float (&er)[16], float (&ei)[16], 
 // sliding window shares it between frame a and frame b), three vector instructions per sample.  Measured forms, incl. the two that put
 // the summation itself into this kernel's prologue and lost (cold one-shot code, the row's first touch from HBM with the whole CU waiting,
 // three barriers): profiles/r04_k0_fuse.txt.
-template <int NW, int HJ, bool TWL, bool K0F = false>
+// G2 (round 4; with K0F and the fused dB stage): the workgroup takes its rows TWO at a time - one queue over the 2 x 29 pairs of both rows, a
+// mel-power image per row in LDS (the stage-1 twiddles then come from global memory: measured free), both dB stages at the end.  A one-second
+// row is 29 pairs on 12 waves = 12 + 12 + 5: its third round keeps 5 of 12 waves busy for ~15 000 of the row's ~64 000 cycles; two rows are
+// 58 pairs = four full rounds + 10, and the tables are staged once for both.
+template <int NW, int HJ, bool TWL, bool K0F = false, bool G2 = false>
 __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows) {
     constexpr int kThreads = 64 * NW;
     constexpr int ND = 16 + HJ;                         // dwords per lane and pair
@@ -1785,28 +1789,40 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
     // Pairs are handed out DYNAMICALLY (an LDS counter per row; wave w starts with pair w): the SIMD issues oldest-wave-first, so its
     // first wave runs a pair in ~12.6 k cycles, its second in ~20 k, its third in ~35 k (profiles/r03_stft_pair_timeline.txt) - with
     // a fixed pr = wave + 12 i the first waves idle at the end while the SIMD that drew the row's 29th pair still works
-    float* const db_redf = reinterpret_cast<float*>(reinterpret_cast<double*>(mp_row + ((p.n_frames * p.n_mels + 3) & ~3)) + 16);   // db_row_from_lds's redf
-    for (int row = blockIdx.x; row < n_rows; row += gridDim.x) {
-        if (K0F) {
+    // LDS behind the waves' scratch: [RB rows of mel power][RB x (16 doubles + 16 floats) of reduction scratch]
+    constexpr int RB = G2 ? 2 : 1;
+    const int mp_floats = (p.n_frames * p.n_mels + 3) & ~3;
+    double* const db_red0 = reinterpret_cast<double*>(mp_row + RB * mp_floats);
+    float* const db_redf = reinterpret_cast<float*>(db_red0 + 16);   // db_row_from_lds's redf (row 1 of a group: 24 doubles further)
+    // the chunk sums of K0's first kernel, folded in numpy's order (chunk 0 first) into the scale - k_rms_fold_apply's thread 0, on every wave
+    auto k0_fold = [&](int row_) {
 #pragma clang fp contract(off)
-            // the chunk sums of K0's first kernel, folded in numpy's order (chunk 0 first) into the scale - k_rms_fold_apply's thread 0, on every wave
-            const int n_ = k0_row_len(row);
-            const int n_chunks = (n_ + kNpChunk - 1) / kNpChunk;
-            const float* cs = p.k0_chunk_sums + (long long)row * p.k0_chunk_stride;
-            float total = 0.0f, sc_ = 1.0f;
-            int good_ = 0;
-            for (int c = 0; c < n_chunks; ++c) total = c == 0 ? cs[0] : total + cs[c];
-            if (n_ > 0) {
-                const float rms = sqrtf(total / (float)n_);
-                if (p.k0_scale_f64) { if (!((double)rms < 1e-4)) { sc_ = (float)(0.05 / ((double)rms + 1e-8)); good_ = 1; } }
-                else if (!(rms < 1e-4f)) { sc_ = 0.05f / (rms + 1e-8f); good_ = 1; }
-            }
-            if (tid == 0) { p.k0_scale[row] = sc_; if (p.k0_ok) p.k0_ok[row] = good_; }
-            k0_sc = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(good_ ? sc_ : 1.0f)));
+        const int n_ = k0_row_len(row_);
+        const int n_chunks = (n_ + kNpChunk - 1) / kNpChunk;
+        const float* cs = p.k0_chunk_sums + (long long)row_ * p.k0_chunk_stride;
+        float total = 0.0f, sc_ = 1.0f;
+        int good_ = 0;
+        for (int c = 0; c < n_chunks; ++c) total = c == 0 ? cs[0] : total + cs[c];
+        if (n_ > 0) {
+            const float rms = sqrtf(total / (float)n_);
+            if (p.k0_scale_f64) { if (!((double)rms < 1e-4)) { sc_ = (float)(0.05 / ((double)rms + 1e-8)); good_ = 1; } }
+            else if (!(rms < 1e-4f)) { sc_ = 0.05f / (rms + 1e-8f); good_ = 1; }
         }
-        float wmax = -INFINITY;                             // the largest mel power this wave has stored for the row (fused dB stage: its max pass)
-        for (int pi = wave, pr_next = 0; pi < n_pairs; pi = pr_next) {
-            const int pr = pair_of(pi);                     // (identity without K0F)
+        if (tid == 0) { p.k0_scale[row_] = sc_; if (p.k0_ok) p.k0_ok[row_] = good_; }
+        return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(good_ ? sc_ : 1.0f)));
+    };
+    for (int row0 = blockIdx.x; row0 < n_rows; row0 += RB * gridDim.x) {
+        const int row1 = row0 + (int)gridDim.x;             // (G2: the group's second row, if the batch has it)
+        const bool has1 = G2 && row1 < n_rows;
+        const int n_q = has1 ? 2 * n_pairs : n_pairs;       // the group's queue: row 0's pairs, then row 1's
+        float sc_row0 = 1.0f, sc_row1 = 1.0f;
+        if (K0F) { sc_row0 = k0_fold(row0); if (has1) sc_row1 = k0_fold(row1); }
+        float wmax = -INFINITY, wmax1 = -INFINITY;          // the largest mel power this wave has stored for the row(s) (fused dB stage: its max pass)
+        for (int pi = wave, pr_next = 0; pi < n_q; pi = pr_next) {
+            const bool sub = G2 && pi >= n_pairs;           // (wave-uniform) which row of the group
+            const int row = sub ? row1 : row0;
+            const int pr = pair_of(sub ? pi - n_pairs : pi);    // (identity without K0F)
+            if (K0F) k0_sc = sub ? sc_row1 : sc_row0;
             // packed pairs: element j of the lane's TWO sequences (sample parity 0 / 1) side by side - dft16_pk
             amph_f2 XR[16], XI[16];
             float4 tw[16];
@@ -1999,8 +2015,9 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
                 int got = 0;
                 if (lane == 0) got = atomicAdd(next_pair, 1);
                 pr_next = __builtin_amdgcn_readfirstlane(got);
-                int nrow = row, npr = pr_next;
-                if (npr >= n_pairs) { nrow = row + gridDim.x; npr = wave; }     // nothing left in this row: the wave's first pair of its next row
+                int nrow = row0, npr = pr_next;
+                if (npr >= n_q) { nrow = row0 + RB * (int)gridDim.x; npr = wave; }     // nothing left in this group: the wave's first pair of its next one
+                else if (G2 && npr >= n_pairs) { nrow = row1; npr -= n_pairs; }
                 fetch(min(nrow, n_rows - 1), pair_of(min(npr, n_pairs - 1)));
             }
             AMPH_PHASE_FENCE();
@@ -2018,7 +2035,7 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
                 const int n_rounds = (p.n_mels + 15) >> 4;
                 const int fa = 2 * pr;
                 const bool has_b = fa + 1 < p.n_frames;     // wave-uniform
-                float* out_a = fuse_db ? mp_row + fa * p.n_mels : p.melpow + ((long long)row * p.n_frames + fa) * p.n_mels;
+                float* out_a = fuse_db ? mp_row + (sub ? mp_floats : 0) + fa * p.n_mels : p.melpow + ((long long)row * p.n_frames + fa) * p.n_mels;
                 float* out_b = out_a + p.n_mels;
                 int4 mt = mel_meta[lane >> 2];
                 for (int r = 0; r < n_rounds; ++r) {
@@ -2056,7 +2073,12 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
                     amph_f2 sa = a0 + a1;
                     sa += amph_f2{dpp_xor1(sa.x), dpp_xor1(sa.y)};
                     sa += amph_f2{dpp_xor2(sa.x), dpp_xor2(sa.y)};
-                    if (q == 0 && m >= 0) { out_a[m] = sa.x; wmax = fmaxf(wmax, sa.x); if (has_b) { out_b[m] = sa.y; wmax = fmaxf(wmax, sa.y); } }
+                    if (q == 0 && m >= 0) {
+                        float wm_ = sa.x;
+                        out_a[m] = sa.x;
+                        if (has_b) { out_b[m] = sa.y; wm_ = fmaxf(wm_, sa.y); }
+                        if (sub) wmax1 = fmaxf(wmax1, wm_); else wmax = fmaxf(wmax, wm_);
+                    }
                 }
             }
             wave_lds_sync();                                // the scratch is rewritten by the next pair
@@ -2075,7 +2097,8 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
         // ---- fused dB stage on the row the workgroup holds (see k_stft_mel_w).  The LAST row (at batch 256: the only one) is
         //      finished behind the loops: inlined here, the stage's per-thread index arithmetic is hoisted in front of the row loop
         //      and sits in ~90 registers across the pair loop
-        if (!fuse_db && row + (int)gridDim.x < n_rows) {  // (every wave has drawn its last index of this row before the counter starts over)
+        const bool more = row0 + RB * (int)gridDim.x < n_rows;   // another group follows
+        if (!fuse_db && more) {                             // (every wave has drawn its last index of this group before the counter starts over)
             __syncthreads();
             if (tid == 0) *next_pair = NW;
             __syncthreads();
@@ -2083,13 +2106,18 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
         if (fuse_db) {                                      // (every wave, also one without pairs: -inf)
             const float wm = wave_max_dpp(wmax);
             if (lane == 63) db_redf[wave] = wm;
+            if (G2) { const float wm1 = wave_max_dpp(wmax1); if (lane == 63) db_redf[48 + wave] = wm1; }      // (row 1's scratch: 24 doubles = 48 floats on)
         }
-        if (fuse_db && row + (int)gridDim.x < n_rows) {
+        if (fuse_db && (more || G2)) {                      // (G2: every group's stages here - two inlined copies behind the loop would hold ~90 registers each)
             __syncthreads();
             if (tid == 0) *next_pair = NW;
             db_row_call<kThreads, 8, true>(mp_row, p.n_frames, p.n_mels, p.db_target_frames, p.db_layout,
-                                  p.db_out + (long long)row * p.db_target_frames * p.n_mels,
-                                  reinterpret_cast<double*>(mp_row + ((p.n_frames * p.n_mels + 3) & ~3)));
+                                  p.db_out + (long long)row0 * p.db_target_frames * p.n_mels, db_red0);
+            if (has1) {
+                __syncthreads();
+                db_row_call<kThreads, 8, true>(mp_row + mp_floats, p.n_frames, p.n_mels, p.db_target_frames, p.db_layout,
+                                      p.db_out + (long long)row1 * p.db_target_frames * p.n_mels, db_red0 + 24);
+            }
             __syncthreads();
         }
     }
@@ -2103,15 +2131,14 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
     }
 #endif
 #undef AMPH_PSTAMP
-    if (fuse_db && (int)blockIdx.x < n_rows) {
+    if (!G2 && fuse_db && (int)blockIdx.x < n_rows) {
         const int last_row = blockIdx.x + (n_rows - 1 - (int)blockIdx.x) / (int)gridDim.x * (int)gridDim.x;
         __syncthreads();
 #ifdef AMPH_STAMPS
         if (tid == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); tl[6] = t_; }
 #endif
         db_row_from_lds<kThreads, 8, true>(mp_row, p.n_frames, p.n_mels, p.db_target_frames, p.db_layout,
-                                  p.db_out + (long long)last_row * p.db_target_frames * p.n_mels,
-                                  reinterpret_cast<double*>(mp_row + ((p.n_frames * p.n_mels + 3) & ~3))
+                                  p.db_out + (long long)last_row * p.db_target_frames * p.n_mels, db_red0
 #ifdef AMPH_STAMPS
                                   , tl + 9
 #endif
@@ -2388,9 +2415,9 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair2(StftParams p, int n_rows
     }
 }
 
-size_t stft_pair_lds_bytes(int n_frames, int n_mels, int mel_w_floats, int n_waves, bool fused) {
+size_t stft_pair_lds_bytes(int n_frames, int n_mels, int mel_w_floats, int n_waves, bool fused, int rows) {
     const size_t meta = (size_t)((n_mels + 15) / 16) * 16 * 16;            // (round, lane quad) entries of 16 bytes
-    const size_t mp = fused ? (((size_t)n_frames * n_mels + 3) & ~(size_t)3) * 4 + 16 * 8 + 16 * 4 : 0;
+    const size_t mp = fused ? (size_t)rows * ((((size_t)n_frames * n_mels + 3) & ~(size_t)3) * 4 + 16 * 8 + 16 * 4) : 0;     // per row: mel power + reduction scratch
     return (size_t)kPairWinBytes + kPairTw2Bytes + meta + (size_t)mel_w_floats * 4 + (size_t)n_waves * kPairScratch + 16 + mp;      // (16: the pair counter)
 }
 size_t stft_pair_tw1_lds_bytes() { return kPairTw1Bytes; }
@@ -2451,11 +2478,12 @@ hipError_t stft_mel_configure(int lds_bytes) {
         e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
     }
-    const void* pfns[10] = {reinterpret_cast<const void*>(&k_stft_pair<8, 3, false>), reinterpret_cast<const void*>(&k_stft_pair<10, 3, false>),
+    const void* pfns[11] = {reinterpret_cast<const void*>(&k_stft_pair<8, 3, false>), reinterpret_cast<const void*>(&k_stft_pair<10, 3, false>),
                             reinterpret_cast<const void*>(&k_stft_pair<11, 3, false>), reinterpret_cast<const void*>(&k_stft_pair<12, 3, false>),
                             reinterpret_cast<const void*>(&k_stft_pair<8, 3, true>), reinterpret_cast<const void*>(&k_stft_pair<10, 3, true>),
                             reinterpret_cast<const void*>(&k_stft_pair<11, 3, true>), reinterpret_cast<const void*>(&k_stft_pair<12, 3, true>),
-                            reinterpret_cast<const void*>(&k_stft_pair<12, 3, false, true>), reinterpret_cast<const void*>(&k_stft_pair<12, 3, true, true>)};
+                            reinterpret_cast<const void*>(&k_stft_pair<12, 3, false, true>), reinterpret_cast<const void*>(&k_stft_pair<12, 3, true, true>),
+                            reinterpret_cast<const void*>(&k_stft_pair<12, 3, false, true, true>)};
     for (const void* f : pfns) {
         e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
@@ -2513,7 +2541,13 @@ void launch_stft_mel(const StftParams& p, int n_rows, int sample_is_pcm16, int n
     else hipLaunchKernelGGL((k_stft_pair<NW_, 3, false>), grid, dim3(64 * NW_), lds, s, p, n_rows);
         (void)block;
         if (p.k0_in) {                                  // K0F (12 waves: the one-second rows of the benchmark; the caller has checked)
-            if (twl) hipLaunchKernelGGL((k_stft_pair<12, 3, true, true>), grid, dim3(64 * 12), lds, s, p, n_rows);
+            // two rows per workgroup and queue (G2) when the batch has more rows than half the CUs and both rows' mel power fits LDS
+            const size_t lds2 = stft_pair_lds_bytes(p.n_frames, p.n_mels, p.pair_mel_w_floats, nw, true, 2);
+            if (p.db_out && p.pair_rows2 && n_rows > g_num_cus / 2 && lds2 <= 160 * 1024) {
+                const dim3 grid2((unsigned)std::min((n_rows + 1) / 2, p.grid_wgs > 0 ? p.grid_wgs : g_num_cus));
+                hipLaunchKernelGGL((k_stft_pair<12, 3, false, true, true>), grid2, dim3(64 * 12), lds2, s, p, n_rows);
+            }
+            else if (twl) hipLaunchKernelGGL((k_stft_pair<12, 3, true, true>), grid, dim3(64 * 12), lds, s, p, n_rows);
             else hipLaunchKernelGGL((k_stft_pair<12, 3, false, true>), grid, dim3(64 * 12), lds, s, p, n_rows);
         }
         else if (nw == 8) { AMPH_PAIR_LAUNCH(8) }

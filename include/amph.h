@@ -148,6 +148,9 @@ const char* amph_last_error(const amph_ctx* ctx);   /* ctx may be NULL: create-t
  *                            the per-chunk sums of squares (K0's first kernel: still a launch) into the scale, reads the raw rows (centre padding,
  *                            fix_length and truncation as index arithmetic) and re-quantises in its decode (default 1; 0 = K0's two launches +
  *                            the padded rows; same bits; profiles/r04_k0_fuse.txt)
+ *   "stft_pair_rows2"  0/1   ... and, when a batch has more rows than half the CUs, two rows per workgroup: one queue over the pairs of both rows (a
+ *                            one-second row's 29 pairs on 12 waves leave the third round 5 / 12 busy; 58 pairs are four full rounds + 10), a mel-power
+ *                            image per row in LDS, the tables staged once for both (default 1; same bits)
  *   "stft_prenorm"     0/1   PCM16 input with apply_rms: the RMS kernel also writes the normalised, re-quantised PCM16
  *                            rows (what 00_normalize_dataset_rms.py puts on disk) and the STFT kernel reads those
  *                            (default 1) instead of normalising every sample of every frame itself (0); same bits

@@ -525,13 +525,19 @@ def test_rms_normalize_inside_the_pair_kernel_is_bit_identical_to_its_own_launch
             lens = rng.integers(1, n_in + 1, size=n_rows).astype(np.int32)
             lens[:6] = (n_in, n_in - 1, 1, 2, 1025, 8193)
         res = {}
-        for knob in (1, 0):
-            sess.configure("stft_k0_fuse", knob)
+        # 1: the default (two rows per workgroup and queue when the batch is large: "stft_pair_rows2"); 2: one row per workgroup; 3: two rows per
+        # group on 50 workgroups (every workgroup runs several groups, the last one of some a single row); 0: K0's own launches
+        for knob in (1, 2, 3, 0):
+            sess.configure("stft_k0_fuse", 1 if knob else 0)
+            sess.configure("stft_pair_rows2", 0 if knob == 2 else 1)
+            sess.configure("stft_grid", 50 if knob == 3 else 0)
             mu, _, ok = sess.encode(pcm, lengths=lens, apply_rms=True)
             img = sess.mel_pcm16(pcm, lengths=lens, apply_rms=True, layout=1)
             res[knob] = (mu.clone(), ok.clone(), img.clone())
         sess.configure("stft_k0_fuse", DEFAULT_K0)
-        for knob in (1,):
+        sess.configure("stft_pair_rows2", 1)
+        sess.configure("stft_grid", 0)
+        for knob in (1, 2, 3):
             assert torch.equal(res[knob][1], res[0][1]), (knob, n_rows, n_in)
             assert torch.equal(res[knob][2], res[0][2]), (knob, n_rows, n_in)
             assert torch.equal(res[knob][0], res[0][0]), (knob, n_rows, n_in)
