@@ -89,7 +89,7 @@ for st, c in sorted(traffic.items()):
 # matrix-pipe work per launch (bench.py's mixed_roofline): MFMA instructions, the cycles the pipe was busy, the launch's GPU-active cycles
 mf = {"_about": "rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE (one pass; per launch of a "
                 "256-chunk batch, bench configuration, 1 lane).  SQ_INSTS_MFMA counts wave instructions; every MFMA of the default path is a "
-                "v_mfma_f32_32x32x16_bf16 (32 matrix-pipe cycles on its SIMD); SQ_VALU_MFMA_BUSY_CYCLES is summed over the chip's 1024 SIMDs; "
+                "v_mfma_f32_32x32x16_f16 on two-term fp16 splits of fp32 operands (32 matrix-pipe cycles on its SIMD); SQ_VALU_MFMA_BUSY_CYCLES is summed over the chip's 1024 SIMDs; "
                 "GRBM_GUI_ACTIVE is summed over the 8 XCDs.", "kernels": {}}
 for st, c in sorted(traffic.items()):
     if "SQ_INSTS_MFMA" in c:

@@ -10,13 +10,13 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err" || exit 1
+python3 bench.py --steps 20 --warmup 5 > "$OUT/bench.json" 2> "$OUT/bench.err" || exit 1
 echo "bench done: $(cut -c1-200 "$OUT/bench.json")"
-python3 bench.py --lanes 1 --cpu-seconds 0 > "$OUT/bench_lanes1.json" 2>> "$OUT/bench.err" || exit 1
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_lanes1" -- python3 bench.py --steps 5 --warmup 2 --cpu-seconds 0 --lanes 1 > "$OUT/bench_rocprof_lanes1.json" 2> "$OUT/stats_lanes1.err" || exit 1
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_lanes4" -- python3 bench.py --steps 5 --warmup 2 --cpu-seconds 0 > "$OUT/bench_rocprof_lanes4.json" 2> "$OUT/stats_lanes4.err" || exit 1
+python3 bench.py --lanes 1 --cpu-seconds 0 --no-extra-legs > "$OUT/bench_lanes1.json" 2>> "$OUT/bench.err" || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_lanes1" -- python3 bench.py --steps 5 --warmup 2 --cpu-seconds 0 --no-extra-legs --lanes 1 > "$OUT/bench_rocprof_lanes1.json" 2> "$OUT/stats_lanes1.err" || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_lanes4" -- python3 bench.py --steps 5 --warmup 2 --cpu-seconds 0 --no-extra-legs > "$OUT/bench_rocprof_lanes4.json" 2> "$OUT/stats_lanes4.err" || exit 1
 echo "kernel stats done"
-PM="python3 bench.py --steps 2 --warmup 1 --prewarm 0 --chunks 5120 --cpu-seconds 0 --lanes 1"
+PM="python3 bench.py --steps 2 --warmup 1 --prewarm 0 --chunks 5120 --cpu-seconds 0 --no-extra-legs --lanes 1"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- $PM > /dev/null 2> "$OUT/pmc_fetch.err" || exit 1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- $PM > /dev/null 2> "$OUT/pmc_write.err" || exit 1
 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$OUT/pmc_l2" -- $PM > /dev/null 2> "$OUT/pmc_l2.err" || exit 1
