@@ -1186,6 +1186,93 @@ __device__ __attribute__((noinline)) void db_row_call(const float* mp, int T, in
     db_row_from_lds<NT, C, HAVE_MAX>(mp, T, M, TT, layout, out, red);
 }
 
+// TWO rows at once (k_stft_pair's G2 form: both rows' mel power in LDS, their maxima already in each row's redf): every pass handles the
+// two rows side by side, so the pair costs one row's barriers and latencies.  Per row the thread -> element map, the per-thread sums,
+// the wave sums and the order of the cross-wave totals are db_row_from_lds<NT, C, true>'s: the same bits.  red: row r's scratch at red + 24 r.
+template <int NT, int C = 8>
+__device__ __attribute__((noinline)) void db_rows2_call(const float* mp0, const float* mp1, int T, int M, int TT, int layout, float* out0, float* out1, double* red) {
+    constexpr int NWV = NT / 64;
+    static_assert(NWV <= 12, "the second sums sit beside the first ones");
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int n = T * M;
+    const float* mp[2] = {mp0, mp1};
+    float* out[2] = {out0, out1};
+    float v[2][C], ref_db[2], mean[2], den[2];
+    double acc[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+#pragma unroll
+        for (int j = 0; j < C; ++j) { const int i = tid + NT * j; v[r][j] = i < n ? mp[r][i] : -INFINITY; }
+        const float* redf = reinterpret_cast<const float*>(red + 24 * r + 16);
+        float mx = redf[0];
+#pragma unroll
+        for (int g = 1; g < NWV; ++g) mx = fmaxf(mx, redf[g]);
+        ref_db[r] = 10.0f * log10f(fmaxf(1e-10f, mx));
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        double a = 0.0;
+#pragma unroll
+        for (int j = 0; j < C; ++j) if (tid + NT * j < n) { v[r][j] = to_db(v[r][j], ref_db[r]); a += (double)v[r][j]; }
+        for (int i = tid + NT * C; i < n; i += NT) a += (double)to_db(mp[r][i], ref_db[r]);
+        acc[r] = wave_sum_dpp(a);
+    }
+    if (lane == 63) { red[w] = acc[0]; red[24 + w] = acc[1]; }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        double tot = 0.0;
+#pragma unroll
+        for (int g = 0; g < NWV; ++g) tot += red[24 * r + g];
+        mean[r] = (float)(tot / (double)n);
+        double a = 0.0;
+#pragma unroll
+        for (int j = 0; j < C; ++j) if (tid + NT * j < n) { const float dlt = v[r][j] - mean[r]; a += (double)(dlt * dlt); }
+        for (int i = tid + NT * C; i < n; i += NT) { const float dlt = to_db(mp[r][i], ref_db[r]) - mean[r]; a += (double)(dlt * dlt); }
+        acc[r] = wave_sum_dpp(a);
+    }
+    if (lane == 63) { red[12 + w] = acc[0]; red[24 + 12 + w] = acc[1]; }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        double tot = 0.0;
+#pragma unroll
+        for (int g = 0; g < NWV; ++g) tot += red[24 * r + 12 + g];
+        den[r] = sqrtf((float)(tot / (double)n)) + 1e-8f;
+    }
+    const int shift = (T >= TT) ? (T - TT) / 2 : -((TT - T) / 2);
+    const int m_sh = (M & (M - 1)) == 0 ? __builtin_ctz(M) : -1;
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        const int e = tid + NT * j;
+        if (e < n) {
+            const int fr = m_sh >= 0 ? e >> m_sh : e / M, m = e - fr * M, tt = fr - shift;
+            if (tt >= 0 && tt < TT) {
+                const int o = layout == 1 ? tt * M + m : m * TT + tt;
+                out[0][o] = (v[0][j] - mean[0]) / den[0];
+                out[1][o] = (v[1][j] - mean[1]) / den[1];
+            }
+        }
+    }
+    for (int e = tid + NT * C; e < n; e += NT) {         // rows larger than the register cache
+        const int fr = e / M, m = e - fr * M, tt = fr - shift;
+        if (tt >= 0 && tt < TT) {
+            const int o = layout == 1 ? tt * M + m : m * TT + tt;
+            out[0][o] = (to_db(mp[0][e], ref_db[0]) - mean[0]) / den[0];
+            out[1][o] = (to_db(mp[1][e], ref_db[1]) - mean[1]) / den[1];
+        }
+    }
+    if (T < TT) {                                        // literal zero padding, left then right
+        const int left = -shift, right0 = left + T;
+        for (int i = tid; i < (TT - T) * M; i += NT) {
+            const int fr = i / M, m = i - fr * M;
+            const int tt = fr < left ? fr : right0 + (fr - left);
+            const int o = layout == 1 ? tt * M + m : m * TT + tt;
+            out[0][o] = 0.0f; out[1][o] = 0.0f;
+        }
+    }
+}
+
 // ----------------------------------------------------------------------------
 // The same transform with INDEPENDENT waves ("w"): no shared sample span, no workgroup barrier after the tables are
 // staged.  See the comment at the frame list below.  Same arithmetic on the same values as k_stft_mel: bit-identical.
@@ -2111,13 +2198,14 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
         if (fuse_db && (more || G2)) {                      // (G2: every group's stages here - two inlined copies behind the loop would hold ~90 registers each)
             __syncthreads();
             if (tid == 0) *next_pair = NW;
-            db_row_call<kThreads, 8, true>(mp_row, p.n_frames, p.n_mels, p.db_target_frames, p.db_layout,
-                                  p.db_out + (long long)row0 * p.db_target_frames * p.n_mels, db_red0);
-            if (has1) {
-                __syncthreads();
-                db_row_call<kThreads, 8, true>(mp_row + mp_floats, p.n_frames, p.n_mels, p.db_target_frames, p.db_layout,
-                                      p.db_out + (long long)row1 * p.db_target_frames * p.n_mels, db_red0 + 24);
-            }
+            if (G2 && has1) {                               // both rows side by side: one row's barriers and latencies for the two
+                if constexpr (NW <= 12)
+                    db_rows2_call<kThreads, 8>(mp_row, mp_row + mp_floats, p.n_frames, p.n_mels, p.db_target_frames, p.db_layout,
+                                               p.db_out + (long long)row0 * p.db_target_frames * p.n_mels,
+                                               p.db_out + (long long)row1 * p.db_target_frames * p.n_mels, db_red0);
+            } else
+                db_row_call<kThreads, 8, true>(mp_row, p.n_frames, p.n_mels, p.db_target_frames, p.db_layout,
+                                      p.db_out + (long long)row0 * p.db_target_frames * p.n_mels, db_red0);
             __syncthreads();
         }
     }
