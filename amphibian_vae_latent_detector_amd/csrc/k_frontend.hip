@@ -432,6 +432,110 @@ __global__ __launch_bounds__(TH) void k_rms_scale(const T* __restrict__ in, long
     rms_scale_row<T, TH, CH>(smem, threadIdx.x, blockIdx.x, blockIdx.y, in, row_stride, lengths, n_in, scale, ok, norm_out, pad, scale_f64, chunk_sums, chunk_stride);
 }
 
+// ----------------------------------------------------------------------------
+// K0's chunk sums, second form (round 4; PCM16 rows, one 256-thread workgroup per (row, numpy chunk)): k_rms_scale<int16_t, 256, 1> gives a
+// leaf - a <= 128-sample block, 8 accumulators - to ONE thread (~600 dependent vector instructions on 64 of its 256 threads) and walks the
+// tree in seven barrier-separated levels.  Here a leaf sits on a lane QUAD: lane q holds numpy's accumulators r[2q], r[2q + 1], fed by one
+// aligned dword per 8 elements (all 16 requested at once); (r0 + r1) + (r2 + r3) and the rest of numpy's combine are two DPP butterflies;
+// 64 leaves = 256 lanes, one round.  Squares of the INTEGER samples: fl(q^2) 2^-30 == fl(y^2), y = q / 32768, and the power of two commutes
+// with every rounding of the sum - scaled once at the end.  A COMPLETE tree (every leaf at the same depth: all full chunks, and e.g. the
+// 5 666-sample tail of a one-second row) is a butterfly of one wave on the DPP network (sums are commutative: either operand order gives
+// the node's bits); anything else takes the level-by-level walk on that wave.  Same leaves, same tree, same bits as the first form
+// (tests/test_gpu_parity.py::test_rms_normalize_pcm16_bit_exact, ..._inside_the_pair_kernel...).
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_rms_chunk_sums_q(const int16_t* __restrict__ in, long long row_stride, const int32_t* __restrict__ lengths, int n_in,
+                                                          float* __restrict__ chunk_sums, int chunk_stride) {
+#pragma clang fp contract(off)
+    __shared__ __attribute__((aligned(16))) char img[kNpChunk * 2 + 64 * 16];
+    __shared__ float heap[256];
+    const int row = blockIdx.x, chunk = blockIdx.y, tid = threadIdx.x, lane = tid & 63, q = tid & 3;
+    const int n = lengths ? min(lengths[row], n_in) : n_in;
+    const int cn = min(kNpChunk, n - chunk * kNpChunk);
+    if (cn <= 0) return;                                          // (uniform: a chunk past the row's end)
+    const int16_t* x = in + (long long)row * row_stride + (long long)chunk * kNpChunk;
+    // ---- stage the chunk: 16 bytes per lane and load where the chunk start is 4-byte aligned (every load requested before the first LDS write)
+    if ((reinterpret_cast<uintptr_t>(x) & 3u) == 0) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<int16_t*>(x), 0, (cn * 2 + 3) & ~3, 0x00020000);   // (past the chunk: zeros)
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * (tid + 256 * u), 0, 0));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int d = tid + 256 * u; if (8 * d < cn) *reinterpret_cast<uint4*>(img + np_lds_off<int16_t>(8 * d)) = v[u]; }
+    } else {
+        for (int e = tid; e < cn; e += 256) *reinterpret_cast<int16_t*>(img + np_lds_off<int16_t>(e)) = x[e];
+    }
+    __syncthreads();
+    // ---- leaves
+    int D = 6;                                                     // depth of the deepest leaf; the leftmost path is the shallowest
+    bool complete = true;
+    if (cn != kNpChunk) {
+        D = np_depth(cn);
+        int m = cn, d = 0;
+        while (m > kNpBlock) { m = np_split(m); ++d; }
+        complete = d == D;
+    }
+    for (int slot = tid >> 2; slot < (1 << D); slot += 64) {       // (one round unless the tree is 7 deep)
+        int off, size, lvl, rem = 0;
+        if (cn == kNpChunk) { off = slot * kNpBlock; size = kNpBlock; lvl = 6; }
+        else {
+            np_walk(cn, slot, D, off, size, lvl);
+            rem = D - lvl;
+            if (slot & ((1 << rem) - 1)) continue;                 // an early leaf belongs to the slot with zero low bits (quad-uniform)
+        }
+        auto sq = [&](int e) { const float y = (float)*reinterpret_cast<const int16_t*>(img + np_lds_off<int16_t>(e)); return y * y; };
+        float res;
+        if (size < 8) {
+            res = -0.0f;
+            for (int i = 0; i < size; ++i) res = res + sq(off + i);
+        } else {
+            const int body = size - (size & 7);
+            uint32_t d[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i)                           // (off: a multiple of 8 - every group of 8 lies inside one 128-element LDS row)
+                d[i] = 8 * i < body ? *reinterpret_cast<const uint32_t*>(img + np_lds_off<int16_t>(off + 8 * i + 2 * q)) : 0u;
+            float r0 = 0.0f, r1 = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float a = (float)(short)(d[i] & 0xFFFFu), c = (float)((int)d[i] >> 16);
+                const float sa = a * a, sb = c * c;
+                if (i == 0) { r0 = sa; r1 = sb; }
+                else if (8 * i < body) { r0 = r0 + sa; r1 = r1 + sb; }
+            }
+            res = r0 + r1;
+            res = res + dpp_xor1(res);
+            res = res + dpp_xor2(res);
+            for (int i = body; i < size; ++i) res = res + sq(off + i);
+        }
+        if (q == 0) heap[(1 << lvl) + (slot >> rem)] = res;
+    }
+    __syncthreads();
+    if (tid >= 64) return;
+    // ---- the tree, on wave 0
+    float root;
+    if (complete) {
+        float v = lane < (1 << D) ? heap[(1 << D) + lane] : 0.0f;
+        int src = 0;
+        if (D >= 1) v = v + dpp_f<0xB1>(v);                       // quad_perm [1, 0, 3, 2]
+        if (D >= 2) v = v + dpp_f<0x4E>(v);                       // quad_perm [2, 3, 0, 1]
+        if (D >= 3) v = v + dpp_f<0x141>(v);                      // row_half_mirror
+        if (D >= 4) v = v + dpp_f<0x140>(v);                      // row_mirror
+        if (D >= 5) { v = v + dpp_f_rows<0x142, 0xA>(v, 0.0f); src = 31; }      // row_bcast:15 into rows 1, 3
+        if (D >= 6) { v = v + dpp_f_rows<0x143, 0xC>(v, 0.0f); src = 63; }      // row_bcast:31 into rows 2, 3
+        root = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), src));
+    } else {
+        for (int lvl = 6; lvl >= 0; --lvl) {                       // deepest level first: value = left + right
+            if (lane < (1 << lvl)) {
+                int off, size, reached;
+                np_walk(cn, lane, lvl, off, size, reached);
+                if (reached == lvl && size > kNpBlock) heap[(1 << lvl) + lane] = heap[2 * ((1 << lvl) + lane)] + heap[2 * ((1 << lvl) + lane) + 1];
+            }
+            wave_lds_sync();
+        }
+        root = heap[1];
+    }
+    if (lane == 0) chunk_sums[(long long)row * chunk_stride + chunk] = root * (1.0f / 1073741824.0f);     // x 2^-30, exact
+}
+
 template <typename T, int CH = NpPass<T>::kChunks>
 static constexpr size_t rms_scale_lds() {
     constexpr int kChunksPerPass = CH;
@@ -2871,8 +2975,7 @@ void launch_rms_scale_pcm16(const int16_t* in, long long row_stride, const int32
 // K0's first kernel alone: the per-chunk sums of squares of every row (k_stft_pair<.., 2> folds them and normalises in its decode)
 void launch_rms_chunk_sums_pcm16(const int16_t* in, long long row_stride, const int32_t* lengths, int n_in, int n_rows, float* chunk_sums, hipStream_t s) {
     const int n_chunks = rms_scale_chunks(n_in);
-    hipLaunchKernelGGL((k_rms_scale<int16_t, 256, 1>), dim3(n_rows, n_chunks), dim3(256), (rms_scale_lds<int16_t, 1>()), s, in, row_stride, lengths, n_in,
-                       static_cast<float*>(nullptr), static_cast<int32_t*>(nullptr), static_cast<int16_t*>(nullptr), NormPad{}, 1, chunk_sums, n_chunks);
+    hipLaunchKernelGGL(k_rms_chunk_sums_q, dim3(n_rows, n_chunks), dim3(256), 0, s, in, row_stride, lengths, n_in, chunk_sums, n_chunks);
 }
 // Rows that are NOT RMS-normalised here (apply_rms == 0: files 00_normalize_dataset_rms.py already processed), PCM16: the
 // same fix_length'd, centre-padded copy K0 writes, so that the independent-wave STFT kernel has no edge frames in this mode
