@@ -1184,8 +1184,15 @@ int run_frontend(amph_ctx* c, Workspace& w, const void* d_wave, bool pcm16, int 
         }
     } else {
         if (d_rms_ok) (void)hipMemsetAsync(d_rms_ok, 0, (size_t)nb * sizeof(int32_t), s);
-        // PCM16 rows used as they are: the same fix_length'd, centre-padded copy, by a copy kernel (timed with the RMS stage)
-        if (pcm16 && c->stft_prenorm && c->stft_prepad && c->stft_indep && !c->generic_stft) {
+        // PCM16 rows used as they are: the same fix_length'd, centre-padded copy, by a copy kernel (timed with the RMS stage) - or, for the
+        // shapes the K0F form of k_stft_pair covers, no copy at all: the kernel reads the raw rows (K0F 2)
+        const bool raw_rows = pcm16 && c->stft_prenorm && c->stft_prepad && c->stft_k0_fuse && c->cfg.n_fft == 2048 && pair_path(c, true) &&
+                              pair_lds(c, c->stft_pair_waves, db_out != nullptr) <= 160 * 1024 && stft_pair_can_fuse_k0(n_in, c->stft_pair_waves) &&
+                              (n_in & 1) == 0 && (reinterpret_cast<uintptr_t>(d_wave) & 3u) == 0;
+        if (raw_rows) {
+            k0 = true;                                      // (k0_sums stays nullptr: no RMS stage)
+            src.lead = c->cfg.n_fft / 2; src.lengths = nullptr;          // the geometry launch_stft_mel keys the pair kernel on; src.wave is not read
+        } else if (pcm16 && c->stft_prenorm && c->stft_prepad && c->stft_indep && !c->generic_stft) {
             StageTimer t(c, ST_RMS, s);
             NormPad pad{};
             pad.lead = c->cfg.n_fft / 2; pad.n_fix = c->cfg.n_samples; pad.mode = c->cfg.pad_mode;

@@ -68,7 +68,7 @@ struct StftParams {
     int k0_n_in, k0_scale_f64;
     float* k0_scale;           // [B] out
     int32_t* k0_ok;            // [B] out (nullable)
-    const float* k0_chunk_sums;   // [B][k0_chunk_stride] sums of squares per numpy chunk (launch_rms_chunk_sums_pcm16)
+    const float* k0_chunk_sums;   // [B][k0_chunk_stride] sums of squares per numpy chunk (launch_rms_chunk_sums_pcm16); nullptr: no RMS stage - the rows as they are
     int k0_chunk_stride;
     int pair_rows2;            // K0F + fused dB stage: two rows per workgroup and pair queue when the batch is large enough ("stft_pair_rows2")
     // per-context launch choices (were process-wide globals until round 3)

@@ -1785,7 +1785,9 @@ __device__ __forceinline__ void dft32_combine(float (&er)[16], float (&ei)[16], 
 // mel-power image per row in LDS (the stage-1 twiddles then come from global memory: measured free), both dB stages at the end.  A one-second
 // row is 29 pairs on 12 waves = 12 + 12 + 5: its third round keeps 5 of 12 waves busy for ~15 000 of the row's ~64 000 cycles; two rows are
 // 58 pairs = four full rounds + 10, and the tables are staged once for both.
-template <int NW, int HJ, bool TWL, bool K0F = false, bool G2 = false>
+// K0F 2: the raw rows as they are (apply_rms == 0: files 00_normalize_dataset_rms.py has already processed) - the same loads and index
+// arithmetic, a plain decode; replaces the pad kernel's fix_length'd, centre-padded copy of every row.
+template <int NW, int HJ, bool TWL, int K0F = 0, bool G2 = false>
 __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows) {
     constexpr int kThreads = 64 * NW;
     constexpr int ND = 16 + HJ;                         // dwords per lane and pair
@@ -2007,13 +2009,13 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
         const bool has1 = G2 && row1 < n_rows;
         const int n_q = has1 ? 2 * n_pairs : n_pairs;       // the group's queue: row 0's pairs, then row 1's
         float sc_row0 = 1.0f, sc_row1 = 1.0f;
-        if (K0F) { sc_row0 = k0_fold(row0); if (has1) sc_row1 = k0_fold(row1); }
+        if (K0F == 1) { sc_row0 = k0_fold(row0); if (has1) sc_row1 = k0_fold(row1); }
         float wmax = -INFINITY, wmax1 = -INFINITY;          // the largest mel power this wave has stored for the row(s) (fused dB stage: its max pass)
         for (int pi = wave, pr_next = 0; pi < n_q; pi = pr_next) {
             const bool sub = G2 && pi >= n_pairs;           // (wave-uniform) which row of the group
             const int row = sub ? row1 : row0;
             const int pr = pair_of(sub ? pi - n_pairs : pi);    // (identity without K0F)
-            if (K0F) k0_sc = sub ? sc_row1 : sc_row0;
+            if (K0F == 1) k0_sc = sub ? sc_row1 : sc_row0;
             // packed pairs: element j of the lane's TWO sequences (sample parity 0 / 1) side by side - dft16_pk
             amph_f2 XR[16], XI[16];
             float4 tw[16];
@@ -2031,6 +2033,7 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
             // roundings; a gated row has sc = 1 and the clip is the identity) - and serves frame a at j and frame b at j - HJ
             auto requant = [&](uint32_t d) {
 #pragma clang fp contract(off)
+                if constexpr (K0F == 2) return amph_f2{(float)(short)(d & 0xFFFFu), (float)((int)d >> 16)};       // (no RMS stage: the sample as it is)
                 amph_f2 t = amph_f2{(float)(short)(d & 0xFFFFu), (float)((int)d >> 16)} * k0_sc;
                 t = amph_f2{__builtin_amdgcn_fmed3f(t.x, -32768.0f, 32768.0f), __builtin_amdgcn_fmed3f(t.y, -32768.0f, 32768.0f)} * (32767.0f / 32768.0f);
                 return amph_f2{__builtin_rintf(t.x), __builtin_rintf(t.y)};
@@ -2670,12 +2673,14 @@ hipError_t stft_mel_configure(int lds_bytes) {
         e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
     }
-    const void* pfns[11] = {reinterpret_cast<const void*>(&k_stft_pair<8, 3, false>), reinterpret_cast<const void*>(&k_stft_pair<10, 3, false>),
+    const void* pfns[14] = {reinterpret_cast<const void*>(&k_stft_pair<8, 3, false>), reinterpret_cast<const void*>(&k_stft_pair<10, 3, false>),
                             reinterpret_cast<const void*>(&k_stft_pair<11, 3, false>), reinterpret_cast<const void*>(&k_stft_pair<12, 3, false>),
                             reinterpret_cast<const void*>(&k_stft_pair<8, 3, true>), reinterpret_cast<const void*>(&k_stft_pair<10, 3, true>),
                             reinterpret_cast<const void*>(&k_stft_pair<11, 3, true>), reinterpret_cast<const void*>(&k_stft_pair<12, 3, true>),
-                            reinterpret_cast<const void*>(&k_stft_pair<12, 3, false, true>), reinterpret_cast<const void*>(&k_stft_pair<12, 3, true, true>),
-                            reinterpret_cast<const void*>(&k_stft_pair<12, 3, false, true, true>)};
+                            reinterpret_cast<const void*>(&k_stft_pair<12, 3, false, 1>), reinterpret_cast<const void*>(&k_stft_pair<12, 3, true, 1>),
+                            reinterpret_cast<const void*>(&k_stft_pair<12, 3, false, 1, true>),
+                            reinterpret_cast<const void*>(&k_stft_pair<12, 3, false, 2>), reinterpret_cast<const void*>(&k_stft_pair<12, 3, true, 2>),
+                            reinterpret_cast<const void*>(&k_stft_pair<12, 3, false, 2, true>)};
     for (const void* f : pfns) {
         e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
@@ -2735,12 +2740,16 @@ void launch_stft_mel(const StftParams& p, int n_rows, int sample_is_pcm16, int n
         if (p.k0_in) {                                  // K0F (12 waves: the one-second rows of the benchmark; the caller has checked)
             // two rows per workgroup and queue (G2) when the batch has more rows than half the CUs and both rows' mel power fits LDS
             const size_t lds2 = stft_pair_lds_bytes(p.n_frames, p.n_mels, p.pair_mel_w_floats, nw, true, 2);
+            const bool rms = p.k0_chunk_sums != nullptr;          // K0F 1 (fold + re-quantise) or 2 (plain decode)
             if (p.db_out && p.pair_rows2 && n_rows > g_num_cus / 2 && lds2 <= 160 * 1024) {
                 const dim3 grid2((unsigned)std::min((n_rows + 1) / 2, p.grid_wgs > 0 ? p.grid_wgs : g_num_cus));
-                hipLaunchKernelGGL((k_stft_pair<12, 3, false, true, true>), grid2, dim3(64 * 12), lds2, s, p, n_rows);
+                if (rms) hipLaunchKernelGGL((k_stft_pair<12, 3, false, 1, true>), grid2, dim3(64 * 12), lds2, s, p, n_rows);
+                else hipLaunchKernelGGL((k_stft_pair<12, 3, false, 2, true>), grid2, dim3(64 * 12), lds2, s, p, n_rows);
             }
-            else if (twl) hipLaunchKernelGGL((k_stft_pair<12, 3, true, true>), grid, dim3(64 * 12), lds, s, p, n_rows);
-            else hipLaunchKernelGGL((k_stft_pair<12, 3, false, true>), grid, dim3(64 * 12), lds, s, p, n_rows);
+            else if (twl && rms) hipLaunchKernelGGL((k_stft_pair<12, 3, true, 1>), grid, dim3(64 * 12), lds, s, p, n_rows);
+            else if (twl) hipLaunchKernelGGL((k_stft_pair<12, 3, true, 2>), grid, dim3(64 * 12), lds, s, p, n_rows);
+            else if (rms) hipLaunchKernelGGL((k_stft_pair<12, 3, false, 1>), grid, dim3(64 * 12), lds, s, p, n_rows);
+            else hipLaunchKernelGGL((k_stft_pair<12, 3, false, 2>), grid, dim3(64 * 12), lds, s, p, n_rows);
         }
         else if (nw == 8) { AMPH_PAIR_LAUNCH(8) }
         else if (nw == 11) { AMPH_PAIR_LAUNCH(11) }

@@ -534,7 +534,9 @@ def test_rms_normalize_inside_the_pair_kernel_is_bit_identical_to_its_own_launch
             sess.configure("stft_grid", 50 if knob == 3 else 0)
             mu, _, ok = sess.encode(pcm, lengths=lens, apply_rms=True)
             img = sess.mel_pcm16(pcm, lengths=lens, apply_rms=True, layout=1)
-            res[knob] = (mu.clone(), ok.clone(), img.clone())
+            # ... and without the RMS stage (files 00 has already normalised): raw rows, plain decode, no padded copy
+            mu0, _, ok0 = sess.encode(pcm, lengths=lens, apply_rms=False)
+            res[knob] = (mu.clone(), ok.clone(), img.clone(), mu0.clone(), ok0.clone())
         sess.configure("stft_k0_fuse", DEFAULT_K0)
         sess.configure("stft_pair_rows2", 1)
         sess.configure("stft_grid", 0)
@@ -542,6 +544,7 @@ def test_rms_normalize_inside_the_pair_kernel_is_bit_identical_to_its_own_launch
             assert torch.equal(res[knob][1], res[0][1]), (knob, n_rows, n_in)
             assert torch.equal(res[knob][2], res[0][2]), (knob, n_rows, n_in)
             assert torch.equal(res[knob][0], res[0][0]), (knob, n_rows, n_in)
+            assert torch.equal(res[knob][3], res[0][3]) and torch.equal(res[knob][4], res[0][4]) and not res[knob][4].any(), (knob, n_rows, n_in)
         assert torch.isfinite(res[1][0]).all()
         assert int(res[1][1][3]) == 0                                       # the silent row was gated
     # and the fused form against the oracle on a few rows of the plain case
