@@ -25,7 +25,7 @@ src, dst = ROOT / "gpurun_out" / f"prof_{tag}", ROOT / "profiles"
 def stage_of(kernel: str, grid: int) -> str:
     k = kernel.split("(")[0].replace("void amph::", "").replace("amph::", "")
     if k.startswith("k_rms_fold_apply"): return "rms_apply"             # second kernel of the chunked K0 path (bench's stage "rms_scale" = both)
-    if k.startswith("k_rms_scale"): return "rms_scale"
+    if k.startswith("k_rms_scale") or k.startswith("k_rms_chunk_sums"): return "rms_scale"     # (round 4: the chunk sums are the whole stage - fold + apply live in k_stft_pair)
     if k.startswith("k_stft_mel") or k.startswith("k_stft_pair"): return "stft_mel"
     if k.startswith("k_dbnorm"): return "dbnorm"
     if k.startswith("k_conv_gemm_f3") or k.startswith("k_conv_gemm_f4") or (k.startswith("k_conv_gemm<") and "true" in k): return "conv2"
