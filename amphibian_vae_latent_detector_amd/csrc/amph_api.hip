@@ -1160,7 +1160,8 @@ int run_frontend(amph_ctx* c, Workspace& w, const void* d_wave, bool pcm16, int 
         // reads the raw rows and re-quantises in its decode - no padded normalised copy
         const bool k0_fused = pcm16 && norm && pad.lead > 0 && c->stft_k0_fuse && c->cfg.n_fft == 2048 && pair_path(c, true) &&
                               pair_lds(c, c->stft_pair_waves, db_out != nullptr) <= 160 * 1024 && stft_pair_can_fuse_k0(n_in, c->stft_pair_waves) &&
-                              (n_in & 1) == 0 && (reinterpret_cast<uintptr_t>(d_wave) & 3u) == 0;      // (its dword loads: every row 4-byte aligned)
+                              (n_in & 1) == 0 && (reinterpret_cast<uintptr_t>(d_wave) & 3u) == 0 &&    // (its dword loads: every row 4-byte aligned)
+                              (long long)nb * n_in * 2 < (1ll << 31);                                  // (32-bit buffer offsets)
         if (k0_fused) {
             const int rcs = ensure_chunk_sums(c, w, n_in, s);
             if (rcs != AMPH_OK) return rcs;
@@ -1188,7 +1189,7 @@ int run_frontend(amph_ctx* c, Workspace& w, const void* d_wave, bool pcm16, int 
         // shapes the K0F form of k_stft_pair covers, no copy at all: the kernel reads the raw rows (K0F 2)
         const bool raw_rows = pcm16 && c->stft_prenorm && c->stft_prepad && c->stft_k0_fuse && c->cfg.n_fft == 2048 && pair_path(c, true) &&
                               pair_lds(c, c->stft_pair_waves, db_out != nullptr) <= 160 * 1024 && stft_pair_can_fuse_k0(n_in, c->stft_pair_waves) &&
-                              (n_in & 1) == 0 && (reinterpret_cast<uintptr_t>(d_wave) & 3u) == 0;
+                              (n_in & 1) == 0 && (reinterpret_cast<uintptr_t>(d_wave) & 3u) == 0 && (long long)nb * n_in * 2 < (1ll << 31);
         if (raw_rows) {
             k0 = true;                                      // (k0_sums stays nullptr: no RMS stage)
             src.lead = c->cfg.n_fft / 2; src.lengths = nullptr;          // the geometry launch_stft_mel keys the pair kernel on; src.wave is not read

@@ -2034,6 +2034,9 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
             auto requant = [&](uint32_t d) {
 #pragma clang fp contract(off)
                 if constexpr (K0F == 2) return amph_f2{(float)(short)(d & 0xFFFFu), (float)((int)d >> 16)};       // (no RMS stage: the sample as it is)
+#ifdef AMPH_ABL_NOREQ                          /* timing-only ablation: what the re-quantisation costs */
+                return amph_f2{(float)(short)(d & 0xFFFFu), (float)((int)d >> 16)} * k0_sc;
+#endif
                 amph_f2 t = amph_f2{(float)(short)(d & 0xFFFFu), (float)((int)d >> 16)} * k0_sc;
                 t = amph_f2{__builtin_amdgcn_fmed3f(t.x, -32768.0f, 32768.0f), __builtin_amdgcn_fmed3f(t.y, -32768.0f, 32768.0f)} * (32767.0f / 32768.0f);
                 return amph_f2{__builtin_rintf(t.x), __builtin_rintf(t.y)};
@@ -2627,7 +2630,7 @@ size_t stft_pair2_tw1_lds_bytes() { return kP2Tw1Bytes; }
 bool stft_pair2_ok(int n_fft, int hop, int p_tail) { return n_fft == 1024 && hop == 256 && 513 + p_tail <= kP2PStride; }
 // the configurations the pair kernel covers (the caller also needs PCM16 rows padded by K0: src.lead == n_fft / 2)
 bool stft_pair_ok(int n_fft, int hop, int p_tail) { return n_fft == 2048 && hop == 384 && 1025 + p_tail <= kPairPStride; }
-bool stft_pair_can_fuse_k0(int n_in, int n_waves) { return n_in > 0 && n_in <= 4 * kNpChunk && n_waves == 12; }
+bool stft_pair_can_fuse_k0(int n_in, int n_waves) { return n_in > 0 && n_waves == 12; }      // (any row length: the fold walks the row's chunk sums)
 
 static int table_bytes_for(int n_fft) { return n_fft == 2048 ? FftGeo<4>::TABLE_BYTES : FftGeo<2>::TABLE_BYTES; }
 
@@ -2967,8 +2970,7 @@ void launch_rms_scale_pcm16(const int16_t* in, long long row_stride, const int32
 #ifdef AMPH_ABL_SKIP
         if (!(g_abl_skip_k0 & 1))
 #endif
-        hipLaunchKernelGGL((k_rms_scale<int16_t, 256, 1>), dim3(n_rows, n_chunks), dim3(256), (rms_scale_lds<int16_t, 1>()), s, in, row_stride, lengths, n_in,
-                           scale, ok, static_cast<int16_t*>(nullptr), NormPad{}, scale_f64, chunk_sums, n_chunks);
+        hipLaunchKernelGGL(k_rms_chunk_sums_q, dim3(n_rows, n_chunks), dim3(256), 0, s, in, row_stride, lengths, n_in, chunk_sums, n_chunks);   // (round 4: leaves on lane quads)
         const int total_out = (pad.lead > 0 ? pad.n_fix : n_in) + 2 * pad.lead;
         const int tiles = norm_out ? std::max(1, std::min(64, total_out / (2 * 256 * 8))) : 1;       // ~8 dwords per thread (16: 21.1 us for K0 on 256 one-second rows, 8: 19.3, 4: 19.9)
 #ifdef AMPH_ABL_SKIP

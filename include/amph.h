@@ -143,7 +143,7 @@ const char* amph_last_error(const amph_ctx* ctx);   /* ctx may be NULL: create-t
  *                            the largest whose LDS image fits; 10, 11 and 12 give identical bits, the 8-wave build differs
  *                            from them in the last bits (3e-7 of a row's peak mel power: another FMA contraction)
  *   "stft_pair_tw_lds" 0/1   its stage-1 twiddles in LDS when the image still fits 160 KB (default 1), else buffer loads
- *   "stft_k0_fuse"     0/1   PCM16 + RMS rows that take k_stft_pair at 12 waves (n_fft 2048 / hop 384, at most 32 768 samples, an even row length):
+ *   "stft_k0_fuse"     0/1   PCM16 rows that take k_stft_pair at 12 waves (n_fft 2048 / hop 384, an even row length; with or without the RMS stage):
  *                            K0's second kernel (fold + apply) and its padded normalised copy of every row move INTO the STFT kernel - it folds
  *                            the per-chunk sums of squares (K0's first kernel: still a launch) into the scale, reads the raw rows (centre padding,
  *                            fix_length and truncation as index arithmetic) and re-quantises in its decode (default 1; 0 = K0's two launches +

@@ -547,6 +547,20 @@ def test_rms_normalize_inside_the_pair_kernel_is_bit_identical_to_its_own_launch
             assert torch.equal(res[knob][3], res[0][3]) and torch.equal(res[knob][4], res[0][4]) and not res[knob][4].any(), (knob, n_rows, n_in)
         assert torch.isfinite(res[1][0]).all()
         assert int(res[1][1][3]) == 0                                       # the silent row was gated
+    # the reference's own default geometry (5 s / 48 kHz: 30 numpy chunks per row, 626 frames = 313 pairs, the dB stage as its own kernel)
+    cfg5 = env.PRESETS["ref-default"]
+    enc5, _, _ = _encoders(env, "thesis-shape", cfg=cfg5, max_batch=8)
+    s5 = enc5.session(cfg5)
+    pcm5 = env.synth(np.arange(900, 906), cfg5.n_samples, cfg5.sr)
+    pcm5[2] = 0
+    lens5 = np.array([cfg5.n_samples, cfg5.n_samples - 3, 100001, cfg5.n_samples, 8192 * 7 + 130, 2049], np.int32)
+    r5 = {}
+    for knob in (1, 0):
+        s5.configure("stft_k0_fuse", knob)
+        a, _, oka = s5.encode(pcm5, lengths=lens5, apply_rms=True)
+        b, _, _ = s5.encode(pcm5, lengths=lens5, apply_rms=False)
+        r5[knob] = (a.clone(), oka.clone(), b.clone())
+    assert all(torch.equal(r5[1][k], r5[0][k]) for k in range(3))
     # and the fused form against the oracle on a few rows of the plain case
     pcm = env.synth(np.arange(20, 26), cfg.n_samples, cfg.sr)
     z, _, _ = sess.encode(pcm, apply_rms=True)
