@@ -1843,7 +1843,7 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
     const int lane4 = lane_dw * 4, lane16 = lane * 16;
     const __amdgpu_buffer_rsrc_t rs_raw = __builtin_amdgcn_make_buffer_rsrc(const_cast<int16_t*>(p.k0_in), 0, -1, 0x00020000);
     auto k0_row_len = [&](int row_) {                        // samples of the row that count (wave-uniform)
-        const int n_ = p.k0_lengths ? min(p.k0_lengths[row_], p.k0_n_in) : p.k0_n_in;
+        const int n_ = p.k0_lengths ? max(0, min(p.k0_lengths[row_], p.k0_n_in)) : p.k0_n_in;
         return __builtin_amdgcn_readfirstlane(n_);
     };
     auto fetch = [&](int row_, int pr_) {

@@ -525,6 +525,7 @@ def test_rms_normalize_inside_the_pair_kernel_is_bit_identical_to_its_own_launch
             lens = rng.integers(1, n_in + 1, size=n_rows).astype(np.int32)
             lens[:6] = (n_in, n_in - 1, 1, 2, 1025, 8193)
             lens[6:10] = (7922, 8191, 16114, 130)                             # numpy trees 7 levels deep / incomplete (the chunk-sum kernel's walk)
+            lens[10] = 0                                                      # an empty row: gated, an all-zero signal
         res = {}
         # 1: the default (two rows per workgroup and queue when the batch is large: "stft_pair_rows2"); 2: one row per workgroup; 3: two rows per
         # group on 50 workgroups (every workgroup runs several groups, the last one of some a single row); 0: K0's own launches
