@@ -110,7 +110,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_f4s(ConvGemmParams p, Patc
     char* const patch1 = smem + 2 * g.plane;
     uint16_t* const img_stage = reinterpret_cast<uint16_t*>(smem + 4 * g.plane);     // [2][2 terms][2 PR + 1][img_row] fp16
     const int img_pl = (g.n_img + 8) & ~7;                                           // elements per term plane
-    char* const part = smem + 4 * g.plane + 2 * 2 * img_pl * 2;                      // [4 consumer waves][4][64] float4
+    char* const part = smem + 4 * g.plane + 2 * 2 * img_pl * 2;                      // [2 tile parities][4 consumer waves][4][64] float4
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);                       // the role branch below is scalar
     const int n_blk = blockIdx.y * 64;
@@ -309,14 +309,12 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_f4s(ConvGemmParams p, Patc
             if (i == 0) AMPH_F4_WRITE_IMG(img_stage + ((i + 1) & 1) * 2 * img_pl)   // that buffer's last read came before the previous X
             AMPH_F4_T(q_b)
             __syncthreads();                                         // X: patch i complete (the consumers are done with patch i - 1)
-            __syncthreads();                                         // Y
 #ifdef AMPH_STAMPS
             AMPH_F4_T(q_c)
             q_s0 += q_b - q_a; q_s1 += q_c - q_b;
 #endif
         }
         __syncthreads();                                             // the consumers' last X
-        __syncthreads();                                             // ... and Y
 #ifdef AMPH_STAMPS
         if (tid == 256 && p.stamps) { unsigned long long* o = p.stamps + (size_t)blockIdx.x * 16; o[8] = q_s0; o[9] = q_s1; o[10] = q_s2; o[11] = q_s3; o[13] = q_p0; o[14] = q_p1; o[15] = q_p2; }   // producer: build | at the barriers | build: image fetch issue | build: groups | groups: window reads | MFMAs | BN + split + stores
 #endif
@@ -355,8 +353,10 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_f4s(ConvGemmParams p, Patc
         e_sh2 = *reinterpret_cast<const float4*>(nb + 16 < p.N ? p.shift + nb + 16 : p.zeros);
         e_sh3 = *reinterpret_cast<const float4*>(nb + 24 < p.N ? p.shift + nb + 24 : p.zeros);
     }
-    float4* const part_out = reinterpret_cast<float4*>(part + (wave ^ 2) * 4096) + lane;      // the partner's inbox
-    const float4* const part_in = reinterpret_cast<const float4*>(part + wave * 4096) + lane;
+    // the inbox has a slot per tile parity (round 4): tile i's partial sums are read behind barrier X(i), the same slot is written again
+    // behind X(i + 1) - no second barrier per tile for "partial sums consumed" (it also held the producers: 2 barriers -> 1)
+    float4* const part_out0 = reinterpret_cast<float4*>(part + (wave ^ 2) * 4096) + lane;     // the partner's inbox
+    const float4* const part_in0 = reinterpret_cast<const float4*>(part + wave * 4096) + lane;
 #ifdef AMPH_STAMPS
     unsigned long long q_u0 = 0, q_u1 = 0, q_u2 = 0;
     AMPH_F4_T(q_u0)
@@ -368,7 +368,6 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_f4s(ConvGemmParams p, Patc
     AMPH_F4_T(q_u2)
 #endif
     __syncthreads();                                                 // X: the first patch is complete
-    __syncthreads();                                                 // Y (nothing to consume yet)
 #ifdef AMPH_STAMPS
     AMPH_F4_T(q_d)
     const unsigned long long q_start = q_d - q_t0;
@@ -442,6 +441,8 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_f4s(ConvGemmParams p, Patc
         AMPH_F4_T(q_b)
         f32x16 keep, send;
         if (th) { keep = acc1; send = acc0; } else { keep = acc0; send = acc1; }
+        float4* const part_out = part_out0 + (i & 1) * 1024;         // (4 x 4096 bytes per parity)
+        const float4* const part_in = part_in0 + (i & 1) * 1024;
 #pragma unroll
         for (int q = 0; q < 4; ++q) part_out[q * 64] = make_float4(send[4 * q], send[4 * q + 1], send[4 * q + 2], send[4 * q + 3]);
         __syncthreads();                                             // X: partial sums published; patch i + 1 complete; patch i free
@@ -449,7 +450,6 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_f4s(ConvGemmParams p, Patc
 #pragma unroll
         for (int q = 0; q < 4; ++q) rv[q] = part_in[q * 64];
         AMPH_F4_T(q_c)
-        __syncthreads();                                             // Y: partial sums consumed
         AMPH_F4_T(q_d)
         {
             const int m = tile * 64 + th * 32 + m0;
@@ -518,7 +518,7 @@ static PatchGeo f4s_geo(const ConvGemmParams& p) {
     g.rt1_off = (32 / p.OW) * 2 * g.RS;
     return g;
 }
-static size_t f4s_lds(const PatchGeo& g) { return (size_t)4 * g.plane + (size_t)2 * 2 * ((g.n_img + 8) & ~7) * sizeof(uint16_t) + 4 * 4096; }
+static size_t f4s_lds(const PatchGeo& g) { return (size_t)4 * g.plane + (size_t)2 * 2 * ((g.n_img + 8) & ~7) * sizeof(uint16_t) + 2 * 4 * 4096; }
 
 // the shapes it covers: 3x3 stride-2 pad-1 twice, 32 layer-1 channels, whole output rows per 64-pixel tile (OW 16 or 32)
 bool conv_gemm_f4s_ok(const ConvGemmParams& p) {
