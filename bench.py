@@ -511,10 +511,11 @@ def main():
                     traffic[k] = traffic.get(k, 0) + int(e["fetch_kb"] * 1024 * 2 + e["write_kb"] * 1024)
             except (OSError, ValueError, KeyError):
                 pass
-        rocprof_iso = {}
+        rocprof_iso, rocprof_grid = {}, {}
         try:                                                            # rocprofv3 --kernel-trace --stats of `bench.py --lanes 1`
             rj = json.load(open(ROOT / "profiles" / "kernel_durations_latest.json"))
-            rocprof_iso = rj.get("avg_us", {}) if (args.batch == 256 and args.preset == "bench-1s" and not args.bf16) else {}
+            if args.batch == 256 and args.preset == "bench-1s" and not args.bf16:
+                rocprof_iso, rocprof_grid = rj.get("avg_us", {}), rj.get("grid", {})
         except (OSError, ValueError):
             pass
 
@@ -559,6 +560,16 @@ def main():
                 roof["traffic_over_algorithmic"] = round(roof["traffic"] / max(1, alg_bytes * args.batch), 2)
         if name in rocprof_iso:
             roof["rocprofv3_avg_launch_ms"] = round(rocprof_iso[name] / 1e3, 5)
+        if name in rocprof_grid:
+            # the dominant kernel may occupy only part of the chip by design (round 4: k_stft_pair runs two rows per workgroup on 128 of the
+            # 256 CUs - one 768-thread, LDS-filling workgroup per CU - and the other lanes' kernels run beside it): `frac` above prices its
+            # launch DURATION against the whole chip's peak, as the contract defines it; frac_on_occupied_cus divides by the share of the
+            # CUs the launch holds, the figure that is comparable with a one-workgroup-per-CU launch of earlier rounds
+            wg_ = rocprof_grid[name]
+            share = min(1.0, wg_["workgroups"] / 256.0) if wg_["threads"] >= 512 else 1.0
+            roof["workgroups_per_launch"] = wg_["workgroups"]
+            roof["cu_share"] = round(share, 4)
+            roof["frac_on_occupied_cus"] = round(ach / PEAK_HBM_GBS / share, 5)
         tfl = stages[dom]["flops_per_chunk"] * iso_cpl / (iso_ms * 1e-3) / 1e12
         if is_mfma(name):
             roof["compute"] = {"bound": "mfma", "achieved_TFLOPs": round(tfl, 2), "peak": peak_mfma, "frac": round(tfl / peak_mfma, 4)}

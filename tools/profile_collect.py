@@ -106,25 +106,29 @@ tl["_source"] = f"profiles/{rnd}_traffic_{tag}.json (rocprofv3 --pmc FETCH_SIZE 
 
 # per-stage kernel durations of FULL-SIZE launches from the 1-lane kernel trace (what bench.py's isolated HIP-event figure must agree with)
 dur = collections.defaultdict(lambda: collections.defaultdict(list))
+wg_threads = {}
 for f in glob.glob(str(src / "stats_lanes1" / "*" / "*_kernel_trace.csv")):
     for r in csv.DictReader(open(f)):
         if "rocclr" in r["Kernel_Name"]:
             continue
         g = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
-        dur[stage_of(r["Kernel_Name"], g)][g].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-avg_us, n_l = {}, {}
+        st_ = stage_of(r["Kernel_Name"], g)
+        dur[st_][g].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        wg_threads[(st_, g)] = int(r["Workgroup_Size_X"]) * int(r["Workgroup_Size_Y"]) * int(r["Workgroup_Size_Z"])
+avg_us, n_l, wgs = {}, {}, {}
 for st, by_g in dur.items():
     if st.startswith("gemm_grid"):                          # GEMM launches of the partial batch
         continue
     g = max(by_g, key=lambda k: len(by_g[k]))            # the full 256-chunk batches (one partial batch per step has its own grid)
     avg_us[st] = round(sum(by_g[g]) / len(by_g[g]), 3)
     n_l[st] = len(by_g[g])
+    wgs[st] = {"workgroups": g // max(1, wg_threads[(st, g)]), "threads": wg_threads[(st, g)]}
 if "rms_apply" in avg_us and "rms_scale" in avg_us:      # the stage bench.py times is the pair
     avg_us["rms_scale_sum_kernel"] = avg_us["rms_scale"]
     avg_us["rms_scale"] = round(avg_us["rms_scale"] + avg_us["rms_apply"], 3)
 kd = {"_source": f"profiles/{rnd}_bench_kernel_stats_{tag}_lanes1.csv run (rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 "
                  f"--cpu-seconds 0 --lanes 1): mean End - Start of the full-size launches of each stage, microseconds",
-      "avg_us": avg_us, "launches": n_l}
+      "avg_us": avg_us, "launches": n_l, "grid": wgs}
 (dst / f"{rnd}_kernel_durations_{tag}.json").write_text(json.dumps(kd, indent=1) + "\n")
 (dst / "kernel_durations_latest.json").write_text(json.dumps(kd, indent=1) + "\n")
 
