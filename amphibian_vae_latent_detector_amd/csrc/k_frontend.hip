@@ -1377,80 +1377,6 @@ __device__ __attribute__((noinline)) void db_rows2_call(const float* mp0, const 
     }
 }
 
-// The same two rows with ROLLED loops and the dB values kept in place in LDS instead of in registers.  A workgroup runs this stage once per
-// kernel: unrolled over 8 register slots x 2 rows it was ~1 500 straight-line instructions fetched cold (14 500 of the G2 kernel's
-// 131 000 cycles for ~300 instructions' worth of arithmetic per thread; profiles/r04_stft_g2_timeline.txt); here every pass is a five-trip loop.
-// Per row the thread -> element map (i = tid + NT j, j ascending), the per-thread sums, the wave sums and the order of the cross-wave totals are
-// db_row_from_lds<NT, 8, true>'s: the same bits.  mp1 == nullptr: one row.  red: row r's scratch at red + 24 r.
-template <int NT>
-__device__ __attribute__((noinline)) void db_rows_rolled(float* mp0, float* mp1, int T, int M, int TT, int layout, float* out0, float* out1, double* red) {
-    constexpr int NWV = NT / 64;
-    static_assert(NWV <= 12, "the second sums sit beside the first ones");
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int n = T * M, R = mp1 ? 2 : 1;
-    float mean0 = 0.0f, mean1 = 0.0f, den0 = 1.0f, den1 = 1.0f;
-#pragma unroll 1
-    for (int r = 0; r < R; ++r) {
-        float* mp = r ? mp1 : mp0;
-        const float* redf = reinterpret_cast<const float*>(red + 24 * r + 16);
-        float mx = redf[0];
-#pragma unroll 1
-        for (int g = 1; g < NWV; ++g) mx = fmaxf(mx, redf[g]);
-        const float ref_db = 10.0f * log10f(fmaxf(1e-10f, mx));
-        double acc = 0.0;
-#pragma unroll 1
-        for (int i = tid; i < n; i += NT) { const float v = to_db(mp[i], ref_db); mp[i] = v; acc += (double)v; }
-        acc = wave_sum_dpp(acc);
-        if (lane == 63) red[24 * r + w] = acc;
-    }
-    __syncthreads();
-#pragma unroll 1
-    for (int r = 0; r < R; ++r) {
-        const float* mp = r ? mp1 : mp0;
-        double tot = 0.0;
-#pragma unroll 1
-        for (int g = 0; g < NWV; ++g) tot += red[24 * r + g];
-        const float mean = (float)(tot / (double)n);
-        double acc = 0.0;
-#pragma unroll 1
-        for (int i = tid; i < n; i += NT) { const float dlt = mp[i] - mean; acc += (double)(dlt * dlt); }
-        acc = wave_sum_dpp(acc);
-        if (lane == 63) red[24 * r + 12 + w] = acc;
-        if (r) mean1 = mean; else mean0 = mean;
-    }
-    __syncthreads();
-    const int shift = (T >= TT) ? (T - TT) / 2 : -((TT - T) / 2);
-    const int m_sh = (M & (M - 1)) == 0 ? __builtin_ctz(M) : -1;
-#pragma unroll 1
-    for (int r = 0; r < R; ++r) {
-        double tot = 0.0;
-#pragma unroll 1
-        for (int g = 0; g < NWV; ++g) tot += red[24 * r + 12 + g];
-        const float den = sqrtf((float)(tot / (double)n)) + 1e-8f;
-        if (r) den1 = den; else den0 = den;
-    }
-#pragma unroll 1
-    for (int e = tid; e < n; e += NT) {
-        const int fr = m_sh >= 0 ? e >> m_sh : e / M, m = e - fr * M, tt = fr - shift;
-        if (tt >= 0 && tt < TT) {
-            const int o = layout == 1 ? tt * M + m : m * TT + tt;
-            out0[o] = (mp0[e] - mean0) / den0;
-            if (mp1) out1[o] = (mp1[e] - mean1) / den1;
-        }
-    }
-    if (T < TT) {                                        // literal zero padding, left then right
-        const int left = -shift, right0 = left + T;
-#pragma unroll 1
-        for (int i = tid; i < (TT - T) * M; i += NT) {
-            const int fr = i / M, m = i - fr * M;
-            const int tt = fr < left ? fr : right0 + (fr - left);
-            const int o = layout == 1 ? tt * M + m : m * TT + tt;
-            out0[o] = 0.0f;
-            if (mp1) out1[o] = 0.0f;
-        }
-    }
-}
-
 // ----------------------------------------------------------------------------
 // The same transform with INDEPENDENT waves ("w"): no shared sample span, no workgroup barrier after the tables are
 // staged.  See the comment at the frame list below.  Same arithmetic on the same values as k_stft_mel: bit-identical.
@@ -2381,22 +2307,16 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
         }
         if (fuse_db && (more || G2)) {                      // (G2: every group's stages here - two inlined copies behind the loop would hold ~90 registers each)
             __syncthreads();
-#ifdef AMPH_STAMPS
-            if (G2 && tid == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); tl[6] = t_; }
-#endif
             if (tid == 0) *next_pair = NW;
-            if (G2) {                                       // both rows side by side: one row's barriers and latencies for the two
+            if (G2 && has1) {                               // both rows side by side: one row's barriers and latencies for the two
                 if constexpr (NW <= 12)
-                    db_rows_rolled<kThreads>(mp_row, has1 ? mp_row + mp_floats : nullptr, p.n_frames, p.n_mels, p.db_target_frames, p.db_layout,
-                                             p.db_out + (long long)row0 * p.db_target_frames * p.n_mels,
-                                             p.db_out + (long long)(has1 ? row1 : row0) * p.db_target_frames * p.n_mels, db_red0);
+                    db_rows2_call<kThreads, 8>(mp_row, mp_row + mp_floats, p.n_frames, p.n_mels, p.db_target_frames, p.db_layout,
+                                               p.db_out + (long long)row0 * p.db_target_frames * p.n_mels,
+                                               p.db_out + (long long)row1 * p.db_target_frames * p.n_mels, db_red0);
             } else
                 db_row_call<kThreads, 8, true>(mp_row, p.n_frames, p.n_mels, p.db_target_frames, p.db_layout,
                                       p.db_out + (long long)row0 * p.db_target_frames * p.n_mels, db_red0);
             __syncthreads();
-#ifdef AMPH_STAMPS
-            if (G2 && tid == 0) { unsigned long long t_; asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); tl[7] = t_; tl[8] = __builtin_amdgcn_s_memrealtime() - pw_rt0; }
-#endif
         }
     }
 #ifdef AMPH_STAMPS
