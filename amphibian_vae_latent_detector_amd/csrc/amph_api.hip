@@ -167,7 +167,7 @@ struct amph_ctx {
     bool bf16_pair = true;                 // bf16 encoder: layers 1 + 2 in bf16 proper (k_conv_gemm_f4b) instead of fp32-accurate with a bf16 epilogue
     bool patch_fused = true;               // ... in its patch-resident form where the shape allows (k_conv_gemm_f4s)
     int patch_wgs = 0;                     // workgroups of that kernel (0: eight tiles each, at most half the CUs)
-    bool split_gemm = true;                // GEMM layers on the bf16 matrix cores with three-term split operands (fp32-accurate)
+    bool split_gemm = true;                // GEMM layers on the f16 matrix cores with two-term fp16 split operands, x = h + 2^-11 l (fp32-accurate; 0: the f32-MFMA kernels)
     int rms_f64_scale = 1;                 // RMS gate + scale in the scalar arithmetic of numpy 1.26 (reference pin) instead of numpy 2.x's
     // radial scratch
     float* d_centroids = nullptr;
@@ -1043,7 +1043,7 @@ int run_encoder(amph_ctx* c, Workspace& w, const float* d_x, int nb, float* d_mu
             launch_conv_gemm_f3s(ps, s);
             continue;
         }
-        // GEMM layers on the bf16 matrix cores with three-term split operands (fp32-accurate): k_encoder_split.hip
+        // GEMM layers on the f16 matrix cores with two-term fp16 split operands (fp32-accurate): k_encoder_split.hip, k_encoder_patch.hip
         if (c->split_gemm && !fused_here && !head && c->gemm[gi].d_w_f4) {
             const int kind = conv_gemm_g4_kind(prm[gi]);
             if (((kind == 3 || kind == 5 || kind == 6) && (c->patch_gemm & 1)) || (kind == 4 && (c->patch_gemm & 2))) {
