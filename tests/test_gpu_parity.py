@@ -1695,3 +1695,24 @@ def test_resampler_against_the_restatement_and_file_ingest(env, fe, tmp_path):
     Z, status = pfolder.encode_paths(encoder, [wav, tmp_path / "missing.wav"], cfg)
     assert status.tolist()[0] == 0 and status.tolist()[1] != 0
     _assert_latents(Z[:1].cpu().numpy(), z[None])
+
+
+def test_bench_ranks_started_by_the_launcher_one_rank_over_rccl(tmp_path):
+    """`python bench.py --gpus N` starts its ranks itself (launcher.launch_ranks: child processes with RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_*; the parent never touches the GPU).  On the one-GPU box the same code path runs with ONE rank: bench.py under the launcher's
+    environment takes the torch.distributed / RCCL path (the all-gather executes for a one-rank group too), and rank 0's stdout carries
+    exactly one JSON line with the rccl object."""
+    import io
+    import sys
+    from amphibian_vae_latent_detector_amd import launcher
+    root = Path(__file__).resolve().parents[1]
+    out, err = io.StringIO(), io.StringIO()
+    rc = launcher.launch_ranks([sys.executable, str(root / "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2", "--prewarm", "2",
+                                "--chunks", "2048", "--cpu-seconds", "0", "--no-detect", "--no-extra-legs"], 1, out=out, err=err)
+    assert rc == 0, err.getvalue()[-2000:]
+    lines = [ln for ln in out.getvalue().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 1 and rec["value"] > 0 and rec["steps"] == 3
+    assert rec["rccl"]["world_size"] == 1 and rec["rccl"]["backend"] == "nccl" and rec["rccl"]["rank0_block_equals_own_latents"]
+    assert rec["fp16_split_range_overflow"] is False
