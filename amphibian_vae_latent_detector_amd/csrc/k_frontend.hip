@@ -1192,6 +1192,7 @@ __global__ __launch_bounds__(64 * NW) void k_stft_mel(StftParams p, int n_tiles)
 // (population std) -> centre crop / zero pad -> [T, M] or [M, T] (map_detector_core.py:229-237, 185-195) for ONE row whose
 // mel power [n_frames][n_mels] the workgroup holds in LDS.  Same arithmetic as k_dbnorm (separately rounded dB terms, sums
 // in double, two-pass std); the mel power never reaches HBM (-3.7 MB written, -1.9 MB read and one launch less per 256 rows).
+__device__ __forceinline__ float db10(float x);
 __device__ __forceinline__ float to_db(float s, float ref_db);
 // HAVE_MAX: the caller's waves have left the maxima of the values they wrote in redf[0 .. NT / 64) (and passed a barrier): no max pass
 template <int NT, int C = 8, bool HAVE_MAX = false>
@@ -1221,7 +1222,7 @@ __device__ __forceinline__ void db_row_from_lds(const float* mp, int T, int M, i
     mx = redf[0];
 #pragma unroll
     for (int g = 1; g < NWV; ++g) mx = fmaxf(mx, redf[g]);
-    const float ref_db = 10.0f * log10f(fmaxf(1e-10f, mx));             // same two operations as to_db (no FMA)
+    const float ref_db = db10(fmaxf(1e-10f, mx));             // same two operations as to_db (no FMA)
     double acc = 0.0;
 #pragma unroll
     for (int j = 0; j < C; ++j) if (tid + NT * j < n) { v[j] = to_db(v[j], ref_db); acc += (double)v[j]; }
@@ -1252,6 +1253,7 @@ __device__ __forceinline__ void db_row_from_lds(const float* mp, int T, int M, i
     for (int g = 0; g < NWV; ++g) tot += red2[g];
     const float sd = sqrtf((float)(tot / (double)n));
     const float den = sd + 1e-8f;
+    const float rden = 1.0f / den;                       // (x / den as x * (1 / den): one IEEE division per row, 1 ulp on z)
     AMPH_DB_T(4)
     // crop_or_pad_time (map_detector_core.py:185-195): destination frame = source frame - shift
     const int shift = (T >= TT) ? (T - TT) / 2 : -((TT - T) / 2);
@@ -1263,7 +1265,7 @@ __device__ __forceinline__ void db_row_from_lds(const float* mp, int T, int M, i
         if (e < n) {
             const int fr = m_sh >= 0 ? e >> m_sh : e / M, m = e - fr * M, tt = fr - shift;
             if (tt >= 0 && tt < TT) {
-                const float z = (v[j] - mean) / den;
+                const float z = (v[j] - mean) * rden;
                 if (layout == 1) out[tt * M + m] = z; else out[m * TT + tt] = z;
             }
         }
@@ -1271,7 +1273,7 @@ __device__ __forceinline__ void db_row_from_lds(const float* mp, int T, int M, i
     for (int e = tid + NT * C; e < n; e += NT) {         // rows larger than the register cache
         const int fr = e / M, m = e - fr * M, tt = fr - shift;
         if (tt >= 0 && tt < TT) {
-            const float z = (to_db(mp[e], ref_db) - mean) / den;
+            const float z = (to_db(mp[e], ref_db) - mean) * rden;
             if (layout == 1) out[tt * M + m] = z; else out[m * TT + tt] = z;
         }
     }
@@ -1311,7 +1313,7 @@ __device__ __attribute__((noinline)) void db_rows2_call(const float* mp0, const 
         float mx = redf[0];
 #pragma unroll
         for (int g = 1; g < NWV; ++g) mx = fmaxf(mx, redf[g]);
-        ref_db[r] = 10.0f * log10f(fmaxf(1e-10f, mx));
+        ref_db[r] = db10(fmaxf(1e-10f, mx));
     }
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
@@ -1342,7 +1344,7 @@ __device__ __attribute__((noinline)) void db_rows2_call(const float* mp0, const 
         double tot = 0.0;
 #pragma unroll
         for (int g = 0; g < NWV; ++g) tot += red[24 * r + 12 + g];
-        den[r] = sqrtf((float)(tot / (double)n)) + 1e-8f;
+        den[r] = 1.0f / (sqrtf((float)(tot / (double)n)) + 1e-8f);       // (the reciprocal: see db_row_from_lds)
     }
     const int shift = (T >= TT) ? (T - TT) / 2 : -((TT - T) / 2);
     const int m_sh = (M & (M - 1)) == 0 ? __builtin_ctz(M) : -1;
@@ -1353,8 +1355,8 @@ __device__ __attribute__((noinline)) void db_rows2_call(const float* mp0, const 
             const int fr = m_sh >= 0 ? e >> m_sh : e / M, m = e - fr * M, tt = fr - shift;
             if (tt >= 0 && tt < TT) {
                 const int o = layout == 1 ? tt * M + m : m * TT + tt;
-                out[0][o] = (v[0][j] - mean[0]) / den[0];
-                out[1][o] = (v[1][j] - mean[1]) / den[1];
+                out[0][o] = (v[0][j] - mean[0]) * den[0];
+                out[1][o] = (v[1][j] - mean[1]) * den[1];
             }
         }
     }
@@ -1362,8 +1364,8 @@ __device__ __attribute__((noinline)) void db_rows2_call(const float* mp0, const 
         const int fr = e / M, m = e - fr * M, tt = fr - shift;
         if (tt >= 0 && tt < TT) {
             const int o = layout == 1 ? tt * M + m : m * TT + tt;
-            out[0][o] = (to_db(mp[0][e], ref_db[0]) - mean[0]) / den[0];
-            out[1][o] = (to_db(mp[1][e], ref_db[1]) - mean[1]) / den[1];
+            out[0][o] = (to_db(mp[0][e], ref_db[0]) - mean[0]) * den[0];
+            out[1][o] = (to_db(mp[1][e], ref_db[1]) - mean[1]) * den[1];
         }
     }
     if (T < TT) {                                        // literal zero padding, left then right
@@ -2857,10 +2859,18 @@ void launch_stft_generic(const StftParams& p, int n_rows, int sample_is_pcm16, c
 // [M, T_raw] array (population std) -> centre crop / zero pad -> [T, M] or [M, T].
 // One 256-thread block per chunk; dB values are recomputed per pass.
 // ----------------------------------------------------------------------------
+// 10 log10(x) as librosa.power_to_db evaluates it (map_detector_core.py:229), on the hardware's base-2 logarithm (v_log_f32, 1 ulp) times
+// 10 log10(2): two roundings like numpy's log10 then x 10, ~2e-5 dB absolute at 100 dB (the library log10f: 6e-6) - 2e-6 on the z-scored
+// image, far inside its 1e-4 bar - for 2 instead of ~14 vector instructions per element; the dB stage is bound by its arithmetic
+// (profiles/r04_stft_g2_timeline.txt).  ref_db is computed by the SAME function: the row's maximum gives exactly 0.
+__device__ __forceinline__ float db10(float x) {
+#pragma clang fp contract(off)
+    return 3.0102999566398120f * __log2f(x);
+}
 __device__ __forceinline__ float to_db(float s, float ref_db) {
 #pragma clang fp contract(off)
     // separately rounded multiply and subtract (numpy order): the max element gives exactly 0
-    const float db = 10.0f * log10f(fmaxf(1e-10f, s));
+    const float db = db10(fmaxf(1e-10f, s));
     return fmaxf(db - ref_db, -80.0f);
 }
 
@@ -2886,7 +2896,7 @@ __global__ __launch_bounds__(NT) void k_dbnorm(DbNormParams p) {
         for (int i = tid; i < n; i += NT) mx = fmaxf(mx, S[i]);
     }
     mx = block_max<NW>(mx, shf);
-    const float ref_db = 10.0f * log10f(fmaxf(1e-10f, mx));             // same two operations as to_db (no FMA)
+    const float ref_db = db10(fmaxf(1e-10f, mx));             // same two operations as to_db (no FMA)
     double acc = 0.0;
     if (kCache > 0) {
 #pragma unroll
@@ -2903,7 +2913,7 @@ __global__ __launch_bounds__(NT) void k_dbnorm(DbNormParams p) {
         for (int i = tid; i < n; i += NT) { const float d = to_db(S[i], ref_db) - mean; acc += (double)(d * d); }
     }
     const float sd = sqrtf((float)(block_sum<NW>(acc, shd) / (double)n));
-    const float den = sd + 1e-8f;
+    const float rden = 1.0f / (sd + 1e-8f);              // (x / den as x * (1 / den): as db_row_from_lds, bit for bit)
     // crop_or_pad_time (map_detector_core.py:185-195): destination frame = source frame - shift
     const int T = p.n_frames, TT = p.target_frames, M = p.n_mels;
     const int shift = (T >= TT) ? (T - TT) / 2 : -((TT - T) / 2);
@@ -2915,7 +2925,7 @@ __global__ __launch_bounds__(NT) void k_dbnorm(DbNormParams p) {
             if (i < n) {
                 const int fr = i / M, m = i - fr * M, tt = fr - shift;
                 if (tt >= 0 && tt < TT) {
-                    const float z = (v[j] - mean) / den;
+                    const float z = (v[j] - mean) * rden;
                     if (p.layout == 1) out[tt * M + m] = z;
                     else out[m * TT + tt] = z;
                 }
@@ -2935,7 +2945,7 @@ __global__ __launch_bounds__(NT) void k_dbnorm(DbNormParams p) {
             const int tt = i / M, m = i - tt * M;
             const int src = tt + shift;
             float z = 0.0f;
-            if (src >= 0 && src < T) z = (to_db(S[src * M + m], ref_db) - mean) / den;
+            if (src >= 0 && src < T) z = (to_db(S[src * M + m], ref_db) - mean) * rden;
             if (p.layout == 1) out[i] = z;
             else out[m * TT + tt] = z;
         }
