@@ -112,6 +112,7 @@ struct amph_ctx {
                                            // included, fits (1 s rows with the fused dB stage: 11 - 29 pairs on 11 waves are 3 rounds, at most 8 pairs per SIMD)
     bool stft_pair_tw_lds = true;          // its stage-1 twiddles in LDS when the image still fits
     bool stft_k0_fuse = true;              // K0's fold + apply + padded copy inside k_stft_pair (its chunk sums stay a launch); same bits
+    bool stft_pair2_regdb = true;          // n_fft 1024 pair kernel: fused dB stage on register-resident mel power (no image in LDS: fits 12 waves at 128 bands)
     bool stft_pair_rows2 = true;           // ... with two rows per workgroup and pair queue when the batch has more rows than half the CUs (same bits)
     int mel_w_floats = 0, mel_p_tail = 0;
     int32_t *d_mel_start = nullptr, *d_mel_len = nullptr, *d_mel_wofs = nullptr;
@@ -1081,7 +1082,7 @@ int run_encoder(amph_ctx* c, Workspace& w, const float* d_x, int nb, float* d_mu
 // LDS image of the pair kernel this context would use (k_stft_pair at n_fft 2048, k_stft_pair2 at 1024)
 size_t pair_lds(const amph_ctx* c, int nw, bool fused) {
     return c->cfg.n_fft == 2048 ? stft_pair_lds_bytes(c->n_frames, c->cfg.n_mels, c->pair_mel_w_floats, nw, fused)
-                                : stft_pair2_lds_bytes(c->n_frames, c->cfg.n_mels, c->mel_w_floats, nw, fused);
+                                : stft_pair2_lds_bytes(c->n_frames, c->cfg.n_mels, c->mel_w_floats, nw, fused, c->stft_pair2_regdb);
 }
 size_t pair_tw1_lds(const amph_ctx* c) { return c->cfg.n_fft == 2048 ? stft_pair_tw1_lds_bytes() : stft_pair2_tw1_lds_bytes(); }
 // do PCM16 rows that K0 / the pad kernel wrote go through a pair kernel?
@@ -1117,6 +1118,7 @@ StftParams make_stft(amph_ctx* c, const WaveSrc& src, float* melpow, float* db_o
         p.pair_tables = c->d_pair_tables; p.pair_tw1 = c->d_pair_tw1; p.pair_waves = c->stft_pair_waves;
         p.pair_mel_meta = c->d_pair_mel_meta; p.pair_mel_w = c->d_pair_mel_w; p.pair_mel_w_floats = c->pair_mel_w_floats;
         p.pair_tw_lds = c->stft_pair_tw_lds ? 1 : 0;
+        p.pair2_regdb = c->stft_pair2_regdb ? 1 : 0;
     }
 #ifdef AMPH_STAMPS
     if (!c->d_stamps) (void)hipMalloc((void**)&c->d_stamps, (size_t)(c->max_batch * 64 + 6 * 4096) * 16 * 8);   // + the pair kernel's timeline region
@@ -1430,6 +1432,7 @@ int amph_configure(amph_ctx* c, const char* key, int value) {
     if (!std::strcmp(key, "stft_pair_tw_lds")) { c->stft_pair_tw_lds = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "stft_k0_fuse")) { c->stft_k0_fuse = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "stft_pair_rows2")) { c->stft_pair_rows2 = value != 0; return AMPH_OK; }
+    if (!std::strcmp(key, "stft_pair2_regdb")) { c->stft_pair2_regdb = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "stft_pair_waves")) {
         const bool okv = c->cfg.n_fft == 2048 ? (value == 8 || value == 10 || value == 11 || value == 12) : (value == 8 || value == 12);
         if (!okv) return fail(c, AMPH_ERR_INVALID_ARG, "stft_pair_waves must be 8, 10, 11 or 12 (n_fft 2048) / 8 or 12 (n_fft 1024)");

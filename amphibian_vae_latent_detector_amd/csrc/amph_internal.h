@@ -70,6 +70,7 @@ struct StftParams {
     int32_t* k0_ok;            // [B] out (nullable)
     const float* k0_chunk_sums;   // [B][k0_chunk_stride] sums of squares per numpy chunk (launch_rms_chunk_sums_pcm16); nullptr: no RMS stage - the rows as they are
     int k0_chunk_stride;
+    int pair2_regdb;           // k_stft_pair2 with the fused dB stage: the row's mel power stays in registers ("stft_pair2_regdb")
     int pair_rows2;            // K0F + fused dB stage: two rows per workgroup and pair queue when the batch is large enough ("stft_pair_rows2")
     // per-context launch choices (were process-wide globals until round 3)
     int indep;                 // 1: k_stft_mel_w (independent waves), 0: the tile-synchronous k_stft_mel
@@ -121,7 +122,8 @@ int stft_pair_table_bytes();
 size_t stft_pair_tw1_lds_bytes();
 bool stft_pair_ok(int n_fft, int hop, int p_tail);
 // ... and its n_fft 1024 / hop 256 form (k_stft_pair2: a pair per half wave, four frames per wave iteration; 8 or 12 waves)
-size_t stft_pair2_lds_bytes(int n_frames, int n_mels, int mel_w_floats, int n_waves, bool fused);
+size_t stft_pair2_lds_bytes(int n_frames, int n_mels, int mel_w_floats, int n_waves, bool fused, bool regdb = true);   // regdb: the dB stage on registers where it applies
+bool stft_pair2_regdb_ok(int n_frames, int n_mels, int n_waves);
 int stft_pair2_table_bytes();
 size_t stft_pair2_tw1_lds_bytes();
 bool stft_pair2_ok(int n_fft, int hop, int p_tail);

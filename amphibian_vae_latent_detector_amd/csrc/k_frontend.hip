@@ -1379,6 +1379,129 @@ __device__ __attribute__((noinline)) void db_rows2_call(const float* mp0, const 
     }
 }
 
+// The dB stage on mel power that never had a ROW image in LDS (k_stft_pair2's RDB form, round 4): lane (quad qd, band column mq = lane >> 2)
+// holds, for slot si (= the wave's si-th group of four frames, q = wave + NW si) and mel round r, the value of frame 4 q + qd and band
+// 16 r + mq in v[8 si + r].  Same arithmetic as db_row_from_lds / k_dbnorm (separately rounded dB terms, per-thread sums in double, wave
+// sums, cross-wave totals in wave order, two-pass std).  44.5 KB less LDS for an 87 x 128 row - what lets the 12-wave workgroup of the
+// 128-band preset run the stage at all (176 KB with the image).
+// Each wave transposes ITS eight frames through its own FFT scratch (free behind its last slot) into image order [frame][band] and takes
+// them back as four float4 per lane - four consecutive bands of one frame: the output is four 16-byte stores per lane on whole 512-byte
+// frame rows (a first form stored each register where it was: sixteen 4-byte stores per lane, 6 k cycles of address processing per row;
+// profiles/r04_pair2_regdb.txt).  A float4 that does not exist (slot past the row's last, frame past its last frame, bands >= M) is skipped.
+// red: 24 doubles (first sums | second sums) + NW floats (maxima); wscr: >= 8 x 144 floats of the wave's scratch; M % 4 == 0, M <= 128
+#if defined(AMPH_ABL_RDB) && AMPH_ABL_RDB == 3
+#define AMPH_RDB_T(i_) { unsigned long long t_; asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); q_t[i_] = (unsigned)t_; }
+#else
+#define AMPH_RDB_T(i_)
+#endif
+template <int NW>
+__device__ __forceinline__ void db_row_from_regs(const float (&v)[16], float* wscr, int wave, int n_slots, int T, int M, int TT, int layout, float* out, double* red, unsigned q_t0 = 0) {
+    constexpr int FS = 144;                              // floats between two frames of the wave's image (= 16 mod 32: two lanes per bank, the minimum, in the writes)
+    const int tid = threadIdx.x, lane = tid & 63, qd = lane & 3, mq = lane >> 2;
+#if defined(AMPH_ABL_RDB) && AMPH_ABL_RDB == 3
+    unsigned q_t[8];
+    q_t[0] = q_t0;
+    AMPH_RDB_T(1)
+#endif
+    float* redf = reinterpret_cast<float*>(red + 24);
+    const int n = T * M;
+    // (1) registers -> image order; the row's maximum on the way
+    {
+        const bool ok0 = wave < n_slots && 4 * wave + qd < T, ok1 = wave + NW < n_slots && 4 * (wave + NW) + qd < T;
+        float* wr = wscr + qd * FS + mq;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            wr[(k >> 3) * 4 * FS + 16 * (k & 7)] = v[k];
+            mx = fmaxf(mx, ((k < 8 ? ok0 : ok1) && 16 * (k & 7) + mq < M) ? v[k] : -INFINITY);
+        }
+        mx = wave_max_dpp(mx);
+        if (lane == 63) redf[wave] = mx;
+    }
+    AMPH_RDB_T(2)
+    __syncthreads();                                     // (also orders the wave's own image writes before the reads below)
+    AMPH_RDB_T(3)
+    // (2) this lane's float4 i: frame slot f8 = 2 i + (lane >> 5) of the wave (slot f8 >> 2, frame f8 & 3 of it), bands 4 c4 .. 4 c4 + 3
+    const int c4 = lane & 31, fh = lane >> 5;
+    float4 x[4];
+    bool ok[4];
+    int tt[4];
+    const int shift = (T >= TT) ? (T - TT) / 2 : -((TT - T) / 2);      // crop_or_pad_time (map_detector_core.py:185-195): destination frame = source frame - shift
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f8 = 2 * i + fh, q = wave + NW * (f8 >> 2), fr = 4 * q + (f8 & 3);
+        ok[i] = q < n_slots && fr < T && 4 * c4 < M;
+        tt[i] = fr - shift;
+        x[i] = *reinterpret_cast<const float4*>(wscr + f8 * FS + 4 * c4);
+    }
+    float mx = redf[0];
+#pragma unroll
+    for (int g = 1; g < NW; ++g) mx = fmaxf(mx, redf[g]);
+    const float ref_db = db10(fmaxf(1e-10f, mx));
+    double acc = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (ok[i]) {
+            x[i].x = to_db(x[i].x, ref_db); x[i].y = to_db(x[i].y, ref_db); x[i].z = to_db(x[i].z, ref_db); x[i].w = to_db(x[i].w, ref_db);
+            acc += (double)x[i].x; acc += (double)x[i].y; acc += (double)x[i].z; acc += (double)x[i].w;
+        }
+    }
+    acc = wave_sum_dpp(acc);
+    if (lane == 63) red[wave] = acc;
+    __syncthreads();
+    double tot = 0.0;
+#pragma unroll
+    for (int g = 0; g < NW; ++g) tot += red[g];
+    const float mean = (float)(tot / (double)n);
+    acc = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (ok[i]) {
+            const float d0 = x[i].x - mean, d1 = x[i].y - mean, d2 = x[i].z - mean, d3 = x[i].w - mean;
+            acc += (double)(d0 * d0); acc += (double)(d1 * d1); acc += (double)(d2 * d2); acc += (double)(d3 * d3);
+        }
+    }
+    acc = wave_sum_dpp(acc);
+    if (lane == 63) red[12 + wave] = acc;
+    AMPH_RDB_T(4)
+    __syncthreads();
+    AMPH_RDB_T(5)
+    tot = 0.0;
+#pragma unroll
+    for (int g = 0; g < NW; ++g) tot += red[12 + g];
+    const float rden = 1.0f / (sqrtf((float)(tot / (double)n)) + 1e-8f);
+#if defined(AMPH_ABL_RDB) && AMPH_ABL_RDB == 3
+    { float r_ = rden; asm volatile("v_mov_b32 %0, %0" : "+v"(r_)); }
+    AMPH_RDB_T(4)
+#endif
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (ok[i] && tt[i] >= 0 && tt[i] < TT) {
+            const float4 z = make_float4((x[i].x - mean) * rden, (x[i].y - mean) * rden, (x[i].z - mean) * rden, (x[i].w - mean) * rden);
+            if (layout == 1) *reinterpret_cast<float4*>(out + tt[i] * M + 4 * c4) = z;
+            else { float* o = out + (4 * c4) * TT + tt[i]; o[0] = z.x; o[TT] = z.y; o[2 * TT] = z.z; o[3 * TT] = z.w; }
+        }
+    }
+#if defined(AMPH_ABL_RDB) && AMPH_ABL_RDB == 3
+    AMPH_RDB_T(2)
+#endif
+    if (T < TT) {                                        // literal zero padding, left then right
+        const int left = -shift, right0 = left + T;
+        for (int i = tid; i < (TT - T) * M; i += 64 * NW) {
+            const int fr = i / M, m = i - fr * M;
+            const int t2 = fr < left ? fr : right0 + (fr - left);
+            if (layout == 1) out[t2 * M + m] = 0.0f; else out[m * TT + t2] = 0.0f;
+        }
+    }
+#if defined(AMPH_ABL_RDB) && AMPH_ABL_RDB == 3
+    AMPH_RDB_T(6)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    AMPH_RDB_T(7)
+    __syncthreads();
+    if (lane == 0) for (int i = 0; i < 8; ++i) out[8 * wave + i] = __uint_as_float(q_t[i]);      // diagnostic build: the row's first 96 values are stamps
+#endif
+}
+
 // ----------------------------------------------------------------------------
 // The same transform with INDEPENDENT waves ("w"): no shared sample span, no workgroup barrier after the tables are
 // staged.  See the comment at the frame list below.  Same arithmetic on the same values as k_stft_mel: bit-identical.
@@ -2364,11 +2487,15 @@ constexpr int kP2Scratch = 2 * kP2Half;
 constexpr int kP2PStride = kP2Half / 8;             // floats between two power spectra (576 >= 513 + tail)
 constexpr int kP2WinBytes = 16 * 32 * 8, kP2Tw1Bytes = 31 * 32 * 8;
 
-template <int NW, bool TWL>
+template <int NW, bool TWL, bool RDB = false>
 __global__ __launch_bounds__(64 * NW) void k_stft_pair2(StftParams p, int n_rows) {
     constexpr int kThreads = 64 * NW;
     constexpr int HJ = 4, ND = 16 + HJ;
     constexpr int kDbC = NW <= 8 ? 24 : 16;              // dB values a thread keeps in registers (87 x 128 on 512 threads: 22)
+#if defined(AMPH_ABL_RDB) && AMPH_ABL_RDB == 3
+    unsigned q_kt0;
+    { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); q_kt0 = (unsigned)t_; }
+#endif
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hw = lane >> 5, lp = lane & 31;
@@ -2385,7 +2512,7 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair2(StftParams p, int n_rows
     float* Pa = T;
     float* Pb = T + kP2PStride;
     float* mp_row = reinterpret_cast<float*>(smem + kTab + meta_bytes + melw_bytes + NW * kP2Scratch);
-    const bool fuse_db = p.db_out != nullptr;
+    const bool fuse_db = !RDB && p.db_out != nullptr;
     {
         const float4* src = reinterpret_cast<const float4*>(p.pair_tables);
         float4* dst = reinterpret_cast<float4*>(smem);
@@ -2425,8 +2552,12 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair2(StftParams p, int n_rows
     if ((int)blockIdx.x < n_rows && wave < n_slots) fetch(blockIdx.x, wave);
 
 #define AMPH_PHASE_FENCE() __builtin_amdgcn_sched_barrier(0)
+    float mpv[16];                                      // RDB: the row's mel power of this lane (db_row_from_regs)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) mpv[k] = 0.0f;
     for (int row = blockIdx.x; row < n_rows; row += gridDim.x) {
-        for (int q = wave; q < n_slots; q += NW) {
+        int si = 0;
+        for (int q = wave; q < n_slots; q += NW, ++si) {
             float xr[2][16], xi[2][16];
             float2 tw[31];
             {
@@ -2585,19 +2716,36 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair2(StftParams p, int n_rows
                     }
 #undef AMPH_MEL_FMA
                     const int m = 16 * r + (lane >> 2);
+                    float keep = 0.0f;
 #pragma unroll
                     for (int f = 0; f < 4; ++f) {
                         float sa = acc[f][0] + acc[f][1];
                         sa += dpp_xor1(sa);
-                        sa += dpp_xor2(sa);
-                        if (qd == 0 && m < p.n_mels && f < nf) out0[f * p.n_mels + m] = sa;
+                        sa += dpp_xor2(sa);                   // (the same bits in the quad's four lanes)
+                        if (RDB) keep = qd == f ? sa : keep;
+                        else if (qd == 0 && m < p.n_mels && f < nf) out0[f * p.n_mels + m] = sa;
+                    }
+                    if (RDB) {
+                        const int k = 8 * si + r;             // wave-uniform
+#pragma unroll
+                        for (int kk = 0; kk < 16; ++kk) mpv[kk] = k == kk ? keep : mpv[kk];
                     }
                 }
             }
             wave_lds_sync();
             AMPH_PHASE_FENCE();
         }
-        if (fuse_db && row + (int)gridDim.x < n_rows) {
+        if (RDB) {
+#if defined(AMPH_ABL_RDB) && AMPH_ABL_RDB == 1
+            if (p.n_mels < 0)           // timing only: no dB stage (mpv stays live)
+#endif
+            db_row_from_regs<NW>(mpv, Tw, wave, n_slots, p.n_frames, p.n_mels, p.db_target_frames, p.db_layout,
+                                 p.db_out + (long long)row * p.db_target_frames * p.n_mels, reinterpret_cast<double*>(mp_row)
+#if defined(AMPH_ABL_RDB) && AMPH_ABL_RDB == 3
+                                 , q_kt0
+#endif
+                                 );
+        } else if (fuse_db && row + (int)gridDim.x < n_rows) {
             __syncthreads();
             db_row_call<kThreads, kDbC>(mp_row, p.n_frames, p.n_mels, p.db_target_frames, p.db_layout,
                                   p.db_out + (long long)row * p.db_target_frames * p.n_mels,
@@ -2606,7 +2754,7 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair2(StftParams p, int n_rows
         }
     }
 #undef AMPH_PHASE_FENCE
-    if (fuse_db && (int)blockIdx.x < n_rows) {
+    if (!RDB && fuse_db && (int)blockIdx.x < n_rows) {
         const int last_row = blockIdx.x + (n_rows - 1 - (int)blockIdx.x) / (int)gridDim.x * (int)gridDim.x;
         __syncthreads();
         db_row_from_lds<kThreads, kDbC>(mp_row, p.n_frames, p.n_mels, p.db_target_frames, p.db_layout,
@@ -2622,9 +2770,15 @@ size_t stft_pair_lds_bytes(int n_frames, int n_mels, int mel_w_floats, int n_wav
 }
 size_t stft_pair_tw1_lds_bytes() { return kPairTw1Bytes; }
 int stft_pair_table_bytes() { return kPairWinBytes + kPairTw2Bytes; }
-size_t stft_pair2_lds_bytes(int n_frames, int n_mels, int mel_w_floats, int n_waves, bool fused) {
+// the dB stage on register-resident mel power (db_row_from_regs): at most two slots of four frames per wave, eight mel rounds
+bool stft_pair2_regdb_ok(int n_frames, int n_mels, int n_waves) {
+    const int n_slots = (((n_frames + 1) >> 1) + 1) >> 1;
+    return n_waves == 12 && n_slots <= 2 * n_waves && n_mels <= 128 && (n_mels % 4) == 0 && n_frames > 0;
+}
+size_t stft_pair2_lds_bytes(int n_frames, int n_mels, int mel_w_floats, int n_waves, bool fused, bool regdb) {
     const size_t meta = ((size_t)n_mels * 12 + 15) & ~(size_t)15;
-    const size_t mp = fused ? (((size_t)n_frames * n_mels + 3) & ~(size_t)3) * 4 + 16 * 8 + 16 * 4 : 0;
+    const bool rdb = fused && regdb && stft_pair2_regdb_ok(n_frames, n_mels, n_waves);
+    const size_t mp = rdb ? 256 : fused ? (((size_t)n_frames * n_mels + 3) & ~(size_t)3) * 4 + 16 * 8 + 16 * 4 : 0;
     return (size_t)kP2WinBytes + meta + (size_t)mel_w_floats * 4 + (size_t)n_waves * kP2Scratch + mp;
 }
 int stft_pair2_table_bytes() { return kP2WinBytes; }
@@ -2690,8 +2844,9 @@ hipError_t stft_mel_configure(int lds_bytes) {
         e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
     }
-    const void* p2fns[4] = {reinterpret_cast<const void*>(&k_stft_pair2<8, false>), reinterpret_cast<const void*>(&k_stft_pair2<8, true>),
-                            reinterpret_cast<const void*>(&k_stft_pair2<12, false>), reinterpret_cast<const void*>(&k_stft_pair2<12, true>)};
+    const void* p2fns[6] = {reinterpret_cast<const void*>(&k_stft_pair2<8, false>), reinterpret_cast<const void*>(&k_stft_pair2<8, true>),
+                            reinterpret_cast<const void*>(&k_stft_pair2<12, false>), reinterpret_cast<const void*>(&k_stft_pair2<12, true>),
+                            reinterpret_cast<const void*>(&k_stft_pair2<12, false, true>), reinterpret_cast<const void*>(&k_stft_pair2<12, true, true>)};
     for (const void* f : p2fns) {
         e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
@@ -2765,11 +2920,15 @@ void launch_stft_mel(const StftParams& p, int n_rows, int sample_is_pcm16, int n
     }
     if (p.pair_tables && sample_is_pcm16 && p.src.lead == p.n_fft / 2 && stft_pair2_ok(p.n_fft, p.hop, p.p_tail)) {
         const int nw = p.pair_waves == 8 ? 8 : 12;
-        size_t lds = stft_pair2_lds_bytes(p.n_frames, p.n_mels, p.mel_w_floats, nw, p.db_out != nullptr);
+        const bool rdb = p.db_out && p.pair2_regdb && stft_pair2_regdb_ok(p.n_frames, p.n_mels, nw);
+        size_t lds = stft_pair2_lds_bytes(p.n_frames, p.n_mels, p.mel_w_floats, nw, p.db_out != nullptr, rdb);
         const bool twl = p.pair_tw_lds && lds + kP2Tw1Bytes <= 160 * 1024;
         if (twl) lds += kP2Tw1Bytes;
         const dim3 grid((unsigned)std::min(n_rows, p.grid_wgs > 0 ? p.grid_wgs : g_num_cus));
-        if (nw == 8) {
+        if (rdb) {
+            if (twl) hipLaunchKernelGGL((k_stft_pair2<12, true, true>), grid, dim3(768), lds, s, p, n_rows);
+            else hipLaunchKernelGGL((k_stft_pair2<12, false, true>), grid, dim3(768), lds, s, p, n_rows);
+        } else if (nw == 8) {
             if (twl) hipLaunchKernelGGL((k_stft_pair2<8, true>), grid, dim3(512), lds, s, p, n_rows);
             else hipLaunchKernelGGL((k_stft_pair2<8, false>), grid, dim3(512), lds, s, p, n_rows);
         } else {
