@@ -954,9 +954,14 @@ int run_encoder(amph_ctx* c, Workspace& w, const float* d_x, int nb, float* d_mu
             {
                 StageTimer t(c, head ? stage_head_gemm(c) : ST_CONV0 + 1 + gi, s);
                 const int kind = (!head && c->gemm[gi].d_w_f4b) ? conv_gemm_g4_kind(c->gemm[gi].prm_m(p.M)) : 0;
-                if (((kind == 3 || kind == 5 || kind == 6) && (c->patch_gemm_bf16 & 1)) || (kind == 4 && (c->patch_gemm_bf16 & 2))) {
+                if (((kind == 3 || kind == 5 || kind == 6) && (c->patch_gemm_bf16 & 1)) || ((kind == 4 || kind == 7) && (c->patch_gemm_bf16 & 2))) {
                     ConvGemmParams pg = c->gemm[gi].prm;              // (fp32 element counts: K, K_pad as the layer has them)
                     pg.x = w.act[gi]; pg.y = w.act[gi + 1]; pg.M = p.M; pg.y_bf16 = 1;
+#ifdef AMPH_STAMPS
+                    if (!c->d_gstamps) (void)hipMalloc((void**)&c->d_gstamps, (size_t)n_gemm * 8192 * 8 * 8);
+                    pg.stamps = c->d_gstamps + (size_t)gi * 8192 * 8;
+                    c->gstamp_wgs[gi] = c->patch_gemm_wgs > 0 ? c->patch_gemm_wgs : 128;
+#endif
                     launch_conv_gemm_g4(pg, c->gemm[gi].d_w_f4b, c->patch_gemm_wgs, 1, s);
                 } else launch_conv_gemm_bf16(p, bm, s);
             }

@@ -835,18 +835,20 @@ struct G4Geo {
 };
 
 // C_IN input channels; KW K parts x CT channel tiles of 32 = 8 waves; RT row tiles of 32 output pixels per tile; IM images per tile;
-// OWL = log2(output width); the input is (2 OW) x (2 OW) x C_IN per image
+// OWL = log2(output width), OH output rows (default: square); the input is (2 OH) x (2 OW) x C_IN per image
 // TERMS = 2: fp32 NHWC input split in two fp16 terms (x = h + 2^-11 l), fp32 output; TERMS = 1 (bf16 encoder): bf16 NHWC input copied, bf16 weights, bf16 output
-template <int C_IN, int KW, int CT, int RT, int IM, int OWL, int TERMS>
-__global__ __launch_bounds__(512, 2) void k_conv_gemm_g4(ConvGemmParams p, G4Geo g, const uint4* __restrict__ wfrag) {
-    constexpr int OW = 1 << OWL, W = 2 * OW, PR = W + 1, PC = W + 1;
-    constexpr int KSTEPS = 9 * C_IN / 16, KPW = KSTEPS / KW;            // k-steps of 16 in all, per wave (9)
+// (round 4: OH != OW and RT = 3 - conv4 of the 128-band geometry of BASELINE configs[3], 12 x 16 x 128 -> 6 x 8 x 256 in bf16: two images = 96
+// output pixels = three row tiles per tile, a row tile may straddle the two images; one workgroup per CU, so up to 256 registers)
+template <int C_IN, int KW, int CT, int RT, int IM, int OWL, int TERMS, int OH = (1 << OWL)>
+__global__ __launch_bounds__(512, RT >= 3 ? 1 : 2) void k_conv_gemm_g4(ConvGemmParams p, G4Geo g, const uint4* __restrict__ wfrag) {
+    constexpr int OW = 1 << OWL, W = 2 * OW, H = 2 * OH, PR = H + 1, PC = W + 1;
+    constexpr int KSTEPS = 9 * C_IN / 16, KPW = KSTEPS / KW;            // k-steps of 16 in all, per wave (9; 18 in the 12 x 16 x 128 form)
     constexpr int SPT = C_IN / 16;                                       // k-steps per tap
     constexpr int TERM_B = 2 * C_IN;
     constexpr int CQ = TERMS != 1 ? C_IN / 4 : C_IN / 8;                 // 16-byte units per input pixel: float4 (fp32) / 8 bf16
-    constexpr int NV = IM * W * W * CQ / 512;                            // units per thread and tile (8 / 4)
+    constexpr int NV = IM * H * W * CQ / 512;                            // units per thread and tile (8 / 4; 12 for the 12 x 16 x 128 bf16 images)
     constexpr int RPO = 16 / KW;                                         // accumulator registers per owner and row tile
-    static_assert(KW * CT == 8 && KPW == 9 && RT * 32 == IM * OW * OW && NV * 512 == IM * W * W * CQ, "shape");
+    static_assert(KW * CT == 8 && KPW * KW == KSTEPS && RT * 32 == IM * OH * OW && NV * 512 == IM * H * W * CQ, "shape");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const patch = smem;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -860,23 +862,25 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_g4(ConvGemmParams p, G4Geo
     const int px = lane & 31, kh2 = lane >> 5;
     // ---- this wave's weights: k-steps 9 kq .. 9 kq + 8 of channel tile (64-wide n tile, half) in fragment order
     const int n_tile = CT == 2 ? blockIdx.y : (blockIdx.y >> 1), half = CT == 2 ? ct : (blockIdx.y & 1);
-    uint4 breg[9 * TERMS];
+    uint4 breg[KPW * TERMS];
     {
         const uint4* wf = wfrag + (((size_t)n_tile * 2 + half) * KSTEPS + KPW * kq) * (TERMS * 64) + lane;
 #pragma unroll
-        for (int f = 0; f < 9 * TERMS; ++f) breg[f] = wf[f * 64];
+        for (int f = 0; f < KPW * TERMS; ++f) breg[f] = wf[f * 64];
     }
-    int aoff[9];                                                         // patch offset of k-step 9 kq + i: tap, channel group
+    int aoff[KPW];                                                       // patch offset of k-step 9 kq + i: tap, channel group
 #pragma unroll
-    for (int i = 0; i < 9; ++i) {
+    for (int i = 0; i < KPW; ++i) {
         const int s = KPW * kq + i, tap = s / SPT, kh = tap / 3, kw = tap - 3 * kh;
         aoff[i] = kh * g.RS + (kw & 1) * g.PL + (kw >> 1) * g.PXB + 32 * (s % SPT);
     }
-    // lane -> output pixel of row tile 0: image, row, column; row tile 1 (RT == 2) is OW * OW / 2 ... i.e. 32 pixels further
-    const int im0 = px >> (2 * OWL), oh0 = (px >> OWL) & (OW - 1), ow0 = px & (OW - 1);
-    const int a_base = im0 * g.IMG_B + oh0 * 2 * g.RS + ow0 * g.PXB + 16 * kh2;
-    constexpr int RT1_ROWS = 32 >> OWL;                                  // output rows between the two row tiles of an image (RT == 2: IM == 1)
-    const int rt1_off = RT1_ROWS * 2 * g.RS;
+    // lane -> output pixel 32 t + px of row tile t: image, row, column
+    int a_base[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        const int pp = 32 * t + px, im_ = pp / (OH * OW), rem_ = pp - im_ * (OH * OW);
+        a_base[t] = im_ * g.IMG_B + (rem_ >> OWL) * 2 * g.RS + (rem_ & (OW - 1)) * g.PXB + 16 * kh2;
+    }
     const int n_base = blockIdx.y * (32 * CT) + ct * 32;                 // first output channel of this wave
     // BN constants of the RPO channels this wave writes out (accumulator register j of a lane = channel 8 (j / 4) + 4 kh2 + (j % 4))
     const int n_own = n_base + 8 * ((RPO * kq) >> 2) + 4 * kh2 + ((RPO * kq) & 3);
@@ -887,14 +891,14 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_g4(ConvGemmParams p, G4Geo
     int in_dst[NV];
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
-        const int i = tid + 512 * u, c4 = i % CQ, pix = i / CQ, im = pix / (W * W), y = (pix / W) % W, x = pix % W;
+        const int i = tid + 512 * u, c4 = i % CQ, pix = i / CQ, im = pix / (H * W), y = (pix / W) % H, x = pix % W;
         in_dst[u] = im * g.IMG_B + (y + 1) * g.RS + ((x + 1) & 1) * g.PL + ((x + 1) >> 1) * g.PXB + (TERMS != 1 ? 8 : 16) * c4;
     }
     float4 v[NV];
-    const int n_v_total = (p.M >> (2 * OWL)) * (W * W * CQ);             // float4 of all the batch's images (a last tile may be short of images)
+    const int n_v_total = (p.M / (OH * OW)) * (H * W * CQ);              // float4 of all the batch's images (a last tile may be short of images)
 #define AMPH_G4_FETCH(tile_)                                                               \
     {                                                                                      \
-        const int base_ = (tile_) * (IM * W * W * CQ) + tid;                               \
+        const int base_ = (tile_) * (IM * H * W * CQ) + tid;                               \
         const float4* src_ = reinterpret_cast<const float4*>(p.x);                         \
         _Pragma("unroll") for (int u = 0; u < NV; ++u)                                     \
             v[u] = (IM == 1 || base_ + 512 * u < n_v_total) ? src_[base_ + 512 * u] : make_float4(0.f, 0.f, 0.f, 0.f); \
@@ -957,20 +961,20 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_g4(ConvGemmParams p, G4Geo
 #define AMPH_G4_FR(ptr_) __builtin_bit_cast(frag_t, *reinterpret_cast<const uint4*>(ptr_))
         frag_t fc[RT][TERMS], fn[RT][TERMS];
         {
-            const char* pa = patch + a_base + aoff[0];
+            const char* pa = patch + aoff[0];
 #pragma unroll
             for (int t = 0; t < RT; ++t)
 #pragma unroll
-                for (int q = 0; q < TERMS; ++q) fc[t][q] = AMPH_G4_FR(pa + t * rt1_off + q * TERM_B);
+                for (int q = 0; q < TERMS; ++q) fc[t][q] = AMPH_G4_FR(pa + a_base[t] + q * TERM_B);
         }
 #pragma unroll
-        for (int i = 0; i < 9; ++i) {
-            if (i < 8) {
-                const char* pa = patch + a_base + aoff[i + 1];
+        for (int i = 0; i < KPW; ++i) {
+            if (i < KPW - 1) {
+                const char* pa = patch + aoff[i + 1];
 #pragma unroll
                 for (int t = 0; t < RT; ++t)
 #pragma unroll
-                    for (int q = 0; q < TERMS; ++q) fn[t][q] = AMPH_G4_FR(pa + t * rt1_off + q * TERM_B);
+                    for (int q = 0; q < TERMS; ++q) fn[t][q] = AMPH_G4_FR(pa + a_base[t] + q * TERM_B);
             }
             const frag_t wh = __builtin_bit_cast(frag_t, breg[TERMS * i]), wl = __builtin_bit_cast(frag_t, breg[TERMS * i + TERMS - 1]);
 #define AMPH_G4_M(a_, w_, q_)                                                              \
@@ -978,7 +982,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_g4(ConvGemmParams p, G4Geo
             if (TERMS == 2) { AMPH_G4_M(accl, wl, 0) AMPH_G4_M(accl, wh, TERMS - 1) }
             AMPH_G4_M(acc, wh, 0)
 #undef AMPH_G4_M
-            if (i < 8) {
+            if (i < KPW - 1) {
 #pragma unroll
                 for (int t = 0; t < RT; ++t)
 #pragma unroll
@@ -1030,7 +1034,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_g4(ConvGemmParams p, G4Geo
                     }
                 }
                 const int n0 = n_own;
-                const int m = m_img * (OW * OW) + 32 * t + px;          // output pixel index: tiles are whole images
+                const int m = m_img * (OH * OW) + 32 * t + px;          // output pixel index: tiles are whole images
                 if (n0 < p.N && m < p.M) {
 #pragma unroll
                     for (int r = 0; r < RPO; ++r) {
@@ -1074,9 +1078,9 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm_g4(ConvGemmParams p, G4Geo
 #undef AMPH_G4_FETCH
 }
 
-template <int C_IN, int IM, int OWL, int TERMS>
+template <int C_IN, int IM, int OWL, int TERMS, int OH = (1 << OWL)>
 static G4Geo g4_geo(const ConvGemmParams& p) {
-    constexpr int OW = 1 << OWL, W = 2 * OW;
+    constexpr int OW = 1 << OWL, W = 2 * OW, H = 2 * OH;
     G4Geo g{};
     g.PXB = TERMS * 2 * C_IN + 16;
     g.PL = (OW + 1) * g.PXB;
@@ -1086,12 +1090,12 @@ static G4Geo g4_geo(const ConvGemmParams& p) {
                                       {0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27}, {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31}};
     const int rs0 = (W + 1) * g.PXB;
     for (int rs = rs0; rs < rs0 + 512; rs += 16)
-        for (int ib = (W + 1) * rs; ib < (W + 1) * rs + 512; ib += 16) {
+        for (int ib = (H + 1) * rs; ib < (H + 1) * rs + 512; ib += 16) {
             bool ok = true;
             for (int gi = 0; gi < 2 && ok; ++gi) {
                 unsigned used = 0;
                 for (int k = 0; k < 16; ++k) {
-                    const int px = groups[gi][k], im = px >> (2 * OWL), oh = (px >> OWL) & (OW - 1), ow = px & (OW - 1);
+                    const int px = groups[gi][k], im = px / (OH * OW), oh = (px - im * (OH * OW)) >> OWL, ow = px & (OW - 1);      // (row tile 0)
                     const int slot = ((im * ib + oh * 2 * rs + ow * g.PXB) >> 4) & 15;
                     if (used & (1u << slot)) { ok = false; break; }
                     used |= 1u << slot;
@@ -1099,10 +1103,10 @@ static G4Geo g4_geo(const ConvGemmParams& p) {
             }
             if (ok) { g.RS = rs; g.IMG_B = ib; goto found; }
         }
-    g.RS = rs0; g.IMG_B = (W + 1) * rs0;                                 // (no conflict-free stride in range: correct, slower)
+    g.RS = rs0; g.IMG_B = (H + 1) * rs0;                                 // (no conflict-free stride in range: correct, slower)
 found:
     g.patch_bytes = IM * g.IMG_B;
-    g.n_tiles = (p.M + IM * OW * OW - 1) / (IM * OW * OW);
+    g.n_tiles = (p.M + IM * OH * OW - 1) / (IM * OH * OW);
     return g;
 }
 
@@ -1344,12 +1348,14 @@ static int conv_gemm_g5_owl(const ConvGemmParams& p) {
     return 0;
 }
 
-// 0: not covered; 3: conv3's shape (16 x 16 x 64 -> 8 x 8 x 128k); 4: conv4's (8 x 8 x 128 -> 4 x 4 x 64k)
+// 0: not covered; 3: conv3's shape (16 x 16 x 64 -> 8 x 8 x 128k); 4: conv4's (8 x 8 x 128 -> 4 x 4 x 64k); 7: conv4 of the 128-band geometry
+// (12 x 16 x 128 -> 6 x 8 x 64k), single-term (bf16) operands only: two images of two terms would not fit LDS
 int conv_gemm_g4_kind(const ConvGemmParams& p) {
     if (!(p.k == 3 && p.stride == 2 && p.pad == 1 && p.K == 9 * p.C_in && p.K_pad == p.K && p.splits == 1 && p.epilogue == 0 && !p.img && p.M > 0))
         return 0;
     if (p.C_in == 64 && p.OW == 8 && p.OH == 8 && p.W == 16 && p.H == 16 && (p.N % 64) == 0 && (p.M % 64) == 0) return 3;
     if (p.C_in == 128 && p.OW == 4 && p.OH == 4 && p.W == 8 && p.H == 8 && (p.N % 64) == 0 && (p.M % 16) == 0) return 4;
+    if (p.C_in == 128 && p.OW == 8 && p.OH == 6 && p.W == 16 && p.H == 12 && (p.N % 64) == 0 && (p.M % 48) == 0) return 7;      // bf16 operands only (LDS)
     const int owl = conv_gemm_g5_owl(p);
     if (owl) return owl + 2;                                             // 5: OW 8, 6: OW 16 (k_conv_gemm_g5)
     return 0;
@@ -1382,6 +1388,19 @@ static void launch_g4_t(const ConvGemmParams& p, const void* wfrag, int wgs, hip
         if (wgs <= 0) wgs = std::min(g_num_cus / 2, (g.n_tiles * ny + 3) / 4);
         const int per = std::max(1, wgs / ny);
         hipLaunchKernelGGL((k_conv_gemm_g4<128, 8, 1, 1, 2, 2, TERMS>), dim3((unsigned)std::min(g.n_tiles, per), (unsigned)ny), dim3(512), (size_t)std::max(g.patch_bytes, 32 * 1024), s, p, g,
+                           reinterpret_cast<const uint4*>(wfrag));
+    } else if (kind == 7) {
+        if (TERMS != 1) return;                                          // (the caller checks: conv_gemm_g4_kind's comment)
+        static bool raised7[64] = {false};
+        if (dev >= 0 && dev < 64 && !raised7[dev]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_gemm_g4<128, 4, 2, 3, 2, 3, 1, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            raised7[dev] = true;
+        }
+        const G4Geo g = g4_geo<128, 2, 3, 1, 6>(p);
+        const int ny = p.N / 64;
+        if (wgs <= 0) wgs = std::min(g_num_cus / 2, (g.n_tiles * ny + 3) / 4);
+        const int per = std::max(1, wgs / ny);
+        hipLaunchKernelGGL((k_conv_gemm_g4<128, 4, 2, 3, 2, 3, 1, 6>), dim3((unsigned)std::min(g.n_tiles, per), (unsigned)ny), dim3(512), (size_t)std::max(g.patch_bytes, 96 * 1024), s, p, g,
                            reinterpret_cast<const uint4*>(wfrag));
     } else if (kind == 5 || kind == 6) {
         static bool raised5[64] = {false};

@@ -14,14 +14,14 @@ for name in N.EXPORTED_SYMBOLS:
     fn.restype, fn.argtypes = ref.restype, ref.argtypes
 N.lib = lib
 from amphibian_vae_latent_detector_amd.encoder import HipEncoder, random_init_state
-cfg = PRESETS["bench-1s"]
-spec = SPECS["thesis-shape"](64, 64)
+args = dict(a.split("=") for a in sys.argv[1:])          # key=value knobs, e.g. patch_fused=0 patch_wgs=128; preset=bench-1s-128 bf16_encoder=1
+cfg = PRESETS[args.pop("preset", "bench-1s")]
+spec = SPECS["thesis-shape"](cfg.target_frames, cfg.n_mels)
 s = HipEncoder(spec, random_init_state(spec, 0), "cuda:0", max_batch=256).session(cfg)
 s.configure("lanes", 1)
-for a in sys.argv[1:]:                                   # key=value knobs, e.g. patch_fused=0 patch_wgs=128
-    k, v = a.split("=")
+for k, v in args.items():
     s.configure(k, int(v))
-x = torch.randn(256, 1, 64, 64, device="cuda:0")
+x = torch.randn(256, 1, cfg.target_frames, cfg.n_mels, device="cuda:0")
 for _ in range(3):
     s.encoder_forward(x)
 torch.cuda.synchronize()
