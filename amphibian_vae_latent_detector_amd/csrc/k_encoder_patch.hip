@@ -826,7 +826,7 @@ void launch_conv_gemm_f4b(const ConvGemmParams& p, const void* wfrag, int wgs, h
 // patch.  Per tile: (1) all eight waves split the fp32 NHWC input of the tile into the patch [image][row][column parity][column / 2]
 // [term][C_in] bf16 (once per element, not once per tap); (2) multiply; (3) the K parts are added through LDS (the retired patch) in
 // part order, BN + ReLU, out.  conv3 (16 x 16 x 64 -> 8 x 8 x 128): tile = one image, 64 channels per workgroup, K in 4 parts;
-// conv4 (8 x 8 x 128 -> 4 x 4 x 256): tile = two images, 32 channels per workgroup, K in 8 parts.
+// conv4 (8 x 8 x 128 -> 4 x 4 x 256): tile = two images, 64 channels per workgroup, K in 4 parts of 18 k-steps (round 4; was 32 channels / 8 parts).
 // ----------------------------------------------------------------------------
 struct G4Geo {
     int PXB, PL, RS, IMG_B;   // bytes per patch pixel (3 terms x C_in bf16 + 16), per even-column plane of a row, per row, per image
@@ -1369,7 +1369,7 @@ static void launch_g4_t(const ConvGemmParams& p, const void* wfrag, int wgs, hip
     (void)hipGetDevice(&dev);
     if (dev >= 0 && dev < 64 && !raised[dev]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_gemm_g4<64, 4, 2, 2, 1, 3, TERMS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_gemm_g4<128, 8, 1, 1, 2, 2, TERMS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_gemm_g4<128, 4, 2, 1, 2, 2, TERMS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         raised[dev] = true;
     }
     const int kind = conv_gemm_g4_kind(p);
@@ -1384,10 +1384,12 @@ static void launch_g4_t(const ConvGemmParams& p, const void* wfrag, int wgs, hip
                            reinterpret_cast<const uint4*>(wfrag));
     } else if (kind == 4) {
         const G4Geo g = g4_geo<128, 2, 2, TERMS>(p);
-        const int ny = p.N / 32;
+        // 64 channels per workgroup, K in four parts of 18 k-steps (round 4; the 32-channel / eight-part form it replaces: 28.9 against 24.8 us per
+        // 256 chunks on 128 workgroups - seven senders per owner in the K-part exchange and 8-byte output stores for half the multiply)
+        const int ny = p.N / 64;
         if (wgs <= 0) wgs = std::min(g_num_cus / 2, (g.n_tiles * ny + 3) / 4);
         const int per = std::max(1, wgs / ny);
-        hipLaunchKernelGGL((k_conv_gemm_g4<128, 8, 1, 1, 2, 2, TERMS>), dim3((unsigned)std::min(g.n_tiles, per), (unsigned)ny), dim3(512), (size_t)std::max(g.patch_bytes, 32 * 1024), s, p, g,
+        hipLaunchKernelGGL((k_conv_gemm_g4<128, 4, 2, 1, 2, 2, TERMS>), dim3((unsigned)std::min(g.n_tiles, per), (unsigned)ny), dim3(512), (size_t)std::max(g.patch_bytes, 32 * 1024), s, p, g,
                            reinterpret_cast<const uint4*>(wfrag));
     } else if (kind == 7) {
         if (TERMS != 1) return;                                          // (the caller checks: conv_gemm_g4_kind's comment)
