@@ -114,6 +114,7 @@ struct amph_ctx {
     bool stft_k0_fuse = true;              // K0's fold + apply + padded copy inside k_stft_pair (its chunk sums stay a launch); same bits
     bool stft_pair2_regdb = true;          // n_fft 1024 pair kernel: fused dB stage on register-resident mel power (no image in LDS: fits 12 waves at 128 bands)
     bool stft_pair_rows2 = true;           // ... with two rows per workgroup and pair queue when the batch has more rows than half the CUs (same bits)
+    int stft_pair_cq = 0;                  // ... > 1: that many rows per workgroup on one continuous pair queue, a row's dB stage by the wave that completes it (same bits)
     int mel_w_floats = 0, mel_p_tail = 0;
     int32_t *d_mel_start = nullptr, *d_mel_len = nullptr, *d_mel_wofs = nullptr;
     float* d_mel_w = nullptr;
@@ -1037,7 +1038,7 @@ int run_encoder(amph_ctx* c, Workspace& w, const float* d_x, int nb, float* d_mu
         const bool fused_here = fuse && gi == 0;
         if (c->split_gemm && c->split_fused && c->patch_fused && fused_here && c->gemm[gi].d_w_f4 && img_checked && conv_gemm_f4s_ok(prm[gi])) {
 #ifdef AMPH_STAMPS
-            c->gstamp_wgs[gi] = std::min(prm[gi].M / 64, c->patch_wgs > 0 ? c->patch_wgs : std::max(1, std::min(amph::g_num_cus / 2, (prm[gi].M / 64 + 7) / 8)));
+            c->gstamp_wgs[gi] = std::min(prm[gi].M / 64, c->patch_wgs > 0 ? c->patch_wgs : std::max(1, std::min(amph::g_num_cus / 4, (prm[gi].M / 64 + 15) / 16)));
             c->gstamp_f4s = true;                               // rows of 16: consumer wave 0 in [0..7], producer wave 4 in [8..15]
 #endif
             launch_conv_gemm_f4s(prm[gi], c->gemm[gi].d_w_f4, c->patch_wgs, s);
@@ -1054,7 +1055,7 @@ int run_encoder(amph_ctx* c, Workspace& w, const float* d_x, int nb, float* d_mu
             const int kind = conv_gemm_g4_kind(prm[gi]);
             if (((kind == 3 || kind == 5 || kind == 6) && (c->patch_gemm & 1)) || (kind == 4 && (c->patch_gemm & 2))) {
 #ifdef AMPH_STAMPS
-                c->gstamp_wgs[gi] = c->patch_gemm_wgs > 0 ? c->patch_gemm_wgs : 128;
+                c->gstamp_wgs[gi] = c->patch_gemm_wgs > 0 ? c->patch_gemm_wgs : 64;
 #endif
                 launch_conv_gemm_g4(prm[gi], c->gemm[gi].d_w_f4, c->patch_gemm_wgs, 3, s);
                 continue;
@@ -1223,6 +1224,7 @@ int run_frontend(amph_ctx* c, Workspace& w, const void* d_wave, bool pcm16, int 
                 sp.k0_scale_f64 = c->rms_f64_scale; sp.k0_scale = w.scale; sp.k0_ok = k0_ok;
                 sp.k0_chunk_sums = k0_sums; sp.k0_chunk_stride = rms_scale_chunks(n_in);
                 sp.pair_rows2 = c->stft_pair_rows2 ? 1 : 0;
+                sp.pair_cq = c->stft_pair_cq;
             }
             if (c->generic_stft) launch_stft_generic(sp, nb, pcm16 ? 1 : 0, c->d_gen_win, c->d_gen_tw, s);
             else launch_stft_mel(sp, nb, pcm16 ? 1 : 0, c->stft_waves, s);
@@ -1437,6 +1439,7 @@ int amph_configure(amph_ctx* c, const char* key, int value) {
     if (!std::strcmp(key, "stft_pair_tw_lds")) { c->stft_pair_tw_lds = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "stft_k0_fuse")) { c->stft_k0_fuse = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "stft_pair_rows2")) { c->stft_pair_rows2 = value != 0; return AMPH_OK; }
+    if (!std::strcmp(key, "stft_pair_cq")) { if (value < 0 || value > 64) return AMPH_ERR_INVALID_ARG; c->stft_pair_cq = value; return AMPH_OK; }
     if (!std::strcmp(key, "stft_pair2_regdb")) { c->stft_pair2_regdb = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "stft_pair_waves")) {
         const bool okv = c->cfg.n_fft == 2048 ? (value == 8 || value == 10 || value == 11 || value == 12) : (value == 8 || value == 12);
@@ -1568,6 +1571,14 @@ int amph_configure(amph_ctx* c, const char* key, int value) {
             }
             if (nn) fprintf(stderr, "    dB stage (thread 0): max + barrier %.0f | log10 + sums %.0f | reduce + barrier %.0f | mean, squares, reduce, barriers %.0f | std %.0f | z + stores %.0f\n",
                             dd[0] / nn, dd[1] / nn, dd[2] / nn, dd[3] / nn, dd[4] / nn, dd[5] / nn);
+        }
+        {
+            double a = 0, b = 0; int m = 0;
+            for (int bb = 0; bb < value; ++bb) {
+                const unsigned long long* t = h.data() + (size_t)bb * 16;
+                if (t[7] && t[9] && t[10] > t[9] && c->stft_pair_cq > 1) { a += (double)(t[9] - t[1]); b += (double)(t[10] - t[9]); ++m; }
+            }
+            if (m) fprintf(stderr, "    continuous queue: row 0's single-wave dB stage starts %.0f cycles after the tables, takes %.0f\n", a / m, b / m);
         }
         if (n) fprintf(stderr, "  k_stft_pair timeline, mean cycles over %d workgroups: tables staged %.0f | pair rounds (last wave) %.0f %.0f %.0f %.0f | to the barrier %.0f | dB stage %.0f | "
                                "total %.0f cycles = %.0f ticks of 10 ns (%.2f GHz)\n", n, d[0] / n, d[1] / n, d[2] / n, d[3] / n, d[4] / n, d[5] / n, d[6] / n, d[7] / n, ticks / n,

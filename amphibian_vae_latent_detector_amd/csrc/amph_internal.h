@@ -72,6 +72,7 @@ struct StftParams {
     int k0_chunk_stride;
     int pair2_regdb;           // k_stft_pair2 with the fused dB stage: the row's mel power stays in registers ("stft_pair2_regdb")
     int pair_rows2;            // K0F + fused dB stage: two rows per workgroup and pair queue when the batch is large enough ("stft_pair_rows2")
+    int pair_cq;               // ... or, > 1: that many rows per workgroup on ONE continuous pair queue, the dB stage of a row run by the wave that completes it ("stft_pair_cq")
     // per-context launch choices (were process-wide globals until round 3)
     int indep;                 // 1: k_stft_mel_w (independent waves), 0: the tile-synchronous k_stft_mel
     int grid_wgs;              // persistent workgroups; 0 = fill the chip

@@ -543,7 +543,9 @@ void launch_conv_gemm_f4s(const ConvGemmParams& p, const void* wfrag, int wgs, h
     const PatchGeo g = f4s_geo(p);
     // eight tiles per workgroup amortise its start-up (weights, first patch: ~10 k cycles, 2.5 tiles' worth); half the CUs at most -
     // the other lanes' kernels fill the rest (tools/sweep.py patch_wgs=...: 64..128 workgroups 2.41 M chunks/s, 256: 2.37 M)
-    if (wgs <= 0) wgs = std::max(1, std::min(g_num_cus / 2, (g.n_tiles + 7) / 8));
+    // (round 4: sixteen tiles each, a quarter of the CUs at most - 64 workgroups at a 256-chunk batch, with 64 for conv3 as well: 4.09 against
+    // 4.04 M chunks/s with 128 + 128, seven alternating rounds on one box, profiles/r04_stft_cq.txt; 48: 3.93 M.  The bf16 encoder keeps 128.)
+    if (wgs <= 0) wgs = std::max(1, std::min(g_num_cus / 4, (g.n_tiles + 15) / 16));
     const dim3 grid((unsigned)std::min(g.n_tiles, wgs), (unsigned)((p.N + 63) / 64), 1);      // persistent
     hipLaunchKernelGGL(k_conv_gemm_f4s, grid, dim3(512), f4s_lds(g), s, p, g, reinterpret_cast<const uint4*>(wfrag));
 }
@@ -1378,7 +1380,8 @@ static void launch_g4_t(const ConvGemmParams& p, const void* wfrag, int wgs, hip
     if (kind == 3) {
         const G4Geo g = g4_geo<64, 1, 3, TERMS>(p);
         const int ny = p.N / 64;
-        if (wgs <= 0) wgs = std::min(g_num_cus / 2, (g.n_tiles * ny + 3) / 4);
+        // (the two-term fp32 form: eight tiles each on a quarter of the CUs - see launch_conv_gemm_f4s)
+        if (wgs <= 0) wgs = TERMS == 2 ? std::min(g_num_cus / 4, (g.n_tiles * ny + 7) / 8) : std::min(g_num_cus / 2, (g.n_tiles * ny + 3) / 4);
         const int per = std::max(1, wgs / ny);
         hipLaunchKernelGGL((k_conv_gemm_g4<64, 4, 2, 2, 1, 3, TERMS>), dim3((unsigned)std::min(g.n_tiles, per), (unsigned)ny), dim3(512), (size_t)std::max(g.patch_bytes, 64 * 1024), s, p, g,
                            reinterpret_cast<const uint4*>(wfrag));

@@ -1379,6 +1379,153 @@ __device__ __attribute__((noinline)) void db_rows2_call(const float* mp0, const 
     }
 }
 
+// The same stage run by ONE wave on a row image it owns (k_stft_pair's continuous-queue form: the wave that completed the row's last pair,
+// while the workgroup's other waves are on the next row's pairs).  The wave plays db_row_from_lds<NT, C, true>'s NT / 64 waves one after
+// the other: virtual thread 64 w + lane takes elements e = 64 w + lane + NT j in the order of j, its double sum goes through the same DPP
+// tree, the wave totals are added in the order of w - the same bits as the NT-thread forms.  The dB values replace the mel power IN PLACE
+// (every element is read and written by the same lane), so the log10 runs once per element; nothing but the image is touched in LDS.
+// mx: the row's largest mel power.  Rolled loops on purpose: the stage is off the critical path here, what it costs is the issue slots it takes.
+__device__ __forceinline__ double readlane63_d(double a) {
+    const long long b = __double_as_longlong(a);
+    return __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(b >> 32), 63) << 32) | (unsigned int)__builtin_amdgcn_readlane((int)b, 63));
+}
+typedef __attribute__((address_space(3))) float lds_float;
+template <int NT, int C = 5>
+__device__ __attribute__((noinline)) void db_row_wave_call(float* mp_g, int T, int M, int TT, int layout, float* out, float mx) {
+    constexpr int NWV = NT / 64;
+    const int lane = threadIdx.x & 63;
+    // (the arguments of a function that is not inlined arrive in vector registers and count as divergent: every `frame < T` below would be
+    // an exec-mask branch, every address a 64-bit per-lane sum)
+    T = __builtin_amdgcn_readfirstlane(T); M = __builtin_amdgcn_readfirstlane(M); TT = __builtin_amdgcn_readfirstlane(TT);
+    layout = __builtin_amdgcn_readfirstlane(layout);
+    mx = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(mx)));
+    {
+        const unsigned long long ob = (unsigned long long)out;
+        out = reinterpret_cast<float*>(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ob >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)ob));
+    }
+    lds_float* const mp = (lds_float*)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)(lds_float*)mp_g);
+    const int n = T * M;
+    const float ref_db = db10(fmaxf(1e-10f, mx));
+    if (M == 64 && n <= NT * C && NWV % 4 == 0) {
+        // 64 bands: element e = 64 w + lane + NT j is band `lane` of frame w + NWV j - no index arithmetic per element.  FOUR virtual waves
+        // at a time (four independent chains of C elements, 4 C LDS reads in flight): a lone wave beside two busy waves of its SIMD runs
+        // DEPENDENT instructions at ~20 cycles apiece - the one-chain form at the end of this function took ~75 000 cycles per row, longer
+        // than the row's pairs take the other eleven waves - and the fully unrolled form (NWV chains, the row in registers) is 30 KB of
+        // code beside a 30 KB pair loop in a 64 KB instruction cache.
+        lds_float* const src = mp + lane;
+        double tot = 0.0;
+#pragma unroll 1
+        for (int w0 = 0; w0 < NWV; w0 += 4) {
+            float v[4][C];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < C; ++j) v[u][j] = w0 + u + NWV * j < T ? src[64 * (w0 + u + NWV * j)] : 0.0f;
+            double a[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                a[u] = 0.0;
+#pragma unroll
+                for (int j = 0; j < C; ++j) {
+                    v[u][j] = to_db(v[u][j], ref_db);
+                    if (w0 + u + NWV * j < T) { src[64 * (w0 + u + NWV * j)] = v[u][j]; a[u] += (double)v[u][j]; }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] = wave_sum_dpp(a[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) tot += readlane63_d(a[u]);
+        }
+        const float mean = (float)(tot / (double)n);
+        wave_lds_sync();
+        tot = 0.0;
+#pragma unroll 1
+        for (int w0 = 0; w0 < NWV; w0 += 4) {
+            float v[4][C];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < C; ++j) v[u][j] = w0 + u + NWV * j < T ? src[64 * (w0 + u + NWV * j)] : 0.0f;
+            double a[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                a[u] = 0.0;
+#pragma unroll
+                for (int j = 0; j < C; ++j) if (w0 + u + NWV * j < T) { const float dlt = v[u][j] - mean; a[u] += (double)(dlt * dlt); }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] = wave_sum_dpp(a[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) tot += readlane63_d(a[u]);
+        }
+        const float den = 1.0f / (sqrtf((float)(tot / (double)n)) + 1e-8f);
+        const int shift = (T >= TT) ? (T - TT) / 2 : -((TT - T) / 2);
+        const int f0 = shift > 0 ? shift : 0, f1 = T < TT + shift ? T : TT + shift;       // source frames f0 .. f1 - 1 land in the image
+        float* const o1 = layout == 1 ? out + lane - 64 * shift : out + lane * TT - shift;  // element (frame fr, band lane) at o1[fr * os]
+        const int os = layout == 1 ? 64 : 1;
+#pragma unroll 8
+        for (int fr = f0; fr < f1; ++fr) o1[fr * os] = (src[64 * fr] - mean) * den;
+        if (T < TT) {                                    // literal zero padding, left then right
+            const int left = -shift, right0 = left + T;
+            for (int fr = 0; fr < TT - T; ++fr) {
+                const int tt = fr < left ? fr : right0 + (fr - left);
+                out[layout == 1 ? tt * 64 + lane : lane * TT + tt] = 0.0f;
+            }
+        }
+        wave_lds_sync();
+        return;
+    }
+    double tot = 0.0;
+    for (int w = 0; w < NWV; ++w) {
+        double a = 0.0;
+        for (int e0 = 64 * w + lane; e0 < n; e0 += 8 * NT) {       // eight elements in flight (the same order of additions as one by one)
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = e0 + NT * j < n ? mp[e0 + NT * j] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = to_db(v[j], ref_db);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (e0 + NT * j < n) { mp[e0 + NT * j] = v[j]; a += (double)v[j]; }
+        }
+        a = wave_sum_dpp(a);
+        const long long b = __double_as_longlong(a);
+        tot += __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(b >> 32), 63) << 32) | (unsigned int)__builtin_amdgcn_readlane((int)b, 63));
+    }
+    const float mean = (float)(tot / (double)n);
+    wave_lds_sync();
+    tot = 0.0;
+    for (int w = 0; w < NWV; ++w) {
+        double a = 0.0;
+        for (int e0 = 64 * w + lane; e0 < n; e0 += 8 * NT) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = e0 + NT * j < n ? mp[e0 + NT * j] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (e0 + NT * j < n) { const float dlt = v[j] - mean; a += (double)(dlt * dlt); }
+        }
+        a = wave_sum_dpp(a);
+        const long long b = __double_as_longlong(a);
+        tot += __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(b >> 32), 63) << 32) | (unsigned int)__builtin_amdgcn_readlane((int)b, 63));
+    }
+    const float den = 1.0f / (sqrtf((float)(tot / (double)n)) + 1e-8f);       // (the reciprocal: see db_row_from_lds)
+    const int shift = (T >= TT) ? (T - TT) / 2 : -((TT - T) / 2);
+    const int m_sh = (M & (M - 1)) == 0 ? __builtin_ctz(M) : -1;
+#pragma unroll 4
+    for (int e = lane; e < n; e += 64) {
+        const int fr = m_sh >= 0 ? e >> m_sh : e / M, m = e - fr * M, tt = fr - shift;
+        if (tt >= 0 && tt < TT) out[layout == 1 ? tt * M + m : m * TT + tt] = (mp[e] - mean) * den;
+    }
+    if (T < TT) {                                        // literal zero padding, left then right
+        const int left = -shift, right0 = left + T;
+        for (int i = lane; i < (TT - T) * M; i += 64) {
+            const int fr = i / M, m = i - fr * M;
+            const int tt = fr < left ? fr : right0 + (fr - left);
+            out[layout == 1 ? tt * M + m : m * TT + tt] = 0.0f;
+        }
+    }
+    wave_lds_sync();                                     // the image's last read lies in front of whatever the caller publishes
+}
+
 // The dB stage on mel power that never had a ROW image in LDS (k_stft_pair2's RDB form, round 4): lane (quad qd, band column mq = lane >> 2)
 // holds, for slot si (= the wave's si-th group of four frames, q = wave + NW si) and mel round r, the value of frame 4 q + qd and band
 // 16 r + mq in v[8 si + r].  Same arithmetic as db_row_from_lds / k_dbnorm (separately rounded dB terms, per-thread sums in double, wave
@@ -1912,8 +2059,9 @@ __device__ __forceinline__ void dft32_combine(float (&er)[16], float (&ei)[16], 
 // 58 pairs = four full rounds + 10, and the tables are staged once for both.
 // K0F 2: the raw rows as they are (apply_rms == 0: files 00_normalize_dataset_rms.py has already processed) - the same loads and index
 // arithmetic, a plain decode; replaces the pad kernel's fix_length'd, centre-padded copy of every row.
-template <int NW, int HJ, bool TWL, int K0F = 0, bool G2 = false>
+template <int NW, int HJ, bool TWL, int K0F = 0, bool G2 = false, bool CQ = false>
 __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows) {
+    static_assert(!CQ || (G2 && K0F != 0 && NW <= 12), "the continuous queue runs on the two-image (G2) layout of the K0F forms");
     constexpr int kThreads = 64 * NW;
     constexpr int ND = 16 + HJ;                         // dwords per lane and pair
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -2067,6 +2215,10 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
         for (int m = tid + kThreads; m < n_meta; m += kThreads) mel_meta[m] = msrc[m];
         if (tid < n_meta) mel_meta[tid] = mm_;
         if (tid == 0) *next_pair = NW;                   // pairs 0 .. NW - 1 are the waves' first ones
+        if (CQ && tid < 8) {                             // the continuous queue's words (see below; on the reduction scratch behind the two images)
+            const int mpf_ = (p.n_frames * p.n_mels + 3) & ~3;
+            reinterpret_cast<int*>(mp_row + 2 * mpf_)[tid] = 0;
+        }
 #pragma unroll
         for (int u = 0; u < UW; ++u) { const int i = tid + kThreads * u; if (i < NWIN) dst[i] = vw[u]; }
 #pragma unroll
@@ -2113,7 +2265,7 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
     double* const db_red0 = reinterpret_cast<double*>(mp_row + RB * mp_floats);
     float* const db_redf = reinterpret_cast<float*>(db_red0 + 16);   // db_row_from_lds's redf (row 1 of a group: 24 doubles further)
     // the chunk sums of K0's first kernel, folded in numpy's order (chunk 0 first) into the scale - k_rms_fold_apply's thread 0, on every wave
-    auto k0_fold = [&](int row_) {
+    auto k0_fold = [&](int row_, bool wr_) {                 // wr_: this thread publishes the row's scale / gate
 #pragma clang fp contract(off)
         const int n_ = k0_row_len(row_);
         const int n_chunks = (n_ + kNpChunk - 1) / kNpChunk;
@@ -2126,21 +2278,42 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
             if (p.k0_scale_f64) { if (!((double)rms < 1e-4)) { sc_ = (float)(0.05 / ((double)rms + 1e-8)); good_ = 1; } }
             else if (!(rms < 1e-4f)) { sc_ = 0.05f / (rms + 1e-8f); good_ = 1; }
         }
-        if (tid == 0) { p.k0_scale[row_] = sc_; if (p.k0_ok) p.k0_ok[row_] = good_; }
+        if (wr_) { p.k0_scale[row_] = sc_; if (p.k0_ok) p.k0_ok[row_] = good_; }
         return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(good_ ? sc_ : 1.0f)));
     };
-    for (int row0 = blockIdx.x; row0 < n_rows; row0 += RB * gridDim.x) {
+    // CQ (round 4, "stft_pair_cq"): ONE queue over ALL the rows of the workgroup (rows blockIdx.x + k gridDim.x, k = 0 .. cq_rows - 1, row k's
+    // mel power in image k & 1) and NO workgroup barrier behind the tables': the wave that completes a row's last pair runs the row's dB
+    // stage ALONE (db_row_wave_call: db_row_from_lds's sums in the same order - twelve virtual waves one after the other - the same bits)
+    // while the other eleven are already on the next row's pairs.  The barrier form pays, per two rows, the queue's tail (waves that find
+    // it empty wait ~12 600 cycles for the last pair) and a dB stage every thread waits through (~14 500) out of ~131 000.
+    // LDS words (cq[], on the reduction scratch the barrier forms use): [0, 1] pairs of the image's row completed, [2, 3] the row's largest
+    // mel power so far (bits of a non-negative float: unsigned order), [4, 5] ordinal + 1 of the last row whose dB stage has left the image.
+    int* const cq = reinterpret_cast<int*>(db_red0);
+    for (int row0 = blockIdx.x; row0 < n_rows; row0 += CQ ? n_rows : RB * gridDim.x) {
         const int row1 = row0 + (int)gridDim.x;             // (G2: the group's second row, if the batch has it)
         const bool has1 = G2 && row1 < n_rows;
-        const int n_q = has1 ? 2 * n_pairs : n_pairs;       // the group's queue: row 0's pairs, then row 1's
+        const int cq_rows = CQ ? (n_rows - 1 - row0) / (int)gridDim.x + 1 : 0;
+        const int n_q = CQ ? cq_rows * n_pairs : has1 ? 2 * n_pairs : n_pairs;       // the group's queue: row 0's pairs, then row 1's
         float sc_row0 = 1.0f, sc_row1 = 1.0f;
-        if (K0F == 1) { sc_row0 = k0_fold(row0); if (has1) sc_row1 = k0_fold(row1); }
+        if (K0F == 1 && !CQ) { sc_row0 = k0_fold(row0, tid == 0); if (has1) sc_row1 = k0_fold(row1, tid == 0); }
+        int cq_k = 0, cq_base = 0;                          // CQ: ordinal of the current pair's row, queue index of that row's first pair
+        int cq_nrow = 0, cq_npr = 0;                        // ... row and pair of the wave's next draw
+        float cq_sc = 1.0f;
+        if (CQ && K0F == 1) cq_sc = k0_fold(row0, false);
         float wmax = -INFINITY, wmax1 = -INFINITY;          // the largest mel power this wave has stored for the row(s) (fused dB stage: its max pass)
         for (int pi = wave, pr_next = 0; pi < n_q; pi = pr_next) {
-            const bool sub = G2 && pi >= n_pairs;           // (wave-uniform) which row of the group
-            const int row = sub ? row1 : row0;
-            const int pr = pair_of(sub ? pi - n_pairs : pi);    // (identity without K0F)
-            if (K0F == 1) k0_sc = sub ? sc_row1 : sc_row0;
+            // (the queue index through readfirstlane: `wave` is uniform only in fact, and a row / pair index the compiler takes for
+            // divergent puts the buffer loads of the fetch into waterfall loops)
+            pi = __builtin_amdgcn_readfirstlane(pi);
+            if constexpr (CQ) {
+                bool moved = false;
+                while (pi >= cq_base + n_pairs) { cq_base += n_pairs; ++cq_k; moved = true; }      // (wave-uniform; one step, rarely two)
+                if (moved && K0F == 1) cq_sc = k0_fold(row0 + cq_k * (int)gridDim.x, false);
+            }
+            const bool sub = CQ ? (cq_k & 1) != 0 : G2 && pi >= n_pairs;           // (wave-uniform) which row of the group / which image
+            const int row = CQ ? row0 + cq_k * (int)gridDim.x : sub ? row1 : row0;
+            const int pr = pair_of(CQ ? pi - cq_base : sub ? pi - n_pairs : pi);    // (identity without K0F)
+            if (K0F == 1) k0_sc = CQ ? cq_sc : sub ? sc_row1 : sc_row0;
             // packed pairs: element j of the lane's TWO sequences (sample parity 0 / 1) side by side - dft16_pk
             amph_f2 XR[16], XI[16];
             float4 tw[16];
@@ -2333,7 +2506,25 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
             // ---- this wave's next pair: its samples are requested now and land under the mel rows
             //      (UNCONDITIONALLY - behind the last pair the row index is clamped and the samples are never used: a conditional
             //      fetch makes the old dwords the value of the not-taken path, i.e. 19 registers live through every phase of the pair)
-            {
+            // CQ: a wave that sees the row's other pairs all counted will complete the row and run its dB stage (tens of thousands of cycles):
+            // it draws its next pair BEHIND that stage - a pair drawn here would sit undone through it (measured: the workgroup's last
+            // barrier 24 000 cycles later) - and requests this pair's samples again instead (the registers must be written on every path)
+            bool cq_defer = false;
+            if constexpr (CQ)
+                cq_defer = cq_k != cq_rows - 1 &&
+                           __builtin_amdgcn_readfirstlane(__hip_atomic_load(&cq[(int)sub], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == n_pairs - 1;
+            auto cq_draw = [&]() {
+                int got = 0;
+                if (lane == 0) got = atomicAdd(next_pair, 1);
+                pr_next = __builtin_amdgcn_readfirstlane(got);
+                int npr = min(pr_next, n_q - 1);             // (behind the queue's end: any valid pair, never used)
+                int nk = cq_k, nb = cq_base;
+                while (npr >= nb + n_pairs) { nb += n_pairs; ++nk; }
+                cq_nrow = row0 + nk * (int)gridDim.x; cq_npr = pair_of(npr - nb);
+            };
+            if (CQ && cq_defer) fetch(row, pr);
+            else if constexpr (CQ) { cq_draw(); fetch(cq_nrow, cq_npr); }
+            else {
                 int got = 0;
                 if (lane == 0) got = atomicAdd(next_pair, 1);
                 pr_next = __builtin_amdgcn_readfirstlane(got);
@@ -2346,6 +2537,21 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
 #ifdef AMPH_STAMPS
             if (wave == 0 && pr == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); if (lane == 0) p.stamps[(size_t)blockIdx.x * 16 + 8] = t_; }
 #endif
+            if constexpr (CQ) {
+                if (cq_k >= 2) {
+                    // image cq_k & 1 still holds row cq_k - 2 until that row's dB stage is through (normally long done).  Waited for HERE,
+                    // not where the pair is drawn: only the mel rows below touch the image, the pair's FFT has run meanwhile.  The wait
+                    // cannot deadlock - that stage waits for nothing, and every pair of the earlier rows is held by a wave whose own wait
+                    // is for an earlier stage - and is bounded anyway (~1 ms: a GPU that is not hung can be debugged).
+                    const int need = cq_k - 1;
+                    for (int spin = 0; spin < 4096; ++spin) {
+                        const int got_ = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&cq[4 + (cq_k & 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                        if (got_ >= need) break;
+                        __builtin_amdgcn_s_sleep(8);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                }
+            }
             // ---- mel rows of both frames at once: 4 lanes per filter, 4 bins per lane and step; the accumulators are (frame a, frame b)
             //      pairs, a bin's two powers one 8-byte LDS element.  Four steps are requested at a time; even steps -> first
             //      accumulator, odd -> second, as in k_stft_mel_w.  Lane q of a quad takes bins 2q, 2q + 1 and 8 + 2q, 8 + 2q + 1 of a
@@ -2405,6 +2611,38 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
             }
             wave_lds_sync();                                // the scratch is rewritten by the next pair
             AMPH_PHASE_FENCE();
+            if constexpr (CQ) {
+                // the pair's mel rows are in the image (LDS operations of a wave complete in order): publish the wave's maximum, count the pair;
+                // whoever counts the row's last pair owns the image until its dB stage is through
+                const float wm_ = wave_max_dpp(fmaxf(fmaxf(wmax, wmax1), 0.0f));
+                wmax = -INFINITY; wmax1 = -INFINITY;
+                int old_ = 0;
+                if (lane == 63) {
+                    __hip_atomic_fetch_max(reinterpret_cast<unsigned*>(&cq[2 + (int)sub]), __float_as_uint(wm_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    old_ = __hip_atomic_fetch_add(&cq[(int)sub], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                old_ = __builtin_amdgcn_readlane(old_, 63);
+                if (__builtin_expect(old_ == n_pairs - 1 && cq_k != cq_rows - 1, 0)) {     // (the workgroup's LAST row: behind the queue, by every wave)
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    const float mx_ = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane(__hip_atomic_load(&cq[2 + (int)sub], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)));
+                    if (K0F == 1) (void)k0_fold(row, lane == 0);
+#ifdef AMPH_STAMPS
+                    if (cq_k == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); if (lane == 0) tl[9] = t_; }
+#endif
+                    __builtin_amdgcn_s_setprio(3);       // (the row's last pair is as a rule a SIMD's youngest wave's: without this the stage runs on what the two older waves leave)
+                    db_row_wave_call<kThreads>(mp_row + (sub ? mp_floats : 0), p.n_frames, p.n_mels, p.db_target_frames, p.db_layout,
+                                               p.db_out + (long long)row * p.db_target_frames * p.n_mels, mx_);
+                    __builtin_amdgcn_s_setprio(0);
+#ifdef AMPH_STAMPS
+                    if (cq_k == 0) { unsigned long long t_; asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); if (lane == 0) tl[10] = t_; }
+#endif
+                    if (lane == 0) { cq[(int)sub] = 0; cq[2 + (int)sub] = 0; }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    if (lane == 0) __hip_atomic_store(&cq[4 + (int)sub], cq_k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (!cq_defer) fetch(cq_nrow, cq_npr);    // (again: the samples requested above need not live through the call)
+                }
+                if (cq_defer) { cq_draw(); fetch(cq_nrow, cq_npr); }
+            }
             AMPH_PSTAMP(9)
 #ifdef AMPH_STAMPS
             {
@@ -2419,6 +2657,27 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair(StftParams p, int n_rows)
         // ---- fused dB stage on the row the workgroup holds (see k_stft_mel_w).  The LAST row (at batch 256: the only one) is
         //      finished behind the loops: inlined here, the stage's per-thread index arithmetic is hoisted in front of the row loop
         //      and sits in ~90 registers across the pair loop
+        if constexpr (CQ) {
+            // the last row's stage by the whole workgroup (nothing else is left to do; the single-wave form would be ~28 000 cycles alone)
+            const int lk = cq_rows - 1, lrow = row0 + lk * (int)gridDim.x;
+            float* const limg = mp_row + ((lk & 1) ? mp_floats : 0);
+            __syncthreads();                                // every pair of the row is in the image, every other row's stage is through
+#ifdef AMPH_STAMPS
+            if (tid == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); tl[6] = t_; }
+#endif
+            const float mx_ = __uint_as_float((unsigned)cq[2 + (lk & 1)]);
+            if (K0F == 1) (void)k0_fold(lrow, tid == 0);
+            __syncthreads();                                // (the queue's words lie where the stage keeps its sums)
+            if (tid < NW) db_redf[tid] = mx_;
+            __syncthreads();
+            db_row_call<kThreads, 8, true>(limg, p.n_frames, p.n_mels, p.db_target_frames, p.db_layout,
+                                           p.db_out + (long long)lrow * p.db_target_frames * p.n_mels, db_red0);
+#ifdef AMPH_STAMPS
+            __syncthreads();
+            if (tid == 0) { unsigned long long t_; asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); tl[7] = t_; tl[8] = __builtin_amdgcn_s_memrealtime() - pw_rt0; }
+#endif
+            break;
+        }
         const bool more = row0 + RB * (int)gridDim.x < n_rows;   // another group follows
         if (!fuse_db && more) {                             // (every wave has drawn its last index of this group before the counter starts over)
             __syncthreads();
@@ -2832,14 +3091,15 @@ hipError_t stft_mel_configure(int lds_bytes) {
         e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
     }
-    const void* pfns[14] = {reinterpret_cast<const void*>(&k_stft_pair<8, 3, false>), reinterpret_cast<const void*>(&k_stft_pair<10, 3, false>),
+    const void* pfns[16] = {reinterpret_cast<const void*>(&k_stft_pair<8, 3, false>), reinterpret_cast<const void*>(&k_stft_pair<10, 3, false>),
                             reinterpret_cast<const void*>(&k_stft_pair<11, 3, false>), reinterpret_cast<const void*>(&k_stft_pair<12, 3, false>),
                             reinterpret_cast<const void*>(&k_stft_pair<8, 3, true>), reinterpret_cast<const void*>(&k_stft_pair<10, 3, true>),
                             reinterpret_cast<const void*>(&k_stft_pair<11, 3, true>), reinterpret_cast<const void*>(&k_stft_pair<12, 3, true>),
                             reinterpret_cast<const void*>(&k_stft_pair<12, 3, false, 1>), reinterpret_cast<const void*>(&k_stft_pair<12, 3, true, 1>),
                             reinterpret_cast<const void*>(&k_stft_pair<12, 3, false, 1, true>),
                             reinterpret_cast<const void*>(&k_stft_pair<12, 3, false, 2>), reinterpret_cast<const void*>(&k_stft_pair<12, 3, true, 2>),
-                            reinterpret_cast<const void*>(&k_stft_pair<12, 3, false, 2, true>)};
+                            reinterpret_cast<const void*>(&k_stft_pair<12, 3, false, 2, true>),
+                            reinterpret_cast<const void*>(&k_stft_pair<12, 3, false, 1, true, true>), reinterpret_cast<const void*>(&k_stft_pair<12, 3, false, 2, true, true>)};
     for (const void* f : pfns) {
         e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
@@ -2901,7 +3161,14 @@ void launch_stft_mel(const StftParams& p, int n_rows, int sample_is_pcm16, int n
             // two rows per workgroup and queue (G2) when the batch has more rows than half the CUs and both rows' mel power fits LDS
             const size_t lds2 = stft_pair_lds_bytes(p.n_frames, p.n_mels, p.pair_mel_w_floats, nw, true, 2);
             const bool rms = p.k0_chunk_sums != nullptr;          // K0F 1 (fold + re-quantise) or 2 (plain decode)
-            if (p.db_out && p.pair_rows2 && n_rows > g_num_cus / 2 && lds2 <= 160 * 1024) {
+            const int n_pairs = (p.n_frames + 1) / 2;
+            if (p.db_out && p.pair_cq > 1 && n_rows > g_num_cus / 2 && lds2 <= 160 * 1024 && n_pairs >= 12 + 4) {
+                // the continuous queue: pair_cq rows per workgroup (rows b, b + grid, ...), no barrier behind the tables'
+                const dim3 gridq((unsigned)std::min((n_rows + p.pair_cq - 1) / p.pair_cq, p.grid_wgs > 0 ? p.grid_wgs : g_num_cus));
+                if (rms) hipLaunchKernelGGL((k_stft_pair<12, 3, false, 1, true, true>), gridq, dim3(64 * 12), lds2, s, p, n_rows);
+                else hipLaunchKernelGGL((k_stft_pair<12, 3, false, 2, true, true>), gridq, dim3(64 * 12), lds2, s, p, n_rows);
+            }
+            else if (p.db_out && p.pair_rows2 && n_rows > g_num_cus / 2 && lds2 <= 160 * 1024) {
                 const dim3 grid2((unsigned)std::min((n_rows + 1) / 2, p.grid_wgs > 0 ? p.grid_wgs : g_num_cus));
                 if (rms) hipLaunchKernelGGL((k_stft_pair<12, 3, false, 1, true>), grid2, dim3(64 * 12), lds2, s, p, n_rows);
                 else hipLaunchKernelGGL((k_stft_pair<12, 3, false, 2, true>), grid2, dim3(64 * 12), lds2, s, p, n_rows);

@@ -515,7 +515,7 @@ def test_rms_normalize_inside_the_pair_kernel_is_bit_identical_to_its_own_launch
     cfg = env.PRESETS["bench-1s"]
     enc, tenc, spec = _encoders(env, "thesis-shape", cfg=cfg, max_batch=320)
     sess = enc.session(cfg)
-    DEFAULT_K0 = 1
+    DEFAULT_K0, DEFAULT_CQ = 1, 0
     rng = np.random.default_rng(77)
     for n_rows, n_in, ragged in ((320, cfg.n_samples, False), (37, 30011, True), (300, 22050, True), (5, 32768, False)):
         pcm = env.synth(np.arange(500, 500 + n_rows), n_in, cfg.sr)
@@ -529,10 +529,13 @@ def test_rms_normalize_inside_the_pair_kernel_is_bit_identical_to_its_own_launch
         res = {}
         # 1: the default (two rows per workgroup and queue when the batch is large: "stft_pair_rows2"); 2: one row per workgroup; 3: two rows per
         # group on 50 workgroups (every workgroup runs several groups, the last one of some a single row); 0: K0's own launches
-        for knob in (1, 2, 3, 0):
+        # 4 / 5 / 6: the continuous queue ("stft_pair_cq": R rows per workgroup on one pair queue, a row's dB stage run by the wave that completes
+        # its last pair, no workgroup barrier) with R = 4, R = 3 on 50 workgroups (six or seven rows each), R = 8
+        for knob in (1, 2, 3, 4, 5, 6, 0):
             sess.configure("stft_k0_fuse", 1 if knob else 0)
             sess.configure("stft_pair_rows2", 0 if knob == 2 else 1)
-            sess.configure("stft_grid", 50 if knob == 3 else 0)
+            sess.configure("stft_pair_cq", {4: 4, 5: 3, 6: 8}.get(knob, 0))
+            sess.configure("stft_grid", 50 if knob in (3, 5) else 0)
             mu, _, ok = sess.encode(pcm, lengths=lens, apply_rms=True)
             img = sess.mel_pcm16(pcm, lengths=lens, apply_rms=True, layout=1)
             # ... and without the RMS stage (files 00 has already normalised): raw rows, plain decode, no padded copy
@@ -540,8 +543,9 @@ def test_rms_normalize_inside_the_pair_kernel_is_bit_identical_to_its_own_launch
             res[knob] = (mu.clone(), ok.clone(), img.clone(), mu0.clone(), ok0.clone())
         sess.configure("stft_k0_fuse", DEFAULT_K0)
         sess.configure("stft_pair_rows2", 1)
+        sess.configure("stft_pair_cq", DEFAULT_CQ)
         sess.configure("stft_grid", 0)
-        for knob in (1, 2, 3):
+        for knob in (1, 2, 3, 4, 5, 6):
             assert torch.equal(res[knob][1], res[0][1]), (knob, n_rows, n_in)
             assert torch.equal(res[knob][2], res[0][2]), (knob, n_rows, n_in)
             assert torch.equal(res[knob][0], res[0][0]), (knob, n_rows, n_in)
