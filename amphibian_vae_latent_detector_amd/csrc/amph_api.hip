@@ -115,6 +115,10 @@ struct amph_ctx {
     bool stft_pair2_regdb = true;          // n_fft 1024 pair kernel: fused dB stage on register-resident mel power (no image in LDS: fits 12 waves at 128 bands)
     bool stft_pair_rows2 = true;           // ... with two rows per workgroup and pair queue when the batch has more rows than half the CUs (same bits)
     int stft_pair_cq = 0;                  // ... > 1: that many rows per workgroup on one continuous pair queue, a row's dB stage by the wave that completes it (same bits)
+    bool k0_call_sums = false;             // K0's chunk sums for ALL the rows of a call in one launch in front of the batches ("k0_call_sums"; same bits;
+                                           // measured 4.10 against 4.16 M chunks/s: the pass over the call's 441 MB runs in front of every lane)
+    float* call_sums = nullptr;            // ... [rows of the call][chunks]
+    size_t call_sums_cap = 0;
     int mel_w_floats = 0, mel_p_tail = 0;
     int32_t *d_mel_start = nullptr, *d_mel_len = nullptr, *d_mel_wofs = nullptr;
     float* d_mel_w = nullptr;
@@ -1095,6 +1099,12 @@ size_t pair_tw1_lds(const amph_ctx* c) { return c->cfg.n_fft == 2048 ? stft_pair
 bool pair_path(const amph_ctx* c, bool pcm16) {
     return pcm16 && c->stft_pair && c->d_pair_tables && c->stft_prenorm && c->stft_prepad && c->stft_indep;
 }
+// does the context's pair kernel have a K0F form (raw rows, RMS scale and re-quantisation inside the kernel)?
+bool pair_can_fuse_k0(const amph_ctx* c, int n_in, bool fused_db) {
+    if (c->cfg.n_fft == 2048) return stft_pair_can_fuse_k0(n_in, c->stft_pair_waves);
+    return c->cfg.n_fft == 1024 && c->cfg.hop_length == 256 &&
+           stft_pair2_can_fuse_k0(n_in, c->n_frames, c->cfg.n_mels, c->stft_pair_waves, fused_db, c->stft_pair2_regdb);
+}
 // pcm16_rows: the call's input is PCM16 (those rows take a pair kernel when the context has one)
 bool can_fuse_db(const amph_ctx* c, bool pcm16_rows = false) {
     if (!c->stft_fuse_db || !c->stft_indep || c->generic_stft) return false;
@@ -1135,8 +1145,18 @@ StftParams make_stft(amph_ctx* c, const WaveSrc& src, float* melpow, float* db_o
 
 // front end for one batch: wave rows -> melpow (-> image)
 // db_out != nullptr (only with can_fuse_db): the kernel writes the standardised image there and melpow stays untouched
+// does a batch of this call take K0's fused form (chunk sums launched, fold + apply inside the pair kernel)?
+bool k0_fused_ok(const amph_ctx* c, bool pcm16, int nb, int n_in, const void* d_wave, bool fused_db) {
+    return pcm16 && c->stft_prenorm && !c->generic_stft && c->stft_indep && c->stft_prepad && c->stft_k0_fuse && pair_path(c, true) &&
+           pair_lds(c, c->stft_pair_waves, fused_db) <= 160 * 1024 && pair_can_fuse_k0(c, n_in, fused_db) &&
+           (n_in & 1) == 0 && (reinterpret_cast<uintptr_t>(d_wave) & 3u) == 0 &&    // (its dword loads: every row 4-byte aligned)
+           (long long)nb * n_in * 2 < (1ll << 31);                                  // (32-bit buffer offsets)
+}
+
+// pre_sums (nullable): the batch's chunk sums, already computed by a launch in front of the call's batches (encode_common)
 int run_frontend(amph_ctx* c, Workspace& w, const void* d_wave, bool pcm16, int nb, int n_in, const int32_t* d_len,
-                 int apply_rms, int32_t* d_rms_ok, float* melpow, hipStream_t s, float* db_out = nullptr, int db_layout = 1) {
+                 int apply_rms, int32_t* d_rms_ok, float* melpow, hipStream_t s, float* db_out = nullptr, int db_layout = 1,
+                 const float* pre_sums = nullptr) {
     WaveSrc src{};
     src.wave = d_wave; src.row_stride = n_in; src.lengths = d_len; src.n_in = n_in;
     src.scale = nullptr; src.requant = 0;
@@ -1166,11 +1186,11 @@ int run_frontend(amph_ctx* c, Workspace& w, const void* d_wave, bool pcm16, int 
         }
         // K0's fold + apply inside the pair kernel (k_frontend.hip, K0F): only the per-chunk sums of squares are launched here; the kernel
         // reads the raw rows and re-quantises in its decode - no padded normalised copy
-        const bool k0_fused = pcm16 && norm && pad.lead > 0 && c->stft_k0_fuse && c->cfg.n_fft == 2048 && pair_path(c, true) &&
-                              pair_lds(c, c->stft_pair_waves, db_out != nullptr) <= 160 * 1024 && stft_pair_can_fuse_k0(n_in, c->stft_pair_waves) &&
-                              (n_in & 1) == 0 && (reinterpret_cast<uintptr_t>(d_wave) & 3u) == 0 &&    // (its dword loads: every row 4-byte aligned)
-                              (long long)nb * n_in * 2 < (1ll << 31);                                  // (32-bit buffer offsets)
-        if (k0_fused) {
+        const bool k0_fused = norm && pad.lead > 0 && k0_fused_ok(c, pcm16, nb, n_in, d_wave, db_out != nullptr);
+        if (k0_fused && pre_sums) {
+            k0 = true;
+            k0_sums = pre_sums;
+        } else if (k0_fused) {
             const int rcs = ensure_chunk_sums(c, w, n_in, s);
             if (rcs != AMPH_OK) return rcs;
             launch_rms_chunk_sums_pcm16((const int16_t*)d_wave, n_in, d_len, n_in, nb, w.chunk_sums, s);
@@ -1195,8 +1215,8 @@ int run_frontend(amph_ctx* c, Workspace& w, const void* d_wave, bool pcm16, int 
         if (d_rms_ok) (void)hipMemsetAsync(d_rms_ok, 0, (size_t)nb * sizeof(int32_t), s);
         // PCM16 rows used as they are: the same fix_length'd, centre-padded copy, by a copy kernel (timed with the RMS stage) - or, for the
         // shapes the K0F form of k_stft_pair covers, no copy at all: the kernel reads the raw rows (K0F 2)
-        const bool raw_rows = pcm16 && c->stft_prenorm && c->stft_prepad && c->stft_k0_fuse && c->cfg.n_fft == 2048 && pair_path(c, true) &&
-                              pair_lds(c, c->stft_pair_waves, db_out != nullptr) <= 160 * 1024 && stft_pair_can_fuse_k0(n_in, c->stft_pair_waves) &&
+        const bool raw_rows = pcm16 && c->stft_prenorm && c->stft_prepad && c->stft_k0_fuse && pair_path(c, true) &&
+                              pair_lds(c, c->stft_pair_waves, db_out != nullptr) <= 160 * 1024 && pair_can_fuse_k0(c, n_in, db_out != nullptr) &&
                               (n_in & 1) == 0 && (reinterpret_cast<uintptr_t>(d_wave) & 3u) == 0 && (long long)nb * n_in * 2 < (1ll << 31);
         if (raw_rows) {
             k0 = true;                                      // (k0_sums stays nullptr: no RMS stage)
@@ -1259,6 +1279,22 @@ int encode_common(amph_ctx* c, const void* d_wave, bool pcm16, int64_t n_rows, i
     // fork: batches go round-robin over the lanes; lane 0 runs on the caller's stream
     const int64_t n_batches = (n_rows + c->max_batch - 1) / c->max_batch;
     const int L = (int)std::min<int64_t>((int64_t)c->lanes.size(), std::max<int64_t>(n_batches, 1));
+    // K0's chunk sums of EVERY row of the call in ONE launch in front of the batches (round 4, off: -1.4 %): one launch less at the head of
+    // every batch's chain, but a serial pass over all the call's rows in front of every lane, and the rows come from HBM twice
+    const float* call_sums = nullptr;
+    const int n_chunks = rms_scale_chunks(n_in);
+    if (apply_rms && c->k0_call_sums && n_batches > 1 && !c->profiling && (long long)n_rows * n_chunks < (1ll << 28) &&
+        k0_fused_ok(c, pcm16, (int)std::min<int64_t>(c->max_batch, n_rows), n_in, d_wave, can_fuse_db(c, pcm16))) {
+        const size_t need = (size_t)n_rows * (size_t)n_chunks;
+        if (c->call_sums_cap < need) {
+            if (c->call_sums) { HIP_TRY(c, hipDeviceSynchronize()); (void)hipFree(c->call_sums); }
+            c->call_sums = nullptr; c->call_sums_cap = 0;
+            HIP_TRY(c, hipMalloc((void**)&c->call_sums, need * sizeof(float)));
+            c->call_sums_cap = need;
+        }
+        launch_rms_chunk_sums_pcm16((const int16_t*)d_wave, n_in, d_len, n_in, (int)n_rows, c->call_sums, s);
+        call_sums = c->call_sums;
+    }
     if (L > 1) {
         HIP_TRY(c, hipEventRecord(c->ev_fork, s));
         for (int l = 1; l < L; ++l) HIP_TRY(c, hipStreamWaitEvent(c->lanes[l].stream, c->ev_fork, 0));
@@ -1279,7 +1315,7 @@ int encode_common(amph_ctx* c, const void* d_wave, bool pcm16, int64_t n_rows, i
         // (lanes on CU-masked streams - halves, quarters, a front-end / encoder split of the CUs - were measured in round 3 and run
         // 5-7x slower than this: profiles/r03_cu_partition_sweep.txt)
         rc = run_frontend(c, w, wv, pcm16, nb, n_in, d_len ? d_len + off : nullptr, apply_rms, d_rms_ok ? d_rms_ok + off : nullptr,
-                          w.melpow, ls, fdb ? w.image : nullptr, 1);
+                          w.melpow, ls, fdb ? w.image : nullptr, 1, call_sums ? call_sums + (size_t)off * n_chunks : nullptr);
         if (rc == AMPH_OK && !fdb) rc = run_dbnorm(c, w.melpow, nb, 1, w.image, ls);
         if (rc == AMPH_OK) rc = run_encoder(c, w, w.image, nb, d_mu + off * D, d_logvar ? d_logvar + off * D : nullptr, ls, L,
                                             c->img_bound < c->img_limit);
@@ -1405,7 +1441,7 @@ void amph_destroy(amph_ctx* c) {
     fr(c->d_mel_start); fr(c->d_mel_len); fr(c->d_mel_wofs); fr(c->d_mel_w);
     fr(c->d_first_w); fr(c->d_first_scale); fr(c->d_first_shift);
     for (auto& g : c->gemm) { fr(g.d_w); fr(g.d_w_s3); fr(g.d_w_h2); fr(g.d_w_f4); fr(g.d_w_f4b); fr(g.d_w_bf16); fr(g.d_scale); fr(g.d_shift); }
-    fr(c->d_head_bias); fr(c->d_zeros);
+    fr(c->d_head_bias); fr(c->d_zeros); fr(c->call_sums);
     for (auto& w : c->lanes) free_lane(w);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     fr(c->d_centroids); fr(c->d_thr); fr(c->d_rank);
@@ -1439,6 +1475,7 @@ int amph_configure(amph_ctx* c, const char* key, int value) {
     if (!std::strcmp(key, "stft_pair_tw_lds")) { c->stft_pair_tw_lds = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "stft_k0_fuse")) { c->stft_k0_fuse = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "stft_pair_rows2")) { c->stft_pair_rows2 = value != 0; return AMPH_OK; }
+    if (!std::strcmp(key, "k0_call_sums")) { c->k0_call_sums = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "stft_pair_cq")) { if (value < 0 || value > 64) return AMPH_ERR_INVALID_ARG; c->stft_pair_cq = value; return AMPH_OK; }
     if (!std::strcmp(key, "stft_pair2_regdb")) { c->stft_pair2_regdb = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "stft_pair_waves")) {

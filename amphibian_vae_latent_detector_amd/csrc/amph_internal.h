@@ -119,6 +119,7 @@ hipError_t stft_mel_configure(int lds_bytes);   // raises the dynamic-LDS limit 
 // the pair kernel (k_stft_pair): LDS image, packed table size, and the configurations it covers
 size_t stft_pair_lds_bytes(int n_frames, int n_mels, int mel_w_floats, int n_waves, bool fused, int rows = 1);   // rows: mel-power images kept in LDS (2: the G2 form)
 bool stft_pair_can_fuse_k0(int n_in, int n_waves);      // the K0F form of k_stft_pair covers this row length / workgroup shape
+bool stft_pair2_can_fuse_k0(int n_in, int n_frames, int n_mels, int n_waves, bool fused_db, bool regdb);
 int stft_pair_table_bytes();
 size_t stft_pair_tw1_lds_bytes();
 bool stft_pair_ok(int n_fft, int hop, int p_tail);

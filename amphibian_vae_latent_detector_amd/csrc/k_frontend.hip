@@ -2746,7 +2746,10 @@ constexpr int kP2Scratch = 2 * kP2Half;
 constexpr int kP2PStride = kP2Half / 8;             // floats between two power spectra (576 >= 513 + tail)
 constexpr int kP2WinBytes = 16 * 32 * 8, kP2Tw1Bytes = 31 * 32 * 8;
 
-template <int NW, bool TWL, bool RDB = false>
+// K0F (round 4, as in k_stft_pair): 1 = the row's RMS scale folded from K0's chunk sums on every wave, the RAW rows read (centre padding,
+// fix_length and truncation as index arithmetic on the two slots of a row that touch them), the samples re-quantised in the decode - K0's
+// second kernel and its padded copy of every row are not launched; 2 = raw rows as they are (no RMS stage: no pad kernel either).
+template <int NW, bool TWL, bool RDB = false, int K0F = 0>
 __global__ __launch_bounds__(64 * NW) void k_stft_pair2(StftParams p, int n_rows) {
     constexpr int kThreads = 64 * NW;
     constexpr int HJ = 4, ND = 16 + HJ;
@@ -2803,12 +2806,71 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair2(StftParams p, int n_rows
     uint32_t nx[ND];
 #pragma unroll
     for (int j = 0; j < ND; ++j) nx[j] = 0;
+    const __amdgpu_buffer_rsrc_t rs_raw = __builtin_amdgcn_make_buffer_rsrc(const_cast<int16_t*>(p.k0_in), 0, K0F ? (int)((long long)n_rows * p.k0_row_stride * 2) : 0, 0x00020000);
+    auto k0_row_len = [&](int row_) {                        // samples of the row that count (wave-uniform)
+        const int n_ = p.k0_lengths ? max(0, min(p.k0_lengths[row_], p.k0_n_in)) : p.k0_n_in;
+        return __builtin_amdgcn_readfirstlane(n_);
+    };
     auto fetch = [&](int row_, int q_) {
-        const int base = __builtin_amdgcn_readfirstlane((int)(((long long)row_ * p.src.row_stride) * 2 + (long long)q_ * p.hop * 8));
+        if constexpr (K0F) {
+            // slot q = padded samples 4 q hop + [0, 2 hop + 64 ND) = raw s0 + ..., s0 = 4 q hop - lead; this half wave's pair starts 2 hop hw further
+            const int lead = p.n_fft >> 1, n_fix = p.n_samples;
+            const int nv = min(k0_row_len(row_), n_fix), nv2 = nv & ~1;
+            const int rbase = __builtin_amdgcn_readfirstlane((int)((long long)row_ * p.k0_row_stride * 2));
+            const int s0 = __builtin_amdgcn_readfirstlane(q_ * 4 * p.hop - lead);
+            if (s0 >= 0 && s0 + 2 * p.hop + 64 * ND <= nv2) {    // (wave-uniform) every sample of the slot is a sample of the row: 20 of a one-second row's 22 slots
+                const int base = rbase + 2 * s0;
 #pragma unroll
-        for (int j = 0; j < ND; ++j) nx[j] = __builtin_amdgcn_raw_buffer_load_b32(rs_x, voff_x, base + 128 * j, 0);
+                for (int j = 0; j < ND; ++j) nx[j] = __builtin_amdgcn_raw_buffer_load_b32(rs_raw, voff_x, base + 128 * j, 0);
+            } else {
+                // the slot touches the centre padding (np.pad mode="reflect" of the fix_length'd row, map_detector_core.py:212-228; mode 1: zeros),
+                // fix_length's zero fill or the row's last odd sample: per sample, through a resource that ends at the row's last valid sample
+                const __amdgpu_buffer_rsrc_t rs_row = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<char*>(reinterpret_cast<const char*>(p.k0_in) + (long long)row_ * p.k0_row_stride * 2), 0, 2 * nv, 0x00020000);
+                uint32_t lo[ND], hi[ND];
+#pragma unroll
+                for (int j = 0; j < ND; ++j) {
+                    uint32_t half[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        int sidx = s0 + 2 * p.hop * hw + 64 * j + 2 * lp + e;
+                        if (p.pad_mode == 0) {
+                            sidx = sidx < 0 ? -sidx : sidx;
+                            if (sidx >= n_fix) sidx = 2 * (n_fix - 1) - sidx;
+                        }
+                        const bool in = (unsigned)sidx < (unsigned)nv;
+                        half[e] = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rs_row, in ? 2 * sidx : 0x7FFFFFF0, 0, 0);
+                    }
+                    lo[j] = half[0]; hi[j] = half[1];
+                }
+#pragma unroll
+                for (int j = 0; j < ND; ++j) nx[j] = lo[j] | (hi[j] << 16);
+            }
+        } else {
+            const int base = __builtin_amdgcn_readfirstlane((int)(((long long)row_ * p.src.row_stride) * 2 + (long long)q_ * p.hop * 8));
+#pragma unroll
+            for (int j = 0; j < ND; ++j) nx[j] = __builtin_amdgcn_raw_buffer_load_b32(rs_x, voff_x, base + 128 * j, 0);
+        }
     };
     if ((int)blockIdx.x < n_rows && wave < n_slots) fetch(blockIdx.x, wave);
+    // the chunk sums of K0's first kernel, folded in numpy's order (chunk 0 first) into the scale - k_rms_fold_apply's thread 0, on every wave
+    auto k0_fold = [&](int row_) {
+#pragma clang fp contract(off)
+        const int n_ = k0_row_len(row_);
+        const int n_chunks = (n_ + kNpChunk - 1) / kNpChunk;
+        const float* cs = p.k0_chunk_sums + (long long)row_ * p.k0_chunk_stride;
+        float total = 0.0f, sc_ = 1.0f;
+        int good_ = 0;
+        for (int c = 0; c < n_chunks; ++c) total = c == 0 ? cs[0] : total + cs[c];
+        if (n_ > 0) {
+            const float rms = sqrtf(total / (float)n_);
+            if (p.k0_scale_f64) { if (!((double)rms < 1e-4)) { sc_ = (float)(0.05 / ((double)rms + 1e-8)); good_ = 1; } }
+            else if (!(rms < 1e-4f)) { sc_ = 0.05f / (rms + 1e-8f); good_ = 1; }
+        }
+        if (tid == 0) { p.k0_scale[row_] = sc_; if (p.k0_ok) p.k0_ok[row_] = good_; }
+        return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(good_ ? sc_ : 1.0f)));
+    };
+    float k0_sc = 1.0f;
 
 #define AMPH_PHASE_FENCE() __builtin_amdgcn_sched_barrier(0)
     float mpv[16];                                      // RDB: the row's mel power of this lane (db_row_from_regs)
@@ -2816,23 +2878,50 @@ __global__ __launch_bounds__(64 * NW) void k_stft_pair2(StftParams p, int n_rows
     for (int k = 0; k < 16; ++k) mpv[k] = 0.0f;
     for (int row = blockIdx.x; row < n_rows; row += gridDim.x) {
         int si = 0;
+        if (K0F == 1) k0_sc = k0_fold(row);
         for (int q = wave; q < n_slots; q += NW, ++si) {
             float xr[2][16], xi[2][16];
             float2 tw[31];
             {
+                // (no contraction of the window products with the first additions of the DFT: the K0F forms must round as the plain one does,
+                // and which of an addition's two products the compiler fuses is its own choice per instantiation)
+#pragma clang fp contract(off)
                 float2 wv[16];
 #pragma unroll
                 for (int j = 0; j < 16; ++j) wv[j] = win[j * 32];
                 // a frame b past the row's last frame must be ZERO, not the next row's samples: the two frames of a pair leak into each
                 // other at the rounding level (1e-7 of the LOUDER one)
                 const bool has_b = 2 * (2 * q + hw) + 1 < p.n_frames;
+                if constexpr (K0F == 1) {
+                    // every dword decoded and re-quantised ONCE - q' = rint(clip(q sc, +-32768) (32767 / 32768)), the PCM16 sample
+                    // 00_normalize_dataset_rms.py:29-57 writes (see k_stft_pair) - and used by frame a at j and by frame b at j - HJ
+                    auto requant = [&](uint32_t d) {
+#pragma clang fp contract(off)
+                        float t0 = (float)(short)(d & 0xFFFFu) * k0_sc, t1 = (float)((int)d >> 16) * k0_sc;
+                        t0 = __builtin_amdgcn_fmed3f(t0, -32768.0f, 32768.0f) * (32767.0f / 32768.0f);
+                        t1 = __builtin_amdgcn_fmed3f(t1, -32768.0f, 32768.0f) * (32767.0f / 32768.0f);
+                        return make_float2(__builtin_rintf(t0), __builtin_rintf(t1));
+                    };
+                    float2 fq[ND];
 #pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const uint32_t da = nx[j], db = has_b ? nx[j + HJ] : 0u;
-                    xr[0][j] = (float)(short)(da & 0xFFFFu) * wv[j].x;
-                    xr[1][j] = (float)((int)da >> 16) * wv[j].y;
-                    xi[0][j] = (float)(short)(db & 0xFFFFu) * wv[j].x;
-                    xi[1][j] = (float)((int)db >> 16) * wv[j].y;
+                    for (int j = 0; j < HJ; ++j) fq[j] = requant(nx[j]);
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        fq[j + HJ] = requant(nx[j + HJ]);
+                        xr[0][j] = fq[j].x * wv[j].x;
+                        xr[1][j] = fq[j].y * wv[j].y;
+                        xi[0][j] = has_b ? fq[j + HJ].x * wv[j].x : 0.0f;
+                        xi[1][j] = has_b ? fq[j + HJ].y * wv[j].y : 0.0f;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const uint32_t da = nx[j], db = has_b ? nx[j + HJ] : 0u;
+                        xr[0][j] = (float)(short)(da & 0xFFFFu) * wv[j].x;
+                        xr[1][j] = (float)((int)da >> 16) * wv[j].y;
+                        xi[0][j] = (float)(short)(db & 0xFFFFu) * wv[j].x;
+                        xi[1][j] = (float)((int)db >> 16) * wv[j].y;
+                    }
                 }
             }
 #pragma unroll
@@ -3045,7 +3134,11 @@ size_t stft_pair2_tw1_lds_bytes() { return kP2Tw1Bytes; }
 bool stft_pair2_ok(int n_fft, int hop, int p_tail) { return n_fft == 1024 && hop == 256 && 513 + p_tail <= kP2PStride; }
 // the configurations the pair kernel covers (the caller also needs PCM16 rows padded by K0: src.lead == n_fft / 2)
 bool stft_pair_ok(int n_fft, int hop, int p_tail) { return n_fft == 2048 && hop == 384 && 1025 + p_tail <= kPairPStride; }
-bool stft_pair_can_fuse_k0(int n_in, int n_waves) { return n_in > 0 && n_waves == 12; }      // (any row length: the fold walks the row's chunk sums)
+bool stft_pair_can_fuse_k0(int n_in, int n_waves) { return n_in > 0 && n_waves == 12; }
+// ... k_stft_pair2's: the 12-wave form with the dB stage on register-resident mel power
+bool stft_pair2_can_fuse_k0(int n_in, int n_frames, int n_mels, int n_waves, bool fused_db, bool regdb) {
+    return n_in > 0 && fused_db && regdb && stft_pair2_regdb_ok(n_frames, n_mels, n_waves == 8 ? 8 : 12);
+}      // (any row length: the fold walks the row's chunk sums)
 
 static int table_bytes_for(int n_fft) { return n_fft == 2048 ? FftGeo<4>::TABLE_BYTES : FftGeo<2>::TABLE_BYTES; }
 
@@ -3104,9 +3197,11 @@ hipError_t stft_mel_configure(int lds_bytes) {
         e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
     }
-    const void* p2fns[6] = {reinterpret_cast<const void*>(&k_stft_pair2<8, false>), reinterpret_cast<const void*>(&k_stft_pair2<8, true>),
-                            reinterpret_cast<const void*>(&k_stft_pair2<12, false>), reinterpret_cast<const void*>(&k_stft_pair2<12, true>),
-                            reinterpret_cast<const void*>(&k_stft_pair2<12, false, true>), reinterpret_cast<const void*>(&k_stft_pair2<12, true, true>)};
+    const void* p2fns[10] = {reinterpret_cast<const void*>(&k_stft_pair2<8, false>), reinterpret_cast<const void*>(&k_stft_pair2<8, true>),
+                             reinterpret_cast<const void*>(&k_stft_pair2<12, false>), reinterpret_cast<const void*>(&k_stft_pair2<12, true>),
+                             reinterpret_cast<const void*>(&k_stft_pair2<12, false, true>), reinterpret_cast<const void*>(&k_stft_pair2<12, true, true>),
+                             reinterpret_cast<const void*>(&k_stft_pair2<12, false, true, 1>), reinterpret_cast<const void*>(&k_stft_pair2<12, true, true, 1>),
+                             reinterpret_cast<const void*>(&k_stft_pair2<12, false, true, 2>), reinterpret_cast<const void*>(&k_stft_pair2<12, true, true, 2>)};
     for (const void* f : p2fns) {
         e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
@@ -3192,7 +3287,14 @@ void launch_stft_mel(const StftParams& p, int n_rows, int sample_is_pcm16, int n
         const bool twl = p.pair_tw_lds && lds + kP2Tw1Bytes <= 160 * 1024;
         if (twl) lds += kP2Tw1Bytes;
         const dim3 grid((unsigned)std::min(n_rows, p.grid_wgs > 0 ? p.grid_wgs : g_num_cus));
-        if (rdb) {
+        if (p.k0_in) {                                  // K0F: the raw rows (the caller has checked stft_pair2_can_fuse_k0: the 12-wave RDB form)
+            const bool rms = p.k0_chunk_sums != nullptr;
+            if (!rdb) return;
+            if (rms && twl) hipLaunchKernelGGL((k_stft_pair2<12, true, true, 1>), grid, dim3(768), lds, s, p, n_rows);
+            else if (rms) hipLaunchKernelGGL((k_stft_pair2<12, false, true, 1>), grid, dim3(768), lds, s, p, n_rows);
+            else if (twl) hipLaunchKernelGGL((k_stft_pair2<12, true, true, 2>), grid, dim3(768), lds, s, p, n_rows);
+            else hipLaunchKernelGGL((k_stft_pair2<12, false, true, 2>), grid, dim3(768), lds, s, p, n_rows);
+        } else if (rdb) {
             if (twl) hipLaunchKernelGGL((k_stft_pair2<12, true, true>), grid, dim3(768), lds, s, p, n_rows);
             else hipLaunchKernelGGL((k_stft_pair2<12, false, true>), grid, dim3(768), lds, s, p, n_rows);
         } else if (nw == 8) {

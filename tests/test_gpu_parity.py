@@ -552,6 +552,42 @@ def test_rms_normalize_inside_the_pair_kernel_is_bit_identical_to_its_own_launch
             assert torch.equal(res[knob][3], res[0][3]) and torch.equal(res[knob][4], res[0][4]) and not res[knob][4].any(), (knob, n_rows, n_in)
         assert torch.isfinite(res[1][0]).all()
         assert int(res[1][1][3]) == 0                                       # the silent row was gated
+    # several batches per call: the chunk sums of all the call's rows from ONE launch in front of the batches ("k0_call_sums", not the default)
+    encb, _, _ = _encoders(env, "thesis-shape", cfg=cfg, max_batch=64)
+    sb = encb.session(cfg)
+    pcm = env.synth(np.arange(40, 340), 30011, cfg.sr)
+    lens = rng.integers(1, 30012, size=300).astype(np.int32)
+    lens[:4] = (30011, 0, 1, 8193)
+    rb = {}
+    for knob in (1, 0):
+        sb.configure("k0_call_sums", knob)
+        mu, _, ok = sb.encode(pcm, lengths=lens, apply_rms=True)
+        rb[knob] = (mu.clone(), ok.clone())
+    sb.configure("k0_call_sums", 0)
+    assert torch.equal(rb[1][0], rb[0][0]) and torch.equal(rb[1][1], rb[0][1]) and torch.isfinite(rb[1][0]).all()
+    # the 128-band preset (BASELINE configs[3]: n_fft 1024 / hop 256, k_stft_pair2): the same fusion on half-wave pairs - raw rows, the two
+    # slots of a row that touch the centre padding per sample, re-quantisation in the decode
+    cfg2 = env.PRESETS["bench-1s-128"]
+    enc2, _, _ = _encoders(env, "thesis-shape", cfg=cfg2, max_batch=320)
+    s2 = enc2.session(cfg2)
+    for n_rows, n_in, ragged in ((320, cfg2.n_samples, False), (37, 30011, True), (300, 22050, True), (5, 32768, False)):
+        pcm = env.synth(np.arange(700, 700 + n_rows), n_in, cfg2.sr)
+        pcm[3] = 0
+        lens = None
+        if ragged:
+            lens = rng.integers(1, n_in + 1, size=n_rows).astype(np.int32)
+            lens[:11] = (n_in, n_in - 1, 1, 2, 513, 8193, 7922, 8191, 16114, 130, 0)
+        r2 = {}
+        for knob in (1, 0):
+            s2.configure("stft_k0_fuse", knob)
+            mu, _, ok = s2.encode(pcm, lengths=lens, apply_rms=True)
+            img = s2.mel_pcm16(pcm, lengths=lens, apply_rms=True, layout=1)
+            mu0, _, ok0 = s2.encode(pcm, lengths=lens, apply_rms=False)
+            r2[knob] = (mu.clone(), ok.clone(), img.clone(), mu0.clone(), ok0.clone())
+        s2.configure("stft_k0_fuse", DEFAULT_K0)
+        for k in range(5):
+            assert torch.equal(r2[1][k], r2[0][k]), ("bench-1s-128", k, n_rows, n_in)
+        assert torch.isfinite(r2[1][0]).all() and int(r2[1][1][3]) == 0
     # the reference's own default geometry (5 s / 48 kHz: 30 numpy chunks per row, 626 frames = 313 pairs, the dB stage as its own kernel)
     cfg5 = env.PRESETS["ref-default"]
     enc5, _, _ = _encoders(env, "thesis-shape", cfg=cfg5, max_batch=8)
