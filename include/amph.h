@@ -143,7 +143,8 @@ const char* amph_last_error(const amph_ctx* ctx);   /* ctx may be NULL: create-t
  *                            the largest whose LDS image fits; 10, 11 and 12 give identical bits, the 8-wave build differs
  *                            from them in the last bits (3e-7 of a row's peak mel power: another FMA contraction)
  *   "stft_pair_tw_lds" 0/1   its stage-1 twiddles in LDS when the image still fits 160 KB (default 1), else buffer loads
- *   "stft_k0_fuse"     0/1   PCM16 rows that take k_stft_pair at 12 waves (n_fft 2048 / hop 384, an even row length; with or without the RMS stage):
+ *   "stft_k0_fuse"     0/1   PCM16 rows that take k_stft_pair at 12 waves (n_fft 2048 / hop 384) or k_stft_pair2's 12-wave form with the dB stage on
+ *                            register-resident mel power (n_fft 1024 / hop 256), an even row length; with or without the RMS stage:
  *                            K0's second kernel (fold + apply) and its padded normalised copy of every row move INTO the STFT kernel - it folds
  *                            the per-chunk sums of squares (K0's first kernel: still a launch) into the scale, reads the raw rows (centre padding,
  *                            fix_length and truncation as index arithmetic) and re-quantises in its decode (default 1; 0 = K0's two launches +
@@ -151,6 +152,11 @@ const char* amph_last_error(const amph_ctx* ctx);   /* ctx may be NULL: create-t
  *   "stft_pair_rows2"  0/1   ... and, when a batch has more rows than half the CUs, two rows per workgroup: one queue over the pairs of both rows (a
  *                            one-second row's 29 pairs on 12 waves leave the third round 5 / 12 busy; 58 pairs are four full rounds + 10), a mel-power
  *                            image per row in LDS, the tables staged once for both (default 1; same bits)
+ *   "stft_pair_cq"     0..64 ... or, > 1: that many rows per workgroup on ONE continuous pair queue - a row's dB stage is run by the wave that
+ *                            completes its last pair while the others are on the next row's pairs, no workgroup barrier behind the tables'
+ *                            (default 0: 12 % less CU-time but a longer launch - nothing end to end at a 256-row batch, +1 - 3 % from 512 rows;
+ *                            same bits; profiles/r04_stft_cq.txt)
+ *   "k0_call_sums"     0/1   K0's chunk sums for all rows of a call in one launch in front of its batches (default 0: -1.4 %; same bits)
  *   "stft_prenorm"     0/1   PCM16 input with apply_rms: the RMS kernel also writes the normalised, re-quantised PCM16
  *                            rows (what 00_normalize_dataset_rms.py puts on disk) and the STFT kernel reads those
  *                            (default 1) instead of normalising every sample of every frame itself (0); same bits
