@@ -190,6 +190,9 @@ struct amph_ctx {
 
     bool profiling = false;
     int profile_only = -1;                 // -1: every stage; >= 0: only that stage
+    int profile_every = 1;                 // bracket every n-th launch of a profiled stage ("profile_every": the two event records per batch
+                                           // of bench.py's in-region bracket cost ~2 % of the headline at 1, a quarter of that at 4)
+    unsigned profile_seen = 0;             // ... launches of profiled stages so far
     std::vector<hipEvent_t> event_pool;    // recycled timing events
     std::vector<Stage> stages;
     hipStream_t last_stream = nullptr;
@@ -298,6 +301,7 @@ struct StageTimer {
     bool on;
     StageTimer(amph_ctx* c_, int stage_, hipStream_t s_) : c(c_), stage(stage_), s(s_) {
         on = c->profiling && (c->profile_only < 0 || c->profile_only == stage);
+        if (on && c->profile_every > 1) on = (c->profile_seen++ % (unsigned)c->profile_every) == 0;
         if (on) {
             a = take_event(c);
             b = take_event(c);
@@ -1476,6 +1480,7 @@ int amph_configure(amph_ctx* c, const char* key, int value) {
     if (!std::strcmp(key, "stft_k0_fuse")) { c->stft_k0_fuse = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "stft_pair_rows2")) { c->stft_pair_rows2 = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "k0_call_sums")) { c->k0_call_sums = value != 0; return AMPH_OK; }
+    if (!std::strcmp(key, "profile_every")) { if (value < 1) return AMPH_ERR_INVALID_ARG; c->profile_every = value; c->profile_seen = 0; return AMPH_OK; }
     if (!std::strcmp(key, "stft_pair_cq")) { if (value < 0 || value > 64) return AMPH_ERR_INVALID_ARG; c->stft_pair_cq = value; return AMPH_OK; }
     if (!std::strcmp(key, "stft_pair2_regdb")) { c->stft_pair2_regdb = value != 0; return AMPH_OK; }
     if (!std::strcmp(key, "stft_pair_waves")) {

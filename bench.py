@@ -82,6 +82,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: f32-input MFMA = fp32 vector peak
+IN_REGION_BRACKET_EVERY = 4     # the dominant kernel's HIP-event bracket inside the timed region: every n-th launch
 PEAK_HBM_GBS = 8000.0             # HBM3E spec peak
 
 
@@ -427,6 +428,7 @@ def main():
     # the dominant stage's event bracket is on from here: the pre-warm and warm-up passes run exactly as the timed steps do, and the timing
     # events the timed region needs (two per batch) exist before it starts - its 1 600 hipEventCreate calls used to sit inside it
     sess.profile_enable(True, only_stage=dom)
+    sess.configure("profile_every", IN_REGION_BRACKET_EVERY)
     for _ in range(max(0, args.prewarm)):              # see --prewarm: brings the GPU out of its idle state; W below is untouched
         step()
     for _ in range(max(1, args.warmup - 1)):
@@ -459,6 +461,7 @@ def main():
             sys.exit("all-gather did not return this rank's latents in place 0")
     prof = sess.profile_read()[dom]
     sess.profile_enable(False)
+    sess.configure("profile_every", 1)
     range_overflow = sess.range_overflow()             # the flag the two-term fp16 kernels raised inside the timed region, if any (include/amph.h)
     files_leg = from_files_leg(enc, cfg, pcm_host, args, dev, world, rank, use_dist, dist) if args.files > 0 else None
 
@@ -578,6 +581,8 @@ def main():
                                "frac": round(tfl / PEAK_F32_MFMA_TFLOPS, 4)}
         launches = max(1, prof["launches"])
         roof["in_timed_region"] = {"avg_bracket_ms": round(prof["total_ms"] / launches, 5), "launches": int(prof["launches"]),
+                                   "bracketed": "every %d-th launch of the kernel inside the timed region (two event records each; "
+                                                "every launch costs ~2 %% of the headline)" % IN_REGION_BRACKET_EVERY,
                                    "concurrent_lanes": n_lanes,
                                    "note": "event bracket around the same kernel while the other lanes' kernels share the GPU: "
                                            "queue-inclusive, not a kernel duration"}
