@@ -603,10 +603,19 @@ def main():
                     if n_mfma > 0:
                         t_us = n_mfma * 32.0 / (SIMDS * CLK) * 1e6
                         pipe_us += t_us * 256.0 / cplk
-                        per_k.append({"kernel": s_["stage"], "mfma_insts_per_launch": int(n_mfma), "matrix_pipe_us": round(t_us, 2),
-                                      "isolated_us": round(iso_us, 2), "mfma_busy_frac_of_isolated": round(t_us / iso_us, 3),
-                                      "mfma_busy_frac_counter": round(m.get("mfma_busy_cycles", 0.0) / SIMDS / max(1.0, m.get("gui_active_sum", 0.0) / 8.0), 3)
-                                      if m.get("gui_active_sum") else None})
+                        busy_c = (round(m.get("mfma_busy_cycles", 0.0) / SIMDS / max(1.0, m.get("gui_active_sum", 0.0) / 8.0), 3)
+                                  if m.get("gui_active_sum") else None)
+                        pk = {"kernel": s_["stage"], "mfma_insts_per_launch": int(n_mfma), "matrix_pipe_us": round(t_us, 2),
+                              "isolated_us": round(iso_us, 2), "mfma_busy_frac_of_isolated": round(t_us / iso_us, 3),
+                              "mfma_busy_frac_counter": busy_c}
+                        g_ = rocprof_grid.get(s_["stage"])
+                        if g_ and busy_c is not None:
+                            # a persistent kernel holds only part of the chip by design (round 4: conv1+2 and conv3 on 64 LDS-filling workgroups =
+                            # a quarter of the CUs; the other lanes' kernels run beside them): the counter above averages over all 1024 SIMDs
+                            share_ = min(1.0, g_["workgroups"] / (256.0 * (1 if g_["threads"] >= 512 else 2)))
+                            pk["cu_share"] = round(share_, 4)
+                            pk["mfma_busy_frac_on_occupied_cus"] = round(busy_c / share_, 3)
+                        per_k.append(pk)
                     else:
                         t_us = s_["flops_per_chunk"] * cplk / (PEAK_F32_MFMA_TFLOPS * 1e12) * 1e6
                         valu_us += t_us * 256.0 / cplk
